@@ -1,0 +1,113 @@
+"""Import the reference's own PIPS / SamPt modules IN PLACE from /root/reference (read-only).
+
+TEST INFRASTRUCTURE ONLY (see oracle/pips_ref.py header).  Nothing is copied: the reference
+packages' ``__init__`` files import cv2 / tensorflow / cotracker (absent here), so empty namespace
+modules are pre-registered in ``sys.modules`` and the few needed leaf modules are imported by path —
+the recipe verified in SURVEY.md Appendix C.  Only usable where /root/reference exists (the build
+container); on the GPU box callers must check ``available()`` first.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+REF = os.environ.get("SAMPT_REFERENCE", "/root/reference")
+
+
+def available() -> bool:
+    return os.path.isdir(os.path.join(REF, "sam_pt", "point_tracker", "pips"))
+
+
+def _ns(name: str, rel: str):
+    if name in sys.modules:
+        return sys.modules[name]
+    m = types.ModuleType(name)
+    m.__path__ = [REF + rel]
+    sys.modules[name] = m
+    return m
+
+
+def _link_children():
+    for name in list(sys.modules):
+        if name.startswith("sam_pt."):
+            parent, _, child = name.rpartition(".")
+            if parent in sys.modules:
+                setattr(sys.modules[parent], child, sys.modules[name])
+
+
+def load_pips():
+    """Returns (Pips class, PipsPointTracker class, PointTracker ABC) of the reference."""
+    assert available(), "reference tree not present"
+    sys.dont_write_bytecode = True  # never write __pycache__ into the reference tree
+    for n, p in [("sam_pt", "/sam_pt"), ("sam_pt.point_tracker", "/sam_pt/point_tracker"),
+                 ("sam_pt.point_tracker.utils", "/sam_pt/point_tracker/utils"),
+                 ("sam_pt.point_tracker.pips", "/sam_pt/point_tracker/pips"),
+                 ("sam_pt.utils", "/sam_pt/utils"), ("sam_pt.modeling", "/sam_pt/modeling")]:
+        _ns(n, p)
+    import sam_pt.point_tracker.tracker as T
+    sys.modules["sam_pt.point_tracker"].PointTracker = T.PointTracker
+    import sam_pt.point_tracker.pips.pips as P
+    sys.modules["sam_pt.point_tracker.pips"].Pips = P.Pips
+    import sam_pt.point_tracker.utils.saverloader as SL
+    sys.modules["sam_pt.point_tracker.utils"].saverloader = SL
+    _link_children()
+    import sam_pt.point_tracker.pips.tracker as PT
+    _link_children()
+    return P.Pips, PT.PipsPointTracker, T.PointTracker
+
+
+def load_sam_pt():
+    """Returns the reference ``SamPt`` class (sam_pt/modeling/sam_pt.py) with absent third-party imports
+    stubbed (segment_anything, skimage, cv2, wandb, sklearn_extra)."""
+    load_pips()
+
+    def stub(name, **attrs):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__path__ = []
+            sys.modules[name] = m
+        for k, v in attrs.items():
+            setattr(sys.modules[name], k, v)
+        return sys.modules[name]
+
+    stub("segment_anything", SamPredictor=object)
+    stub("segment_anything.modeling", Sam=object)
+    stub("skimage", color=types.SimpleNamespace())
+    stub("cv2")
+    stub("wandb")
+    stub("sklearn_extra")
+    stub("sklearn_extra.cluster", KMedoids=object)
+    stub("matplotlib") if "matplotlib" not in sys.modules else None
+
+    class _NoSuperGlue:  # isinstance() target only (sam_pt.py:189)
+        pass
+
+    sys.modules["sam_pt.point_tracker"].SuperGluePointTracker = _NoSuperGlue
+    import importlib
+    try:
+        U = importlib.import_module("sam_pt.utils.util")
+    except Exception:
+        # util.py pulls cv2/wandb/matplotlib at import; only the enum is needed on the hot path
+        from enum import IntEnum
+
+        class PointVisibilityType(IntEnum):  # values: sam_pt/utils/util.py:267-282
+            VISIBLE = 1
+            INVISIBLE = 0
+            REINIT_FAILED = -1
+            OUTSIDE_FRAME = -2
+            PATCH_NON_SIMILAR = -3
+            REJECTED_AFTER_PATCH_WAS_NON_SIMILAR = -4
+
+        U = stub("sam_pt.utils.util", PointVisibilityType=PointVisibilityType)
+    if "sam_pt.utils.query_points" not in sys.modules:
+        try:
+            importlib.import_module("sam_pt.utils.query_points")
+        except Exception:
+            def _na(*a, **k):
+                raise NotImplementedError("query-point selection needs cv2/sklearn_extra (absent)")
+            stub("sam_pt.utils.query_points", extract_kmedoid_points=_na, extract_random_mask_points=_na,
+                 extract_corner_points=_na, extract_mixed_points=_na)
+    _link_children()
+    M = importlib.import_module("sam_pt.modeling.sam_pt")
+    return M.SamPt
