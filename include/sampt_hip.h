@@ -1,0 +1,149 @@
+/* sampt_hip.h — C ABI of libsampt_hip.so, the MI355X (gfx950) HIP implementation of the SAM-PT hot path.
+ *
+ * The reference (SysCV/sam-pt) has no native code and no FFI: its "plugin boundary" is duck typing through Hydra
+ * `_target_`s.  This header is therefore the binding a maintainer of the reference would add
+ * underneath the two Python seams — see INTEGRATION.md for the ctypes stub:
+ *
+ *   seam 1  sam_pt.point_tracker.PointTracker.forward(rgbs, query_points)        sam_pt/point_tracker/tracker.py:26-51
+ *           as implemented by PipsPointTracker                                   sam_pt/point_tracker/pips/tracker.py:42-201
+ *   seam 2  SamPredictor.set_image / predict_torch as driven by SamPt            sam_pt/modeling/sam_pt.py:771, 783-828, 849
+ *
+ * Conventions: every function returns 0 (SAMPT_OK) or a negative error code and never throws; all pointers named
+ * `*_dev` / documented "device" are HIP device pointers owned by the caller; kernels never allocate; work is
+ * enqueued on the given hipStream_t (passed as void*) and no function synchronises unless documented.  Activation
+ * scratch comes from a caller-provided workspace: call the *_workspace_bytes query first.
+ */
+#ifndef SAMPT_HIP_H
+#define SAMPT_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SAMPT_OK 0
+#define SAMPT_ERR_ARG (-1)
+#define SAMPT_ERR_HIP (-2)
+#define SAMPT_ERR_UNSUPPORTED (-3)
+#define SAMPT_ERR_WORKSPACE (-4)
+
+typedef void* sampt_stream_t; /* hipStream_t */
+typedef struct sampt_pips* sampt_pips_t;
+typedef struct sampt_vit* sampt_vit_t;
+typedef struct sampt_dec* sampt_dec_t;
+
+int sampt_version(void);
+/* Last error message of the calling thread's most recent failing call ("" if none). */
+const char* sampt_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * seam 1 — PIPS point tracker.  Weights: `n` (name, device pointer) pairs keyed by the upstream checkpoint keys
+ * (model-*.pth['model_state_dict'], module tree pips.py:191-287, 290-317, 410-437) after the host-side repack
+ * documented in sam_pt_amd/pack.py (conv weights -> [Cout][KH][KW][Cin], stem Cin padded to 4, mixer input
+ * weight K padded 519 -> 520, "ffeat_updater.0.weight_t", "__times").
+ * --------------------------------------------------------------------------------------------------------- */
+int sampt_pips_create(const char* const* names, const void* const* ptrs, int n, int stride, int S, sampt_pips_t* out);
+void sampt_pips_destroy(sampt_pips_t h);
+
+/* Pips.fnet (BasicEncoder, pips.py:254-287) + CorrBlock pyramid (pips.py:355-361) for `nf` frames.
+ * frames_dev: uint8 (nf,3,H,W) as handed to PointTracker.forward.  pyr_dev[l]: float32 [nf][H_l][W_l][128] (NHWC),
+ * H_0 = H/stride, H_{l+1} = H_l/2.  Replaces `self.fnet(rgbs_)` at pips.py:453-455 and CorrBlock.__init__. */
+int sampt_pips_fnet_workspace_bytes(sampt_pips_t h, int nf, int H, int W, size_t* bytes);
+int sampt_pips_fnet_f32(sampt_pips_t h, const uint8_t* frames_dev, int nf, int H, int W, float* const pyr_dev[4],
+                        void* workspace_dev, size_t workspace_bytes, sampt_stream_t stream);
+
+/* Initial point features: bilinear_sample2d(fmaps[:,0], xy/stride) (pips.py:469-475, utils/samp.py:6-80).
+ * fmap_dev: one level-0 frame [H0][W0][128]; xy_dev: [n][2] in feature-map pixels; out_dev: [n][128]. */
+int sampt_pips_sample_feat_f32(const float* fmap_dev, int H0, int W0, const float* xy_dev, int n, float* out_dev,
+                               sampt_stream_t stream);
+
+/* One 8-frame window of Pips.forward's iterative update (pips.py:458-476, 507-568) + sigmoid (pips/tracker.py:102).
+ * frame_idx_dev: int32 [S] indices into the pyramid's frame axis (window frames, tail repeated: tracker.py:73-78);
+ * xys_dev: [n][2] pixels at the window's first frame; feat_init_dev: [n][128].
+ * traj_out_dev: [S][n][2] pixels (last iteration); vis_out_dev: [S][n] in (0,1). */
+int sampt_pips_update_workspace_bytes(sampt_pips_t h, int n, size_t* bytes);
+int sampt_pips_update_f32(sampt_pips_t h, const float* const pyr_dev[4], int H0, int W0, const int32_t* frame_idx_dev,
+                          int n, const float* xys_dev, const float* feat_init_dev, int iters, float* traj_out_dev,
+                          float* vis_out_dev, void* workspace_dev, size_t workspace_bytes, sampt_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * seam 2a — SAM image encoder = SamPredictor.set_image (Sam.preprocess + ImageEncoderViT, Appendix A-1..A-3).
+ * cfg: see sampt_vit_config.  Weight names: upstream sam_vit_*.pth keys; GEMM weights as ".f16" copies when
+ * cfg.f16 != 0; "image_encoder.neck.2.weight_khwc"; "__win_rows" (window-partition row map for win_batches frames).
+ * --------------------------------------------------------------------------------------------------------- */
+typedef struct sampt_vit_config {
+  int embed_dim, depth, num_heads, grid, window, patch, out_chans, mlp_ratio, img_size;
+  int global_mask; /* bit i: block i uses global attention (configs/model/sam/image_encoder/vit_*.yaml) */
+  int f16;         /* 1: fp16 MFMA + flash attention (fp32 accumulate/softmax/LN/residual); 0: exact fp32 */
+  float pixel_mean[3], pixel_std[3];
+} sampt_vit_config;
+
+int sampt_vit_create(const sampt_vit_config* cfg, const char* const* names, const void* const* ptrs, int n,
+                     int win_batches, sampt_vit_t* out);
+void sampt_vit_destroy(sampt_vit_t h);
+int sampt_vit_encode_workspace_bytes(sampt_vit_t h, int B, size_t* bytes);
+/* frames_dev: uint8, (B,3,H,W) if chw else (B,H,W,3), H,W <= img_size with the longest side == img_size already
+ * (the reference pipelines resize before SamPt: configs/demo.yaml:20, configs/vos_eval_root.yaml:28).
+ * features_dev: float32 [B][grid*grid][out_chans] — the (B,256,64,64) embedding in NHWC / token-major order. */
+int sampt_vit_encode(sampt_vit_t h, const uint8_t* frames_dev, int chw, int B, int H, int W, float* features_dev,
+                     void* workspace_dev, size_t workspace_bytes, sampt_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * seam 2b — prompt encoder + mask decoder + postprocess = SamPredictor.predict_torch(multimask_output=False,
+ * return_logits=True) as called at sam_pt.py:783-828.
+ * --------------------------------------------------------------------------------------------------------- */
+int sampt_dec_create(const char* const* names, const void* const* ptrs, int n, int grid, int img_size, sampt_dec_t* out);
+void sampt_dec_destroy(sampt_dec_t h);
+int sampt_dec_workspace_bytes(sampt_dec_t h, int out_h, int out_w, size_t* bytes);
+/* features_dev [grid*grid][256]; pts_dev [k][2] (input-frame pixels), labels_dev int32 [k]; box_dev 4 floats or
+ * NULL; mask_in_dev [4*grid][4*grid] low-res logits or NULL.  Outputs: logits_out_dev [out_h][out_w],
+ * iou_out_dev [1], low_res_out_dev [4*grid][4*grid]. */
+int sampt_sam_decode(sampt_dec_t h, const float* features_dev, const float* pts_dev, const int32_t* labels_dev, int k,
+                     const float* box_dev, const float* mask_in_dev, int in_h, int in_w, int out_h, int out_w,
+                     float* logits_out_dev, float* iou_out_dev, float* low_res_out_dev, void* workspace_dev,
+                     size_t workspace_bytes, sampt_stream_t stream);
+/* Whole SamPt.predict_mask chain for one (frame, object) (sam_pt.py:760-837) without host synchronisation:
+ * [positives-only pass when 0 < n_pos_first < k] -> all-points pass -> `refine_iters` box+mask refinement passes
+ * (bbox of logits>0 and the `sum < 2 -> stop` rule evaluated on device) -> logits = -inf if iou < iou_thr.
+ * final_logits_dev [out_h][out_w]; score_out_dev [1] = predicted IoU. */
+int sampt_sam_track_decode(sampt_dec_t h, const float* features_dev, const float* pts_dev, const int32_t* labels_dev,
+                           int k, int n_pos_first, int refine_iters, float iou_thr, int in_h, int in_w, int out_h,
+                           int out_w, float* final_logits_dev, float* score_out_dev, void* workspace_dev,
+                           size_t workspace_bytes, sampt_stream_t stream);
+int sampt_postprocess_masks(const float* low_res_dev, int L, int img_size, int in_h, int in_w, float* out_dev, int out_h,
+                            int out_w, sampt_stream_t stream);
+/* bbox_state_dev: int32[5] = {xmin, ymin, xmax, ymax, count} over logits > 0 (sam_pt.py:809-820). */
+int sampt_bbox_from_logits(const float* logits_dev, int h, int w, int32_t* bbox_state_dev, sampt_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Kernel-level entry points (used by the parity tests and the roofline bench; same kernels the engines launch).
+ * --------------------------------------------------------------------------------------------------------- */
+/* C[M][N] = act(alpha * A[M][K] . W[N][K]^T + bias) (+ res).  dtype: 0 = f32 (exact f32 MFMA), 1 = f16 in / f32 out,
+ * 2 = f16 in / f16 out.  act: 0 none, 1 relu, 2 gelu(erf). */
+int sampt_gemm(int dtype, const void* A_dev, const void* W_dev, const float* bias_dev, const float* res_dev,
+               void* C_dev, int M, int N, int K, int act, float alpha, sampt_stream_t stream);
+/* NHWC convolution as implicit GEMM: x [n][H][W][Cin], w [Cout][KH][KW][Cin], y [n][OH][OW][Cout] (f32 out). */
+int sampt_conv2d_nhwc(int dtype, const void* x_dev, const void* w_dev, const float* bias_dev, float* y_dev, int n,
+                      int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, sampt_stream_t stream);
+int sampt_instance_norm_nhwc(float* x_dev, int n, int hw, int C, float eps, int relu, const float* skip_dev,
+                             void* workspace_dev, size_t workspace_bytes, sampt_stream_t stream);
+size_t sampt_instance_norm_workspace_bytes(int n, int hw, int C);
+int sampt_layernorm(const float* x_dev, const float* w_dev, const float* b_dev, void* y_dev, int M, int D, float eps,
+                    int out_f16, int act, sampt_stream_t stream);
+int sampt_resize_bilinear_nhwc(const float* src_dev, int n, int sh, int sw, int C, float* dst_dev, int dh, int dw,
+                               int dstC, int c_off, int align_corners, sampt_stream_t stream);
+int sampt_avgpool2x2_nhwc(const float* src_dev, int n, int h, int w, int C, float* dst_dev, sampt_stream_t stream);
+/* Fused correlation + 7x7x4-level window sampler (CorrBlock.corr + .sample, pips.py:364-407).
+ * ffeats_dev [n][S][128]; coords_dev [S][n][2] (level-0 feature-map pixels); out_dev [n][S][196]. */
+int sampt_corr_sample_f32(const float* const pyr_dev[4], int H0, int W0, const int32_t* frame_idx_dev, int S, int n,
+                          const float* ffeats_dev, const float* coords_dev, float* out_dev, sampt_stream_t stream);
+/* ViT attention on a packed qkv matrix [B*S*S][3*heads*hd] (f16), decomposed rel-pos tables (2S-1, hd) f32.
+ * out_dev f16 [B*S*S][heads*hd]; workspace: 2 * B*heads*S*S*S floats. */
+int sampt_vit_attention_f16(const void* qkv_dev, const float* rel_h_dev, const float* rel_w_dev, void* out_dev, int B,
+                            int S, int heads, int hd, void* workspace_dev, size_t workspace_bytes, sampt_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAMPT_HIP_H */

@@ -1,0 +1,281 @@
+// SAM ViT attention on gfx950:
+//   attn = softmax(q.k^T * scale + rel_h[q, kh] + rel_w[q, kw]) . v      (decomposed relative position bias)
+//
+//  * vit_rel_bias            — the two small bias tables per query (shared by both modes)
+//  * softmax_rel_rows        — exact-fp32 mode: bias + softmax over a materialised score matrix
+//  * vit_flash_attention_f16 — fused flash-style kernel: fp16 MFMA (32x32x16), fp32 online softmax, K / V^T tiles
+//                              and the bias tables staged in LDS, scores never leave registers.
+#include "ops.h"
+
+namespace sampt {
+
+// ---------------------------------------------------------------------------------------------
+// rel tables: relhT[bh][kh][q] = <q_vec, rel_pos_h[qh - kh + S-1]>,  relwT[bh][kw][q] likewise with qw
+// One workgroup per (grid row qh, head, batch): its S query vectors are staged in LDS as fp32.
+// ---------------------------------------------------------------------------------------------
+template <typename TQ>
+__global__ __launch_bounds__(256) void k_vit_rel_bias(const TQ* __restrict__ qkv, const float* __restrict__ rel_h,
+                                                      const float* __restrict__ rel_w, int S, int heads, int hd,
+                                                      float* __restrict__ relhT, float* __restrict__ relwT) {
+  extern __shared__ float qs[];  // [S][hd+1]
+  const int qh = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int N = S * S, D = heads * hd, ldq = hd + 1;
+  for (int i = threadIdx.x; i < S * hd; i += 256) {
+    int t = i / hd, c = i - t * hd;
+    qs[t * ldq + c] = (float)qkv[((long)(b * N + qh * S + t)) * 3 * D + h * hd + c];
+  }
+  __syncthreads();
+  const long bh = (long)b * heads + h;
+  for (int i = threadIdx.x; i < S * 2 * S; i += 256) {
+    int kk = i / S, qw = i - kk * S;  // kk in [0, 2S): first S -> relh (key row), next S -> relw (key col)
+    const float* tab;
+    if (kk < S) tab = rel_h + (long)(qh - kk + S - 1) * hd;
+    else tab = rel_w + (long)(qw - (kk - S) + S - 1) * hd;
+    const float* qv = qs + qw * ldq;
+    float a = 0.f;
+    for (int c = 0; c < hd; ++c) a += qv[c] * tab[c];
+    int q = qh * S + qw;
+    if (kk < S) relhT[(bh * S + kk) * N + q] = a;
+    else relwT[(bh * S + (kk - S)) * N + q] = a;
+  }
+}
+
+int vit_rel_bias(const void* qkv, int qkv_f16, const float* rel_h, const float* rel_w, int B, int S, int heads,
+                 int hd, float* relh, float* relw, hipStream_t s) {
+  dim3 grid(S, heads, B), block(256);
+  size_t sh = (size_t)S * (hd + 1) * sizeof(float);
+  if (qkv_f16)
+    hipLaunchKernelGGL(k_vit_rel_bias<half_t>, grid, block, sh, s, (const half_t*)qkv, rel_h, rel_w, S, heads, hd, relh,
+                       relw);
+  else
+    hipLaunchKernelGGL(k_vit_rel_bias<float>, grid, block, sh, s, (const float*)qkv, rel_h, rel_w, S, heads, hd, relh,
+                       relw);
+  SAMPT_CHECK_LAUNCH("vit_rel_bias");
+  return SAMPT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// exact mode: scores[bh][q][k] += relhT[bh][k/S][q] + relwT[bh][k%S][q]; softmax over k (in place)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_softmax_rel_rows(float* __restrict__ scores, const float* __restrict__ relhT,
+                                                          const float* __restrict__ relwT, int N, int S) {
+  __shared__ float red[8];
+  const int q = blockIdx.x;
+  const long bh = blockIdx.y;
+  float* row = scores + (bh * N + q) * N;
+  const float* rh = relhT + bh * S * N + q;
+  const float* rw = relwT + bh * S * N + q;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float m = -INFINITY;
+  for (int k = tid; k < N; k += 256) {
+    float v = row[k] + rh[(long)(k / S) * N] + rw[(long)(k % S) * N];
+    row[k] = v;
+    m = fmaxf(m, v);
+  }
+  m = wave_max(m);
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+  for (int k = tid; k < N; k += 256) {
+    float e = expf(row[k] - m);
+    row[k] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) red[4 + wave] = sum;
+  __syncthreads();
+  sum = (red[4] + red[5]) + (red[6] + red[7]);
+  for (int k = tid; k < N; k += 256) row[k] = row[k] / sum;
+}
+
+int softmax_rel_rows(float* scores, const float* relh, const float* relw, long BH, int Nq, int S, hipStream_t s) {
+  if (Nq != S * S) return SAMPT_ERR_ARG;
+  hipLaunchKernelGGL(k_softmax_rel_rows, dim3(Nq, (unsigned)BH), dim3(256), 0, s, scores, relh, relw, Nq, S);
+  SAMPT_CHECK_LAUNCH("softmax_rel_rows");
+  return SAMPT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fused flash attention, f16 MFMA 32x32x16.
+//
+// "Swapped" formulation: each wave owns 32 queries and computes S^T = K.Q^T (A = K tile rows, B = Q^T), so a
+// lane holds 16 keys x ONE query column per 32x32 tile: softmax row statistics are per-lane (+1 exchange with
+// lane^32) and the per-query rescale factors line up with O^T = V^T.P^T, whose columns are the same queries.
+// P^T is fed to the second MFMA straight from the score registers (any k-slot permutation is legal as long as
+// the A operand uses the same one, and V^T is read from LDS with exactly that permutation).
+// ---------------------------------------------------------------------------------------------
+template <int HD, int NW, int SG>
+__global__ __launch_bounds__(NW * 64) void k_flash_f16(const half_t* __restrict__ qkv, const float* __restrict__ relhT,
+                                                       const float* __restrict__ relwT, half_t* __restrict__ out, int N,
+                                                       int heads, float scale) {
+  constexpr int KS = HD / 16;            // k-steps of QK^T
+  constexpr int DT = (HD + 31) / 32;     // 32-row tiles of O^T
+  constexpr int QT = NW * 32;
+  constexpr int NT = NW * 64;
+  constexpr int KLD = HD + 8, VLD = 64 + 8, RLD = QT + 2;
+  __shared__ __attribute__((aligned(16))) half_t Ks[64][KLD];
+  __shared__ __attribute__((aligned(16))) half_t Vt[DT * 32][VLD];
+  __shared__ half_t relh_s[SG][RLD];
+  __shared__ half_t relw_s[SG][RLD];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, hi = lane >> 5;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int D = heads * HD;
+  const long tok0 = (long)b * N;
+  const int qblk = blockIdx.x * QT;
+  const int ql = wave * 32 + li;
+  const int q = qblk + ql;
+  const long bh = (long)b * heads + h;
+
+  // ---- prologue: bias tables (fp16 in LDS), zero the unused V^T rows, Q fragments
+  for (int i = tid; i < SG * QT; i += NT) {
+    int kk = i / QT, qq = i - kk * QT;
+    int gq = qblk + qq;
+    float vh = 0.f, vw = 0.f;
+    if (gq < N) {
+      vh = relhT[(bh * SG + kk) * N + gq];
+      vw = relwT[(bh * SG + kk) * N + gq];
+    }
+    relh_s[kk][qq] = (half_t)vh;
+    relw_s[kk][qq] = (half_t)vw;
+  }
+  if (DT * 32 > HD) {
+    for (int i = tid; i < (DT * 32 - HD) * VLD; i += NT) Vt[HD + i / VLD][i % VLD] = (half_t)0.f;
+  }
+  h8 qf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    if (q < N) qf[ks] = *(const h8*)(qkv + (tok0 + q) * 3 * D + h * HD + ks * 16 + hi * 8);
+    else qf[ks] = (h8){0, 0, 0, 0, 0, 0, 0, 0};
+  }
+
+  f32x16 o[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  for (int kt0 = 0; kt0 < N; kt0 += 64) {
+    __syncthreads();  // previous tile fully consumed (also orders the prologue LDS writes)
+    // ---- stage K tile [64][HD] and V^T tile [HD][64]
+    for (int v = tid; v < 64 * (HD / 8); v += NT) {
+      int kr = v / (HD / 8), kv = v - kr * (HD / 8);
+      h8 val = (h8){0, 0, 0, 0, 0, 0, 0, 0};
+      if (kt0 + kr < N) val = *(const h8*)(qkv + (tok0 + kt0 + kr) * 3 * D + D + h * HD + kv * 8);
+      *(h8*)&Ks[kr][kv * 8] = val;
+    }
+    for (int v = tid; v < 64 * (HD / 8); v += NT) {
+      int kr = v & 63, dv = v >> 6;
+      h8 val = (h8){0, 0, 0, 0, 0, 0, 0, 0};
+      if (kt0 + kr < N) val = *(const h8*)(qkv + (tok0 + kt0 + kr) * 3 * D + 2 * D + h * HD + dv * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) Vt[dv * 8 + e][kr] = val[e];
+    }
+    __syncthreads();
+
+    // ---- S^T = K . Q^T  (two 32-key tiles)
+    f32x16 st[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        h8 kf = *(const h8*)&Ks[kt * 32 + li][ks * 16 + hi * 8];
+        st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], st[kt], 0, 0, 0);
+      }
+    }
+    // ---- scale + decomposed rel-pos bias + key mask, running max
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int key = kt0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float sv;
+        if (key < N) {
+          int kh = key / SG, kw = key - kh * SG;
+          sv = st[kt][r] * scale + (float)relh_s[kh][ql] + (float)relw_s[kw][ql];
+        } else {
+          sv = -INFINITY;
+        }
+        st[kt][r] = sv;
+        mloc = fmaxf(mloc, sv);
+      }
+    }
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    const float m_new = fmaxf(m_run, mloc);          // finite: every tile holds >= 1 valid key
+    const float alpha = expf(m_run - m_new);          // exp(-inf) = 0 on the first tile
+    float lsum = 0.f;
+    h8 pb[4];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float p = expf(st[kt][r] - m_new);
+        lsum += p;
+        pb[kt * 2 + (r >> 3)][r & 7] = (half_t)p;
+      }
+    }
+    lsum += __shfl_xor(lsum, 32, 64);
+    l_run = l_run * alpha + lsum;
+    m_run = m_new;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    // ---- O^T += V^T . P^T : k-slot (hi, j) of step t is key 16t + 4hi + (j&3) + 8(j>>2) on BOTH operands
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const half_t* vp = &Vt[dt * 32 + li][16 * t + 4 * hi];
+        h4 v0 = *(const h4*)vp, v1 = *(const h4*)(vp + 8);
+        h8 vf = (h8){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pb[t], o[dt], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: out[q][h*HD + d] = O^T[d][q] / l
+  if (q < N) {
+    const float inv = 1.0f / l_run;
+    half_t* op = out + (tok0 + q) * D + h * HD;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        int d0 = dt * 32 + 8 * g + 4 * hi;
+        if (d0 < HD) {
+          h4 v = (h4){(half_t)(o[dt][4 * g] * inv), (half_t)(o[dt][4 * g + 1] * inv), (half_t)(o[dt][4 * g + 2] * inv),
+                      (half_t)(o[dt][4 * g + 3] * inv)};
+          *(h4*)(op + d0) = v;
+        }
+      }
+    }
+  }
+}
+
+int vit_flash_attention_f16(const half_t* qkv, const float* relh, const float* relw, half_t* out, int B, int S,
+                            int heads, int hd, hipStream_t s) {
+  const int N = S * S;
+  const float scale = 1.0f / sqrtf((float)hd);
+#define FL(HDv, NWv, SGv)                                                                                        \
+  hipLaunchKernelGGL((k_flash_f16<HDv, NWv, SGv>), dim3(cdiv(N, NWv * 32), heads, B), dim3(NWv * 64), 0, s, qkv, \
+                     relh, relw, out, N, heads, scale)
+  if (S == 64 && hd == 80) FL(80, 4, 64);
+  else if (S == 64 && hd == 64) FL(64, 4, 64);
+  else if (S == 14 && hd == 80) FL(80, 7, 14);
+  else if (S == 14 && hd == 64) FL(64, 7, 14);
+  else if (S == 16 && hd == 32) FL(32, 4, 16);   // reduced test geometry (vit_test)
+  else if (S == 6 && hd == 32) FL(32, 2, 6);
+  else return SAMPT_ERR_UNSUPPORTED;
+#undef FL
+  SAMPT_CHECK_LAUNCH("vit_flash_attention_f16");
+  return SAMPT_OK;
+}
+
+}  // namespace sampt

@@ -1,0 +1,265 @@
+// extern "C" surface of libsampt_hip.so (declared in include/sampt_hip.h).
+#include <string.h>
+
+#include <string>
+
+#include "../../include/sampt_hip.h"
+#include "engine.h"
+
+namespace sampt {
+static thread_local std::string g_err;
+void set_error(const char* where, hipError_t e) {
+  g_err = std::string(where) + ": " + hipGetErrorString(e);
+}
+const char* last_error() { return g_err.c_str(); }
+static int fail(int rc, const std::string& msg) {
+  g_err = msg;
+  return rc;
+}
+static WeightMap make_map(const char* const* names, const void* const* ptrs, int n) {
+  WeightMap w;
+  for (int i = 0; i < n; ++i) w.m[names[i]] = ptrs[i];
+  return w;
+}
+}  // namespace sampt
+
+using namespace sampt;
+
+struct sampt_pips { PipsEngine e; };
+struct sampt_vit { VitEngine e; };
+struct sampt_dec { DecEngine e; };
+
+extern "C" {
+
+int sampt_version(void) { return 1; }
+const char* sampt_last_error(void) { return last_error(); }
+
+// ------------------------------------------------------------------------------------------- PIPS
+int sampt_pips_create(const char* const* names, const void* const* ptrs, int n, int stride, int S, sampt_pips_t* out) {
+  if (!names || !ptrs || !out || S != 8) return fail(SAMPT_ERR_ARG, "sampt_pips_create: bad arguments (S must be 8)");
+  sampt_pips* h = new sampt_pips();
+  h->e.S = S, h->e.stride = stride;
+  WeightMap w = make_map(names, ptrs, n);
+  int rc = h->e.init(w);
+  if (rc != SAMPT_OK) {
+    std::string m = h->e.error;
+    delete h;
+    return fail(rc, m);
+  }
+  *out = h;
+  return SAMPT_OK;
+}
+void sampt_pips_destroy(sampt_pips_t h) { delete h; }
+
+int sampt_pips_fnet_workspace_bytes(sampt_pips_t h, int nf, int H, int W, size_t* bytes) {
+  if (!h || !bytes) return SAMPT_ERR_ARG;
+  Arena a(nullptr, 0);
+  float* out[4] = {nullptr, nullptr, nullptr, nullptr};
+  int rc = h->e.fnet(nullptr, nf, H, W, out, a, nullptr);
+  *bytes = a.peak + 256;
+  return rc;
+}
+
+int sampt_pips_fnet_f32(sampt_pips_t h, const uint8_t* frames, int nf, int H, int W, float* const pyr[4], void* ws,
+                        size_t ws_bytes, sampt_stream_t stream) {
+  if (!h || !frames || !pyr || !ws || H % h->e.stride || W % h->e.stride || (H / h->e.stride) % 8 || (W / h->e.stride) % 8)
+    return fail(SAMPT_ERR_ARG, "sampt_pips_fnet_f32: bad arguments (H, W must be multiples of 8*stride)");
+  Arena a(ws, ws_bytes);
+  return h->e.fnet(frames, nf, H, W, pyr, a, (hipStream_t)stream);
+}
+
+int sampt_pips_sample_feat_f32(const float* fmap, int H0, int W0, const float* xy, int n, float* out,
+                               sampt_stream_t stream) {
+  return pips_sample_feat(fmap, H0, W0, 128, xy, n, out, (hipStream_t)stream);
+}
+
+int sampt_pips_update_workspace_bytes(sampt_pips_t h, int n, size_t* bytes) {
+  if (!h || !bytes || n <= 0) return SAMPT_ERR_ARG;
+  Arena a(nullptr, 0);
+  PyramidLevels p = {};
+  int rc = h->e.update(p, nullptr, n, nullptr, nullptr, 6, nullptr, nullptr, a, nullptr);
+  *bytes = a.peak + 256;
+  return rc;
+}
+
+static PyramidLevels make_pyr(const float* const pyr[4], int H0, int W0) {
+  PyramidLevels p;
+  int h = H0, w = W0;
+  for (int l = 0; l < 4; ++l) {
+    p.base[l] = pyr[l], p.H[l] = h, p.W[l] = w;
+    h /= 2, w /= 2;
+  }
+  return p;
+}
+
+int sampt_pips_update_f32(sampt_pips_t h, const float* const pyr[4], int H0, int W0, const int32_t* frame_idx, int n,
+                          const float* xys, const float* feat_init, int iters, float* traj_out, float* vis_out, void* ws,
+                          size_t ws_bytes, sampt_stream_t stream) {
+  if (!h || !pyr || !frame_idx || !xys || !feat_init || !traj_out || !vis_out || !ws || n <= 0)
+    return fail(SAMPT_ERR_ARG, "sampt_pips_update_f32: bad arguments");
+  Arena a(ws, ws_bytes);
+  return h->e.update(make_pyr(pyr, H0, W0), frame_idx, n, xys, feat_init, iters, traj_out, vis_out, a,
+                     (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------- ViT
+int sampt_vit_create(const sampt_vit_config* cfg, const char* const* names, const void* const* ptrs, int n,
+                     int win_batches, sampt_vit_t* out) {
+  if (!cfg || !names || !ptrs || !out || cfg->depth > 32) return fail(SAMPT_ERR_ARG, "sampt_vit_create: bad arguments");
+  sampt_vit* h = new sampt_vit();
+  VitConfig c;
+  c.D = cfg->embed_dim, c.depth = cfg->depth, c.heads = cfg->num_heads, c.grid = cfg->grid, c.window = cfg->window;
+  c.patch = cfg->patch, c.out_chans = cfg->out_chans, c.mlp_ratio = cfg->mlp_ratio, c.img = cfg->img_size;
+  c.global_mask = cfg->global_mask, c.f16 = cfg->f16;
+  for (int i = 0; i < 3; ++i) c.mean[i] = cfg->pixel_mean[i], c.stdv[i] = cfg->pixel_std[i];
+  WeightMap w = make_map(names, ptrs, n);
+  int rc = h->e.init(w, c, win_batches);
+  if (rc != SAMPT_OK) {
+    std::string m = h->e.error;
+    delete h;
+    return fail(rc, m);
+  }
+  *out = h;
+  return SAMPT_OK;
+}
+void sampt_vit_destroy(sampt_vit_t h) { delete h; }
+
+int sampt_vit_encode_workspace_bytes(sampt_vit_t h, int B, size_t* bytes) {
+  if (!h || !bytes || B <= 0) return SAMPT_ERR_ARG;
+  Arena a(nullptr, 0);
+  int rc = h->e.encode(nullptr, 1, B, h->e.c.img, h->e.c.img, nullptr, a, nullptr);
+  *bytes = a.peak + 256;
+  return rc;
+}
+
+int sampt_vit_encode(sampt_vit_t h, const uint8_t* frames, int chw, int B, int H, int W, float* features, void* ws,
+                     size_t ws_bytes, sampt_stream_t stream) {
+  if (!h || !frames || !features || !ws || B <= 0) return fail(SAMPT_ERR_ARG, "sampt_vit_encode: bad arguments");
+  if (H > h->e.c.img || W > h->e.c.img || (H != h->e.c.img && W != h->e.c.img))
+    return fail(SAMPT_ERR_UNSUPPORTED,
+                "sampt_vit_encode: the frame's longest side must equal img_size (resize before SamPt, as the reference "
+                "pipelines do)");
+  Arena a(ws, ws_bytes);
+  return h->e.encode(frames, chw, B, H, W, features, a, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------- decoder
+int sampt_dec_create(const char* const* names, const void* const* ptrs, int n, int grid, int img_size, sampt_dec_t* out) {
+  if (!names || !ptrs || !out) return SAMPT_ERR_ARG;
+  sampt_dec* h = new sampt_dec();
+  DecConfig c;
+  c.grid = grid, c.img = img_size;
+  WeightMap w = make_map(names, ptrs, n);
+  int rc = h->e.init(w, c);
+  if (rc != SAMPT_OK) {
+    std::string m = h->e.error;
+    delete h;
+    return fail(rc, m);
+  }
+  *out = h;
+  return SAMPT_OK;
+}
+void sampt_dec_destroy(sampt_dec_t h) { delete h; }
+
+int sampt_dec_workspace_bytes(sampt_dec_t h, int oh, int ow, size_t* bytes) {
+  if (!h || !bytes) return SAMPT_ERR_ARG;
+  Arena a(nullptr, 0);
+  float dummy = 0.f;
+  int rc = h->e.track_decode(&dummy, &dummy, nullptr, 32, 0, 1, 0.f, oh, ow, oh, ow, nullptr, nullptr, a, nullptr);
+  *bytes = a.peak + 256;
+  return rc;
+}
+
+int sampt_sam_decode(sampt_dec_t h, const float* features, const float* pts, const int32_t* labels, int k,
+                     const float* box, const float* mask_in, int in_h, int in_w, int oh, int ow, float* logits_out,
+                     float* iou_out, float* low_out, void* ws, size_t ws_bytes, sampt_stream_t stream) {
+  if (!h || !features || !pts || !labels || !logits_out || !iou_out || !low_out || !ws || k <= 0)
+    return fail(SAMPT_ERR_ARG, "sampt_sam_decode: bad arguments");
+  Arena a(ws, ws_bytes);
+  return h->e.decode(features, pts, labels, k, box, mask_in, in_h, in_w, oh, ow, logits_out, iou_out, low_out, nullptr,
+                     a, (hipStream_t)stream);
+}
+
+int sampt_sam_track_decode(sampt_dec_t h, const float* features, const float* pts, const int32_t* labels, int k,
+                           int n_pos_first, int refine_iters, float iou_thr, int in_h, int in_w, int oh, int ow,
+                           float* final_logits, float* score_out, void* ws, size_t ws_bytes, sampt_stream_t stream) {
+  if (!h || !features || !pts || !labels || !final_logits || !score_out || !ws || k <= 0)
+    return fail(SAMPT_ERR_ARG, "sampt_sam_track_decode: bad arguments");
+  Arena a(ws, ws_bytes);
+  return h->e.track_decode(features, pts, labels, k, n_pos_first, refine_iters, iou_thr, in_h, in_w, oh, ow,
+                           final_logits, score_out, a, (hipStream_t)stream);
+}
+
+int sampt_postprocess_masks(const float* low, int L, int img, int in_h, int in_w, float* out, int oh, int ow,
+                            sampt_stream_t stream) {
+  return sam_postprocess(low, L, img, in_h, in_w, out, oh, ow, (hipStream_t)stream);
+}
+
+int sampt_bbox_from_logits(const float* logits, int h, int w, int32_t* bbox_state, sampt_stream_t stream) {
+  return bbox_from_logits_state(logits, h, w, (int*)bbox_state, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------- kernel-level
+int sampt_gemm(int dtype, const void* A, const void* W, const float* bias, const float* res, void* C, int M, int N, int K,
+               int act, float alpha, sampt_stream_t stream) {
+  GemmP p;
+  p.A = A, p.W = W, p.bias = bias, p.res = res, p.C = C;
+  p.M = M, p.N = N, p.K = K, p.lda = K, p.ldw = K, p.ldc = N, p.ldr = N, p.act = act, p.alpha = alpha;
+  p.out_f16 = dtype == 2;
+  return dtype == 0 ? gemm_f32(p, (hipStream_t)stream) : gemm_f16(p, (hipStream_t)stream);
+}
+
+int sampt_conv2d_nhwc(int dtype, const void* x, const void* w, const float* bias, float* y, int n, int H, int W, int Cin,
+                      int Cout, int KH, int KW, int stride, int pad, sampt_stream_t stream) {
+  GemmP p;
+  p.OH = (H + 2 * pad - KH) / stride + 1, p.OW = (W + 2 * pad - KW) / stride + 1;
+  p.A = x, p.W = w, p.bias = bias, p.C = y;
+  p.M = n * p.OH * p.OW, p.N = Cout, p.K = KH * KW * Cin, p.ldw = p.K, p.ldc = Cout;
+  p.conv = 1, p.cH = H, p.cW = W, p.cC = Cin, p.KH = KH, p.KW = KW, p.cstride = stride, p.cpad = pad;
+  return dtype == 0 ? gemm_f32(p, (hipStream_t)stream) : gemm_f16(p, (hipStream_t)stream);
+}
+
+size_t sampt_instance_norm_workspace_bytes(int n, int hw, int C) {
+  return instnorm_partial_doubles(n, hw, C) * sizeof(double) + (size_t)n * C * 2 * sizeof(float) + 512;
+}
+
+int sampt_instance_norm_nhwc(float* x, int n, int hw, int C, float eps, int relu, const float* skip, void* ws,
+                             size_t ws_bytes, sampt_stream_t stream) {
+  if (ws_bytes < sampt_instance_norm_workspace_bytes(n, hw, C)) return SAMPT_ERR_WORKSPACE;
+  Arena a(ws, ws_bytes);
+  double* part = (double*)a.get(instnorm_partial_doubles(n, hw, C) * sizeof(double));
+  float* mr = a.f32((size_t)n * C * 2);
+  SAMPT_TRY(instnorm_stats(x, n, hw, C, eps, part, mr, (hipStream_t)stream));
+  return instnorm_apply(x, mr, skip, x, n, hw, C, relu, (hipStream_t)stream);
+}
+
+int sampt_layernorm(const float* x, const float* w, const float* b, void* y, int M, int D, float eps, int out_f16,
+                    int act, sampt_stream_t stream) {
+  return layernorm_rows(x, w, b, y, M, D, eps, nullptr, out_f16, act, (hipStream_t)stream);
+}
+
+int sampt_resize_bilinear_nhwc(const float* src, int n, int sh, int sw, int C, float* dst, int dh, int dw, int dstC,
+                               int c_off, int align_corners, sampt_stream_t stream) {
+  return resize_bilinear_nhwc(src, n, sh, sw, C, dst, dh, dw, dstC, c_off, align_corners, (hipStream_t)stream);
+}
+
+int sampt_avgpool2x2_nhwc(const float* src, int n, int h, int w, int C, float* dst, sampt_stream_t stream) {
+  return avgpool2x2_nhwc(src, n, h, w, C, dst, (hipStream_t)stream);
+}
+
+int sampt_corr_sample_f32(const float* const pyr[4], int H0, int W0, const int32_t* frame_idx, int S, int n,
+                          const float* ffeats, const float* coords, float* out, sampt_stream_t stream) {
+  return pips_corr_sample(make_pyr(pyr, H0, W0), frame_idx, S, n, 128, ffeats, coords, out, 196, 0, (hipStream_t)stream);
+}
+
+int sampt_vit_attention_f16(const void* qkv, const float* rel_h, const float* rel_w, void* out, int B, int S, int heads,
+                            int hd, void* ws, size_t ws_bytes, sampt_stream_t stream) {
+  size_t n = (size_t)B * heads * S * S * S;
+  if (ws_bytes < 2 * n * sizeof(float)) return SAMPT_ERR_WORKSPACE;
+  float* relh = (float*)ws;
+  float* relw = relh + n;
+  SAMPT_TRY(vit_rel_bias(qkv, 1, rel_h, rel_w, B, S, heads, hd, relh, relw, (hipStream_t)stream));
+  return vit_flash_attention_f16((const half_t*)qkv, relh, relw, (half_t*)out, B, S, heads, hd, (hipStream_t)stream);
+}
+
+}  // extern "C"

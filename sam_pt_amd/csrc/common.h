@@ -1,0 +1,100 @@
+// Shared definitions for the sam-pt MI355X (gfx950 / CDNA4) HIP library.
+// Everything in csrc/ is written for gfx950 only: wave64, MFMA, 160 KiB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SAMPT_OK 0
+#define SAMPT_ERR_ARG (-1)       // bad argument (shape / alignment / null pointer)
+#define SAMPT_ERR_HIP (-2)       // a HIP runtime call failed (see sampt_last_error)
+#define SAMPT_ERR_UNSUPPORTED (-3)
+#define SAMPT_ERR_WORKSPACE (-4) // caller-provided workspace too small
+
+typedef _Float16 half_t;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+
+namespace sampt {
+
+void set_error(const char* where, hipError_t e);
+const char* last_error();
+
+#define SAMPT_CHECK_LAUNCH(name)                                   \
+  do {                                                             \
+    hipError_t _e = hipGetLastError();                             \
+    if (_e != hipSuccess) { sampt::set_error(name, _e); return SAMPT_ERR_HIP; } \
+  } while (0)
+
+#define SAMPT_TRY(expr)                          \
+  do {                                           \
+    int _rc = (expr);                            \
+    if (_rc != SAMPT_OK) return _rc;             \
+  } while (0)
+
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
+
+__device__ __forceinline__ float gelu_erf(float x) {
+  // exact (erf) GELU, matching torch.nn.GELU() default
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+__device__ __forceinline__ float apply_act(float x, int act) {
+  if (act == ACT_RELU) return x > 0.f ? x : 0.f;
+  if (act == ACT_GELU) return gelu_erf(x);
+  return x;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------------------------------------
+// GEMM / implicit-GEMM convolution (gemm.hip)
+//   C[m][n] = epi( alpha * sum_k A[m][k] * W[n][k]  (+ bias[n]) ) (+ res)       (W_KN=0)
+//   C[m][n] = epi( alpha * sum_k A[m][k] * W[k][n]  (+ bias[n]) ) (+ res)       (W_KN=1, f32 only)
+// A may be an implicit im2col view of an NHWC tensor (conv != 0).
+// ---------------------------------------------------------------------------------------------
+struct GemmP {
+  const void* A = nullptr;
+  const void* W = nullptr;
+  const float* bias = nullptr;   // [N] or null
+  const float* res = nullptr;    // residual, f32, row stride ldr, or null
+  void* C = nullptr;
+  const int* rowmap = nullptr;   // optional: destination row of C/res for GEMM row m (-1 = drop the row)
+  int M = 0, N = 0, K = 0;
+  int lda = 0, ldw = 0, ldc = 0, ldr = 0;
+  // batching: blockIdx.z = z1 * nb2 + z2, element strides
+  int nb1 = 1, nb2 = 1;
+  long sA1 = 0, sA2 = 0, sW1 = 0, sW2 = 0, sC1 = 0, sC2 = 0;
+  long sRowmap1 = 0;             // rowmap offset per z1
+  int res_mod = 0;               // >0: residual row = row % res_mod (broadcast, e.g. positional embedding)
+  int act = ACT_NONE;
+  int out_f16 = 0;               // C is half (only when the input type is half)
+  int w_kn = 0;                  // W stored [K][N]
+  float alpha = 1.0f;
+  // implicit-GEMM convolution over an NHWC input: A is [Nimg][H][W][Cin], W is [Cout][KH*KW*Cin]
+  int conv = 0;
+  int cH = 0, cW = 0, cC = 0, KH = 0, KW = 0, cstride = 1, cpad = 0, OH = 0, OW = 0;
+};
+
+int gemm_f32(const GemmP& p, hipStream_t s);
+int gemm_f16(const GemmP& p, hipStream_t s);
+
+}  // namespace sampt

@@ -1,0 +1,365 @@
+// HBM-bound elementwise / normalisation / resampling kernels (NHWC, f32 unless noted).
+// All of them are pure streaming kernels: one pass over the data, 16-byte accesses where the layout allows,
+// grids of >> 256 workgroups so that all 8 XCDs stay busy.
+#include "ops.h"
+
+namespace sampt {
+
+// ---------------------------------------------------------------------------------------------
+// uint8 CHW -> normalised f32 NHWC4
+// ---------------------------------------------------------------------------------------------
+__global__ void k_rgb_u8chw_to_nhwc4(const uint8_t* __restrict__ src, float4* __restrict__ dst, long npix_total,
+                                     long hw) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix_total) return;
+  long t = i / hw, p = i - t * hw;
+  const uint8_t* b = src + t * 3 * hw + p;
+  float r = 2.0f * ((float)b[0] / 255.0f) - 1.0f;
+  float g = 2.0f * ((float)b[hw] / 255.0f) - 1.0f;
+  float bl = 2.0f * ((float)b[2 * hw] / 255.0f) - 1.0f;
+  dst[i] = make_float4(r, g, bl, 0.f);
+}
+
+int rgb_u8chw_to_nhwc4(const uint8_t* src, float* dst, int T, int H, int W, hipStream_t s) {
+  long hw = (long)H * W, n = hw * T;
+  hipLaunchKernelGGL(k_rgb_u8chw_to_nhwc4, dim3(cdiv(n, 256)), dim3(256), 0, s, src, (float4*)dst, n, hw);
+  SAMPT_CHECK_LAUNCH("rgb_u8chw_to_nhwc4");
+  return SAMPT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// InstanceNorm2d statistics: deterministic two-stage reduction in fp64
+// ---------------------------------------------------------------------------------------------
+static constexpr int IN_PIX_PER_BLOCK = 512;
+
+size_t instnorm_partial_doubles(int nimg, long hw, int C) {
+  return (size_t)nimg * cdiv(hw, IN_PIX_PER_BLOCK) * C * 2;
+}
+
+__global__ void k_instnorm_partial(const float* __restrict__ x, long hw, int C, double* __restrict__ part) {
+  // block = (C, ny); grid = (nchunks, nimg)
+  extern __shared__ double sh[];  // [ny][C][2]
+  const int c = threadIdx.x, ty = threadIdx.y, ny = blockDim.y;
+  const long img = blockIdx.y, chunk = blockIdx.x;
+  long p0 = chunk * IN_PIX_PER_BLOCK, p1 = p0 + IN_PIX_PER_BLOCK;
+  if (p1 > hw) p1 = hw;
+  const float* base = x + img * hw * C + c;
+  double s1 = 0.0, s2 = 0.0;
+  for (long p = p0 + ty; p < p1; p += ny) {
+    double v = (double)base[p * C];
+    s1 += v;
+    s2 += v * v;
+  }
+  sh[(ty * C + c) * 2] = s1;
+  sh[(ty * C + c) * 2 + 1] = s2;
+  __syncthreads();
+  if (ty == 0) {
+    for (int j = 1; j < ny; ++j) {
+      s1 += sh[(j * C + c) * 2];
+      s2 += sh[(j * C + c) * 2 + 1];
+    }
+    double* o = part + ((img * gridDim.x + chunk) * C + c) * 2;
+    o[0] = s1;
+    o[1] = s2;
+  }
+}
+
+__global__ void k_instnorm_final(const double* __restrict__ part, int nchunks, long hw, int C, float eps,
+                                 float* __restrict__ mean_rstd) {
+  int c = threadIdx.x;
+  long img = blockIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int j = 0; j < nchunks; ++j) {
+    const double* o = part + ((img * nchunks + j) * C + c) * 2;
+    s1 += o[0];
+    s2 += o[1];
+  }
+  double mean = s1 / (double)hw;
+  double var = s2 / (double)hw - mean * mean;
+  if (var < 0.0) var = 0.0;
+  mean_rstd[(img * C + c) * 2] = (float)mean;
+  mean_rstd[(img * C + c) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+int instnorm_stats(const float* x, int nimg, long hw, int C, float eps, double* partials, float* mean_rstd,
+                   hipStream_t s) {
+  if (C > 1024 || C <= 0) return SAMPT_ERR_ARG;
+  int ny = 256 / C;
+  if (ny < 1) ny = 1;
+  int nchunks = cdiv(hw, IN_PIX_PER_BLOCK);
+  hipLaunchKernelGGL(k_instnorm_partial, dim3(nchunks, nimg), dim3(C, ny), (size_t)ny * C * 2 * sizeof(double), s, x,
+                     hw, C, partials);
+  SAMPT_CHECK_LAUNCH("instnorm_partial");
+  hipLaunchKernelGGL(k_instnorm_final, dim3(nimg), dim3(C), 0, s, partials, nchunks, hw, C, eps, mean_rstd);
+  SAMPT_CHECK_LAUNCH("instnorm_final");
+  return SAMPT_OK;
+}
+
+__global__ void k_instnorm_apply(const float4* __restrict__ x, const float* __restrict__ mr,
+                                 const float4* __restrict__ skip, float4* __restrict__ y, long n4, long hwc4, int c4n,
+                                 int relu1) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  long img = i / hwc4;
+  int c = (int)(i % c4n) * 4;
+  const float* m = mr + (img * c4n * 4 + c) * 2;
+  float4 v = x[i];
+  float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    o[j] = (o[j] - m[2 * j]) * m[2 * j + 1];
+    if (relu1) o[j] = fmaxf(o[j], 0.f);
+  }
+  if (skip) {
+    float4 k = skip[i];
+    o[0] = fmaxf(o[0] + k.x, 0.f);
+    o[1] = fmaxf(o[1] + k.y, 0.f);
+    o[2] = fmaxf(o[2] + k.z, 0.f);
+    o[3] = fmaxf(o[3] + k.w, 0.f);
+  }
+  y[i] = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+int instnorm_apply(const float* x, const float* mean_rstd, const float* skip, float* y, int nimg, long hw, int C,
+                   int relu1, hipStream_t s) {
+  if (C % 4) return SAMPT_ERR_ARG;
+  long n4 = (long)nimg * hw * C / 4;
+  hipLaunchKernelGGL(k_instnorm_apply, dim3(cdiv(n4, 256)), dim3(256), 0, s, (const float4*)x, mean_rstd,
+                     (const float4*)skip, (float4*)y, n4, hw * C / 4, C / 4, relu1);
+  SAMPT_CHECK_LAUNCH("instnorm_apply");
+  return SAMPT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// bilinear resize (torch F.interpolate semantics), NHWC, writes a channel slice of the destination
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bilinear_src(int d, int in, int out, int align, int& i0, int& i1, float& l1) {
+  float src;
+  if (align) {
+    float scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+    src = scale * (float)d;
+  } else {
+    float scale = (float)in / (float)out;
+    src = scale * ((float)d + 0.5f) - 0.5f;
+    if (src < 0.f) src = 0.f;
+  }
+  i0 = (int)src;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  l1 = fminf(fmaxf(src - (float)i0, 0.f), 1.f);
+}
+
+__global__ void k_resize_bilinear_nhwc(const float4* __restrict__ src, int sh, int sw, int c4n, float4* __restrict__ dst,
+                                       int dh, int dw, int dst_c4n, int c_off4, int align, long total) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int c = (int)(i % c4n);
+  long r = i / c4n;
+  int x = (int)(r % dw);
+  r /= dw;
+  int y = (int)(r % dh);
+  long n = r / dh;
+  int y0, y1, x0, x1;
+  float ly, lx;
+  bilinear_src(y, sh, dh, align, y0, y1, ly);
+  bilinear_src(x, sw, dw, align, x0, x1, lx);
+  const float4* b = src + n * sh * sw * c4n + c;
+  float4 v00 = b[((long)y0 * sw + x0) * c4n], v01 = b[((long)y0 * sw + x1) * c4n];
+  float4 v10 = b[((long)y1 * sw + x0) * c4n], v11 = b[((long)y1 * sw + x1) * c4n];
+  float hy = 1.f - ly, hx = 1.f - lx;
+  float4 o;
+  o.x = hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
+  o.y = hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
+  o.z = hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z);
+  o.w = hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
+  dst[((n * dh + y) * dw + x) * dst_c4n + c_off4 + c] = o;
+}
+
+int resize_bilinear_nhwc(const float* src, int n, int sh, int sw, int C, float* dst, int dh, int dw, int dstC,
+                         int c_off, int align_corners, hipStream_t s) {
+  if (C % 4 || dstC % 4 || c_off % 4) return SAMPT_ERR_ARG;
+  long total = (long)n * dh * dw * (C / 4);
+  hipLaunchKernelGGL(k_resize_bilinear_nhwc, dim3(cdiv(total, 256)), dim3(256), 0, s, (const float4*)src, sh, sw, C / 4,
+                     (float4*)dst, dh, dw, dstC / 4, c_off / 4, align_corners, total);
+  SAMPT_CHECK_LAUNCH("resize_bilinear_nhwc");
+  return SAMPT_OK;
+}
+
+__global__ void k_avgpool2x2(const float4* __restrict__ src, int h, int w, int c4n, float4* __restrict__ dst, long total) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int oh = h / 2, ow = w / 2;
+  int c = (int)(i % c4n);
+  long r = i / c4n;
+  int x = (int)(r % ow);
+  r /= ow;
+  int y = (int)(r % oh);
+  long n = r / oh;
+  const float4* b = src + ((n * h + 2 * y) * w + 2 * x) * c4n + c;
+  float4 a0 = b[0], a1 = b[c4n], a2 = b[(long)w * c4n], a3 = b[(long)w * c4n + c4n];
+  float4 o;
+  o.x = (((a0.x + a1.x) + a2.x) + a3.x) / 4.0f;
+  o.y = (((a0.y + a1.y) + a2.y) + a3.y) / 4.0f;
+  o.z = (((a0.z + a1.z) + a2.z) + a3.z) / 4.0f;
+  o.w = (((a0.w + a1.w) + a2.w) + a3.w) / 4.0f;
+  dst[i] = o;
+}
+
+int avgpool2x2_nhwc(const float* src, int n, int h, int w, int C, float* dst, hipStream_t s) {
+  if (C % 4) return SAMPT_ERR_ARG;
+  long total = (long)n * (h / 2) * (w / 2) * (C / 4);
+  hipLaunchKernelGGL(k_avgpool2x2, dim3(cdiv(total, 256)), dim3(256), 0, s, (const float4*)src, h, w, C / 4,
+                     (float4*)dst, total);
+  SAMPT_CHECK_LAUNCH("avgpool2x2");
+  return SAMPT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm over rows: one wave per row, the row lives in registers (two-pass mean / variance)
+// ---------------------------------------------------------------------------------------------
+template <int NI>
+__global__ __launch_bounds__(256) void k_layernorm_rows(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ b, void* __restrict__ y, long M, int D,
+                                                        float eps, const int* __restrict__ src_rows, int out_f16,
+                                                        int act) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  long srow = src_rows ? (long)src_rows[row] : row;
+  if (srow < 0) {  // padded row of a window partition: zeros (App. A-3: pad AFTER norm1)
+    for (int i = 0; i < NI; ++i) {
+      int idx = lane + 64 * i;
+      if (idx < D) {
+        if (out_f16) ((half_t*)y)[row * D + idx] = (half_t)0.f;
+        else ((float*)y)[row * D + idx] = 0.f;
+      }
+    }
+    return;
+  }
+  const float* xr = x + srow * D;
+  float v[NI];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    int idx = lane + 64 * i;
+    v[i] = idx < D ? xr[idx] : 0.f;
+    sum += v[i];
+  }
+  float mean = wave_sum(sum) / (float)D;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    int idx = lane + 64 * i;
+    float d = idx < D ? v[i] - mean : 0.f;
+    sq += d * d;
+  }
+  float var = wave_sum(sq) / (float)D;
+  float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    int idx = lane + 64 * i;
+    if (idx < D) {
+      float o = (v[i] - mean) * rstd * w[idx] + b[idx];
+      o = apply_act(o, act);
+      if (out_f16) ((half_t*)y)[row * D + idx] = (half_t)o;
+      else ((float*)y)[row * D + idx] = o;
+    }
+  }
+}
+
+int layernorm_rows(const float* x, const float* w, const float* b, void* y, long M, int D, float eps,
+                   const int* src_rows, int out_f16, int act, hipStream_t s) {
+  if (D <= 0 || D > 2048 || M <= 0) return SAMPT_ERR_ARG;
+  dim3 grid(cdiv(M, 4)), block(256);
+  int ni = cdiv(D, 64);
+#define LN(NIv) hipLaunchKernelGGL(k_layernorm_rows<NIv>, grid, block, 0, s, x, w, b, y, M, D, eps, src_rows, out_f16, act)
+  if (ni <= 1) LN(1);
+  else if (ni <= 4) LN(4);
+  else if (ni <= 8) LN(8);
+  else if (ni <= 12) LN(12);
+  else if (ni <= 16) LN(16);
+  else if (ni <= 20) LN(20);
+  else LN(32);
+#undef LN
+  SAMPT_CHECK_LAUNCH("layernorm_rows");
+  return SAMPT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void k_add_bcast(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long n,
+                            long bmod) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[i] = a[i] + b[i % bmod];
+}
+
+int add_bcast(const float* a, const float* b, float* out, long n, long bmod, hipStream_t s) {
+  if (n <= 0 || bmod <= 0) return SAMPT_ERR_ARG;
+  hipLaunchKernelGGL(k_add_bcast, dim3(cdiv(n, 256)), dim3(256), 0, s, a, b, out, n, bmod);
+  SAMPT_CHECK_LAUNCH("add_bcast");
+  return SAMPT_OK;
+}
+
+__global__ void k_cast_f32_f16(const float* __restrict__ x, half_t* __restrict__ y, long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = (half_t)x[i];
+}
+
+int cast_f32_f16(const float* x, half_t* y, long n, hipStream_t s) {
+  hipLaunchKernelGGL(k_cast_f32_f16, dim3(cdiv(n, 256)), dim3(256), 0, s, x, y, n);
+  SAMPT_CHECK_LAUNCH("cast_f32_f16");
+  return SAMPT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// SAM preprocess + 16x16 patch im2col (uint8 frames -> GEMM A operand)
+// ---------------------------------------------------------------------------------------------
+template <typename TO>
+__global__ void k_sam_patchify(const uint8_t* __restrict__ frames, int B, int H, int W, int img, int P, int chw,
+                               float m0, float m1, float m2, float s0, float s1, float s2, TO* __restrict__ A) {
+  // one thread per (patch row-of-P pixels): writes P contiguous k entries
+  const int g = img / P;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = (long)B * g * g * 3 * P;
+  if (i >= total) return;
+  int ky = (int)(i % P);
+  long r = i / P;
+  int c = (int)(r % 3);
+  r /= 3;
+  long patch = r;  // b*g*g + py*g + px
+  int px = (int)(patch % g);
+  int py = (int)((patch / g) % g);
+  long b = patch / ((long)g * g);
+  int y = py * P + ky;
+  float mean = c == 0 ? m0 : (c == 1 ? m1 : m2);
+  float sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+  TO* o = A + patch * (3 * P * P) + c * P * P + ky * P;
+  for (int kx = 0; kx < P; ++kx) {
+    int x = px * P + kx;
+    float v = 0.f;
+    if (y < H && x < W) {
+      uint8_t u = chw ? frames[((b * 3 + c) * H + y) * (long)W + x] : frames[((b * H + y) * (long)W + x) * 3 + c];
+      v = ((float)u - mean) / sd;
+    }
+    o[kx] = (TO)v;
+  }
+}
+
+int sam_patchify(const uint8_t* frames, int chw, int B, int H, int W, int img, int P, const float* mean,
+                 const float* stdv, void* A, int out_f16, hipStream_t s) {
+  if (H > img || W > img || img % P) return SAMPT_ERR_ARG;
+  int g = img / P;
+  long total = (long)B * g * g * 3 * P;
+  dim3 grid(cdiv(total, 256)), block(256);
+  if (out_f16)
+    hipLaunchKernelGGL(k_sam_patchify<half_t>, grid, block, 0, s, frames, B, H, W, img, P, chw, mean[0], mean[1], mean[2],
+                       stdv[0], stdv[1], stdv[2], (half_t*)A);
+  else
+    hipLaunchKernelGGL(k_sam_patchify<float>, grid, block, 0, s, frames, B, H, W, img, P, chw, mean[0], mean[1], mean[2],
+                       stdv[0], stdv[1], stdv[2], (float*)A);
+  SAMPT_CHECK_LAUNCH("sam_patchify");
+  return SAMPT_OK;
+}
+
+}  // namespace sampt

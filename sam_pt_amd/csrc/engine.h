@@ -1,0 +1,142 @@
+// Host-side "engines": fixed launch sequences over the kernels in ops.h for the three stages of the SAM-PT hot
+// path.  They own no device memory: weights are caller-owned device buffers looked up by their upstream
+// checkpoint key, activations live in a caller-provided workspace carved by a bump allocator.
+#pragma once
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "ops.h"
+
+namespace sampt {
+
+struct WeightMap {
+  std::unordered_map<std::string, const void*> m;
+  mutable std::string missing;
+  const void* get(const std::string& k) const {
+    auto it = m.find(k);
+    if (it == m.end()) {
+      if (missing.size() < 900) missing += k + " ";
+      return nullptr;
+    }
+    return it->second;
+  }
+  const float* f(const std::string& k) const { return (const float*)get(k); }
+  const half_t* h(const std::string& k) const { return (const half_t*)get(k); }
+  const int* i(const std::string& k) const { return (const int*)get(k); }
+  bool has(const std::string& k) const { return m.count(k) != 0; }
+};
+
+// bump allocator over the caller's workspace; with base == nullptr it only measures.
+struct Arena {
+  char* base;
+  size_t cap, off = 0, peak = 0;
+  Arena(void* b, size_t c) : base((char*)b), cap(c) {}
+  void* get(size_t bytes) {
+    size_t a = (off + 255) & ~(size_t)255;
+    off = a + bytes;
+    if (off > peak) peak = off;
+    return base ? (void*)(base + a) : (void*)(uintptr_t)(a + 256);  // fake non-null address when measuring
+  }
+  float* f32(size_t n) { return (float*)get(n * 4); }
+  half_t* f16(size_t n) { return (half_t*)get(n * 2); }
+  bool ok() const { return base == nullptr || peak <= cap; }
+  bool dry() const { return base == nullptr; }
+};
+
+// -------------------------------------------------------------------------------------------------
+struct ConvW {
+  const float* w = nullptr;  // [Cout][KH*KW*Cin] (ci fastest), f32
+  const float* b = nullptr;
+  int cin = 0, cout = 0, k = 0, stride = 1, pad = 0;
+};
+
+struct PipsEngine {
+  int S = 8, stride = 4;
+  ConvW stem, conv2, conv3;
+  ConvW blk[4][2][3];  // [layer][block][conv1, conv2, downsample]
+  bool has_down[4][2] = {};
+  // mixer
+  const float *in_w, *in_b, *head_w, *head_b, *oln_w, *oln_b;
+  struct MixBlk {
+    const float *ln1w, *ln1b, *tw1, *tb1, *tw2, *tb2, *ln2w, *ln2b, *cw1, *cb1, *cw2, *cb2;
+  } mix[12];
+  const float *gn_w, *gn_b, *up_wT, *up_b, *vis_w, *vis_b, *times;
+  std::string error;
+
+  int init(const WeightMap& w);
+  // frames: uint8 (nf,3,H,W).  out[l]: level-l feature maps [nf][H_l][W_l][128] f32 (H_0 = H/stride).
+  int fnet(const uint8_t* frames, int nf, int H, int W, float* const out[4], Arena& ws, hipStream_t s);
+  // one PIPS window: frame_idx (device, [S] ints into the pyramid), xys (device [n][2], px at window frame 0),
+  // feat_init (device [n][128]).  traj_out [S][n][2] px, vis_out [S][n] = sigmoid(logit).
+  int update(const PyramidLevels& pyr, const int* frame_idx, int n, const float* xys, const float* feat_init, int iters,
+             float* traj_out, float* vis_out, Arena& ws, hipStream_t s);
+};
+
+// -------------------------------------------------------------------------------------------------
+struct VitConfig {
+  int D = 768, depth = 12, heads = 12, grid = 64, window = 14, patch = 16, out_chans = 256, mlp_ratio = 4;
+  int img = 1024;
+  int global_mask = 0;  // bit i set -> block i uses global attention (depth <= 32)
+  int f16 = 1;          // 1: fp16 MFMA GEMMs + flash attention ; 0: exact fp32 everywhere
+  float mean[3] = {123.675f, 116.28f, 103.53f}, stdv[3] = {58.395f, 57.12f, 57.375f};
+};
+
+struct VitEngine {
+  VitConfig c;
+  struct Blk {
+    const float *ln1w, *ln1b, *ln2w, *ln2b, *qkv_b, *proj_b, *b1, *b2, *rel_h, *rel_w;
+    const void *qkv_w, *proj_w, *w1, *w2;  // f16 or f32 depending on c.f16
+  };
+  std::vector<Blk> blk;
+  const void *patch_w, *neck0_w, *neck2_w;
+  const float *patch_b, *pos, *neck1w, *neck1b, *neck3w, *neck3b;
+  const int* win_rows;  // [Bmax * nwin * window^2] -> token row or -1
+  int win_rows_batches = 0;
+  std::string error;
+
+  int init(const WeightMap& w, const VitConfig& cfg, int win_rows_batches);
+  // frames: uint8 (B,3,H,W) if chw else (B,H,W,3); features out: [B][grid*grid][out_chans] f32 (NHWC)
+  int encode(const uint8_t* frames, int chw, int B, int H, int W, float* features, Arena& ws, hipStream_t s);
+};
+
+// -------------------------------------------------------------------------------------------------
+struct DecConfig {
+  int grid = 64, C = 256, heads = 8, depth = 2, mlp = 2048, img = 1024;
+};
+
+struct DecEngine {
+  DecConfig c;
+  struct Attn {
+    const float *qw, *qb, *kw, *kb, *vw, *vb, *ow, *ob;
+    int inner;
+  };
+  struct Layer {
+    Attn self, t2i, i2t;
+    const float *n1w, *n1b, *n2w, *n2b, *n3w, *n3b, *n4w, *n4b, *m1w, *m1b, *m2w, *m2b;
+  } layer[4];
+  Attn fin;
+  const float *nfw, *nfb;
+  const float *out_tokens;                       // [5][256] = iou_token, mask_tokens
+  const float *gauss, *point_emb, *not_a_point, *no_mask, *dense_pe;
+  MaskEmbedW me;
+  const float *up0_w, *up0_b, *upln_w, *upln_b, *up1_w, *up1_b;  // ConvT weights packed [(dy,dx)][cout][cin]
+  const int *up0_map, *up1_map;                                   // pixel-shuffle row maps [4][g*g], [4][4*g*g]
+  const float *hyp_w[3], *hyp_b[3], *iou_w[3], *iou_b[3];         // hypernetwork MLP 0 and IoU head
+  std::string error;
+
+  int init(const WeightMap& w, const DecConfig& cfg);
+  // One predict_torch pass (multimask_output=False, return_logits=True).  pts/labels/box/mask_in: device.
+  // logits_out (oh x ow), iou_out (1), low_out (4g x 4g); bbox_out: optional int[5] state of logits > 0.
+  int decode(const float* features, const float* pts, const int* labels, int k, const float* box, const float* mask_in,
+             int in_h, int in_w, int oh, int ow, float* logits_out, float* iou_out, float* low_out, int* bbox_out,
+             Arena& ws, hipStream_t s);
+  // The whole per-(frame, object) chain of SamPt.predict_mask (sam_pt.py:760-837) on device, no host sync:
+  // pass 1 (positives only, when n_pos < k) -> pass 2 (all points + mask) -> R box-refinement passes gated on device
+  // -> IoU-threshold rejection.  final_logits (oh x ow) and score (1) are written.
+  int track_decode(const float* features, const float* pts, const int* labels, int k, int n_pos_first, int R,
+                   float iou_thr, int in_h, int in_w, int oh, int ow, float* final_logits, float* score_out, Arena& ws,
+                   hipStream_t s);
+};
+
+}  // namespace sampt

@@ -1,0 +1,190 @@
+// PIPS engine: fnet (BasicEncoder, pips.py:191-287) and the iterative point-update window (pips.py:439-620).
+#include "engine.h"
+
+namespace sampt {
+
+static int load_conv(const WeightMap& w, const std::string& name, int cin, int cout, int k, int stride, int pad,
+                     ConvW& c) {
+  c.w = w.f(name + ".weight");
+  c.b = w.f(name + ".bias");
+  c.cin = cin, c.cout = cout, c.k = k, c.stride = stride, c.pad = pad;
+  return (c.w && c.b) ? SAMPT_OK : SAMPT_ERR_ARG;
+}
+
+int PipsEngine::init(const WeightMap& w) {
+  int rc = SAMPT_OK;
+  // conv weights arrive repacked [Cout][KH*KW*Cin] (ci fastest); the stem's Cin is zero-padded 3 -> 4
+  rc |= load_conv(w, "fnet.conv1", 4, 64, 7, 2, 3, stem);
+  const int dims[4] = {64, 96, 128, 128}, strides[4] = {1, 2, 2, 2};
+  int in_planes = 64;
+  for (int li = 0; li < 4; ++li) {
+    for (int bi = 0; bi < 2; ++bi) {
+      int cin = bi == 0 ? in_planes : dims[li];
+      int st = bi == 0 ? strides[li] : 1;
+      std::string p = "fnet.layer" + std::to_string(li + 1) + "." + std::to_string(bi);
+      rc |= load_conv(w, p + ".conv1", cin, dims[li], 3, st, 1, blk[li][bi][0]);
+      rc |= load_conv(w, p + ".conv2", dims[li], dims[li], 3, 1, 1, blk[li][bi][1]);
+      has_down[li][bi] = (bi == 0 && st != 1);
+      if (has_down[li][bi]) rc |= load_conv(w, p + ".downsample.0", cin, dims[li], 1, st, 0, blk[li][bi][2]);
+    }
+    in_planes = dims[li];
+  }
+  rc |= load_conv(w, "fnet.conv2", 416, 256, 3, 1, 1, conv2);
+  rc |= load_conv(w, "fnet.conv3", 256, 128, 1, 1, 0, conv3);
+  const std::string d = "delta_block.to_delta.";
+  in_w = w.f(d + "0.weight"), in_b = w.f(d + "0.bias");
+  for (int i = 0; i < 12; ++i) {
+    std::string p = d + std::to_string(i + 1);
+    MixBlk& m = mix[i];
+    m.ln1w = w.f(p + ".0.norm.weight"), m.ln1b = w.f(p + ".0.norm.bias");
+    m.tw1 = w.f(p + ".0.fn.0.weight"), m.tb1 = w.f(p + ".0.fn.0.bias");
+    m.tw2 = w.f(p + ".0.fn.3.weight"), m.tb2 = w.f(p + ".0.fn.3.bias");
+    m.ln2w = w.f(p + ".1.norm.weight"), m.ln2b = w.f(p + ".1.norm.bias");
+    m.cw1 = w.f(p + ".1.fn.0.weight"), m.cb1 = w.f(p + ".1.fn.0.bias");
+    m.cw2 = w.f(p + ".1.fn.3.weight"), m.cb2 = w.f(p + ".1.fn.3.bias");
+  }
+  oln_w = w.f(d + "13.weight"), oln_b = w.f(d + "13.bias");
+  head_w = w.f(d + "15.weight"), head_b = w.f(d + "15.bias");
+  gn_w = w.f("norm.weight"), gn_b = w.f("norm.bias");
+  up_wT = w.f("ffeat_updater.0.weight_t"), up_b = w.f("ffeat_updater.0.bias");
+  vis_w = w.f("vis_predictor.0.weight"), vis_b = w.f("vis_predictor.0.bias");
+  times = w.f("__times");
+  if (rc != SAMPT_OK || !w.missing.empty()) {
+    error = "PipsEngine: missing weights: " + w.missing;
+    return SAMPT_ERR_ARG;
+  }
+  return SAMPT_OK;
+}
+
+// conv (implicit GEMM, bias fused) -> raw output; returns output dims
+static int run_conv(const ConvW& c, const float* x, int n, int H, int W, float* y, int& OH, int& OW, bool dry,
+                    hipStream_t s) {
+  OH = (H + 2 * c.pad - c.k) / c.stride + 1;
+  OW = (W + 2 * c.pad - c.k) / c.stride + 1;
+  if (dry) return SAMPT_OK;
+  GemmP p;
+  p.A = x, p.W = c.w, p.bias = c.b, p.C = y;
+  p.M = n * OH * OW, p.N = c.cout, p.K = c.k * c.k * c.cin;
+  p.ldw = p.K, p.ldc = c.cout;
+  p.conv = 1, p.cH = H, p.cW = W, p.cC = c.cin, p.KH = c.k, p.KW = c.k, p.cstride = c.stride, p.cpad = c.pad;
+  p.OH = OH, p.OW = OW;
+  return gemm_f32(p, s);
+}
+
+struct NormCtx {
+  double* partials;
+  float* mean_rstd;
+};
+
+// InstanceNorm (+ReLU) (+skip add + ReLU), in place on y
+static int run_inorm(const NormCtx& nc, float* y, int n, long hw, int C, int relu1, const float* skip, bool dry,
+                     hipStream_t s) {
+  if (dry) return SAMPT_OK;
+  SAMPT_TRY(instnorm_stats(y, n, hw, C, 1e-5f, nc.partials, nc.mean_rstd, s));
+  return instnorm_apply(y, nc.mean_rstd, skip, y, n, hw, C, relu1, s);
+}
+
+int PipsEngine::fnet(const uint8_t* frames, int nf, int H, int W, float* const out[4], Arena& ws, hipStream_t s) {
+  const bool dry = ws.dry();
+  const int H2 = (H + 6 - 7) / 2 + 1, W2 = (W + 6 - 7) / 2 + 1;
+  NormCtx nc;
+  nc.partials = (double*)ws.get(instnorm_partial_doubles(nf, (long)H2 * W2, 256) * sizeof(double));
+  nc.mean_rstd = ws.f32((size_t)nf * 256 * 2);
+  float* x0 = ws.f32((size_t)nf * H * W * 4);
+  if (!dry) SAMPT_TRY(rgb_u8chw_to_nhwc4(frames, x0, nf, H, W, s));
+  int h, w;
+  float* cur = ws.f32((size_t)nf * H2 * W2 * 64);
+  SAMPT_TRY(run_conv(stem, x0, nf, H, W, cur, h, w, dry, s));
+  SAMPT_TRY(run_inorm(nc, cur, nf, (long)h * w, 64, 1, nullptr, dry, s));
+  const int dims[4] = {64, 96, 128, 128};
+  float* scale_out[4];
+  int sh[4], sw[4];
+  for (int li = 0; li < 4; ++li) {
+    for (int bi = 0; bi < 2; ++bi) {
+      const ConvW& c1 = blk[li][bi][0];
+      const ConvW& c2 = blk[li][bi][1];
+      int oh, ow, oh2, ow2;
+      int ohh = (h + 2 - 3) / c1.stride + 1, oww = (w + 2 - 3) / c1.stride + 1;
+      float* y1 = ws.f32((size_t)nf * ohh * oww * dims[li]);
+      float* y2 = ws.f32((size_t)nf * ohh * oww * dims[li]);
+      SAMPT_TRY(run_conv(c1, cur, nf, h, w, y1, oh, ow, dry, s));
+      SAMPT_TRY(run_inorm(nc, y1, nf, (long)oh * ow, dims[li], 1, nullptr, dry, s));
+      SAMPT_TRY(run_conv(c2, y1, nf, oh, ow, y2, oh2, ow2, dry, s));
+      const float* skip = cur;
+      if (has_down[li][bi]) {
+        float* dn = y1;  // y1 is dead after conv2 has consumed it (stream order)
+        int dh, dw;
+        SAMPT_TRY(run_conv(blk[li][bi][2], cur, nf, h, w, dn, dh, dw, dry, s));
+        SAMPT_TRY(run_inorm(nc, dn, nf, (long)dh * dw, dims[li], 0, nullptr, dry, s));
+        skip = dn;
+      }
+      SAMPT_TRY(run_inorm(nc, y2, nf, (long)oh2 * ow2, dims[li], 1, skip, dry, s));
+      cur = y2, h = oh2, w = ow2;
+    }
+    scale_out[li] = cur, sh[li] = h, sw[li] = w;
+  }
+  const int H4 = H / stride, W4 = W / stride;
+  float* cat = ws.f32((size_t)nf * H4 * W4 * 416);
+  const int coff[4] = {0, 64, 160, 288};
+  if (!dry)
+    for (int li = 0; li < 4; ++li)
+      SAMPT_TRY(resize_bilinear_nhwc(scale_out[li], nf, sh[li], sw[li], dims[li], cat, H4, W4, 416, coff[li], 1, s));
+  float* y = ws.f32((size_t)nf * H4 * W4 * 256);
+  int oh, ow;
+  SAMPT_TRY(run_conv(conv2, cat, nf, H4, W4, y, oh, ow, dry, s));
+  SAMPT_TRY(run_inorm(nc, y, nf, (long)oh * ow, 256, 1, nullptr, dry, s));
+  SAMPT_TRY(run_conv(conv3, y, nf, oh, ow, out[0], oh, ow, dry, s));
+  if (!dry) {
+    int ph = H4, pw = W4;
+    for (int l = 1; l < 4; ++l) {
+      SAMPT_TRY(avgpool2x2_nhwc(out[l - 1], nf, ph, pw, 128, out[l], s));
+      ph /= 2, pw /= 2;
+    }
+  }
+  return ws.ok() ? SAMPT_OK : SAMPT_ERR_WORKSPACE;
+}
+
+static int lin(const float* A, int M, int K, int lda, const float* W, const float* b, float* C, int N, int act,
+               const float* res, hipStream_t s) {
+  GemmP p;
+  p.A = A, p.W = W, p.bias = b, p.C = C, p.res = res;
+  p.M = M, p.N = N, p.K = K, p.lda = lda, p.ldw = K, p.ldc = N, p.ldr = N, p.act = act;
+  return gemm_f32(p, s);
+}
+
+int PipsEngine::update(const PyramidLevels& pyr, const int* frame_idx, int n, const float* xys, const float* feat_init,
+                       int iters, float* traj_out, float* vis_out, Arena& ws, hipStream_t s) {
+  const bool dry = ws.dry();
+  const int LDX = 520, D = 512, R = n * S;
+  float* coords = ws.f32((size_t)S * n * 2);
+  float* coords0 = ws.f32((size_t)n * 2);
+  float* ffeats = ws.f32((size_t)R * 128);
+  float* x = ws.f32((size_t)R * LDX);
+  float* hbuf = ws.f32((size_t)R * D);
+  float* lnb = ws.f32((size_t)R * D);
+  float* hid = ws.f32((size_t)R * 4 * D);
+  float* mean = ws.f32((size_t)n * D);
+  float* delta = ws.f32((size_t)n * S * 130);
+  if (!ws.ok()) return SAMPT_ERR_WORKSPACE;
+  if (dry) return SAMPT_OK;
+  SAMPT_TRY(pips_init_state(xys, feat_init, (float)stride, S, n, coords, coords0, ffeats, s));
+  for (int it = 0; it < iters; ++it) {
+    SAMPT_TRY(pips_corr_sample(pyr, frame_idx, S, n, 128, ffeats, coords, x, LDX, 128, s));
+    SAMPT_TRY(pips_build_input(ffeats, coords, times, S, n, x, LDX, s));
+    SAMPT_TRY(lin(x, R, LDX, LDX, in_w, in_b, hbuf, D, ACT_NONE, nullptr, s));
+    for (int i = 0; i < 12; ++i) {
+      const MixBlk& m = mix[i];
+      SAMPT_TRY(pips_token_mix(hbuf, m.ln1w, m.ln1b, m.tw1, m.tb1, m.tw2, m.tb2, n, S, D, s));
+      SAMPT_TRY(layernorm_rows(hbuf, m.ln2w, m.ln2b, lnb, R, D, 1e-5f, nullptr, 0, ACT_NONE, s));
+      SAMPT_TRY(lin(lnb, R, D, D, m.cw1, m.cb1, hid, 4 * D, ACT_GELU, nullptr, s));
+      SAMPT_TRY(lin(hid, R, 4 * D, 4 * D, m.cw2, m.cb2, hbuf, D, ACT_NONE, hbuf, s));
+    }
+    SAMPT_TRY(pips_ln_mean(hbuf, oln_w, oln_b, mean, n, S, D, s));
+    SAMPT_TRY(lin(mean, n, D, D, head_w, head_b, delta, S * 130, ACT_NONE, nullptr, s));
+    SAMPT_TRY(pips_update(delta, gn_w, gn_b, up_wT, up_b, ffeats, coords, coords0, S, n, s));
+  }
+  SAMPT_TRY(pips_finalize(ffeats, vis_w, vis_b, coords, (float)stride, S, n, traj_out, vis_out, s));
+  return SAMPT_OK;
+}
+
+}  // namespace sampt

@@ -1,0 +1,154 @@
+// SAM image encoder (ImageEncoderViT) as a fixed launch sequence.
+//   fast mode (c.f16 = 1): fp16 MFMA GEMMs with fused bias / GELU / residual epilogues, fused flash attention with
+//                          on-the-fly decomposed rel-pos bias, fp32 residual stream / LayerNorm / softmax.
+//   exact mode (c.f16 = 0): the same graph in fp32 (f32 MFMA GEMMs, materialised scores) — parity reference.
+// Activations are token-major [rows][channels] throughout (NHWC): the neck's output is directly the decoder's
+// image-token matrix.
+#include "engine.h"
+
+namespace sampt {
+
+int VitEngine::init(const WeightMap& w, const VitConfig& cfg, int wrb) {
+  c = cfg;
+  win_rows_batches = wrb;
+  const std::string sfx = c.f16 ? ".f16" : "";
+  const std::string e = "image_encoder.";
+  patch_w = w.get(e + "patch_embed.proj.weight" + sfx);
+  patch_b = w.f(e + "patch_embed.proj.bias");
+  pos = w.f(e + "pos_embed");
+  blk.resize(c.depth);
+  for (int i = 0; i < c.depth; ++i) {
+    std::string p = e + "blocks." + std::to_string(i);
+    Blk& b = blk[i];
+    b.ln1w = w.f(p + ".norm1.weight"), b.ln1b = w.f(p + ".norm1.bias");
+    b.ln2w = w.f(p + ".norm2.weight"), b.ln2b = w.f(p + ".norm2.bias");
+    b.qkv_w = w.get(p + ".attn.qkv.weight" + sfx), b.qkv_b = w.f(p + ".attn.qkv.bias");
+    b.proj_w = w.get(p + ".attn.proj.weight" + sfx), b.proj_b = w.f(p + ".attn.proj.bias");
+    b.rel_h = w.f(p + ".attn.rel_pos_h"), b.rel_w = w.f(p + ".attn.rel_pos_w");
+    b.w1 = w.get(p + ".mlp.lin1.weight" + sfx), b.b1 = w.f(p + ".mlp.lin1.bias");
+    b.w2 = w.get(p + ".mlp.lin2.weight" + sfx), b.b2 = w.f(p + ".mlp.lin2.bias");
+  }
+  neck0_w = w.get(e + "neck.0.weight" + sfx);
+  neck1w = w.f(e + "neck.1.weight"), neck1b = w.f(e + "neck.1.bias");
+  neck2_w = w.get(e + "neck.2.weight_khwc" + sfx);  // repacked [Cout][ky][kx][Cin]
+  neck3w = w.f(e + "neck.3.weight"), neck3b = w.f(e + "neck.3.bias");
+  win_rows = w.i("__win_rows");
+  if (!w.missing.empty()) {
+    error = "VitEngine: missing weights: " + w.missing;
+    return SAMPT_ERR_ARG;
+  }
+  return SAMPT_OK;
+}
+
+namespace {
+struct G {
+  bool f16;
+  hipStream_t s;
+  // C = act(A.W^T + bias) (+ residual at the (row-mapped) destination row)
+  int run(const void* A, int M, int K, const void* W, const float* bias, void* C, int N, int act, bool out_f16,
+          const float* res, int ldr, const int* rowmap, int res_mod) const {
+    GemmP p;
+    p.A = A, p.W = W, p.bias = bias, p.C = C, p.res = res, p.rowmap = rowmap;
+    p.M = M, p.N = N, p.K = K, p.lda = K, p.ldw = K, p.ldc = N, p.ldr = ldr, p.act = act, p.res_mod = res_mod;
+    p.out_f16 = out_f16 ? 1 : 0;
+    return f16 ? gemm_f16(p, s) : gemm_f32(p, s);
+  }
+};
+}  // namespace
+
+int VitEngine::encode(const uint8_t* frames, int chw, int B, int H, int W, float* features, Arena& ws, hipStream_t s) {
+  const bool dry = ws.dry();
+  const int g = c.grid, T = g * g, D = c.D, ws_ = c.window, hd = D / c.heads;
+  const int gp = ((g + ws_ - 1) / ws_) * ws_, nw1 = gp / ws_, nwin = nw1 * nw1, wt = ws_ * ws_;
+  const long Mg = (long)B * T, Mw = (long)B * nwin * wt, Mmax = Mw > Mg ? Mw : Mg;
+  const size_t esz = c.f16 ? 2 : 4;
+  const int Kp = 3 * c.patch * c.patch;
+  if (B > win_rows_batches) return SAMPT_ERR_ARG;
+
+  float* x = ws.f32((size_t)Mg * D);
+  void* xn = ws.get((size_t)Mmax * (D > Kp ? D : Kp) * esz);       // LN output / patch matrix / attention output
+  void* qkv = ws.get((size_t)Mmax * 3 * D * esz);
+  void* att = ws.get((size_t)Mmax * D * esz);
+  void* hid = ws.get((size_t)Mg * c.mlp_ratio * D * esz);
+  const int Smax = g > ws_ ? g : ws_;
+  const long BHg = (long)B * c.heads, BHw = (long)B * nwin * c.heads;
+  size_t rel_elems = (size_t)BHg * g * T;
+  if ((size_t)BHw * ws_ * wt > rel_elems) rel_elems = (size_t)BHw * ws_ * wt;
+  float* relh = ws.f32(rel_elems);
+  float* relw = ws.f32(rel_elems);
+  float* scores = nullptr;
+  if (!c.f16) {
+    size_t sg = (size_t)BHg * T * T, sw2 = (size_t)BHw * wt * wt;
+    scores = ws.f32(sg > sw2 ? sg : sw2);
+  }
+  float* neck_a = ws.f32((size_t)Mg * c.out_chans);
+  void* neck_b = ws.get((size_t)Mg * c.out_chans * esz);
+  if (!ws.ok()) return SAMPT_ERR_WORKSPACE;
+  if (dry) return SAMPT_OK;
+  (void)Smax;
+
+  G gm{c.f16 != 0, s};
+  // ---- patch embedding: preprocess + im2col, GEMM + bias + positional embedding (broadcast over the batch)
+  SAMPT_TRY(sam_patchify(frames, chw, B, H, W, c.img, c.patch, c.mean, c.stdv, xn, c.f16, s));
+  SAMPT_TRY(gm.run(xn, (int)Mg, Kp, patch_w, patch_b, x, D, ACT_NONE, false, pos, D, nullptr, T));
+
+  const float scale = 1.0f / sqrtf((float)hd);
+  for (int i = 0; i < c.depth; ++i) {
+    const Blk& b = blk[i];
+    const bool glob = (c.global_mask >> i) & 1;
+    const int S = glob ? g : ws_, N = S * S;
+    const int Bw = glob ? B : B * nwin;
+    const long M = (long)Bw * N;
+    const int* map = glob ? nullptr : win_rows;
+    // norm1 (+ window partition with zero padding AFTER the norm)
+    SAMPT_TRY(layernorm_rows(x, b.ln1w, b.ln1b, xn, M, D, 1e-6f, map, c.f16, ACT_NONE, s));
+    SAMPT_TRY(gm.run(xn, (int)M, D, b.qkv_w, b.qkv_b, qkv, 3 * D, ACT_NONE, c.f16 != 0, nullptr, 0, nullptr, 0));
+    SAMPT_TRY(vit_rel_bias(qkv, c.f16, b.rel_h, b.rel_w, Bw, S, c.heads, hd, relh, relw, s));
+    if (c.f16) {
+      SAMPT_TRY(vit_flash_attention_f16((const half_t*)qkv, relh, relw, (half_t*)att, Bw, S, c.heads, hd, s));
+    } else {
+      const float* q = (const float*)qkv;
+      GemmP p;  // scores[bw][h] = scale * Q K^T
+      p.A = q, p.W = q + D, p.C = scores;
+      p.M = N, p.N = N, p.K = hd, p.lda = 3 * D, p.ldw = 3 * D, p.ldc = N;
+      p.nb1 = Bw, p.nb2 = c.heads;
+      p.sA1 = (long)N * 3 * D, p.sA2 = hd, p.sW1 = (long)N * 3 * D, p.sW2 = hd;
+      p.sC1 = (long)c.heads * N * N, p.sC2 = (long)N * N;
+      p.alpha = scale;
+      SAMPT_TRY(gemm_f32(p, s));
+      SAMPT_TRY(softmax_rel_rows(scores, relh, relw, (long)Bw * c.heads, N, S, s));
+      GemmP v;  // out[bw][:, h*hd:(h+1)*hd] = P V
+      v.A = scores, v.W = q + 2 * D, v.C = att, v.w_kn = 1;
+      v.M = N, v.N = hd, v.K = N, v.lda = N, v.ldw = 3 * D, v.ldc = D;
+      v.nb1 = Bw, v.nb2 = c.heads;
+      v.sA1 = (long)c.heads * N * N, v.sA2 = (long)N * N, v.sW1 = (long)N * 3 * D, v.sW2 = hd;
+      v.sC1 = (long)N * D, v.sC2 = hd;
+      SAMPT_TRY(gemm_f32(v, s));
+    }
+    // proj + bias + residual, un-partitioning windows through the row map (padded rows are dropped)
+    SAMPT_TRY(gm.run(att, (int)M, D, b.proj_w, b.proj_b, x, D, ACT_NONE, false, x, D, map, 0));
+    // MLP
+    SAMPT_TRY(layernorm_rows(x, b.ln2w, b.ln2b, xn, Mg, D, 1e-6f, nullptr, c.f16, ACT_NONE, s));
+    SAMPT_TRY(gm.run(xn, (int)Mg, D, b.w1, b.b1, hid, c.mlp_ratio * D, ACT_GELU, c.f16 != 0, nullptr, 0, nullptr, 0));
+    SAMPT_TRY(gm.run(hid, (int)Mg, c.mlp_ratio * D, b.w2, b.b2, x, D, ACT_NONE, false, x, D, nullptr, 0));
+  }
+  // ---- neck: conv1x1 (no bias) -> LayerNorm2d -> conv3x3 (no bias) -> LayerNorm2d
+  const void* xin = x;
+  if (c.f16) {
+    SAMPT_TRY(cast_f32_f16(x, (half_t*)xn, Mg * D, s));
+    xin = xn;
+  }
+  SAMPT_TRY(gm.run(xin, (int)Mg, D, neck0_w, nullptr, neck_a, c.out_chans, ACT_NONE, false, nullptr, 0, nullptr, 0));
+  SAMPT_TRY(layernorm_rows(neck_a, neck1w, neck1b, neck_b, Mg, c.out_chans, 1e-6f, nullptr, c.f16, ACT_NONE, s));
+  {
+    GemmP p;
+    p.A = neck_b, p.W = neck2_w, p.C = neck_a;
+    p.M = (int)Mg, p.N = c.out_chans, p.K = 9 * c.out_chans, p.ldw = p.K, p.ldc = c.out_chans;
+    p.conv = 1, p.cH = g, p.cW = g, p.cC = c.out_chans, p.KH = 3, p.KW = 3, p.cstride = 1, p.cpad = 1, p.OH = g, p.OW = g;
+    SAMPT_TRY(c.f16 ? gemm_f16(p, s) : gemm_f32(p, s));
+  }
+  SAMPT_TRY(layernorm_rows(neck_a, neck3w, neck3b, features, Mg, c.out_chans, 1e-6f, nullptr, 0, ACT_NONE, s));
+  return SAMPT_OK;
+}
+
+}  // namespace sampt

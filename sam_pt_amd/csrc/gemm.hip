@@ -1,0 +1,245 @@
+// MFMA GEMM + implicit-GEMM (NHWC) convolution for gfx950.
+//
+//  * f32 path: v_mfma_f32_16x16x4_f32 — exact fp32 (bitwise a k-ordered fmaf chain), used for the whole PIPS
+//    tracker (trajectories must stay index-identical to the fp32 reference), the mask decoder and the
+//    "exact" ViT mode.  Peak 157 TFLOP/s.
+//  * f16 path: v_mfma_f32_16x16x32_f16 — fp16 operands, fp32 accumulate, used for the ViT image encoder
+//    (qkv / proj / MLP / patch-embed / neck GEMMs).  Peak ~2.5 PFLOP/s.
+//
+// Structure: 256 threads = 4 waves (2 x 2), block tile BM x BN (128x128 or 64x64), wave tile (BM/2)x(BN/2) made of
+// 16x16 MFMA fragments; K streamed through LDS in BK slabs with register prefetch of the next slab while the
+// current one is multiplied.  Operands are K-contiguous ("A row-major, W = torch Linear weight [N][K]"), so both
+// fragment reads are contiguous 4-byte (f32) / 16-byte (f16) LDS reads.  The optional W_KN layout (W stored
+// [K][N], f32 only) serves P.V products.  The A operand may be an im2col view of an NHWC tensor computed on the
+// fly (convolution = GEMM with M = output pixels, K = (ky,kx,ci), N = Cout).
+#include "common.h"
+
+namespace sampt {
+
+template <typename T> struct GT;
+template <> struct GT<float> {
+  static constexpr int VEC = 4, BK = 16, KSTEP = 4, PAD = 4;
+  typedef float4 vec_t;
+  __device__ static vec_t zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+};
+template <> struct GT<half_t> {
+  static constexpr int VEC = 8, BK = 64, KSTEP = 32, PAD = 8;
+  typedef h8 vec_t;
+  __device__ static vec_t zero() { return (h8){0, 0, 0, 0, 0, 0, 0, 0}; }
+};
+
+template <typename T, int BM, int BN, bool CONV, bool W_KN>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
+  typedef GT<T> G;
+  typedef typename G::vec_t vec_t;
+  constexpr int VEC = G::VEC, BK = G::BK, PAD = G::PAD;
+  constexpr int WTM = BM / 2, WTN = BN / 2, FM = WTM / 16, FN = WTN / 16;
+  constexpr int KV = BK / VEC;                  // vectors per A/W row of the slab
+  constexpr int A_IT = BM * KV / 256;
+  constexpr int B_IT = W_KN ? (BK * (BN / VEC) / 256) : (BN * KV / 256);
+  static_assert(A_IT >= 1 && B_IT >= 1, "tile too small for 256 threads");
+  static_assert(!W_KN || sizeof(T) == 4, "W_KN layout is f32 only");
+
+  constexpr int B_ROWS = W_KN ? BK : BN;
+  constexpr int B_COLS = W_KN ? BN + PAD : BK + PAD;
+  __shared__ __attribute__((aligned(16))) T As[BM][BK + PAD];
+  __shared__ __attribute__((aligned(16))) T Bs[B_ROWS][B_COLS];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int z = blockIdx.z, z1 = z / p.nb2, z2 = z - z1 * p.nb2;
+
+  const T* __restrict__ A = (const T*)p.A + z1 * p.sA1 + z2 * p.sA2;
+  const T* __restrict__ W = (const T*)p.W + z1 * p.sW1 + z2 * p.sW2;
+
+  // ---- per-thread A row bookkeeping (rows are fixed across the K loop)
+  int a_row[A_IT], a_kv[A_IT];
+  long a_off[A_IT];          // plain: m*lda ; conv: image base offset
+  int a_iy0[A_IT], a_ix0[A_IT];
+  bool a_ok[A_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    int v = tid + i * 256;
+    a_row[i] = v / KV;
+    a_kv[i] = (v % KV) * VEC;
+    int m = m0 + a_row[i];
+    a_ok[i] = m < p.M;
+    if (CONV) {
+      int ohw = p.OH * p.OW;
+      int img = m / ohw, rem = m - img * ohw;
+      int oy = rem / p.OW, ox = rem - oy * p.OW;
+      a_off[i] = (long)img * p.cH * p.cW * p.cC;
+      a_iy0[i] = oy * p.cstride - p.cpad;
+      a_ix0[i] = ox * p.cstride - p.cpad;
+    } else {
+      a_off[i] = (long)m * p.lda;
+      a_iy0[i] = a_ix0[i] = 0;
+    }
+  }
+
+  auto load_a = [&](int i, int k0) -> vec_t {
+    int k = k0 + a_kv[i];
+    if (!a_ok[i] || k >= p.K) return G::zero();
+    if (CONV) {
+      int kpos = k / p.cC, ci = k - kpos * p.cC;
+      int ky = kpos / p.KW, kx = kpos - ky * p.KW;
+      int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
+      if (iy < 0 || iy >= p.cH || ix < 0 || ix >= p.cW) return G::zero();
+      return *(const vec_t*)(A + a_off[i] + ((long)iy * p.cW + ix) * p.cC + ci);
+    } else {
+      return *(const vec_t*)(A + a_off[i] + k);
+    }
+  };
+  auto load_b = [&](int i, int k0) -> vec_t {
+    int v = tid + i * 256;
+    if (W_KN) {
+      constexpr int NV = BN / VEC;
+      int kr = v / NV, nv = (v % NV) * VEC;
+      int k = k0 + kr, n = n0 + nv;
+      if (k >= p.K || n >= p.N) return G::zero();
+      return *(const vec_t*)(W + (long)k * p.ldw + n);
+    } else {
+      int r = v / KV, kv = (v % KV) * VEC;
+      int n = n0 + r, k = k0 + kv;
+      if (n >= p.N || k >= p.K) return G::zero();
+      return *(const vec_t*)(W + (long)n * p.ldw + k);
+    }
+  };
+  auto store_a = [&](int i, const vec_t& v) { *(vec_t*)&As[a_row[i]][a_kv[i]] = v; };
+  auto store_b = [&](int i, const vec_t& val) {
+    int v = tid + i * 256;
+    if (W_KN) {
+      constexpr int NV = BN / VEC;
+      *(vec_t*)&Bs[v / NV][(v % NV) * VEC] = val;
+    } else {
+      *(vec_t*)&Bs[v / KV][(v % KV) * VEC] = val;
+    }
+  };
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  vec_t ra[A_IT], rb[B_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) ra[i] = load_a(i, 0);
+#pragma unroll
+  for (int i = 0; i < B_IT; ++i) rb[i] = load_b(i, 0);
+
+  const int nk = (p.K + BK - 1) / BK;
+  const int lr = lane & 15, lq = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) store_a(i, ra[i]);
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) store_b(i, rb[i]);
+    __syncthreads();
+    if (kt + 1 < nk) {
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) ra[i] = load_a(i, (kt + 1) * BK);
+#pragma unroll
+      for (int i = 0; i < B_IT; ++i) rb[i] = load_b(i, (kt + 1) * BK);
+    }
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+      for (int kk = 0; kk < BK / 4; ++kk) {
+        float a[FM], b[FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) a[i] = ((const float(*)[BK + PAD])As)[wm * WTM + i * 16 + lr][kk * 4 + lq];
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          if (W_KN) b[j] = ((const float(*)[B_COLS])Bs)[kk * 4 + lq][wn * WTN + j * 16 + lr];
+          else b[j] = ((const float(*)[B_COLS])Bs)[wn * WTN + j * 16 + lr][kk * 4 + lq];
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < BK / 32; ++kk) {
+        h8 a[FM], b[FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) a[i] = *(const h8*)&As[wm * WTM + i * 16 + lr][kk * 32 + lq * 8];
+#pragma unroll
+        for (int j = 0; j < FN; ++j) b[j] = *(const h8*)&Bs[wn * WTN + j * 16 + lr][kk * 32 + lq * 8];
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D fragment layout col = lane & 15, row = (lane >> 4) * 4 + reg
+  const int* rowmap = p.rowmap ? p.rowmap + z1 * p.sRowmap1 : nullptr;
+  const long c_off = z1 * p.sC1 + z2 * p.sC2;
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int row = m0 + wm * WTM + i * 16 + lq * 4 + r;
+      if (row >= p.M) continue;
+      int drow = rowmap ? rowmap[row] : row;
+      if (drow < 0) continue;
+      int rrow = p.res_mod > 0 ? drow % p.res_mod : drow;
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        int col = n0 + wn * WTN + j * 16 + lr;
+        if (col >= p.N) continue;
+        float v = acc[i][j][r] * p.alpha;
+        if (p.bias) v += p.bias[col];
+        v = apply_act(v, p.act);
+        if (p.res) v += p.res[(long)rrow * p.ldr + col];
+        if (sizeof(T) == 2 && p.out_f16) ((half_t*)p.C)[c_off + (long)drow * p.ldc + col] = (half_t)v;
+        else ((float*)p.C)[c_off + (long)drow * p.ldc + col] = v;
+      }
+    }
+  }
+}
+
+template <typename T>
+static int gemm_dispatch(const GemmP& p, hipStream_t s) {
+  constexpr int VEC = GT<T>::VEC;
+  if (!p.A || !p.W || !p.C || p.M <= 0 || p.N <= 0 || p.K <= 0) return SAMPT_ERR_ARG;
+  if (p.K % VEC) return SAMPT_ERR_ARG;
+  if (p.conv) {
+    if (p.cC % VEC || p.K != p.KH * p.KW * p.cC || p.w_kn) return SAMPT_ERR_ARG;
+  } else if (p.lda % VEC) {
+    return SAMPT_ERR_ARG;
+  }
+  if (p.w_kn ? (p.N % VEC || p.ldw % VEC) : (p.ldw % VEC)) return SAMPT_ERR_ARG;
+  if (((uintptr_t)p.A | (uintptr_t)p.W) & 15) return SAMPT_ERR_ARG;
+  if ((p.sA1 | p.sA2 | p.sW1 | p.sW2) % VEC) return SAMPT_ERR_ARG;
+  const bool big = p.M > 64 && p.N > 64;
+  const int BM = big ? 128 : 64, BN = BM;
+  dim3 grid(cdiv(p.N, BN), cdiv(p.M, BM), p.nb1 * p.nb2), block(256);
+#define LAUNCH(BMv, CONVv, KNv) \
+  hipLaunchKernelGGL((gemm_kernel<T, BMv, BMv, CONVv, KNv>), grid, block, 0, s, p)
+  if (p.w_kn) {
+    if constexpr (sizeof(T) == 4) {
+      if (big) LAUNCH(128, false, true); else LAUNCH(64, false, true);
+    } else {
+      return SAMPT_ERR_UNSUPPORTED;
+    }
+  } else if (p.conv) {
+    if (big) LAUNCH(128, true, false); else LAUNCH(64, true, false);
+  } else {
+    if (big) LAUNCH(128, false, false); else LAUNCH(64, false, false);
+  }
+#undef LAUNCH
+  SAMPT_CHECK_LAUNCH("gemm");
+  return SAMPT_OK;
+}
+
+int gemm_f32(const GemmP& p, hipStream_t s) { return gemm_dispatch<float>(p, s); }
+int gemm_f16(const GemmP& p, hipStream_t s) { return gemm_dispatch<half_t>(p, s); }
+
+}  // namespace sampt

@@ -1,0 +1,117 @@
+// Internal C++ launcher API of the HIP library (one function per kernel family).
+// All tensors are device pointers owned by the caller; every launcher is stream-ordered, allocation-free and
+// returns SAMPT_OK or a negative SAMPT_ERR_* code.
+#pragma once
+#include "common.h"
+
+namespace sampt {
+
+// ---- elementwise.hip ------------------------------------------------------------------------
+// uint8 CHW frames (T,3,H,W) -> f32 NHWC4 (T,H,W,4) = 2*(x/255)-1, 4th channel 0      (pips.py:446)
+int rgb_u8chw_to_nhwc4(const uint8_t* src, float* dst, int T, int H, int W, hipStream_t s);
+// per-(image, channel) mean / rstd over H*W of an NHWC f32 tensor (InstanceNorm2d, eps, biased variance)
+// partials: workspace of at least instnorm_partial_floats(nimg, hw, C) doubles
+size_t instnorm_partial_doubles(int nimg, long hw, int C);
+int instnorm_stats(const float* x, int nimg, long hw, int C, float eps, double* partials, float* mean_rstd,
+                   hipStream_t s);
+// y = (x-mean)*rstd ; if relu1: y = max(y,0) ; if skip: y = max(y + skip, 0)
+int instnorm_apply(const float* x, const float* mean_rstd, const float* skip, float* y, int nimg, long hw, int C,
+                   int relu1, hipStream_t s);
+// bilinear resize of an NHWC f32 tensor into channels [c_off, c_off+C) of a dstC-channel NHWC tensor
+int resize_bilinear_nhwc(const float* src, int n, int sh, int sw, int C, float* dst, int dh, int dw, int dstC,
+                         int c_off, int align_corners, hipStream_t s);
+int avgpool2x2_nhwc(const float* src, int n, int h, int w, int C, float* dst, hipStream_t s);
+// LayerNorm over the last dim of rows. src_rows: optional gather (row index into x, or -1 -> output row = 0).
+// out_f16: y is half. act: applied after the affine transform (ACT_GELU for LayerNorm2d+GELU).
+int layernorm_rows(const float* x, const float* w, const float* b, void* y, long M, int D, float eps,
+                   const int* src_rows, int out_f16, int act, hipStream_t s);
+// out[i] = a[i] + b[i % bmod] (f32).  n, bmod in elements.
+int add_bcast(const float* a, const float* b, float* out, long n, long bmod, hipStream_t s);
+int cast_f32_f16(const float* x, half_t* y, long n, hipStream_t s);
+// SAM preprocess + patch im2col: frames u8 HWC (B,H,W,3) -> A[B*g*g][3*P*P] with k = c*P*P + ky*P + kx,
+// value = (x-mean[c])/std[c] inside the h x w image, 0 in the padded region (Sam.preprocess, App. A-2)
+// chw: frames are (B,3,H,W) planar instead of (B,H,W,3).  mean/stdv are HOST pointers (3 floats each).
+int sam_patchify(const uint8_t* frames, int chw, int B, int H, int W, int img, int P, const float* mean,
+                 const float* stdv, void* A, int out_f16, hipStream_t s);
+
+// ---- attention.hip --------------------------------------------------------------------------
+// Decomposed relative-position terms of SAM's ViT attention (App. A-3):
+//   relh[bh][q][kh] = <q_vec, rel_pos_h[qh - kh + S-1]>, relw likewise.  qkv: [B*S*S][3*D] (f32 or f16),
+//   outputs f32 [B*heads][S*S][S].
+int vit_rel_bias(const void* qkv, int qkv_f16, const float* rel_h, const float* rel_w, int B, int S, int heads,
+                 int hd, float* relh, float* relw, hipStream_t s);
+// scores[bh][q][k] (already scaled) += relh[bh][q][k/S] + relw[bh][q][k%S]; softmax over k, in place (f32).
+int softmax_rel_rows(float* scores, const float* relh, const float* relw, long BH, int Nq, int S, hipStream_t s);
+// Fused flash-style attention, f16 operands, fp32 softmax/accumulate.  qkv f16 [B*S*S][3*D]; out f16 [B*S*S][D].
+int vit_flash_attention_f16(const half_t* qkv, const float* relh, const float* relw, half_t* out, int B, int S,
+                            int heads, int hd, hipStream_t s);
+
+// ---- pips.hip ---------------------------------------------------------------------------------
+struct PyramidLevels {
+  const float* base[4];   // level l: [nframes][H_l][W_l][C] f32 NHWC
+  int H[4], W[4];
+};
+// ffeat[n][c] = bilinear_sample2d(fmap[frame], x/stride..)   (samp.py:6-80)
+int pips_sample_feat(const float* fmap, int H, int W, int C, const float* xy, int n, float* out, hipStream_t s);
+// fused correlation + 7x7 window sampler (pips.py:364-407): writes x[n][s][xoff + lvl*49 + i*7+j]
+int pips_corr_sample(const PyramidLevels& pyr, const int* frame_idx, int S, int n, int C, const float* ffeats,
+                     const float* coords, float* x, int ldx, int xoff, hipStream_t s);
+// mixer input assembly: x[n][s][0:128]=ffeats, x[...][324:519] = sincos embedding of (flow, t) (misc.py:30-55)
+// times: device [S] = torch.linspace(0, S, S) (pips.py:527)
+int pips_build_input(const float* ffeats, const float* coords, const float* times, int S, int n, float* x, int ldx,
+                     hipStream_t s);
+// coords[s][pt] = coords0[pt] = xys[pt]/stride ; ffeats[pt][s] = feat_init[pt]     (pips.py:458-476)
+int pips_init_state(const float* xys, const float* feat_init, float stride, int S, int n, float* coords,
+                    float* coords0, float* ffeats, hipStream_t s);
+// token-mixing PreNormResidual block of the MLP-Mixer, one workgroup per sequence (pips.py:116,120-121)
+int pips_token_mix(float* x, const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
+                   const float* b2, int nseq, int S, int D, hipStream_t s);
+// mean over the S tokens of LN(x): out[n][D]
+int pips_ln_mean(const float* x, const float* lnw, const float* lnb, float* out, int nseq, int S, int D, hipStream_t s);
+// feature / coordinate update (pips.py:536-544): delta [n][S][130]; ffeats [n][S][128]; coords [S][n][2]
+// up_wT: ffeat_updater weight transposed to [in][out]
+int pips_update(const float* delta, const float* gn_w, const float* gn_b, const float* up_wT, const float* up_b,
+                float* ffeats, float* coords, const float* coords0, int S, int n, hipStream_t s);
+// vis[s][n] = sigmoid(<ffeats[n][s], w> + b) ; traj[s][n][2] = coords*stride
+int pips_finalize(const float* ffeats, const float* vis_w, const float* vis_b, const float* coords, float stride,
+                  int S, int n, float* traj, float* vis, hipStream_t s);
+
+// ---- sam_decoder.hip --------------------------------------------------------------------------
+// sparse prompt tokens (App. A-4). points xy in input-frame px (device), labels i32 (device), box 4 f32 (device) or null.
+int sam_prompt_tokens(const float* pts, const int* labels, int k, const float* box, const float* gauss,
+                      const float* point_emb /*[4][256]*/, const float* not_a_point, float img_size, float* tokens_out,
+                      hipStream_t s);
+// small f32 attention, one workgroup per (query, head): q [Nq][H*hd], k,v [Nk][H*hd] -> out [Nq][H*hd]
+int attn_rowblock(const float* q, const float* k, const float* v, float* out, int Nq, int Nk, int heads, int hd,
+                  hipStream_t s);
+// small f32 attention with few keys (Nk <= 64): one thread per (query, head)
+int attn_fewkeys(const float* q, const float* k, const float* v, float* out, int Nq, int Nk, int heads, int hd,
+                 hipStream_t s);
+// low_res[p] = <hyper[32], up[p][32]>
+int sam_mask_dot(const float* up, const float* hyper, float* low_res, int npix, int C, hipStream_t s);
+// fused Sam.postprocess_masks: low (L x L) -> bilinear to (img x img) -> crop (in_h,in_w) -> bilinear to (oh,ow)
+int sam_postprocess(const float* low, int L, int img, int in_h, int in_w, float* out, int oh, int ow, hipStream_t s);
+// bbox state: int[5] = {xmin, ymin, xmax, ymax, count} of logits > 0 (the refinement box of sam_pt.py:809-820)
+int bbox_state_init(int* bbox, hipStream_t s);
+int sam_postprocess_bbox(const float* low, int L, int img, int in_h, int in_w, float* out, int oh, int ow, int* bbox,
+                         hipStream_t s);
+int bbox_from_logits_state(const float* logits, int h, int w, int* bbox_state, hipStream_t s);
+int bbox_to_float(const int* bbox, float* box_out, int* count_out, hipStream_t s);
+// mask-input embedding (PromptEncoder.mask_downscaling, App. A-4) fused with "src = image_embedding + dense":
+//   mask (4g x 4g) -> conv2x2s2(1->c1) LN2d GELU -> conv2x2s2(c1->c2) LN2d GELU -> conv1x1(c2->256) ; src = feat + dense
+struct MaskEmbedW {
+  const float *w0, *b0, *ln0w, *ln0b, *w1, *b1, *ln1w, *ln1b, *w2, *b2;  // torch layouts [out][in][kh][kw]
+};
+int sam_mask_embed_src(const float* mask, int g, const MaskEmbedW& w, const float* feat, float* tmp0, float* tmp1,
+                       float* src, hipStream_t s);
+// refinement gating (sam_pt.py:809-811): st = {active, ...}; active &= count(bbox_cur) >= 2 ; box_f = bbox_cur
+int sam_refine_gate(int* active, const int* bbox_cur, float* box_f, hipStream_t s);
+// if *active: cur <- cand for logits (n_logits), low-res (n_low), iou (1 float) and the bbox state (5 ints)
+int sam_commit(const int* active, const float* cand_logits, float* cur_logits, long n_logits, const float* cand_low,
+               float* cur_low, long n_low, const float* cand_iou, float* cur_iou, const int* cand_bbox, int* cur_bbox,
+               hipStream_t s);
+// out = (iou >= thr) ? logits : -inf ; score_out = iou   (sam_pt.py:830-837)
+int sam_finalize_mask(const float* logits, const float* iou, float thr, float* out, float* score_out, long n,
+                      hipStream_t s);
+
+}  // namespace sampt
