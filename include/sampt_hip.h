@@ -104,7 +104,8 @@ int sampt_sam_decode(sampt_dec_t h, const float* features_dev, const float* pts_
                      float* logits_out_dev, float* iou_out_dev, float* low_res_out_dev, void* workspace_dev,
                      size_t workspace_bytes, sampt_stream_t stream);
 /* Whole SamPt.predict_mask chain for one (frame, object) (sam_pt.py:760-837) without host synchronisation:
- * [positives-only pass when 0 < n_pos_first < k] -> all-points pass -> `refine_iters` box+mask refinement passes
+ * [positives-only pass over the first n_pos_first points when n_pos_first >= 0, i.e. negative_points_per_mask > 0;
+ * pass -1 for the single-pass case] -> all-points pass -> `refine_iters` box+mask refinement passes
  * (bbox of logits>0 and the `sum < 2 -> stop` rule evaluated on device) -> logits = -inf if iou < iou_thr.
  * final_logits_dev [out_h][out_w]; score_out_dev [1] = predicted IoU. */
 int sampt_sam_track_decode(sampt_dec_t h, const float* features_dev, const float* pts_dev, const int32_t* labels_dev,

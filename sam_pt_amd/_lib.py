@@ -1,0 +1,114 @@
+"""ctypes binding of libsampt_hip.so (C ABI: include/sampt_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsampt_hip.so")
+
+c_void_p, c_int, c_size_t, c_float, c_char_p = C.c_void_p, C.c_int, C.c_size_t, C.c_float, C.c_char_p
+
+
+class SamptError(RuntimeError):
+    pass
+
+
+class VitConfigC(C.Structure):
+    _fields_ = [("embed_dim", c_int), ("depth", c_int), ("num_heads", c_int), ("grid", c_int), ("window", c_int),
+                ("patch", c_int), ("out_chans", c_int), ("mlp_ratio", c_int), ("img_size", c_int),
+                ("global_mask", c_int), ("f16", c_int), ("pixel_mean", c_float * 3), ("pixel_std", c_float * 3)]
+
+
+# name -> (restype, argtypes); every symbol declared in include/sampt_hip.h
+_P = c_void_p
+_SIGS = {
+    "sampt_version": (c_int, []),
+    "sampt_last_error": (c_char_p, []),
+    "sampt_pips_create": (c_int, [C.POINTER(c_char_p), C.POINTER(_P), c_int, c_int, c_int, C.POINTER(_P)]),
+    "sampt_pips_destroy": (None, [_P]),
+    "sampt_pips_fnet_workspace_bytes": (c_int, [_P, c_int, c_int, c_int, C.POINTER(c_size_t)]),
+    "sampt_pips_fnet_f32": (c_int, [_P, _P, c_int, c_int, c_int, C.POINTER(_P), _P, c_size_t, _P]),
+    "sampt_pips_sample_feat_f32": (c_int, [_P, c_int, c_int, _P, c_int, _P, _P]),
+    "sampt_pips_update_workspace_bytes": (c_int, [_P, c_int, C.POINTER(c_size_t)]),
+    "sampt_pips_update_f32": (c_int, [_P, C.POINTER(_P), c_int, c_int, _P, c_int, _P, _P, c_int, _P, _P, _P, c_size_t, _P]),
+    "sampt_vit_create": (c_int, [C.POINTER(VitConfigC), C.POINTER(c_char_p), C.POINTER(_P), c_int, c_int, C.POINTER(_P)]),
+    "sampt_vit_destroy": (None, [_P]),
+    "sampt_vit_encode_workspace_bytes": (c_int, [_P, c_int, C.POINTER(c_size_t)]),
+    "sampt_vit_encode": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, c_size_t, _P]),
+    "sampt_dec_create": (c_int, [C.POINTER(c_char_p), C.POINTER(_P), c_int, c_int, c_int, C.POINTER(_P)]),
+    "sampt_dec_destroy": (None, [_P]),
+    "sampt_dec_workspace_bytes": (c_int, [_P, c_int, c_int, C.POINTER(c_size_t)]),
+    "sampt_sam_decode": (c_int, [_P, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_size_t, _P]),
+    "sampt_sam_track_decode": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_int, c_int, c_int, c_int, _P, _P,
+                                       _P, c_size_t, _P]),
+    "sampt_postprocess_masks": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P]),
+    "sampt_bbox_from_logits": (c_int, [_P, c_int, c_int, _P, _P]),
+    "sampt_gemm": (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
+    "sampt_conv2d_nhwc": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "sampt_instance_norm_nhwc": (c_int, [_P, c_int, c_int, c_int, c_float, c_int, _P, _P, c_size_t, _P]),
+    "sampt_instance_norm_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "sampt_layernorm": (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, c_int, c_int, _P]),
+    "sampt_resize_bilinear_nhwc": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "sampt_avgpool2x2_nhwc": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
+    "sampt_corr_sample_f32": (c_int, [C.POINTER(_P), c_int, c_int, _P, c_int, c_int, _P, _P, _P, _P]),
+    "sampt_vit_attention_f16": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
+}
+
+_lib = None
+
+
+def exported_symbols() -> List[str]:
+    return list(_SIGS)
+
+
+def load():
+    """Load the HIP library; raises SamptError if it has not been built (`python -c 'import __graft_entry__ as g; g.build()'`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SamptError(f"{LIB_PATH} not found: build it with `make -C sam_pt_amd/csrc` "
+                         "(there is no CPU or PyTorch fallback for the SAM-PT hot path)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().sampt_last_error()
+        raise SamptError(f"{what} failed with code {rc}: {msg.decode() if msg else ''}")
+
+
+def ptr(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "device-resident contiguous tensor required"
+    return c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def name_table(named: Dict[str, torch.Tensor]):
+    """(names array, ptrs array, n) for the *_create functions; keeps the byte strings alive."""
+    keys = list(named)
+    names = (c_char_p * len(keys))(*[k.encode() for k in keys])
+    ptrs = (_P * len(keys))(*[named[k].data_ptr() for k in keys])
+    return names, ptrs, len(keys)
+
+
+def ptr_array(ts: Sequence[torch.Tensor]):
+    return (_P * len(ts))(*[t.data_ptr() for t in ts])

@@ -173,7 +173,7 @@ int sampt_dec_workspace_bytes(sampt_dec_t h, int oh, int ow, size_t* bytes) {
 int sampt_sam_decode(sampt_dec_t h, const float* features, const float* pts, const int32_t* labels, int k,
                      const float* box, const float* mask_in, int in_h, int in_w, int oh, int ow, float* logits_out,
                      float* iou_out, float* low_out, void* ws, size_t ws_bytes, sampt_stream_t stream) {
-  if (!h || !features || !pts || !labels || !logits_out || !iou_out || !low_out || !ws || k <= 0)
+  if (!h || !features || !logits_out || !iou_out || !low_out || !ws || k < 0 || (k > 0 && (!pts || !labels)))
     return fail(SAMPT_ERR_ARG, "sampt_sam_decode: bad arguments");
   Arena a(ws, ws_bytes);
   return h->e.decode(features, pts, labels, k, box, mask_in, in_h, in_w, oh, ow, logits_out, iou_out, low_out, nullptr,
@@ -183,7 +183,7 @@ int sampt_sam_decode(sampt_dec_t h, const float* features, const float* pts, con
 int sampt_sam_track_decode(sampt_dec_t h, const float* features, const float* pts, const int32_t* labels, int k,
                            int n_pos_first, int refine_iters, float iou_thr, int in_h, int in_w, int oh, int ow,
                            float* final_logits, float* score_out, void* ws, size_t ws_bytes, sampt_stream_t stream) {
-  if (!h || !features || !pts || !labels || !final_logits || !score_out || !ws || k <= 0)
+  if (!h || !features || !pts || !labels || !final_logits || !score_out || !ws || k <= 0 || n_pos_first > k)
     return fail(SAMPT_ERR_ARG, "sampt_sam_track_decode: bad arguments");
   Arena a(ws, ws_bytes);
   return h->e.track_decode(features, pts, labels, k, n_pos_first, refine_iters, iou_thr, in_h, in_w, oh, ow,

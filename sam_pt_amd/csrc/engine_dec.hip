@@ -203,7 +203,7 @@ int DecEngine::track_decode(const float* features, const float* pts, const int* 
   float *cur_iou = scal, *cand_iou = scal + 1, *boxf = scal + 4;
   int *cur_bb = ist, *cand_bb = ist + 5, *active = ist + 10;
   const float* mask_in = nullptr;
-  if (n_pos_first > 0 && n_pos_first < k) {  // sam_pt.py:791-807: positives only, then all points + low-res mask
+  if (n_pos_first >= 0) {  // negative_points_per_mask > 0 (sam_pt.py:791-807): positives only, then all + low-res mask
     ws.off = mark;
     SAMPT_TRY(decode(features, pts, labels, n_pos_first, nullptr, nullptr, in_h, in_w, oh, ow, cand_logits, cand_iou,
                      low0, nullptr, ws, s));

@@ -1,0 +1,128 @@
+"""Host-side weight repacking: upstream-layout state dicts -> the named device buffers the HIP engines expect.
+
+This is load-time plumbing (runs once per model on the CPU, then uploads): no hot-path arithmetic happens here.
+
+Layouts (see sam_pt_amd/csrc/engine_*.hip):
+  * conv weights   torch [Cout][Cin][KH][KW]  ->  [Cout][KH][KW][Cin]  (implicit-GEMM K order, NHWC activations)
+  * PIPS stem      Cin zero-padded 3 -> 4 so that one float4 is one pixel
+  * mixer input    Linear(519 -> 512) weight K-padded to 520 (16-byte rows)
+  * ViT GEMMs      fp16 copies under "<key>.f16" for the fast mode, fp32 originals for the exact mode
+  * ConvTranspose  torch [Cin][Cout][2][2] -> [(dy,dx)][Cout][Cin] + pixel-shuffle row maps
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+
+from .weights import SamConfig
+
+
+def _khwc(w: torch.Tensor, pad_cin_to: int = 0) -> torch.Tensor:
+    w = w.permute(0, 2, 3, 1).contiguous()  # [Cout][KH][KW][Cin]
+    if pad_cin_to and w.shape[-1] < pad_cin_to:
+        w = torch.nn.functional.pad(w, (0, pad_cin_to - w.shape[-1]))
+    return w.reshape(w.shape[0], -1).contiguous()
+
+
+def pack_pips(sd: Dict[str, torch.Tensor], device, S: int = 8) -> Dict[str, torch.Tensor]:
+    out: Dict[str, torch.Tensor] = {}
+    for k, v in sd.items():
+        v = v.detach().float()
+        if k.startswith("fnet.") and k.endswith(".weight"):
+            out[k] = _khwc(v, pad_cin_to=4 if k == "fnet.conv1.weight" else 0)
+        elif k == "delta_block.to_delta.0.weight":
+            out[k] = torch.nn.functional.pad(v, (0, 520 - v.shape[1])).contiguous()
+        elif ".0.fn." in k and k.endswith(".weight"):
+            out[k] = v.reshape(v.shape[0], v.shape[1]).contiguous()  # Conv1d(k=1) -> [out][in]
+        else:
+            out[k] = v.contiguous()
+    out["ffeat_updater.0.weight_t"] = sd["ffeat_updater.0.weight"].detach().float().t().contiguous()
+    out["vis_predictor.0.weight"] = sd["vis_predictor.0.weight"].detach().float().reshape(-1).contiguous()
+    out["__times"] = torch.linspace(0, S, S)  # pips.py:527
+    return {k: v.to(device) for k, v in out.items()}
+
+
+def window_row_map(grid: int, window: int, batches: int) -> torch.Tensor:
+    """Row map of SAM's window_partition (App. A-3): entry ((b*nwin + w)*window^2 + i) = source token row
+    b*grid^2 + y*grid + x, or -1 where the window hangs over the zero padding."""
+    n1 = (grid + window - 1) // window
+    ys = torch.arange(n1 * window).view(n1, window)
+    m = torch.full((n1, n1, window, window), -1, dtype=torch.int64)
+    for wy in range(n1):
+        for wx in range(n1):
+            yy = ys[wy].view(window, 1).expand(window, window)
+            xx = ys[wx].view(1, window).expand(window, window)
+            ok = (yy < grid) & (xx < grid)
+            m[wy, wx] = torch.where(ok, yy * grid + xx, torch.full_like(yy, -1))
+    m = m.reshape(1, -1).repeat(batches, 1)
+    off = (torch.arange(batches) * grid * grid).view(batches, 1)
+    m = torch.where(m >= 0, m + off, m)
+    return m.reshape(-1).to(torch.int32)
+
+
+def pack_vit(sd: Dict[str, torch.Tensor], cfg: SamConfig, device, f16: bool, win_batches: int) -> Dict[str, torch.Tensor]:
+    out: Dict[str, torch.Tensor] = {}
+    e = "image_encoder."
+    gemm_keys = [e + "patch_embed.proj.weight", e + "neck.0.weight"]
+    for i in range(cfg.depth):
+        p = f"{e}blocks.{i}."
+        gemm_keys += [p + "attn.qkv.weight", p + "attn.proj.weight", p + "mlp.lin1.weight", p + "mlp.lin2.weight"]
+    for k, v in sd.items():
+        if not k.startswith(e):
+            continue
+        v = v.detach().float()
+        if k == e + "pos_embed":
+            out[k] = v.reshape(-1, v.shape[-1]).contiguous()
+        elif k == e + "neck.2.weight":
+            w = _khwc(v)
+            out[e + "neck.2.weight_khwc" + (".f16" if f16 else "")] = w.half() if f16 else w
+        elif k in gemm_keys:
+            w = v.reshape(v.shape[0], -1).contiguous()
+            out[k + (".f16" if f16 else "")] = w.half() if f16 else w
+        else:
+            out[k] = v.contiguous()
+    out["__win_rows"] = window_row_map(cfg.grid, cfg.window, win_batches)
+    return {k: v.to(device) for k, v in out.items()}
+
+
+def dense_pe(gauss: torch.Tensor, grid: int) -> torch.Tensor:
+    """PromptEncoder.get_dense_pe() (App. A-4) as a token-major [grid*grid][256] constant."""
+    import math
+    ones = torch.ones(grid, grid)
+    y = (ones.cumsum(0) - 0.5) / grid
+    x = (ones.cumsum(1) - 0.5) / grid
+    c = 2 * torch.stack([x, y], dim=-1) - 1
+    c = 2 * math.pi * (c @ gauss)
+    return torch.cat([torch.sin(c), torch.cos(c)], dim=-1).reshape(grid * grid, -1).contiguous()
+
+
+def _convt_pack(w: torch.Tensor) -> torch.Tensor:
+    # torch ConvTranspose2d weight [Cin][Cout][2][2] -> [(dy,dx)][Cout][Cin]
+    return w.permute(2, 3, 1, 0).reshape(4, w.shape[1], w.shape[0]).contiguous()
+
+
+def _shuffle_map(side: int) -> torch.Tensor:
+    # input pixel p = y*side + x of a (side x side) map -> output row (2y+dy)*(2*side) + 2x+dx, for (dy,dx) in order
+    y = torch.arange(side).view(side, 1).expand(side, side)
+    x = torch.arange(side).view(1, side).expand(side, side)
+    maps = [((2 * y + dy) * (2 * side) + 2 * x + dx).reshape(-1) for dy in range(2) for dx in range(2)]
+    return torch.stack(maps).to(torch.int32).contiguous()
+
+
+def pack_decoder(sd: Dict[str, torch.Tensor], cfg: SamConfig, device) -> Dict[str, torch.Tensor]:
+    out: Dict[str, torch.Tensor] = {}
+    for k, v in sd.items():
+        if k.startswith("mask_decoder.") or k.startswith("prompt_encoder."):
+            out[k] = v.detach().float().contiguous()
+    out["mask_decoder.__out_tokens"] = torch.cat([sd["mask_decoder.iou_token.weight"],
+                                                   sd["mask_decoder.mask_tokens.weight"]], dim=0).float().contiguous()
+    out["prompt_encoder.__point_embeddings"] = torch.cat(
+        [sd[f"prompt_encoder.point_embeddings.{i}.weight"] for i in range(4)], dim=0).float().contiguous()
+    g = sd["prompt_encoder.pe_layer.positional_encoding_gaussian_matrix"].float()
+    out["prompt_encoder.__dense_pe"] = dense_pe(g, cfg.grid)
+    out["mask_decoder.output_upscaling.0.weight_packed"] = _convt_pack(sd["mask_decoder.output_upscaling.0.weight"].float())
+    out["mask_decoder.output_upscaling.3.weight_packed"] = _convt_pack(sd["mask_decoder.output_upscaling.3.weight"].float())
+    out["mask_decoder.__up0_map"] = _shuffle_map(cfg.grid)
+    out["mask_decoder.__up1_map"] = _shuffle_map(2 * cfg.grid)
+    return {k: v.to(device) for k, v in out.items()}

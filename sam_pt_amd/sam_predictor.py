@@ -1,0 +1,253 @@
+"""Seam 2 of the drop-in boundary: a ``segment_anything.SamPredictor``-compatible object backed by the HIP library.
+
+What the reference touches on a predictor and therefore what is provided, with the same names:
+``.model`` (``.device``, ``.mask_threshold``), ``.transform.apply_coords`` / ``apply_coords_torch``,
+``.original_size`` / ``.input_size`` / ``.features`` / ``.is_image_set``, ``set_image(np HxWx3 uint8)``,
+``predict_torch(point_coords, point_labels, boxes, mask_input, multimask_output, return_logits)`` and the numpy
+``predict``.  Call sites: sam_pt/modeling/sam_pt.py:771, 783-828, 849; sam_pt/vos_eval/eval.py:243-250.
+
+Beyond the reference API (used by our own ``SamPt`` for speed, legal inside the same seam — SURVEY.md §7.1):
+``encode_frames`` (batched image encoding of a whole clip, embeddings stay in HBM) and ``track_decode`` (the whole
+per-(frame, object) prompt chain of ``SamPt.predict_mask`` on device without host syncs).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib
+from .pack import pack_decoder, pack_vit
+from .weights import SAM_CONFIGS, SamConfig, init_sam_state_dict
+
+
+class ResizeLongestSide:
+    """Coordinate part of segment_anything.utils.transforms.ResizeLongestSide (App. A-1)."""
+
+    def __init__(self, target_length: int):
+        self.target_length = target_length
+
+    @staticmethod
+    def get_preprocess_shape(oldh: int, oldw: int, long_side_length: int) -> Tuple[int, int]:
+        scale = long_side_length * 1.0 / max(oldh, oldw)
+        return int(oldh * scale + 0.5), int(oldw * scale + 0.5)
+
+    def apply_coords(self, coords: np.ndarray, original_size) -> np.ndarray:
+        old_h, old_w = original_size
+        new_h, new_w = self.get_preprocess_shape(old_h, old_w, self.target_length)
+        coords = np.array(coords, dtype=float, copy=True)
+        coords[..., 0] = coords[..., 0] * (new_w / old_w)
+        coords[..., 1] = coords[..., 1] * (new_h / old_h)
+        return coords
+
+    def apply_coords_torch(self, coords: torch.Tensor, original_size) -> torch.Tensor:
+        old_h, old_w = original_size
+        new_h, new_w = self.get_preprocess_shape(old_h, old_w, self.target_length)
+        coords = coords.clone().to(torch.float)
+        coords[..., 0] = coords[..., 0] * (new_w / old_w)
+        coords[..., 1] = coords[..., 1] * (new_h / old_h)
+        return coords
+
+    def apply_boxes(self, boxes: np.ndarray, original_size) -> np.ndarray:
+        return self.apply_coords(boxes.reshape(-1, 2, 2), original_size).reshape(-1, 4)
+
+
+class SamHip(nn.Module):
+    """The ``Sam``-like object a predictor exposes as ``.model`` (sam_pt.py:96, 118-120, 334).  Holds the upstream-layout
+    state dict; the constructor keywords mirror ``BaseHydra`` (sam_pt/modeling/sam.py:18-31)."""
+
+    mask_threshold: float = 0.0
+    image_format: str = "RGB"
+
+    def __init__(self, variant: str = "vit_h", checkpoint: Optional[str] = None, state_dict=None, seed: int = 72,
+                 precision: str = "f16", config: Optional[SamConfig] = None, max_batch: int = 8, **hydra_kwargs):
+        super().__init__()
+        self.cfg = config if config is not None else SAM_CONFIGS[variant]
+        if state_dict is None and checkpoint is not None:
+            with open(checkpoint, "rb") as f:
+                state_dict = torch.load(f, map_location="cpu")
+        self.sd = state_dict if state_dict is not None else init_sam_state_dict(self.cfg, seed)
+        assert precision in ("f16", "f32")
+        self.precision = precision
+        self.max_batch = max_batch
+        self.register_buffer("pixel_mean", torch.tensor(self.cfg.pixel_mean).view(-1, 1, 1), persistent=False)
+        self.prompt_embed_dim, self.image_size = self.cfg.out_chans, self.cfg.img_size
+        self.vit_patch_size, self.image_embedding_size = self.cfg.patch_size, self.cfg.grid
+
+    @property
+    def device(self):
+        return self.pixel_mean.device
+
+
+class SamPredictor:
+    def __init__(self, sam_model: SamHip):
+        self.model = sam_model
+        self.transform = ResizeLongestSide(sam_model.cfg.img_size)
+        self._vit = self._dec = None
+        self._dev = None
+        self._ws_vit: Dict[int, torch.Tensor] = {}
+        self._ws_dec: Dict[Tuple[int, int], torch.Tensor] = {}
+        self.reset_image()
+        self.stats = {"set_image": 0, "predict": 0, "encoded_frames": 0}
+
+    def reset_image(self):
+        self.is_image_set = False
+        self.features = None
+        self._feat_tokens = None
+        self.original_size = self.input_size = None
+
+    # -- engines -------------------------------------------------------------------------------------
+    def _ensure(self):
+        dev = self.model.device
+        if self._vit is not None and self._dev == dev:
+            return
+        if dev.type != "cuda":
+            raise _lib.SamptError("SamPredictor runs on the HIP device only (no CPU fallback); model is on " + str(dev))
+        lib = _lib.load()
+        cfg, m = self.model.cfg, self.model
+        f16 = m.precision == "f16"
+        self._wv = pack_vit(m.sd, cfg, dev, f16, m.max_batch)
+        c = _lib.VitConfigC()
+        c.embed_dim, c.depth, c.num_heads, c.grid, c.window = cfg.embed_dim, cfg.depth, cfg.num_heads, cfg.grid, cfg.window_size
+        c.patch, c.out_chans, c.mlp_ratio, c.img_size = cfg.patch_size, cfg.out_chans, cfg.mlp_ratio, cfg.img_size
+        c.global_mask = sum(1 << i for i in cfg.global_attn_indexes)
+        c.f16 = 1 if f16 else 0
+        for i in range(3):
+            c.pixel_mean[i], c.pixel_std[i] = cfg.pixel_mean[i], cfg.pixel_std[i]
+        names, ptrs, n = _lib.name_table(self._wv)
+        h = C.c_void_p()
+        _lib.check(lib.sampt_vit_create(C.byref(c), names, ptrs, n, m.max_batch, C.byref(h)), "sampt_vit_create")
+        self._vit = h
+        self._wd = pack_decoder(m.sd, cfg, dev)
+        names, ptrs, n = _lib.name_table(self._wd)
+        h2 = C.c_void_p()
+        _lib.check(lib.sampt_dec_create(names, ptrs, n, cfg.grid, cfg.img_size, C.byref(h2)), "sampt_dec_create")
+        self._dec, self._dev, self._lib = h2, dev, lib
+
+    def __del__(self):
+        try:
+            if self._vit is not None:
+                self._lib.sampt_vit_destroy(self._vit)
+            if self._dec is not None:
+                self._lib.sampt_dec_destroy(self._dec)
+        except Exception:
+            pass
+
+    def _vit_ws(self, B: int) -> torch.Tensor:
+        if B not in self._ws_vit:
+            n = C.c_size_t()
+            _lib.check(self._lib.sampt_vit_encode_workspace_bytes(self._vit, B, C.byref(n)), "vit_workspace")
+            self._ws_vit = {B: torch.empty(n.value, dtype=torch.uint8, device=self._dev)}  # keep only the latest size
+        return self._ws_vit[B]
+
+    def _dec_ws(self, oh: int, ow: int) -> torch.Tensor:
+        if (oh, ow) not in self._ws_dec:
+            n = C.c_size_t()
+            _lib.check(self._lib.sampt_dec_workspace_bytes(self._dec, oh, ow, C.byref(n)), "dec_workspace")
+            self._ws_dec = {(oh, ow): torch.empty(n.value, dtype=torch.uint8, device=self._dev)}
+        return self._ws_dec[(oh, ow)]
+
+    # -- image encoder -------------------------------------------------------------------------------
+    @torch.no_grad()
+    def encode_frames(self, frames: torch.Tensor, chw: bool = True) -> torch.Tensor:
+        """frames uint8 (T,3,H,W) [chw] or (T,H,W,3) on device -> token-major embeddings (T, grid*grid, 256) f32."""
+        self._ensure()
+        frames = frames.to(self._dev).contiguous()
+        T = frames.shape[0]
+        H, W = (frames.shape[2], frames.shape[3]) if chw else (frames.shape[1], frames.shape[2])
+        g, Cc = self.model.cfg.grid, self.model.cfg.out_chans
+        out = torch.empty((T, g * g, Cc), dtype=torch.float32, device=self._dev)
+        Bm = self.model.max_batch
+        for t0 in range(0, T, Bm):
+            B = min(Bm, T - t0)
+            ws = self._vit_ws(B)
+            _lib.check(self._lib.sampt_vit_encode(self._vit, _lib.ptr(frames[t0:t0 + B]), 1 if chw else 0, B, H, W,
+                                                  _lib.ptr(out[t0:t0 + B]), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()),
+                       "sampt_vit_encode")
+        self.stats["encoded_frames"] += T
+        return out
+
+    def set_features(self, feat_tokens: torch.Tensor, original_size, input_size=None):
+        """Install a pre-computed embedding (one frame of ``encode_frames``) as the current image."""
+        g, Cc = self.model.cfg.grid, self.model.cfg.out_chans
+        self._feat_tokens = feat_tokens.contiguous()
+        self.features = self._feat_tokens.view(g, g, Cc).permute(2, 0, 1).unsqueeze(0)  # (1,256,g,g) view, as upstream
+        self.original_size = tuple(original_size)
+        self.input_size = tuple(input_size) if input_size is not None else tuple(original_size)
+        self.is_image_set = True
+
+    @torch.no_grad()
+    def set_image(self, image: np.ndarray, image_format: str = "RGB") -> None:
+        assert image_format in ("RGB", "BGR")
+        if image_format != self.model.image_format:
+            image = image[..., ::-1]
+        H, W = image.shape[:2]
+        if self.transform.get_preprocess_shape(H, W, self.model.cfg.img_size) != (H, W):
+            raise NotImplementedError("set_image: the frame's longest side must equal img_size; the reference pipelines "
+                                      "resize before SamPt (configs/demo.yaml:20, configs/vos_eval_root.yaml:28)")
+        self._ensure()
+        t = torch.as_tensor(np.ascontiguousarray(image), device=self._dev)
+        feats = self.encode_frames(t[None], chw=False)
+        self.set_features(feats[0], (H, W), (H, W))
+        self.stats["set_image"] += 1
+
+    # -- prompt encoder + mask decoder ---------------------------------------------------------------
+    @torch.no_grad()
+    def predict_torch(self, point_coords, point_labels, boxes=None, mask_input=None, multimask_output: bool = True,
+                      return_logits: bool = False):
+        if not self.is_image_set:
+            raise RuntimeError("An image must be set with .set_image(...) before mask prediction.")
+        if multimask_output:
+            raise NotImplementedError("multimask_output=True is not on the SAM-PT path (sam_pt.py:787, 796, 805, 826)")
+        if point_coords is None or point_coords.shape[0] != 1:
+            raise NotImplementedError("predict_torch: exactly one prompt batch with points is supported")
+        self._ensure()
+        dev = self._dev
+        oh, ow = self.original_size
+        ih, iw = self.input_size
+        pts = point_coords[0].to(dev, torch.float32).contiguous()
+        lab = point_labels[0].to(dev, torch.int32).contiguous()
+        box = boxes.reshape(-1)[:4].to(dev, torch.float32).contiguous() if boxes is not None else None
+        L = 4 * self.model.cfg.grid
+        mi = mask_input.reshape(L, L).to(dev, torch.float32).contiguous() if mask_input is not None else None
+        logits = torch.empty((1, 1, oh, ow), dtype=torch.float32, device=dev)
+        iou = torch.empty((1, 1), dtype=torch.float32, device=dev)
+        low = torch.empty((1, 1, L, L), dtype=torch.float32, device=dev)
+        ws = self._dec_ws(oh, ow)
+        _lib.check(self._lib.sampt_sam_decode(self._dec, _lib.ptr(self._feat_tokens), _lib.ptr(pts), _lib.ptr(lab),
+                                              pts.shape[0], _lib.ptr(box), _lib.ptr(mi), ih, iw, oh, ow, _lib.ptr(logits),
+                                              _lib.ptr(iou), _lib.ptr(low), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()),
+                   "sampt_sam_decode")
+        self.stats["predict"] += 1
+        masks = logits if return_logits else logits > self.model.mask_threshold
+        return masks, iou, low
+
+    def predict(self, point_coords=None, point_labels=None, box=None, mask_input=None, multimask_output=True,
+                return_logits=False):
+        """numpy flavour (App. A-1; used at sam_pt/vos_eval/eval.py:244-250)."""
+        dev = self.model.device
+        pc = torch.as_tensor(self.transform.apply_coords(point_coords, self.original_size), dtype=torch.float, device=dev)[None]
+        pl = torch.as_tensor(point_labels, dtype=torch.int, device=dev)[None]
+        bx = None
+        if box is not None:
+            bx = torch.as_tensor(self.transform.apply_boxes(box, self.original_size), dtype=torch.float, device=dev)[None]
+        mi = torch.as_tensor(mask_input, dtype=torch.float, device=dev)[None] if mask_input is not None else None
+        m, i, l = self.predict_torch(pc, pl, bx, mi, multimask_output, return_logits)
+        return m[0].cpu().numpy(), i[0].cpu().numpy(), l[0].cpu().numpy()
+
+    @torch.no_grad()
+    def track_decode(self, feat_tokens: torch.Tensor, pts: torch.Tensor, labels: torch.Tensor, n_pos_first: int,
+                     refine_iters: int, iou_thr: float, size_hw, out_logits: torch.Tensor, out_score: torch.Tensor):
+        """SamPt.predict_mask (sam_pt.py:760-837) for one (frame, object), on device, no host sync.
+        pts (k,2) f32 in input-frame px, labels (k,) i32 (positives first); results written into the given
+        (H,W) logits slice and 1-element score tensor."""
+        self._ensure()
+        oh, ow = size_hw
+        ws = self._dec_ws(oh, ow)
+        _lib.check(self._lib.sampt_sam_track_decode(self._dec, _lib.ptr(feat_tokens), _lib.ptr(pts), _lib.ptr(labels),
+                                                    pts.shape[0], n_pos_first, refine_iters, float(iou_thr), oh, ow, oh, ow,
+                                                    _lib.ptr(out_logits), _lib.ptr(out_score), _lib.ptr(ws), ws.numel(),
+                                                    _lib.stream_ptr()), "sampt_sam_track_decode")

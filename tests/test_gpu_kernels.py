@@ -1,0 +1,208 @@
+"""GPU parity tests, kernel level: every HIP kernel family against a plain PyTorch fp32/fp64 reference of the same op
+(or the oracle) on the same seeded inputs.  All calls go through the C ABI (ctypes)."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.util import max_abs, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from sam_pt_amd import _lib
+    return _lib.load()
+
+
+def P(t):
+    from sam_pt_amd import _lib
+    return _lib.ptr(t)
+
+
+def S():
+    from sam_pt_amd import _lib
+    return _lib.stream_ptr()
+
+
+def ok(rc, what=""):
+    from sam_pt_amd import _lib
+    _lib.check(rc, what)
+
+
+@pytest.mark.parametrize("M,N,K,act", [(300, 200, 64, 0), (64, 1040, 512, 0), (1, 32, 256, 1), (4096, 128, 256, 0),
+                                         (130, 70, 520, 2), (16, 2048, 512, 2), (777, 513, 36, 0)])
+def test_gemm_f32(lib, dev, M, N, K, act):
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    R = torch.randn(M, N, generator=g)
+    ref = A.double() @ W.double().t() * 0.5 + b.double()
+    ref = F.relu(ref) if act == 1 else (F.gelu(ref) if act == 2 else ref)
+    ref = ref + R.double()
+    Ad, Wd, bd, Rd = A.to(dev), W.to(dev), b.to(dev), R.to(dev)
+    Cd = torch.empty(M, N, device=dev)
+    ok(lib.sampt_gemm(0, P(Ad), P(Wd), P(bd), P(Rd), P(Cd), M, N, K, act, 0.5, S()), "gemm f32")
+    assert rel_err(Cd, ref) < 2e-6
+
+
+@pytest.mark.parametrize("M,N,K,dtype", [(256, 256, 128, 1), (4900, 3840, 1280, 2), (100, 72, 64, 1), (4096, 768, 768, 2)])
+def test_gemm_f16(lib, dev, M, N, K, dtype):
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randn(M, K, generator=g).half()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).half()
+    b = torch.randn(N, generator=g)
+    ref = F.gelu(A.double() @ W.double().t() + b.double())
+    Ad, Wd, bd = A.to(dev), W.to(dev), b.to(dev)
+    Cd = torch.empty(M, N, device=dev, dtype=torch.float16 if dtype == 2 else torch.float32)
+    ok(lib.sampt_gemm(dtype, P(Ad), P(Wd), P(bd), None, P(Cd), M, N, K, 2, 1.0, S()), "gemm f16")
+    assert rel_err(Cd.float(), ref) < (2e-3 if dtype == 2 else 2e-5 * K ** 0.5)
+
+
+@pytest.mark.parametrize("n,H,W,Cin,Cout,k,s,p", [(2, 20, 28, 64, 96, 3, 2, 1), (1, 32, 48, 4, 64, 7, 2, 3),
+                                                  (2, 17, 23, 96, 128, 1, 2, 0), (1, 16, 24, 416, 256, 3, 1, 1)])
+def test_conv_f32(lib, dev, n, H, W, Cin, Cout, k, s, p):
+    g = torch.Generator().manual_seed(Cin + Cout)
+    x = torch.randn(n, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=s, padding=p).permute(0, 2, 3, 1)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(dev)
+    y = torch.empty(ref.shape, device=dev)
+    ok(lib.sampt_conv2d_nhwc(0, P(xd), P(wd), P(b.to(dev)), P(y), n, H, W, Cin, Cout, k, k, s, p, S()), "conv f32")
+    assert rel_err(y, ref) < 2e-6
+
+
+def test_conv_f16(lib, dev):
+    n, H, W, Cin, Cout = 2, 16, 16, 256, 256
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, Cin, H, W, generator=g).half()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).half()
+    ref = F.conv2d(x.double(), w.double(), None, padding=1).permute(0, 2, 3, 1)
+    y = torch.empty(ref.shape, device=dev)
+    ok(lib.sampt_conv2d_nhwc(1, P(x.permute(0, 2, 3, 1).contiguous().to(dev)), P(w.permute(0, 2, 3, 1).contiguous().to(dev)),
+                             None, P(y), n, H, W, Cin, Cout, 3, 3, 1, 1, S()), "conv f16")
+    assert rel_err(y, ref) < 1e-4
+
+
+@pytest.mark.parametrize("C_", [64, 96, 128, 256])
+def test_instance_norm(lib, dev, C_):
+    n, H, W = 3, 37, 52
+    g = torch.Generator().manual_seed(C_)
+    x = torch.randn(n, C_, H, W, generator=g) * 3 + 1
+    skip = torch.randn(n, C_, H, W, generator=g)
+    ref = F.relu(F.relu(F.instance_norm(x.double(), eps=1e-5)) + skip.double()).permute(0, 2, 3, 1)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    sd = skip.permute(0, 2, 3, 1).contiguous().to(dev)
+    nb = lib.sampt_instance_norm_workspace_bytes(n, H * W, C_)
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    ok(lib.sampt_instance_norm_nhwc(P(xd), n, H * W, C_, 1e-5, 1, P(sd), P(ws), nb, S()), "instnorm")
+    assert max_abs(xd, ref) < 5e-6
+
+
+@pytest.mark.parametrize("D,f16,act", [(64, 0, 2), (256, 0, 0), (512, 0, 0), (768, 1, 0), (1280, 1, 0), (4, 0, 2), (16, 0, 0)])
+def test_layernorm(lib, dev, D, f16, act):
+    M = 333
+    g = torch.Generator().manual_seed(D)
+    x = torch.randn(M, D, generator=g) * 2 + 0.5
+    w, b = torch.randn(D, generator=g), torch.randn(D, generator=g)
+    ref = F.layer_norm(x.double(), (D,), w.double(), b.double(), 1e-6)
+    ref = F.gelu(ref) if act == 2 else ref
+    y = torch.empty(M, D, device=dev, dtype=torch.float16 if f16 else torch.float32)
+    ok(lib.sampt_layernorm(P(x.to(dev)), P(w.to(dev)), P(b.to(dev)), P(y), M, D, 1e-6, f16, act, S()), "layernorm")
+    assert max_abs(y.float(), ref) < (2e-2 if f16 else 1e-5)
+
+
+@pytest.mark.parametrize("align", [0, 1])
+@pytest.mark.parametrize("sh,sw,dh,dw", [(36, 64, 144, 256), (40, 52, 20, 26), (16, 24, 16, 24), (9, 13, 21, 30)])
+def test_resize_bilinear(lib, dev, align, sh, sw, dh, dw):
+    n, C_ = 2, 8
+    x = torch.randn(n, C_, sh, sw, generator=torch.Generator().manual_seed(sh))
+    ref = F.interpolate(x, (dh, dw), mode="bilinear", align_corners=bool(align)).permute(0, 2, 3, 1)
+    y = torch.zeros(n, dh, dw, 12, device=dev)
+    ok(lib.sampt_resize_bilinear_nhwc(P(x.permute(0, 2, 3, 1).contiguous().to(dev)), n, sh, sw, C_, P(y), dh, dw, 12, 4,
+                                      align, S()), "resize")
+    assert max_abs(y[..., 4:], ref) < 2e-6
+    assert float(y[..., :4].abs().max()) == 0.0
+
+
+def test_avgpool(lib, dev):
+    x = torch.randn(2, 128, 16, 24, generator=torch.Generator().manual_seed(1))
+    ref = F.avg_pool2d(x, 2, stride=2).permute(0, 2, 3, 1)
+    y = torch.empty(2, 8, 12, 128, device=dev)
+    ok(lib.sampt_avgpool2x2_nhwc(P(x.permute(0, 2, 3, 1).contiguous().to(dev)), 2, 16, 24, 128, P(y), S()), "avgpool")
+    assert max_abs(y, ref) < 1e-6
+
+
+def test_corr_sample_vs_oracle(lib, dev):
+    """Fused local correlation + 7x7 sampler == CorrBlock.corr + CorrBlock.sample (pips.py:364-407), including
+    points near / outside the border (zeros padding) and integer-valued coordinates."""
+    from oracle import pips_ref as O
+    from sam_pt_amd import _lib
+    g = torch.Generator().manual_seed(3)
+    S_, n, H0, W0 = 8, 6, 32, 48
+    fm = torch.randn(S_, 128, H0, W0, generator=g)
+    pyr = O.build_pyramid(fm)
+    ffeats = torch.randn(S_, n, 128, generator=g)
+    coords = torch.rand(S_, n, 2, generator=g) * torch.tensor([W0 - 1.0, H0 - 1.0])
+    coords[:, 0] = torch.tensor([0.3, 0.2])          # near the top-left corner
+    coords[:, 1] = torch.tensor([W0 + 2.5, H0 - 0.5])  # partly outside
+    coords[:, 2] = torch.tensor([10.0, 7.0])          # exactly integral
+    ref = O.sample_corr(O.corr_volumes(pyr, ffeats), coords)           # S,N,196
+    pyr_d = [p.permute(0, 2, 3, 1).contiguous().to(dev) for p in pyr]
+    fidx = torch.arange(S_, dtype=torch.int32, device=dev)
+    ff_d = ffeats.permute(1, 0, 2).contiguous().to(dev)                # [n][S][128]
+    out = torch.empty(n, S_, 196, device=dev)
+    ok(lib.sampt_corr_sample_f32(_lib.ptr_array(pyr_d), H0, W0, P(fidx), S_, n, P(ff_d), P(coords.contiguous().to(dev)),
+                                 P(out), S()), "corr_sample")
+    assert max_abs(out.permute(1, 0, 2), ref) < 2e-5 * float(ref.abs().max())
+
+
+def _ref_vit_attention(qkv, rel_h, rel_w, B, S_, heads, hd):
+    N, D = S_ * S_, heads * hd
+    q, k, v = qkv.double().reshape(B, N, 3, heads, hd).permute(2, 0, 3, 1, 4).reshape(3, B * heads, N, hd).unbind(0)
+    attn = (q * hd ** -0.5) @ k.transpose(-2, -1)
+    idx = torch.arange(S_)[:, None] - torch.arange(S_)[None, :] + (S_ - 1)
+    Rh, Rw = rel_h.double()[idx], rel_w.double()[idx]
+    rq = q.reshape(B * heads, S_, S_, hd)
+    attn = attn.view(-1, S_, S_, S_, S_) + torch.einsum("bhwc,hkc->bhwk", rq, Rh)[..., None] \
+        + torch.einsum("bhwc,wkc->bhwk", rq, Rw)[:, :, :, None, :]
+    attn = attn.view(-1, N, N).softmax(-1)
+    return (attn @ v).view(B, heads, N, hd).permute(0, 2, 1, 3).reshape(B * N, D)
+
+
+@pytest.mark.parametrize("B,S_,heads,hd", [(2, 64, 2, 80), (3, 14, 4, 80), (1, 64, 3, 64), (5, 14, 2, 64), (2, 16, 2, 32),
+                                            (4, 6, 2, 32)])
+def test_vit_flash_attention(lib, dev, B, S_, heads, hd):
+    g = torch.Generator().manual_seed(S_ * hd)
+    N, D = S_ * S_, heads * hd
+    qkv = (torch.randn(B * N, 3 * D, generator=g) * 1.5).half()
+    rel_h = torch.randn(2 * S_ - 1, hd, generator=g) * 0.3
+    rel_w = torch.randn(2 * S_ - 1, hd, generator=g) * 0.3
+    ref = _ref_vit_attention(qkv, rel_h, rel_w, B, S_, heads, hd)
+    out = torch.empty(B * N, D, device=dev, dtype=torch.float16)
+    nb = 2 * B * heads * S_ * S_ * S_ * 4
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    ok(lib.sampt_vit_attention_f16(P(qkv.to(dev)), P(rel_h.to(dev)), P(rel_w.to(dev)), P(out), B, S_, heads, hd, P(ws), nb,
+                                   S()), "flash")
+    assert max_abs(out.float(), ref) < 6e-3 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("in_h,in_w,oh,ow", [(576, 1024, 576, 1024), (576, 1024, 480, 854), (1024, 683, 300, 200)])
+def test_postprocess_and_bbox(lib, dev, in_h, in_w, oh, ow):
+    low = torch.randn(1, 1, 256, 256, generator=torch.Generator().manual_seed(oh)) * 2 - 1.0
+    ref = F.interpolate(low, (1024, 1024), mode="bilinear", align_corners=False)[..., :in_h, :in_w]
+    ref = F.interpolate(ref, (oh, ow), mode="bilinear", align_corners=False)[0, 0]
+    out = torch.empty(oh, ow, device=dev)
+    ok(lib.sampt_postprocess_masks(P(low.to(dev)), 256, 1024, in_h, in_w, P(out), oh, ow, S()), "postprocess")
+    assert max_abs(out, ref) < 1e-5
+    bb = torch.zeros(5, dtype=torch.int32, device=dev)
+    ok(lib.sampt_bbox_from_logits(P(out), oh, ow, P(bb), S()), "bbox")
+    m = out.cpu() > 0
+    yx = m.nonzero()
+    exp = [int(yx[:, 1].min()), int(yx[:, 0].min()), int(yx[:, 1].max()), int(yx[:, 0].max()), int(m.sum())]
+    assert bb.cpu().tolist() == exp

@@ -1,0 +1,199 @@
+"""GPU parity tests, module level: the HIP engines behind the two drop-in seams against the CPU oracle
+(oracle/pips_ref.py pinned to the reference's own PIPS; oracle/sam_ref.py pinned to HF transformers.sam) on the same
+seeded weights and inputs.  Tolerances are stated per test; trajectories must agree in index space
+(round(traj) identical), masks within 1e-3 IoU."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import disc_queries, iou, max_abs, rel_err, synthetic_clip
+
+pytestmark = pytest.mark.gpu
+
+
+# ------------------------------------------------------------------------------------------ PIPS
+@pytest.fixture(scope="module")
+def pips_sd():
+    from sam_pt_amd.weights import init_pips_state_dict
+    return init_pips_state_dict(72)
+
+
+@pytest.fixture(scope="module")
+def clip():
+    return synthetic_clip(T=12, H=128, W=256, seed=72)
+
+
+def test_fnet_vs_oracle(dev, pips_sd, clip):
+    """fnet + pyramid (exact-f32 MFMA implicit-GEMM convs, fp64-accumulated instance norm) vs pips.py:254-287."""
+    from oracle import pips_ref as O
+    from sam_pt_amd.point_tracker import PipsPointTracker
+    frames, _ = clip
+    trk = PipsPointTracker(state_dict=pips_sd, fnet_chunk=2)
+    pyr = trk.compute_pyramid(frames[:3].to(dev))
+    ref = O.fnet(pips_sd, O.normalize_rgbs(frames[:3]), 4)
+    refp = O.build_pyramid(ref)
+    for l in range(4):
+        got = pyr[l].permute(0, 3, 1, 2)
+        assert got.shape == refp[l].shape
+        assert rel_err(got, refp[l]) < 2e-5, f"level {l}"
+
+
+def test_update_window_vs_oracle(dev, pips_sd, clip):
+    """One 8-frame window (6 iterations: corr sampler, mixer, feature/coord update, vis head) vs Pips.forward."""
+    from oracle import pips_ref as O
+    from sam_pt_amd import _lib
+    from sam_pt_amd.point_tracker import PipsPointTracker
+    frames, centres = clip
+    q = disc_queries(centres, n_pos=5, r=9.0)
+    trk = PipsPointTracker(state_dict=pips_sd)
+    pyr = trk.compute_pyramid(frames[:8].to(dev))
+    fm = pyr[0].permute(0, 3, 1, 2).cpu()                      # feed the oracle OUR fmaps: isolates the window
+    xys = q[:, 1:]
+    preds, vlog, ffeat = O.pips_forward(pips_sd, xys, fm, None, iters=6)
+    lib = _lib.load()
+    nb = C.c_size_t()
+    _lib.check(lib.sampt_pips_update_workspace_bytes(trk._h, 5, C.byref(nb)), "ws")
+    ws = torch.empty(nb.value, dtype=torch.uint8, device=dev)
+    fi = torch.empty(5, 128, device=dev)
+    xy0 = (xys / 4.0).contiguous().to(dev)
+    _lib.check(lib.sampt_pips_sample_feat_f32(_lib.ptr(pyr[0][0]), 32, 64, _lib.ptr(xy0), 5, _lib.ptr(fi), _lib.stream_ptr()), "feat")
+    assert max_abs(fi, ffeat) < 1e-5
+    fidx = torch.arange(8, dtype=torch.int32, device=dev)
+    tr = torch.empty(8, 5, 2, device=dev)
+    vi = torch.empty(8, 5, device=dev)
+    _lib.check(lib.sampt_pips_update_f32(trk._h, _lib.ptr_array(pyr), 32, 64, _lib.ptr(fidx), 5, _lib.ptr(xys.contiguous().to(dev)),
+                                         _lib.ptr(fi), 6, _lib.ptr(tr), _lib.ptr(vi), _lib.ptr(ws), nb.value, _lib.stream_ptr()), "update")
+    assert max_abs(tr, preds[-1]) < 2e-3, "trajectory (px)"
+    assert max_abs(vi, torch.sigmoid(vlog)) < 1e-4
+
+
+def test_tracker_vs_oracle(dev, pips_sd, clip):
+    """PipsPointTracker.forward (both directions, linking) vs the oracle tracker == the reference's tracker."""
+    from oracle import pips_ref as O
+    from sam_pt_amd.point_tracker import PipsPointTracker
+    frames, centres = clip
+    q = torch.cat([disc_queries(centres, n_pos=4, r=9.0, t=0), disc_queries(centres, n_pos=2, r=6.0, t=5),
+                   disc_queries(centres, n_pos=1, r=3.0, t=11)])[None]
+    rgbs = frames[None]
+    tr_ref, vi_ref = O.PipsTrackerRef(pips_sd).forward(rgbs, q)
+    trk = PipsPointTracker(state_dict=pips_sd)
+    out = trk.evaluate_batch(rgbs.to(dev), q.to(dev))
+    tr, vi = out["trajectories_pred"], out["visibilities_pred"]
+    assert tr.shape == (1, 12, 7, 2) and vi.shape == (1, 12, 7)
+    assert (vi.bool() == vi_ref).all(), "visibilities differ"
+    assert max_abs(tr, tr_ref) < 5e-3
+    assert (tr.round() == tr_ref.round()).all(), "trajectories differ in index space"
+
+
+# ------------------------------------------------------------------------------------------ SAM
+def _sam(variant, precision, seed=72, max_batch=2):
+    from sam_pt_amd.sam_predictor import SamHip, SamPredictor
+    return SamPredictor(SamHip(variant, precision=precision, seed=seed, max_batch=max_batch).cuda())
+
+
+@pytest.mark.parametrize("precision,tol", [("f32", 3e-5), ("f16", 2e-2)])
+def test_vit_test_encoder_vs_oracle(dev, precision, tol):
+    """Reduced geometry (2 blocks: 1 windowed with padding 16->18, 1 global), batch 2, non-square frame."""
+    from oracle import sam_ref as R
+    from sam_pt_amd.weights import SAM_CONFIGS, init_sam_state_dict
+    cfg = SAM_CONFIGS["vit_test"]
+    sd = init_sam_state_dict(cfg, 72)
+    frames, _ = synthetic_clip(T=2, H=144, W=256, seed=5)
+    pred = _sam("vit_test", precision)
+    feats = pred.encode_frames(frames.to(dev))                                    # (2, 256, 256)
+    ref = R.image_encoder(sd, cfg, R.preprocess(cfg, frames.float()))             # (2,256,16,16)
+    got = feats.view(2, 16, 16, 256).permute(0, 3, 1, 2)
+    assert rel_err(got, ref) < tol
+
+
+@pytest.mark.parametrize("precision,tol", [("f32", 1e-4), ("f16", 3e-2)])
+def test_vit_b_encoder_vs_oracle(dev, precision, tol):
+    from oracle import sam_ref as R
+    from sam_pt_amd.weights import SAM_CONFIGS, init_sam_state_dict
+    cfg = SAM_CONFIGS["vit_b"]
+    sd = init_sam_state_dict(cfg, 72)
+    frames, _ = synthetic_clip(T=1, H=576, W=1024, seed=9, disc_r=60)
+    pred = _sam("vit_b", precision, max_batch=1)
+    feats = pred.encode_frames(frames.to(dev))
+    ref = R.image_encoder(sd, cfg, R.preprocess(cfg, frames.float()))
+    got = feats.view(1, 64, 64, 256).permute(0, 3, 1, 2)
+    assert rel_err(got, ref) < tol
+
+
+def test_predict_torch_vs_oracle(dev):
+    """SamPredictor.set_image / predict_torch (points; points+mask; points+box+mask) on ViT-B in exact-f32 mode."""
+    from oracle import sam_ref as R
+    from sam_pt_amd.weights import SAM_CONFIGS, init_sam_state_dict
+    cfg = SAM_CONFIGS["vit_b"]
+    sd = init_sam_state_dict(cfg, 72)
+    frames, centres = synthetic_clip(T=1, H=576, W=1024, seed=9, disc_r=60)
+    img = frames[0].permute(1, 2, 0).numpy()
+    ref = R.SamPredictorRef(sd, cfg)
+    ref.set_image(img)
+    pred = _sam("vit_b", "f32", max_batch=1)
+    pred.set_image(img)
+    assert pred.features.shape == (1, 256, 64, 64)
+    assert rel_err(pred.features, ref.features) < 1e-4
+    # decode against the ORACLE's features to isolate the decoder
+    pred.set_features(ref.features[0].permute(1, 2, 0).reshape(4096, 256).to(dev), (576, 1024))
+    q = disc_queries(centres, n_pos=6, r=30.0)[:, 1:]
+    pts = torch.as_tensor(pred.transform.apply_coords(q.numpy(), (576, 1024)), dtype=torch.float)[None]
+    lab = torch.tensor([[1, 1, 1, 1, 0, 0]], dtype=torch.int)
+    m0, i0, l0 = ref.predict_torch(pts, lab, None, None, False, True)
+    m1, i1, l1 = pred.predict_torch(pts.to(dev), lab.to(dev), None, None, False, True)
+    assert max_abs(l1, l0) < 2e-4 and max_abs(i1, i0) < 1e-4 and max_abs(m1, m0) < 2e-4
+    assert iou(m1 > 0, m0 > 0) >= 1 - 1e-3
+    box = torch.tensor([[[200.0, 100.0, 700.0, 500.0]]])
+    m2, i2, l2 = ref.predict_torch(pts, lab, box, l0, False, True)
+    m3, i3, l3 = pred.predict_torch(pts.to(dev), lab.to(dev), box.to(dev), l0.to(dev), False, True)
+    assert max_abs(l3, l2) < 2e-4 and max_abs(i3, i2) < 1e-4
+    assert iou(m3 > 0, m2 > 0) >= 1 - 1e-3
+    m4, i4, l4 = ref.predict_torch(pts[:, :4], lab[:, :4], None, l0, False, True)
+    m5, i5, l5 = pred.predict_torch(pts[:, :4].to(dev), lab[:, :4].to(dev), None, l0.to(dev), False, True)
+    assert max_abs(l5, l4) < 2e-4 and iou(m5 > 0, m4 > 0) >= 1 - 1e-3
+
+
+@pytest.mark.parametrize("neg", [0, 2])
+def test_sampt_end_to_end_vs_oracle(dev, neg):
+    """Whole SamPt.forward on the reduced SAM geometry + full PIPS: our fused device path vs our SamPt host logic
+    driving the CPU oracle predictor/tracker call by call (the reference protocol)."""
+    from oracle import pips_ref as PO
+    from oracle import sam_ref as R
+    from sam_pt_amd.point_tracker import PipsPointTracker, PointTracker
+    from sam_pt_amd.sam_predictor import SamHip, SamPredictor
+    from sam_pt_amd.sam_pt import SamPt
+    from sam_pt_amd.weights import SAM_CONFIGS, init_pips_state_dict, init_sam_state_dict
+    cfg = SAM_CONFIGS["vit_test"]
+    sd, psd = init_sam_state_dict(cfg, 72), init_pips_state_dict(72)
+    frames, centres = synthetic_clip(T=10, H=128, W=256, seed=72)
+    npos = 4
+    q = disc_queries(centres, n_pos=npos + neg, r=9.0)
+    if neg:
+        q[npos:, 1:] += torch.tensor([40.0, 30.0])
+    q2 = disc_queries(centres, n_pos=npos + neg, r=5.0)
+    q2[:, 1:] += torch.tensor([-60.0, 20.0])
+    qp = torch.stack([q, q2])                                          # 2 objects
+    video = {"image": [f for f in frames], "target_hw": (128, 256), "query_points": qp}
+    kw = dict(sam_iou_threshold=-1e9, positive_points_per_mask=npos, negative_points_per_mask=neg,
+              iterative_refinement_iterations=3, point_tracker_mask_batch_size=5)
+
+    class OracleTracker(PointTracker):
+        def forward(self, rgbs, query_points):
+            return PO.PipsTrackerRef(psd).forward(rgbs.cpu(), query_points.cpu())
+
+    ref_model = SamPt(OracleTracker(), R.SamPredictorRef(sd, cfg), **kw).eval()
+    ref = ref_model(video)
+    ours = SamPt(PipsPointTracker(state_dict=psd), SamPredictor(SamHip(config=cfg, state_dict=sd, precision="f32").cuda()),
+                 **kw).eval()
+    out = ours({**video, "image": [f.to(dev) for f in frames]})
+    assert (out["visibilities"] == ref["visibilities"]).all()
+    assert (out["trajectories"].round() == ref["trajectories"].round()).all()
+    for m in range(2):
+        a, b = out["logits"][m].cpu(), ref["logits"][m]
+        fin = torch.isfinite(b)
+        assert (torch.isfinite(a) == fin).all()
+        for t in range(10):
+            assert iou(a[t] > 0, b[t] > 0) >= 1 - 1e-3, f"mask IoU object {m} frame {t}"
+    assert np.allclose(np.array(out["scores_per_frame"]), np.array(ref["scores_per_frame"]), atol=1e-3)
