@@ -82,7 +82,7 @@ def pack_vit(sd: Dict[str, torch.Tensor], cfg: SamConfig, device, f16: bool, win
             out[k + (".f16" if f16 else "")] = w.half() if f16 else w
         else:
             out[k] = v.contiguous()
-    out["__win_rows"] = window_row_map(cfg.grid, cfg.window, win_batches)
+    out["__win_rows"] = window_row_map(cfg.grid, cfg.window_size, win_batches)
     return {k: v.to(device) for k, v in out.items()}
 
 

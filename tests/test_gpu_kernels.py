@@ -72,8 +72,9 @@ def test_conv_f32(lib, dev, n, H, W, Cin, Cout, k, s, p):
     ref = F.conv2d(x.double(), w.double(), b.double(), stride=s, padding=p).permute(0, 2, 3, 1)
     xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
     wd = w.permute(0, 2, 3, 1).contiguous().to(dev)
+    bd = b.to(dev)
     y = torch.empty(ref.shape, device=dev)
-    ok(lib.sampt_conv2d_nhwc(0, P(xd), P(wd), P(b.to(dev)), P(y), n, H, W, Cin, Cout, k, k, s, p, S()), "conv f32")
+    ok(lib.sampt_conv2d_nhwc(0, P(xd), P(wd), P(bd), P(y), n, H, W, Cin, Cout, k, k, s, p, S()), "conv f32")
     assert rel_err(y, ref) < 2e-6
 
 
@@ -84,8 +85,8 @@ def test_conv_f16(lib, dev):
     w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).half()
     ref = F.conv2d(x.double(), w.double(), None, padding=1).permute(0, 2, 3, 1)
     y = torch.empty(ref.shape, device=dev)
-    ok(lib.sampt_conv2d_nhwc(1, P(x.permute(0, 2, 3, 1).contiguous().to(dev)), P(w.permute(0, 2, 3, 1).contiguous().to(dev)),
-                             None, P(y), n, H, W, Cin, Cout, 3, 3, 1, 1, S()), "conv f16")
+    xd, wd = x.permute(0, 2, 3, 1).contiguous().to(dev), w.permute(0, 2, 3, 1).contiguous().to(dev)  # keep alive
+    ok(lib.sampt_conv2d_nhwc(1, P(xd), P(wd), None, P(y), n, H, W, Cin, Cout, 3, 3, 1, 1, S()), "conv f16")
     assert rel_err(y, ref) < 1e-4
 
 
@@ -113,7 +114,8 @@ def test_layernorm(lib, dev, D, f16, act):
     ref = F.layer_norm(x.double(), (D,), w.double(), b.double(), 1e-6)
     ref = F.gelu(ref) if act == 2 else ref
     y = torch.empty(M, D, device=dev, dtype=torch.float16 if f16 else torch.float32)
-    ok(lib.sampt_layernorm(P(x.to(dev)), P(w.to(dev)), P(b.to(dev)), P(y), M, D, 1e-6, f16, act, S()), "layernorm")
+    xd, wd, bd = x.to(dev), w.to(dev), b.to(dev)  # keep the device copies alive across the async launch
+    ok(lib.sampt_layernorm(P(xd), P(wd), P(bd), P(y), M, D, 1e-6, f16, act, S()), "layernorm")
     assert max_abs(y.float(), ref) < (2e-2 if f16 else 1e-5)
 
 
@@ -124,7 +126,8 @@ def test_resize_bilinear(lib, dev, align, sh, sw, dh, dw):
     x = torch.randn(n, C_, sh, sw, generator=torch.Generator().manual_seed(sh))
     ref = F.interpolate(x, (dh, dw), mode="bilinear", align_corners=bool(align)).permute(0, 2, 3, 1)
     y = torch.zeros(n, dh, dw, 12, device=dev)
-    ok(lib.sampt_resize_bilinear_nhwc(P(x.permute(0, 2, 3, 1).contiguous().to(dev)), n, sh, sw, C_, P(y), dh, dw, 12, 4,
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    ok(lib.sampt_resize_bilinear_nhwc(P(xd), n, sh, sw, C_, P(y), dh, dw, 12, 4,
                                       align, S()), "resize")
     assert max_abs(y[..., 4:], ref) < 2e-6
     assert float(y[..., :4].abs().max()) == 0.0
@@ -134,7 +137,8 @@ def test_avgpool(lib, dev):
     x = torch.randn(2, 128, 16, 24, generator=torch.Generator().manual_seed(1))
     ref = F.avg_pool2d(x, 2, stride=2).permute(0, 2, 3, 1)
     y = torch.empty(2, 8, 12, 128, device=dev)
-    ok(lib.sampt_avgpool2x2_nhwc(P(x.permute(0, 2, 3, 1).contiguous().to(dev)), 2, 16, 24, 128, P(y), S()), "avgpool")
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    ok(lib.sampt_avgpool2x2_nhwc(P(xd), 2, 16, 24, 128, P(y), S()), "avgpool")
     assert max_abs(y, ref) < 1e-6
 
 
@@ -157,8 +161,8 @@ def test_corr_sample_vs_oracle(lib, dev):
     fidx = torch.arange(S_, dtype=torch.int32, device=dev)
     ff_d = ffeats.permute(1, 0, 2).contiguous().to(dev)                # [n][S][128]
     out = torch.empty(n, S_, 196, device=dev)
-    ok(lib.sampt_corr_sample_f32(_lib.ptr_array(pyr_d), H0, W0, P(fidx), S_, n, P(ff_d), P(coords.contiguous().to(dev)),
-                                 P(out), S()), "corr_sample")
+    co_d = coords.contiguous().to(dev)
+    ok(lib.sampt_corr_sample_f32(_lib.ptr_array(pyr_d), H0, W0, P(fidx), S_, n, P(ff_d), P(co_d), P(out), S()), "corr_sample")
     assert max_abs(out.permute(1, 0, 2), ref) < 2e-5 * float(ref.abs().max())
 
 
@@ -187,8 +191,8 @@ def test_vit_flash_attention(lib, dev, B, S_, heads, hd):
     out = torch.empty(B * N, D, device=dev, dtype=torch.float16)
     nb = 2 * B * heads * S_ * S_ * S_ * 4
     ws = torch.empty(nb, dtype=torch.uint8, device=dev)
-    ok(lib.sampt_vit_attention_f16(P(qkv.to(dev)), P(rel_h.to(dev)), P(rel_w.to(dev)), P(out), B, S_, heads, hd, P(ws), nb,
-                                   S()), "flash")
+    qd, hd_, wd_ = qkv.to(dev), rel_h.to(dev), rel_w.to(dev)
+    ok(lib.sampt_vit_attention_f16(P(qd), P(hd_), P(wd_), P(out), B, S_, heads, hd, P(ws), nb, S()), "flash")
     assert max_abs(out.float(), ref) < 6e-3 * float(ref.abs().max())
 
 
@@ -198,7 +202,8 @@ def test_postprocess_and_bbox(lib, dev, in_h, in_w, oh, ow):
     ref = F.interpolate(low, (1024, 1024), mode="bilinear", align_corners=False)[..., :in_h, :in_w]
     ref = F.interpolate(ref, (oh, ow), mode="bilinear", align_corners=False)[0, 0]
     out = torch.empty(oh, ow, device=dev)
-    ok(lib.sampt_postprocess_masks(P(low.to(dev)), 256, 1024, in_h, in_w, P(out), oh, ow, S()), "postprocess")
+    low_d = low.to(dev)
+    ok(lib.sampt_postprocess_masks(P(low_d), 256, 1024, in_h, in_w, P(out), oh, ow, S()), "postprocess")
     assert max_abs(out, ref) < 1e-5
     bb = torch.zeros(5, dtype=torch.int32, device=dev)
     ok(lib.sampt_bbox_from_logits(P(out), oh, ow, P(bb), S()), "bbox")

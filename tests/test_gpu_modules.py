@@ -63,7 +63,8 @@ def test_update_window_vs_oracle(dev, pips_sd, clip):
     fidx = torch.arange(8, dtype=torch.int32, device=dev)
     tr = torch.empty(8, 5, 2, device=dev)
     vi = torch.empty(8, 5, device=dev)
-    _lib.check(lib.sampt_pips_update_f32(trk._h, _lib.ptr_array(pyr), 32, 64, _lib.ptr(fidx), 5, _lib.ptr(xys.contiguous().to(dev)),
+    xys_d = xys.contiguous().to(dev)
+    _lib.check(lib.sampt_pips_update_f32(trk._h, _lib.ptr_array(pyr), 32, 64, _lib.ptr(fidx), 5, _lib.ptr(xys_d),
                                          _lib.ptr(fi), 6, _lib.ptr(tr), _lib.ptr(vi), _lib.ptr(ws), nb.value, _lib.stream_ptr()), "update")
     assert max_abs(tr, preds[-1]) < 2e-3, "trajectory (px)"
     assert max_abs(vi, torch.sigmoid(vlog)) < 1e-4
