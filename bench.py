@@ -1,0 +1,208 @@
+#!/usr/bin/env python
+"""bench.py — end-to-end SAM-PT frames/sec on MI355X (BASELINE.json metric).
+
+A "step" = one pass of the hot path over one synthetic clip: ``SamPt.forward(video)`` (PIPS tracking of 8 query
+points, SAM ViT image encoding of every frame, 1 + R prompt/refinement decoder passes per frame) plus the
+background-stack softmax/argmax of the reference's timed window (sam_pt/vos_eval/eval.py:262-268, 304-337).
+Frames are uint8 tensors already resident in HBM when the timed region starts.  With N > 1 every rank processes
+its own clip (sequence sharding, no data-path collective) and the final uint8 masks are gathered to rank 0 over
+RCCL inside the timed region; value = all frames of all ranks / max-over-ranks time.
+
+Launch: ``python bench.py --gpus 1`` or ``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N``.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--model", default="vit_h", choices=["vit_h", "vit_l", "vit_b"])
+    ap.add_argument("--frames", type=int, default=24)
+    ap.add_argument("--points", type=int, default=8)
+    ap.add_argument("--refine", type=int, default=12)
+    ap.add_argument("--precision", default="f16", choices=["f16", "f32"])
+    ap.add_argument("--encode-batch", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def build_model(args, dev):
+    from sam_pt_amd.point_tracker import PipsPointTracker
+    from sam_pt_amd.sam_predictor import SamHip, SamPredictor
+    from sam_pt_amd.sam_pt import SamPt
+    sam = SamHip(args.model, precision=args.precision, seed=72, max_batch=args.encode_batch).to(dev)
+    model = SamPt(PipsPointTracker(seed=72, fnet_chunk=8), SamPredictor(sam), sam_iou_threshold=-1e9,
+                  positive_points_per_mask=args.points, negative_points_per_mask=0,
+                  iterative_refinement_iterations=args.refine, point_tracker_mask_batch_size=5).eval()
+    return model
+
+
+def one_step(model, video, max_frames):
+    from sam_pt_amd.dist import gather_masks, index_masks
+    out = model(video)
+    logits = torch.stack(out["logits"], dim=0)          # (M,T,H,W) on device
+    masks = index_masks(logits)                          # bg stack + softmax + argmax (eval.py:304-326)
+    gathered = gather_masks(masks, max_frames)           # RCCL gather of uint8 masks (no-op for 1 GPU)
+    return masks, gathered
+
+
+def gemm_roofline(args, dev):
+    """Dominant kernel = the fp16 MFMA GEMM of the ViT encoder (gemm_kernel<_Float16,128,128>).  Each distinct launch
+    shape of one encode call is timed with HIP events on the launching stream; achieved = algorithmic FLOP of all those
+    launches / their total duration."""
+    from sam_pt_amd import _lib
+    from sam_pt_amd.weights import SAM_CONFIGS
+    lib = _lib.load()
+    cfg = SAM_CONFIGS[args.model]
+    B, D = args.encode_batch, cfg.embed_dim
+    Mg, Mw = B * 4096, B * 25 * 196
+    nglob = len(cfg.global_attn_indexes)
+    nwin = cfg.depth - nglob
+    shapes = [  # (M, N, K, dtype(2 = f16 out, 1 = f32 out), count per encode call)
+        (Mw, 3 * D, D, 2, nwin), (Mg, 3 * D, D, 2, nglob), (Mw, D, D, 1, nwin), (Mg, D, D, 1, nglob),
+        (Mg, 4 * D, D, 2, cfg.depth), (Mg, D, 4 * D, 1, cfg.depth), (Mg, D, 768, 1, 1), (Mg, 256, D, 1, 1)]
+    tot_flop = tot_t = 0.0
+    launches = 0
+    g = torch.Generator(device="cpu").manual_seed(0)
+    for (M, N, K, dt, cnt) in shapes:
+        A = (torch.randn(M, K, generator=g) * 0.5).half().to(dev)
+        W = (torch.randn(N, K, generator=g) / K ** 0.5).half().to(dev)
+        bias = torch.zeros(N, device=dev)
+        Cc = torch.empty(M, N, device=dev, dtype=torch.float16 if dt == 2 else torch.float32)
+        for _ in range(2):
+            _lib.check(lib.sampt_gemm(dt, _lib.ptr(A), _lib.ptr(W), _lib.ptr(bias), None, _lib.ptr(Cc), M, N, K, 0, 1.0,
+                                      _lib.stream_ptr()), "gemm")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 8
+        e0.record()
+        for _ in range(reps):
+            lib.sampt_gemm(dt, _lib.ptr(A), _lib.ptr(W), _lib.ptr(bias), None, _lib.ptr(Cc), M, N, K, 0, 1.0, _lib.stream_ptr())
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) / reps * 1e-3
+        tot_flop += 2.0 * M * N * K * cnt
+        tot_t += t * cnt
+        launches += cnt
+        del A, W, Cc
+    ach = tot_flop / tot_t / 1e12
+    return {"bound": "mfma", "kernel": "gemm_kernel<_Float16,128,128> (ViT qkv/proj/MLP/patch/neck GEMMs)",
+            "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
+            "traffic": None, "launches_per_encode_call": launches,
+            "avg_launch_us": round(tot_t / launches * 1e6, 1), "encode_batch": B}
+
+
+def cpu_baseline(args, frames, qp):
+    """Reference CPU path (PyTorch fp32 oracle = the reference's PIPS + the restated SAM) on this box's host cores,
+    on a bounded sample: 1 frame through the image encoder, 1 frame through fnet, one 8-frame PIPS window, and the
+    1 + R decoder passes of one frame; per-frame time = enc + fnet + window/7 + decoder."""
+    from oracle import pips_ref as PO
+    from oracle import sam_ref as R
+    from sam_pt_amd.weights import SAM_CONFIGS, init_pips_state_dict, init_sam_state_dict
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = SAM_CONFIGS[args.model]
+    sd, psd = init_sam_state_dict(cfg, 72), init_pips_state_dict(72)
+    f = frames[:1].cpu()
+    with torch.no_grad():
+        t0 = time.time()
+        x = R.preprocess(cfg, f.float())
+        emb = R.image_encoder(sd, cfg, x)
+        t_enc = time.time() - t0
+        t0 = time.time()
+        fm1 = PO.fnet(psd, PO.normalize_rgbs(f), 4)
+        t_fnet = time.time() - t0
+        fm = fm1.repeat(8, 1, 1, 1)
+        t0 = time.time()
+        PO.pips_forward(psd, qp[0, :, 1:].cpu(), fm, None, iters=6)
+        t_win = time.time() - t0
+        pred = R.SamPredictorRef(sd, cfg)
+        pred.features, pred.original_size, pred.input_size = emb, tuple(f.shape[-2:]), tuple(f.shape[-2:])
+        pts = qp[0, :, 1:].cpu()[None]
+        lab = torch.ones(1, pts.shape[1], dtype=torch.int)
+        t0 = time.time()
+        m, iou, low = pred.predict_torch(pts, lab, None, None, False, True)
+        for _ in range(args.refine):
+            box = torch.tensor([[[300.0, 200.0, 500.0, 400.0]]])
+            m, iou, low = pred.predict_torch(pts, lab, box, low, False, True)
+        t_dec = time.time() - t0
+    per_frame = t_enc + t_fnet + t_win / 7.0 + t_dec
+    return {"value": round(1.0 / per_frame, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"1 frame: image encoder {t_enc:.1f}s + fnet {t_fnet:.1f}s + one 8-frame PIPS window {t_win:.1f}s/7 "
+                      f"+ {1 + args.refine} decoder passes {t_dec:.1f}s (PyTorch-CPU fp32 oracle, {cores} threads)"}
+
+
+def main():
+    args = parse()
+    from sam_pt_amd.dist import init_from_env
+    from sam_pt_amd.synth import bench_clip
+    rank, world, local = init_from_env()
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback for the hot path)"
+    if world != args.gpus:
+        assert world == 1 and args.gpus == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch through torch.distributed.run"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    frames, qp = bench_clip(T=args.frames, seed=72 + rank, n_pos=args.points)
+    H, W = frames.shape[-2:]
+    model = build_model(args, dev)
+    frames_dev = frames.to(dev)
+    video = {"image": [f for f in frames_dev], "target_hw": (H, W), "query_points": qp}
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step(model, video, args.frames)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        masks, _ = one_step(model, video, args.frames)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    total_frames = world * args.frames * args.steps
+    fps = total_frames / dt
+    if rank == 0:
+        res = {"metric": "frames/sec end-to-end (SAM-PT: ViT + PIPS, 480p, 8 pts, 1 obj)", "value": round(fps, 3),
+               "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None,
+               "dtype": "f16" if args.precision == "f16" else "f32", "data": "synthetic",
+               "config": {"workload": f"SAM {args.model} + PIPS, {args.points} query points, 1 object, "
+                                      f"{args.frames}x 480p synthetic frames upscaled to {H}x{W}, "
+                                      f"{args.refine} refinement iterations, random-init weights (seed 72)",
+                          "frames_per_step": args.frames, "parallelism": f"sequence-sharded x{world}",
+                          "vit_precision": args.precision + " MFMA inputs, fp32 accumulate/LN/softmax/residual",
+                          "tracker_precision": "fp32 (exact f32 MFMA)", "decoder_precision": "fp32"},
+               "mask_foreground_fraction": round(float((masks > 0).float().mean()), 4),
+               "published_reference_fps_unstated_hw": {"vit_h": 1.4, "vit_l": 1.8, "vit_b": 2.6}[args.model]}
+        if not args.no_roofline and args.precision == "f16":
+            res["roofline"] = gemm_roofline(args, dev)
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(args, frames, qp)
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

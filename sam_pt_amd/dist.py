@@ -1,0 +1,71 @@
+"""Multi-GPU sharding of the SAM-PT hot path: one process per GPU, no data-path collective.
+
+Sequences (or frame batches of one sequence) are independent, so ranks never exchange activations; the only
+communication is the final gather of the uint8 index masks to rank 0 (0.59 MB per 576x1024 frame), which replaces the
+reference's pickled-RLE ``comm.gather`` (vis_eval/mask2former_video/data_video/ytvis_eval.py:119-131).  On ROCm the
+``nccl`` backend is RCCL; the payload is far below one xGMI link's capacity, so a single fixed-shape all-gather is used.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: Optional[str] = None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun contract). Returns (rank, world, local)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def lpt_assign(lengths: Sequence[int], world: int) -> List[List[int]]:
+    """Longest-processing-time-first assignment of sequences to ranks (balanced version of detectron2's contiguous
+    InferenceSampler, vis_eval/mask2former_video/data_video/build.py:222-229).  Returns per-rank lists of indices."""
+    order = sorted(range(len(lengths)), key=lambda i: (-lengths[i], i))
+    loads = [0] * world
+    out: List[List[int]] = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: (loads[k], k))
+        out[r].append(i)
+        loads[r] += lengths[i]
+    return out
+
+
+def frame_batches(n_frames: int, world: int, rank: int, batch: int = 8) -> List[range]:
+    """Config #5 style sharding inside one sequence: frame batches b = rank (mod world)."""
+    starts = list(range(0, n_frames, batch))
+    return [range(s, min(s + batch, n_frames)) for i, s in enumerate(starts) if i % world == rank]
+
+
+def index_masks(logits: torch.Tensor) -> torch.Tensor:
+    """(M,T,H,W) per-object logits -> uint8 (T,H,W) object index map with background 0 (bg logit 0 stacked in front,
+    softmax/argmax over objects: sam_pt/vos_eval/eval.py:304, 326, 355)."""
+    M, T, H, W = logits.shape
+    bg = torch.zeros((1, T, H, W), dtype=logits.dtype, device=logits.device)
+    prob = torch.softmax(torch.cat([bg, logits], dim=0), dim=0)
+    return prob.argmax(dim=0).to(torch.uint8)
+
+
+def gather_masks(masks: torch.Tensor, max_frames: int) -> Optional[torch.Tensor]:
+    """All ranks call with their uint8 (T_local,H,W) masks; rank 0 receives (world, max_frames, H, W) (zero padded).
+    Single fixed-shape collective over RCCL/xGMI (or gloo on CPU)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return masks[None]
+    T, H, W = masks.shape
+    pad = torch.zeros((max_frames, H, W), dtype=torch.uint8, device=masks.device)
+    pad[:T] = masks
+    outs = [torch.empty_like(pad) for _ in range(dist.get_world_size())]
+    dist.all_gather(outs, pad)
+    return torch.stack(outs) if dist.get_rank() == 0 else None
