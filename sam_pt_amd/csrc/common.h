@@ -90,6 +90,10 @@ struct GemmP {
   int w_kn = 0;                  // W stored [K][N]
   float alpha = 1.0f;
   // implicit-GEMM convolution over an NHWC input: A is [Nimg][H][W][Cin], W is [Cout][KH*KW*Cin]
+  // split-K (set by the dispatcher; callers only provide the workspace): partial tiles [splitk][M][N] f32
+  int splitk = 1;
+  float* splitk_ws = nullptr;
+  size_t splitk_ws_floats = 0;
   int conv = 0;
   int cH = 0, cW = 0, cC = 0, KH = 0, KW = 0, cstride = 1, cpad = 0, OH = 0, OW = 0;
 };

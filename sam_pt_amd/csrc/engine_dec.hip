@@ -115,6 +115,7 @@ int DecEngine::decode(const float* features, const float* pts, const int* labels
   b.up1 = ws.f32((size_t)16 * P * (C / 8));
   b.t0 = ws.f32(C), b.t1 = ws.f32(C), b.t2 = ws.f32(C);
   b.me0 = ws.f32((size_t)4 * P * 4), b.me1 = ws.f32((size_t)P * 16);
+  int* bbox_partial = (int*)ws.get(bbox_partial_ints(oh, ow) * sizeof(int));
   if (!ws.ok()) return SAMPT_ERR_WORKSPACE;
   if (ws.dry()) return SAMPT_OK;
   L l{s};
@@ -177,7 +178,7 @@ int DecEngine::decode(const float* features, const float* pts, const int* labels
   SAMPT_TRY(l.lin(b.t0, 1, C, iou_w[1], iou_b[1], b.t1, C, ACT_RELU));
   SAMPT_TRY(l.lin(b.t1, 1, C, iou_w[2], iou_b[2], iou_out, 1, ACT_NONE));  // N = 1: only IoU slot 0 is needed
   // ---- Sam.postprocess_masks
-  SAMPT_TRY(sam_postprocess_bbox(low_out, 4 * g, c.img, in_h, in_w, logits_out, oh, ow, bbox_out, s));
+  SAMPT_TRY(sam_postprocess_bbox(low_out, 4 * g, c.img, in_h, in_w, logits_out, oh, ow, bbox_out, bbox_partial, s));
   return SAMPT_OK;
 }
 

@@ -145,9 +145,10 @@ int PipsEngine::fnet(const uint8_t* frames, int nf, int H, int W, float* const o
 }
 
 static int lin(const float* A, int M, int K, int lda, const float* W, const float* b, float* C, int N, int act,
-               const float* res, hipStream_t s) {
+               const float* res, hipStream_t s, float* skws = nullptr, size_t skn = 0) {
   GemmP p;
   p.A = A, p.W = W, p.bias = b, p.C = C, p.res = res;
+  p.splitk_ws = skws, p.splitk_ws_floats = skn;
   p.M = M, p.N = N, p.K = K, p.lda = lda, p.ldw = K, p.ldc = N, p.ldr = N, p.act = act;
   return gemm_f32(p, s);
 }
@@ -161,26 +162,29 @@ int PipsEngine::update(const PyramidLevels& pyr, const int* frame_idx, int n, co
   float* ffeats = ws.f32((size_t)R * 128);
   float* x = ws.f32((size_t)R * LDX);
   float* hbuf = ws.f32((size_t)R * D);
+  float* hbuf2 = ws.f32((size_t)R * D);
   float* lnb = ws.f32((size_t)R * D);
   float* hid = ws.f32((size_t)R * 4 * D);
   float* mean = ws.f32((size_t)n * D);
   float* delta = ws.f32((size_t)n * S * 130);
+  const size_t skn = (size_t)8 * R * 4 * D;  // split-K partials of the weight-bandwidth-bound mixer GEMMs
+  float* skws = ws.f32(skn);
   if (!ws.ok()) return SAMPT_ERR_WORKSPACE;
   if (dry) return SAMPT_OK;
   SAMPT_TRY(pips_init_state(xys, feat_init, (float)stride, S, n, coords, coords0, ffeats, s));
   for (int it = 0; it < iters; ++it) {
     SAMPT_TRY(pips_corr_sample(pyr, frame_idx, S, n, 128, ffeats, coords, x, LDX, 128, s));
     SAMPT_TRY(pips_build_input(ffeats, coords, times, S, n, x, LDX, s));
-    SAMPT_TRY(lin(x, R, LDX, LDX, in_w, in_b, hbuf, D, ACT_NONE, nullptr, s));
+    SAMPT_TRY(lin(x, R, LDX, LDX, in_w, in_b, hbuf, D, ACT_NONE, nullptr, s, skws, skn));
     for (int i = 0; i < 12; ++i) {
       const MixBlk& m = mix[i];
-      SAMPT_TRY(pips_token_mix(hbuf, m.ln1w, m.ln1b, m.tw1, m.tb1, m.tw2, m.tb2, n, S, D, s));
-      SAMPT_TRY(layernorm_rows(hbuf, m.ln2w, m.ln2b, lnb, R, D, 1e-5f, nullptr, 0, ACT_NONE, s));
-      SAMPT_TRY(lin(lnb, R, D, D, m.cw1, m.cb1, hid, 4 * D, ACT_GELU, nullptr, s));
-      SAMPT_TRY(lin(hid, R, 4 * D, 4 * D, m.cw2, m.cb2, hbuf, D, ACT_NONE, hbuf, s));
+      SAMPT_TRY(pips_token_mix(hbuf, hbuf2, m.ln1w, m.ln1b, m.tw1, m.tb1, m.tw2, m.tb2, n, S, D, s));
+      SAMPT_TRY(layernorm_rows(hbuf2, m.ln2w, m.ln2b, lnb, R, D, 1e-5f, nullptr, 0, ACT_NONE, s));
+      SAMPT_TRY(lin(lnb, R, D, D, m.cw1, m.cb1, hid, 4 * D, ACT_GELU, nullptr, s, skws, skn));
+      SAMPT_TRY(lin(hid, R, 4 * D, 4 * D, m.cw2, m.cb2, hbuf, D, ACT_NONE, hbuf2, s, skws, skn));
     }
     SAMPT_TRY(pips_ln_mean(hbuf, oln_w, oln_b, mean, n, S, D, s));
-    SAMPT_TRY(lin(mean, n, D, D, head_w, head_b, delta, S * 130, ACT_NONE, nullptr, s));
+    SAMPT_TRY(lin(mean, n, D, D, head_w, head_b, delta, S * 130, ACT_NONE, nullptr, s, skws, skn));
     SAMPT_TRY(pips_update(delta, gn_w, gn_b, up_wT, up_b, ffeats, coords, coords0, S, n, s));
   }
   SAMPT_TRY(pips_finalize(ffeats, vis_w, vis_b, coords, (float)stride, S, n, traj_out, vis_out, s));

@@ -12,27 +12,33 @@
 // fragment reads are contiguous 4-byte (f32) / 16-byte (f16) LDS reads.  The optional W_KN layout (W stored
 // [K][N], f32 only) serves P.V products.  The A operand may be an im2col view of an NHWC tensor computed on the
 // fly (convolution = GEMM with M = output pixels, K = (ky,kx,ci), N = Cout).
+//
+// Latency-bound shapes of the decoder / mixer get two extra paths (both deterministic):
+//  * split-K: grids with too few tiles to fill 256 CUs slice K over blockIdx.z, write fp32 partial tiles to a
+//    caller-provided workspace and a second kernel reduces them in a fixed order and applies the epilogue;
+//  * skinny (M <= 32): no MFMA at all — each wave owns two output columns, lanes stride K with 16-byte loads of the
+//    weight row (weight-bandwidth bound, one pass over W), wave-shuffle reduction.
 #include "common.h"
 
 namespace sampt {
 
 template <typename T> struct GT;
 template <> struct GT<float> {
-  static constexpr int VEC = 4, BK = 16, KSTEP = 4, PAD = 4;
+  static constexpr int VEC = 4, PAD = 4;
   typedef float4 vec_t;
   __device__ static vec_t zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 };
 template <> struct GT<half_t> {
-  static constexpr int VEC = 8, BK = 64, KSTEP = 32, PAD = 8;
+  static constexpr int VEC = 8, PAD = 8;
   typedef h8 vec_t;
   __device__ static vec_t zero() { return (h8){0, 0, 0, 0, 0, 0, 0, 0}; }
 };
 
-template <typename T, int BM, int BN, bool CONV, bool W_KN>
+template <typename T, int BM, int BN, int BK, bool CONV, bool W_KN>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   typedef GT<T> G;
   typedef typename G::vec_t vec_t;
-  constexpr int VEC = G::VEC, BK = G::BK, PAD = G::PAD;
+  constexpr int VEC = G::VEC, PAD = G::PAD;
   constexpr int WTM = BM / 2, WTN = BN / 2, FM = WTM / 16, FN = WTN / 16;
   constexpr int KV = BK / VEC;                  // vectors per A/W row of the slab
   constexpr int A_IT = BM * KV / 256;
@@ -48,7 +54,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int z = blockIdx.z, z1 = z / p.nb2, z2 = z - z1 * p.nb2;
+  int z = blockIdx.z, ks = 0;
+  if (p.splitk > 1) {
+    ks = z % p.splitk;
+    z /= p.splitk;
+  }
+  const int z1 = z / p.nb2, z2 = z - z1 * p.nb2;
+  // K range of this block (split-K slices are multiples of BK)
+  const int kslice = p.splitk > 1 ? ((p.K + p.splitk * BK - 1) / (p.splitk * BK)) * BK : p.K;
+  const int kbeg = ks * kslice;
+  const int kend = min(p.K, kbeg + kslice);
 
   const T* __restrict__ A = (const T*)p.A + z1 * p.sA1 + z2 * p.sA2;
   const T* __restrict__ W = (const T*)p.W + z1 * p.sW1 + z2 * p.sW2;
@@ -80,7 +95,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 
   auto load_a = [&](int i, int k0) -> vec_t {
     int k = k0 + a_kv[i];
-    if (!a_ok[i] || k >= p.K) return G::zero();
+    if (!a_ok[i] || k >= kend) return G::zero();
     if (CONV) {
       int kpos = k / p.cC, ci = k - kpos * p.cC;
       int ky = kpos / p.KW, kx = kpos - ky * p.KW;
@@ -97,12 +112,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
       constexpr int NV = BN / VEC;
       int kr = v / NV, nv = (v % NV) * VEC;
       int k = k0 + kr, n = n0 + nv;
-      if (k >= p.K || n >= p.N) return G::zero();
+      if (k >= kend || n >= p.N) return G::zero();
       return *(const vec_t*)(W + (long)k * p.ldw + n);
     } else {
       int r = v / KV, kv = (v % KV) * VEC;
       int n = n0 + r, k = k0 + kv;
-      if (n >= p.N || k >= p.K) return G::zero();
+      if (n >= p.N || k >= kend) return G::zero();
       return *(const vec_t*)(W + (long)n * p.ldw + k);
     }
   };
@@ -125,11 +140,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 
   vec_t ra[A_IT], rb[B_IT];
 #pragma unroll
-  for (int i = 0; i < A_IT; ++i) ra[i] = load_a(i, 0);
+  for (int i = 0; i < A_IT; ++i) ra[i] = load_a(i, kbeg);
 #pragma unroll
-  for (int i = 0; i < B_IT; ++i) rb[i] = load_b(i, 0);
+  for (int i = 0; i < B_IT; ++i) rb[i] = load_b(i, kbeg);
 
-  const int nk = (p.K + BK - 1) / BK;
+  const int nk = (kend - kbeg + BK - 1) / BK;
   const int lr = lane & 15, lq = lane >> 4;
   for (int kt = 0; kt < nk; ++kt) {
 #pragma unroll
@@ -139,9 +154,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     __syncthreads();
     if (kt + 1 < nk) {
 #pragma unroll
-      for (int i = 0; i < A_IT; ++i) ra[i] = load_a(i, (kt + 1) * BK);
+      for (int i = 0; i < A_IT; ++i) ra[i] = load_a(i, kbeg + (kt + 1) * BK);
 #pragma unroll
-      for (int i = 0; i < B_IT; ++i) rb[i] = load_b(i, (kt + 1) * BK);
+      for (int i = 0; i < B_IT; ++i) rb[i] = load_b(i, kbeg + (kt + 1) * BK);
     }
     if constexpr (sizeof(T) == 4) {
 #pragma unroll
@@ -178,6 +193,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     __syncthreads();
   }
 
+  // ---- split-K: raw partial tile, the epilogue runs in k_splitk_reduce
+  if (p.splitk > 1) {
+    float* part = p.splitk_ws + (long)ks * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int row = m0 + wm * WTM + i * 16 + lq * 4 + r;
+        if (row >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          int col = n0 + wn * WTN + j * 16 + lr;
+          if (col < p.N) part[(long)row * p.N + col] = acc[i][j][r];
+        }
+      }
+    return;
+  }
+
   // ---- epilogue: C/D fragment layout col = lane & 15, row = (lane >> 4) * 4 + reg
   const int* rowmap = p.rowmap ? p.rowmap + z1 * p.sRowmap1 : nullptr;
   const long c_off = z1 * p.sC1 + z2 * p.sC2;
@@ -205,9 +238,69 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   }
 }
 
+// fixed-order reduction of the split-K partials + epilogue (f32 output only)
+__global__ void k_splitk_reduce(GemmP p) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = (long)p.M * p.N;
+  if (i >= total) return;
+  int row = (int)(i / p.N), col = (int)(i - (long)row * p.N);
+  float v = 0.f;
+  for (int s = 0; s < p.splitk; ++s) v += p.splitk_ws[(long)s * total + i];
+  v *= p.alpha;
+  if (p.bias) v += p.bias[col];
+  v = apply_act(v, p.act);
+  int rrow = p.res_mod > 0 ? row % p.res_mod : row;
+  if (p.res) v += p.res[(long)rrow * p.ldr + col];
+  ((float*)p.C)[(long)row * p.ldc + col] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// skinny f32 GEMM (M <= MT): wave -> 2 output columns, lanes stride K (float4), shuffle reduce
+// ---------------------------------------------------------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(256) void gemm_skinny_f32(GemmP p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n0 = (blockIdx.x * 4 + wave) * 2;
+  if (n0 >= p.N) return;
+  const bool two = n0 + 1 < p.N;
+  const float* A = (const float*)p.A;
+  const float* W0 = (const float*)p.W + (long)n0 * p.ldw;
+  const float* W1 = two ? W0 + p.ldw : W0;
+  float acc0[MT], acc1[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) acc0[m] = acc1[m] = 0.f;
+  for (int k = lane * 4; k < p.K; k += 256) {
+    float4 w0 = *(const float4*)(W0 + k), w1 = *(const float4*)(W1 + k);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      if (m < p.M) {
+        float4 a = *(const float4*)(A + (long)m * p.lda + k);
+        acc0[m] += a.x * w0.x + a.y * w0.y + a.z * w0.z + a.w * w0.w;
+        acc1[m] += a.x * w1.x + a.y * w1.y + a.z * w1.z + a.w * w1.w;
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    if (m < p.M) {
+      float s0 = wave_sum(acc0[m]), s1 = wave_sum(acc1[m]);
+      if (lane < 2 && (lane == 0 || two)) {
+        int col = n0 + lane;
+        float v = (lane == 0 ? s0 : s1) * p.alpha;
+        if (p.bias) v += p.bias[col];
+        v = apply_act(v, p.act);
+        int rrow = p.res_mod > 0 ? m % p.res_mod : m;
+        if (p.res) v += p.res[(long)rrow * p.ldr + col];
+        ((float*)p.C)[(long)m * p.ldc + col] = v;
+      }
+    }
+  }
+}
+
 template <typename T>
-static int gemm_dispatch(const GemmP& p, hipStream_t s) {
+static int gemm_dispatch(const GemmP& p_in, hipStream_t s) {
   constexpr int VEC = GT<T>::VEC;
+  GemmP p = p_in;
   if (!p.A || !p.W || !p.C || p.M <= 0 || p.N <= 0 || p.K <= 0) return SAMPT_ERR_ARG;
   if (p.K % VEC) return SAMPT_ERR_ARG;
   if (p.conv) {
@@ -218,24 +311,62 @@ static int gemm_dispatch(const GemmP& p, hipStream_t s) {
   if (p.w_kn ? (p.N % VEC || p.ldw % VEC) : (p.ldw % VEC)) return SAMPT_ERR_ARG;
   if (((uintptr_t)p.A | (uintptr_t)p.W) & 15) return SAMPT_ERR_ARG;
   if ((p.sA1 | p.sA2 | p.sW1 | p.sW2) % VEC) return SAMPT_ERR_ARG;
-  const bool big = p.M > 64 && p.N > 64;
-  const int BM = big ? 128 : 64, BN = BM;
-  dim3 grid(cdiv(p.N, BN), cdiv(p.M, BM), p.nb1 * p.nb2), block(256);
-#define LAUNCH(BMv, CONVv, KNv) \
-  hipLaunchKernelGGL((gemm_kernel<T, BMv, BMv, CONVv, KNv>), grid, block, 0, s, p)
-  if (p.w_kn) {
-    if constexpr (sizeof(T) == 4) {
-      if (big) LAUNCH(128, false, true); else LAUNCH(64, false, true);
-    } else {
-      return SAMPT_ERR_UNSUPPORTED;
+  const int batch = p.nb1 * p.nb2;
+  const bool plain = !p.conv && !p.w_kn && batch == 1 && !p.rowmap;
+
+  // ---- skinny path
+  if constexpr (sizeof(T) == 4) {
+    if (plain && p.M <= 32) {
+      p.splitk = 1;
+      dim3 grid(cdiv(p.N, 8)), block(256);
+      if (p.M <= 16) hipLaunchKernelGGL(gemm_skinny_f32<16>, grid, block, 0, s, p);
+      else hipLaunchKernelGGL(gemm_skinny_f32<32>, grid, block, 0, s, p);
+      SAMPT_CHECK_LAUNCH("gemm_skinny");
+      return SAMPT_OK;
     }
-  } else if (p.conv) {
-    if (big) LAUNCH(128, true, false); else LAUNCH(64, true, false);
+  }
+
+  // ---- tile selection: the big tile only when it still yields enough workgroups for 256 CUs
+  const long big_tiles = (long)cdiv(p.M, 128) * cdiv(p.N, 128) * batch;
+  const bool big = p.M > 64 && p.N > 64 && big_tiles >= 192;
+  const int BM = big ? 128 : 64, BN = BM;
+  const long tiles = (long)cdiv(p.M, BM) * cdiv(p.N, BN) * batch;
+  // ---- split-K for latency-bound shapes (few tiles, long K); deterministic two-stage reduction
+  p.splitk = 1;
+  if (plain && !p.out_f16 && p.splitk_ws && tiles < 128 && p.K >= 512) {
+    int want = (int)((255 + tiles) / tiles);
+    int maxs = p.K / 256;
+    int sk = want < maxs ? want : maxs;
+    if (sk > 16) sk = 16;
+    while (sk > 1 && (size_t)sk * p.M * p.N > p.splitk_ws_floats) --sk;
+    if (sk > 1) p.splitk = sk;
+  }
+  dim3 grid(cdiv(p.N, BN), cdiv(p.M, BM), batch * p.splitk), block(256);
+#define LAUNCH(BMv, BKv, CONVv, KNv) \
+  hipLaunchKernelGGL((gemm_kernel<T, BMv, BMv, BKv, CONVv, KNv>), grid, block, 0, s, p)
+  if constexpr (sizeof(T) == 4) {
+    if (p.w_kn) {
+      if (big) LAUNCH(128, 16, false, true); else LAUNCH(64, 16, false, true);
+    } else if (p.conv) {
+      if (big) LAUNCH(128, 32, true, false); else LAUNCH(64, 64, true, false);
+    } else {
+      if (big) LAUNCH(128, 32, false, false); else LAUNCH(64, 64, false, false);
+    }
   } else {
-    if (big) LAUNCH(128, false, false); else LAUNCH(64, false, false);
+    if (p.w_kn) return SAMPT_ERR_UNSUPPORTED;
+    if (p.conv) {
+      if (big) LAUNCH(128, 64, true, false); else LAUNCH(64, 64, true, false);
+    } else {
+      if (big) LAUNCH(128, 64, false, false); else LAUNCH(64, 64, false, false);
+    }
   }
 #undef LAUNCH
   SAMPT_CHECK_LAUNCH("gemm");
+  if (p.splitk > 1) {
+    long total = (long)p.M * p.N;
+    hipLaunchKernelGGL(k_splitk_reduce, dim3(cdiv(total, 256)), dim3(256), 0, s, p);
+    SAMPT_CHECK_LAUNCH("splitk_reduce");
+  }
   return SAMPT_OK;
 }
 

@@ -64,8 +64,9 @@ int pips_build_input(const float* ffeats, const float* coords, const float* time
 int pips_init_state(const float* xys, const float* feat_init, float stride, int S, int n, float* coords,
                     float* coords0, float* ffeats, hipStream_t s);
 // token-mixing PreNormResidual block of the MLP-Mixer, one workgroup per sequence (pips.py:116,120-121)
-int pips_token_mix(float* x, const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
-                   const float* b2, int nseq, int S, int D, hipStream_t s);
+// out of place: xo != x
+int pips_token_mix(const float* x, float* xo, const float* lnw, const float* lnb, const float* w1, const float* b1,
+                   const float* w2, const float* b2, int nseq, int S, int D, hipStream_t s);
 // mean over the S tokens of LN(x): out[n][D]
 int pips_ln_mean(const float* x, const float* lnw, const float* lnb, float* out, int nseq, int S, int D, hipStream_t s);
 // feature / coordinate update (pips.py:536-544): delta [n][S][130]; ffeats [n][S][128]; coords [S][n][2]
@@ -93,8 +94,10 @@ int sam_mask_dot(const float* up, const float* hyper, float* low_res, int npix, 
 int sam_postprocess(const float* low, int L, int img, int in_h, int in_w, float* out, int oh, int ow, hipStream_t s);
 // bbox state: int[5] = {xmin, ymin, xmax, ymax, count} of logits > 0 (the refinement box of sam_pt.py:809-820)
 int bbox_state_init(int* bbox, hipStream_t s);
+// bbox_partial: scratch of bbox_partial_ints(oh, ow) ints (deterministic two-stage reduction, no atomics)
+size_t bbox_partial_ints(int oh, int ow);
 int sam_postprocess_bbox(const float* low, int L, int img, int in_h, int in_w, float* out, int oh, int ow, int* bbox,
-                         hipStream_t s);
+                         int* bbox_partial, hipStream_t s);
 int bbox_from_logits_state(const float* logits, int h, int w, int* bbox_state, hipStream_t s);
 int bbox_to_float(const int* bbox, float* box_out, int* count_out, hipStream_t s);
 // mask-input embedding (PromptEncoder.mask_downscaling, App. A-4) fused with "src = image_embedding + dense":

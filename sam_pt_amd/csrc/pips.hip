@@ -169,22 +169,25 @@ int pips_init_state(const float* xys, const float* feat_init, float stride, int 
 // One workgroup per sequence; the 8 x 512 activations live in LDS.
 // ---------------------------------------------------------------------------------------------
 template <int S, int D>
-__global__ __launch_bounds__(256) void k_pips_token_mix(float* __restrict__ x, const float* __restrict__ lnw,
-                                                        const float* __restrict__ lnb, const float* __restrict__ w1,
-                                                        const float* __restrict__ b1, const float* __restrict__ w2,
-                                                        const float* __restrict__ b2) {
-  constexpr int H = 4 * S;
-  __shared__ float ys[S][D];
+__global__ __launch_bounds__(256) void k_pips_token_mix(const float* __restrict__ x, float* __restrict__ xo,
+                                                        const float* __restrict__ lnw, const float* __restrict__ lnb,
+                                                        const float* __restrict__ w1, const float* __restrict__ b1,
+                                                        const float* __restrict__ w2, const float* __restrict__ b2) {
+  // grid = (sequence, D/64 channel chunks).  Every workgroup recomputes the LayerNorm statistics of the 8 tokens
+  // (16 KiB of L2-resident reads) and then mixes its own 64 channels; out of place, so chunks never race.
+  constexpr int H = 4 * S, CH = 64;
+  __shared__ float stat[S][2];
   __shared__ float sw1[H][S], sb1[H], sw2[S][H], sb2[S];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float* xs = x + (long)blockIdx.x * S * D;
+  const float* xs = x + (long)blockIdx.x * S * D;
+  float* xos = xo + (long)blockIdx.x * S * D;
+  const int c0 = blockIdx.y * CH;
   for (int i = tid; i < H * S; i += 256) {
     ((float*)sw1)[i] = w1[i];
     ((float*)sw2)[i] = w2[i];
   }
   if (tid < H) sb1[tid] = b1[tid];
   if (tid < S) sb2[tid] = b2[tid];
-  // LayerNorm(512) of each token: one wave per token (2 tokens per wave)
   for (int tok = wave; tok < S; tok += 4) {
     float v[D / 64];
     float sum = 0.f;
@@ -201,38 +204,47 @@ __global__ __launch_bounds__(256) void k_pips_token_mix(float* __restrict__ x, c
       sq += d * d;
     }
     float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)D + 1e-5f);
-#pragma unroll
-    for (int i = 0; i < D / 64; ++i) {
-      int c = lane + 64 * i;
-      ys[tok][c] = (v[i] - mean) * rstd * lnw[c] + lnb[c];
-    }
+    if (lane == 0) stat[tok][0] = mean, stat[tok][1] = rstd;
   }
   __syncthreads();
-  for (int c = tid; c < D; c += 256) {
-    float y[S], h[H];
+  // thread -> (channel c, hidden-unit group og): 4 adjacent lanes share a channel and split the 32 hidden units
+  const int c = c0 + (tid >> 2), og = tid & 3;
+  const float gw = lnw[c], gb = lnb[c];
+  float xin[S], y[S];
 #pragma unroll
-    for (int t = 0; t < S; ++t) y[t] = ys[t][c];
-#pragma unroll
-    for (int o = 0; o < H; ++o) {
-      float a = sb1[o];
-#pragma unroll
-      for (int t = 0; t < S; ++t) a += sw1[o][t] * y[t];
-      h[o] = gelu_erf(a);
-    }
-#pragma unroll
-    for (int t = 0; t < S; ++t) {
-      float a = sb2[t];
-#pragma unroll
-      for (int o = 0; o < H; ++o) a += sw2[t][o] * h[o];
-      xs[t * D + c] += a;
-    }
+  for (int t = 0; t < S; ++t) {
+    xin[t] = xs[t * D + c];
+    y[t] = (xin[t] - stat[t][0]) * stat[t][1] * gw + gb;
   }
+  float part[S];
+#pragma unroll
+  for (int t = 0; t < S; ++t) part[t] = 0.f;
+#pragma unroll
+  for (int oo = 0; oo < H / 4; ++oo) {
+    const int o = og * (H / 4) + oo;
+    float a = sb1[o];
+#pragma unroll
+    for (int t = 0; t < S; ++t) a += sw1[o][t] * y[t];
+    const float h = gelu_erf(a);
+#pragma unroll
+    for (int t = 0; t < S; ++t) part[t] += sw2[t][o] * h;
+  }
+#pragma unroll
+  for (int t = 0; t < S; ++t) {
+    float a = part[t];
+    a += __shfl_xor(a, 1, 64);
+    a += __shfl_xor(a, 2, 64);
+    part[t] = a;
+  }
+#pragma unroll
+  for (int t = 0; t < S; ++t)
+    if ((t & 3) == og) xos[t * D + c] = xin[t] + (part[t] + sb2[t]);
 }
 
-int pips_token_mix(float* x, const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
-                   const float* b2, int nseq, int S, int D, hipStream_t s) {
-  if (S != 8 || D != 512 || nseq <= 0) return SAMPT_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((k_pips_token_mix<8, 512>), dim3(nseq), dim3(256), 0, s, x, lnw, lnb, w1, b1, w2, b2);
+int pips_token_mix(const float* x, float* xo, const float* lnw, const float* lnb, const float* w1, const float* b1,
+                   const float* w2, const float* b2, int nseq, int S, int D, hipStream_t s) {
+  if (S != 8 || D != 512 || nseq <= 0 || x == xo) return SAMPT_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL((k_pips_token_mix<8, 512>), dim3(nseq, D / 64), dim3(256), 0, s, x, xo, lnw, lnb, w1, b1, w2, b2);
   SAMPT_CHECK_LAUNCH("pips_token_mix");
   return SAMPT_OK;
 }

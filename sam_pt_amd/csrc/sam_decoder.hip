@@ -275,6 +275,8 @@ __global__ __launch_bounds__(256) void k_sam_postprocess(const float* __restrict
     pos = v > 0.f;
   }
   if (bbox) {
+    // deterministic two-stage reduction: per-workgroup partial {xmin,ymin,xmax,ymax,count} -> k_bbox_final
+    __shared__ int red[4][5];
     int xmin = pos ? x : 0x7fffffff, xmax = pos ? x : -1, ymin = pos ? y : 0x7fffffff, ymax = pos ? y : -1;
     int cnt = pos ? 1 : 0;
 #pragma unroll
@@ -285,15 +287,52 @@ __global__ __launch_bounds__(256) void k_sam_postprocess(const float* __restrict
       ymax = max(ymax, __shfl_xor(ymax, o, 64));
       cnt += __shfl_xor(cnt, o, 64);
     }
-    if ((threadIdx.x & 63) == 0 && cnt > 0) {
-      atomicMin(&bbox[0], xmin);
-      atomicMin(&bbox[1], ymin);
-      atomicMax(&bbox[2], xmax);
-      atomicMax(&bbox[3], ymax);
-      atomicAdd(&bbox[4], cnt);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+      red[wave][0] = xmin, red[wave][1] = ymin, red[wave][2] = xmax, red[wave][3] = ymax, red[wave][4] = cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int* o = bbox + 5 * (blockIdx.y * gridDim.x + blockIdx.x);
+      o[0] = min(min(red[0][0], red[1][0]), min(red[2][0], red[3][0]));
+      o[1] = min(min(red[0][1], red[1][1]), min(red[2][1], red[3][1]));
+      o[2] = max(max(red[0][2], red[1][2]), max(red[2][2], red[3][2]));
+      o[3] = max(max(red[0][3], red[1][3]), max(red[2][3], red[3][3]));
+      o[4] = red[0][4] + red[1][4] + red[2][4] + red[3][4];
     }
   }
 }
+
+__global__ __launch_bounds__(256) void k_bbox_final(const int* __restrict__ partial, int nblocks, int* __restrict__ bbox) {
+  __shared__ int red[4][5];
+  int xmin = 0x7fffffff, ymin = 0x7fffffff, xmax = -1, ymax = -1, cnt = 0;
+  for (int i = threadIdx.x; i < nblocks; i += 256) {
+    const int* o = partial + 5 * i;
+    xmin = min(xmin, o[0]), ymin = min(ymin, o[1]), xmax = max(xmax, o[2]), ymax = max(ymax, o[3]), cnt += o[4];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    xmin = min(xmin, __shfl_xor(xmin, o, 64));
+    xmax = max(xmax, __shfl_xor(xmax, o, 64));
+    ymin = min(ymin, __shfl_xor(ymin, o, 64));
+    ymax = max(ymax, __shfl_xor(ymax, o, 64));
+    cnt += __shfl_xor(cnt, o, 64);
+  }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    red[wave][0] = xmin, red[wave][1] = ymin, red[wave][2] = xmax, red[wave][3] = ymax, red[wave][4] = cnt;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    bbox[0] = min(min(red[0][0], red[1][0]), min(red[2][0], red[3][0]));
+    bbox[1] = min(min(red[0][1], red[1][1]), min(red[2][1], red[3][1]));
+    bbox[2] = max(max(red[0][2], red[1][2]), max(red[2][2], red[3][2]));
+    bbox[3] = max(max(red[0][3], red[1][3]), max(red[2][3], red[3][3]));
+    bbox[4] = red[0][4] + red[1][4] + red[2][4] + red[3][4];
+  }
+}
+
+size_t bbox_partial_ints(int oh, int ow) { return (size_t)5 * cdiv(ow, 64) * cdiv(oh, 4); }
 
 __global__ void k_bbox_state_init(int* bbox) {
   bbox[0] = 0x7fffffff;
@@ -310,17 +349,21 @@ int bbox_state_init(int* bbox, hipStream_t s) {
 }
 
 int sam_postprocess_bbox(const float* low, int L, int img, int in_h, int in_w, float* out, int oh, int ow, int* bbox,
-                         hipStream_t s) {
-  if (in_h > img || in_w > img) return SAMPT_ERR_ARG;
-  if (bbox) SAMPT_TRY(bbox_state_init(bbox, s));
-  hipLaunchKernelGGL(k_sam_postprocess, dim3(cdiv(ow, 64), cdiv(oh, 4)), dim3(256), 0, s, low, L, img, in_h, in_w, out,
-                     oh, ow, bbox);
+                         int* bbox_partial, hipStream_t s) {
+  if (in_h > img || in_w > img || (bbox && !bbox_partial)) return SAMPT_ERR_ARG;
+  dim3 grid(cdiv(ow, 64), cdiv(oh, 4));
+  hipLaunchKernelGGL(k_sam_postprocess, grid, dim3(256), 0, s, low, L, img, in_h, in_w, out, oh, ow,
+                     bbox ? bbox_partial : nullptr);
   SAMPT_CHECK_LAUNCH("sam_postprocess");
+  if (bbox) {
+    hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(256), 0, s, bbox_partial, (int)(grid.x * grid.y), bbox);
+    SAMPT_CHECK_LAUNCH("bbox_final");
+  }
   return SAMPT_OK;
 }
 
 int sam_postprocess(const float* low, int L, int img, int in_h, int in_w, float* out, int oh, int ow, hipStream_t s) {
-  return sam_postprocess_bbox(low, L, img, in_h, in_w, out, oh, ow, nullptr, s);
+  return sam_postprocess_bbox(low, L, img, in_h, in_w, out, oh, ow, nullptr, nullptr, s);
 }
 
 // standalone bbox of logits > 0
