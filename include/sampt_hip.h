@@ -93,29 +93,36 @@ int sampt_vit_encode(sampt_vit_t h, const uint8_t* frames_dev, int chw, int B, i
  * seam 2b — prompt encoder + mask decoder + postprocess = SamPredictor.predict_torch(multimask_output=False,
  * return_logits=True) as called at sam_pt.py:783-828.
  * --------------------------------------------------------------------------------------------------------- */
-int sampt_dec_create(const char* const* names, const void* const* ptrs, int n, int grid, int img_size, sampt_dec_t* out);
+/* max_frames: capacity of the frame batch of sampt_sam_track_decode (the packed pixel-shuffle row maps
+ * "mask_decoder.__up0_map" / "__up1_map" must cover it, see sam_pt_amd/pack.py). */
+int sampt_dec_create(const char* const* names, const void* const* ptrs, int n, int grid, int img_size, int max_frames,
+                     sampt_dec_t* out);
 void sampt_dec_destroy(sampt_dec_t h);
-int sampt_dec_workspace_bytes(sampt_dec_t h, int out_h, int out_w, size_t* bytes);
-/* features_dev [grid*grid][256]; pts_dev [k][2] (input-frame pixels), labels_dev int32 [k]; box_dev 4 floats or
- * NULL; mask_in_dev [4*grid][4*grid] low-res logits or NULL.  Outputs: logits_out_dev [out_h][out_w],
- * iou_out_dev [1], low_res_out_dev [4*grid][4*grid]. */
+int sampt_dec_workspace_bytes(sampt_dec_t h, int frames, int out_h, int out_w, size_t* bytes);
+/* One pass, one frame.  features_dev [grid*grid][256]; pts_dev [k][2] (input-frame pixels), labels_dev int32 [k];
+ * box_dev 4 floats or NULL; mask_in_dev [4*grid][4*grid] low-res logits or NULL.  Outputs: logits_out_dev
+ * [out_h][out_w], iou_out_dev [1], low_res_out_dev [4*grid][4*grid]. */
 int sampt_sam_decode(sampt_dec_t h, const float* features_dev, const float* pts_dev, const int32_t* labels_dev, int k,
                      const float* box_dev, const float* mask_in_dev, int in_h, int in_w, int out_h, int out_w,
                      float* logits_out_dev, float* iou_out_dev, float* low_res_out_dev, void* workspace_dev,
                      size_t workspace_bytes, sampt_stream_t stream);
-/* Whole SamPt.predict_mask chain for one (frame, object) (sam_pt.py:760-837) without host synchronisation:
+/* Whole SamPt.predict_mask chain (sam_pt.py:760-837) for `frames` independent (frame, object) items that share the
+ * visible-point count k, batched into one launch sequence and without host synchronisation:
  * [positives-only pass over the first n_pos_first points when n_pos_first >= 0, i.e. negative_points_per_mask > 0;
  * pass -1 for the single-pass case] -> all-points pass -> `refine_iters` box+mask refinement passes
- * (bbox of logits>0 and the `sum < 2 -> stop` rule evaluated on device) -> logits = -inf if iou < iou_thr.
- * final_logits_dev [out_h][out_w]; score_out_dev [1] = predicted IoU. */
-int sampt_sam_track_decode(sampt_dec_t h, const float* features_dev, const float* pts_dev, const int32_t* labels_dev,
-                           int k, int n_pos_first, int refine_iters, float iou_thr, int in_h, int in_w, int out_h,
-                           int out_w, float* final_logits_dev, float* score_out_dev, void* workspace_dev,
-                           size_t workspace_bytes, sampt_stream_t stream);
+ * (bbox of logits>0 and the `sum < 2 -> stop` rule evaluated per item on device) -> logits = -inf if iou < iou_thr.
+ * features_dev [frames][grid*grid][256]; pts_dev [frames][ld_pts][2]; labels_dev int32 [frames][ld_pts];
+ * final_logits_dev [frames][out_h][out_w]; score_out_dev [frames] = predicted IoU. */
+int sampt_sam_track_decode(sampt_dec_t h, int frames, const float* features_dev, const float* pts_dev,
+                           const int32_t* labels_dev, int k, int ld_pts, int n_pos_first, int refine_iters, float iou_thr,
+                           int in_h, int in_w, int out_h, int out_w, float* final_logits_dev, float* score_out_dev,
+                           void* workspace_dev, size_t workspace_bytes, sampt_stream_t stream);
 int sampt_postprocess_masks(const float* low_res_dev, int L, int img_size, int in_h, int in_w, float* out_dev, int out_h,
                             int out_w, sampt_stream_t stream);
 /* bbox_state_dev: int32[5] = {xmin, ymin, xmax, ymax, count} over logits > 0 (sam_pt.py:809-820). */
-int sampt_bbox_from_logits(const float* logits_dev, int h, int w, int32_t* bbox_state_dev, sampt_stream_t stream);
+size_t sampt_bbox_workspace_bytes(int h, int w);
+int sampt_bbox_from_logits(const float* logits_dev, int h, int w, int32_t* bbox_state_dev, void* workspace_dev,
+                           size_t workspace_bytes, sampt_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Kernel-level entry points (used by the parity tests and the roofline bench; same kernels the engines launch).

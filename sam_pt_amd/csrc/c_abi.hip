@@ -144,11 +144,13 @@ int sampt_vit_encode(sampt_vit_t h, const uint8_t* frames, int chw, int B, int H
 }
 
 // ------------------------------------------------------------------------------------------- decoder
-int sampt_dec_create(const char* const* names, const void* const* ptrs, int n, int grid, int img_size, sampt_dec_t* out) {
-  if (!names || !ptrs || !out) return SAMPT_ERR_ARG;
+int sampt_dec_create(const char* const* names, const void* const* ptrs, int n, int grid, int img_size, int max_frames,
+                     sampt_dec_t* out) {
+  if (!names || !ptrs || !out || max_frames <= 0) return SAMPT_ERR_ARG;
   sampt_dec* h = new sampt_dec();
   DecConfig c;
   c.grid = grid, c.img = img_size;
+  h->e.max_frames = max_frames;
   WeightMap w = make_map(names, ptrs, n);
   int rc = h->e.init(w, c);
   if (rc != SAMPT_OK) {
@@ -161,11 +163,12 @@ int sampt_dec_create(const char* const* names, const void* const* ptrs, int n, i
 }
 void sampt_dec_destroy(sampt_dec_t h) { delete h; }
 
-int sampt_dec_workspace_bytes(sampt_dec_t h, int oh, int ow, size_t* bytes) {
-  if (!h || !bytes) return SAMPT_ERR_ARG;
+int sampt_dec_workspace_bytes(sampt_dec_t h, int frames, int oh, int ow, size_t* bytes) {
+  if (!h || !bytes || frames <= 0 || frames > h->e.max_frames) return SAMPT_ERR_ARG;
   Arena a(nullptr, 0);
   float dummy = 0.f;
-  int rc = h->e.track_decode(&dummy, &dummy, nullptr, 32, 0, 1, 0.f, oh, ow, oh, ow, nullptr, nullptr, a, nullptr);
+  int rc = h->e.track_decode(frames, &dummy, &dummy, nullptr, 56, 56, 0, 1, 0.f, oh, ow, oh, ow, nullptr, nullptr, a,
+                             nullptr);
   *bytes = a.peak + 256;
   return rc;
 }
@@ -176,18 +179,20 @@ int sampt_sam_decode(sampt_dec_t h, const float* features, const float* pts, con
   if (!h || !features || !logits_out || !iou_out || !low_out || !ws || k < 0 || (k > 0 && (!pts || !labels)))
     return fail(SAMPT_ERR_ARG, "sampt_sam_decode: bad arguments");
   Arena a(ws, ws_bytes);
-  return h->e.decode(features, pts, labels, k, box, mask_in, in_h, in_w, oh, ow, logits_out, iou_out, low_out, nullptr,
-                     a, (hipStream_t)stream);
+  return h->e.decode(1, features, pts, labels, k, k > 0 ? k : 1, box, mask_in, in_h, in_w, oh, ow, logits_out, iou_out,
+                     low_out, nullptr, a, (hipStream_t)stream);
 }
 
-int sampt_sam_track_decode(sampt_dec_t h, const float* features, const float* pts, const int32_t* labels, int k,
-                           int n_pos_first, int refine_iters, float iou_thr, int in_h, int in_w, int oh, int ow,
-                           float* final_logits, float* score_out, void* ws, size_t ws_bytes, sampt_stream_t stream) {
-  if (!h || !features || !pts || !labels || !final_logits || !score_out || !ws || k <= 0 || n_pos_first > k)
+int sampt_sam_track_decode(sampt_dec_t h, int frames, const float* features, const float* pts, const int32_t* labels,
+                           int k, int ld_pts, int n_pos_first, int refine_iters, float iou_thr, int in_h, int in_w,
+                           int oh, int ow, float* final_logits, float* score_out, void* ws, size_t ws_bytes,
+                           sampt_stream_t stream) {
+  if (!h || !features || !pts || !labels || !final_logits || !score_out || !ws || k <= 0 || n_pos_first > k ||
+      ld_pts < k || frames <= 0 || frames > h->e.max_frames)
     return fail(SAMPT_ERR_ARG, "sampt_sam_track_decode: bad arguments");
   Arena a(ws, ws_bytes);
-  return h->e.track_decode(features, pts, labels, k, n_pos_first, refine_iters, iou_thr, in_h, in_w, oh, ow,
-                           final_logits, score_out, a, (hipStream_t)stream);
+  return h->e.track_decode(frames, features, pts, labels, k, ld_pts, n_pos_first, refine_iters, iou_thr, in_h, in_w, oh,
+                           ow, final_logits, score_out, a, (hipStream_t)stream);
 }
 
 int sampt_postprocess_masks(const float* low, int L, int img, int in_h, int in_w, float* out, int oh, int ow,
@@ -195,8 +200,12 @@ int sampt_postprocess_masks(const float* low, int L, int img, int in_h, int in_w
   return sam_postprocess(low, L, img, in_h, in_w, out, oh, ow, (hipStream_t)stream);
 }
 
-int sampt_bbox_from_logits(const float* logits, int h, int w, int32_t* bbox_state, sampt_stream_t stream) {
-  return bbox_from_logits_state(logits, h, w, (int*)bbox_state, (hipStream_t)stream);
+size_t sampt_bbox_workspace_bytes(int h, int w) { return bbox_partial_ints(h, w) * sizeof(int); }
+
+int sampt_bbox_from_logits(const float* logits, int h, int w, int32_t* bbox_state, void* ws, size_t ws_bytes,
+                           sampt_stream_t stream) {
+  if (!logits || !bbox_state || !ws || ws_bytes < sampt_bbox_workspace_bytes(h, w)) return SAMPT_ERR_WORKSPACE;
+  return bbox_from_logits_state(logits, h, w, (int*)bbox_state, (int*)ws, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------- kernel-level

@@ -107,6 +107,7 @@ struct DecConfig {
 
 struct DecEngine {
   DecConfig c;
+  int max_frames = 1;  // frame-batch capacity of the pixel-shuffle row maps
   struct Attn {
     const float *qw, *qb, *kw, *kb, *vw, *vb, *ow, *ob;
     int inner;
@@ -121,22 +122,24 @@ struct DecEngine {
   const float *gauss, *point_emb, *not_a_point, *no_mask, *dense_pe;
   MaskEmbedW me;
   const float *up0_w, *up0_b, *upln_w, *upln_b, *up1_w, *up1_b;  // ConvT weights packed [(dy,dx)][cout][cin]
-  const int *up0_map, *up1_map;                                   // pixel-shuffle row maps [4][g*g], [4][4*g*g]
+  const int *up0_map, *up1_map;                  // pixel-shuffle row maps [4][max_frames*g*g], [4][max_frames*4*g*g]
   const float *hyp_w[3], *hyp_b[3], *iou_w[3], *iou_b[3];         // hypernetwork MLP 0 and IoU head
   std::string error;
 
   int init(const WeightMap& w, const DecConfig& cfg);
-  // One predict_torch pass (multimask_output=False, return_logits=True).  pts/labels/box/mask_in: device.
-  // logits_out (oh x ow), iou_out (1), low_out (4g x 4g); bbox_out: optional int[5] state of logits > 0.
-  int decode(const float* features, const float* pts, const int* labels, int k, const float* box, const float* mask_in,
-             int in_h, int in_w, int oh, int ow, float* logits_out, float* iou_out, float* low_out, int* bbox_out,
-             Arena& ws, hipStream_t s);
-  // The whole per-(frame, object) chain of SamPt.predict_mask (sam_pt.py:760-837) on device, no host sync:
-  // pass 1 (positives only, when n_pos < k) -> pass 2 (all points + mask) -> R box-refinement passes gated on device
-  // -> IoU-threshold rejection.  final_logits (oh x ow) and score (1) are written.
-  int track_decode(const float* features, const float* pts, const int* labels, int k, int n_pos_first, int R,
-                   float iou_thr, int in_h, int in_w, int oh, int ow, float* final_logits, float* score_out, Arena& ws,
-                   hipStream_t s);
+  // One predict_torch pass (multimask_output=False, return_logits=True) for F frames with the same prompt shape.
+  // features [F][g*g][256]; pts [F][ld_pts][2], labels [F][ld_pts] (first k used); box [F][4] or null;
+  // mask_in [F][4g][4g] or null.  logits_out [F][oh][ow], iou_out [F], low_out [F][4g][4g];
+  // bbox_out: optional int [F][5] state of logits > 0.
+  int decode(int F, const float* features, const float* pts, const int* labels, int k, int ld_pts, const float* box,
+             const float* mask_in, int in_h, int in_w, int oh, int ow, float* logits_out, float* iou_out, float* low_out,
+             int* bbox_out, Arena& ws, hipStream_t s);
+  // The whole per-(frame, object) chain of SamPt.predict_mask (sam_pt.py:760-837) for F frames, no host sync:
+  // [positives-only pass when n_pos_first >= 0] -> all-points pass (+ mask) -> R box-refinement passes gated per frame
+  // on device -> IoU-threshold rejection.  final_logits [F][oh][ow], score_out [F].
+  int track_decode(int F, const float* features, const float* pts, const int* labels, int k, int ld_pts, int n_pos_first,
+                   int R, float iou_thr, int in_h, int in_w, int oh, int ow, float* final_logits, float* score_out,
+                   Arena& ws, hipStream_t s);
 };
 
 }  // namespace sampt

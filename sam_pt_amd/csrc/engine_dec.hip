@@ -1,9 +1,13 @@
 // SAM prompt encoder + two-way-transformer mask decoder + postprocess, fp32.
-// `decode` is one SamPredictor.predict_torch pass; `track_decode` chains the 1-2 + R passes that
-// SamPt.predict_mask issues per (frame, object) (sam_pt/modeling/sam_pt.py:760-837) entirely on the device:
-// the refinement box comes from an on-device bbox reduction and the reference's `m.sum() < 2 -> break` is a
-// device-side predicate (later passes still run but are not committed), so the chain has no host sync and a
-// launch sequence that depends only on the token count.
+//
+// `decode` is one SamPredictor.predict_torch pass for a BATCH of F independent frames that share the prompt-token
+// count; `track_decode` chains the 1-2 + R passes that SamPt.predict_mask issues per (frame, object)
+// (sam_pt/modeling/sam_pt.py:760-837) entirely on the device for all F frames at once:
+//   * frame batching: the reference decodes frame after frame; the chains of different frames are independent, so
+//     pass r of all frames is ONE launch sequence whose GEMMs have M = F*Nt token rows / F*4096 image rows;
+//   * the refinement box comes from an on-device bbox reduction and the reference's `m.sum() < 2 -> break` is a
+//     per-frame device-side predicate (later passes still run but are not committed): no host sync, and a launch
+//     sequence that depends only on the token count.
 #include "engine.h"
 
 namespace sampt {
@@ -66,11 +70,14 @@ int DecEngine::init(const WeightMap& w, const DecConfig& cfg) {
 namespace {
 struct L {
   hipStream_t s;
+  float* skws;
+  size_t skn;
   int lin(const float* A, int M, int K, const float* W, const float* b, float* C, int N, int act = ACT_NONE,
-          const float* res = nullptr) const {
+          const float* res = nullptr, int lda = 0) const {
     GemmP p;
     p.A = A, p.W = W, p.bias = b, p.C = C, p.res = res;
-    p.M = M, p.N = N, p.K = K, p.lda = K, p.ldw = K, p.ldc = N, p.ldr = N, p.act = act;
+    p.M = M, p.N = N, p.K = K, p.lda = lda ? lda : K, p.ldw = K, p.ldc = N, p.ldr = N, p.act = act;
+    p.splitk_ws = skws, p.splitk_ws_floats = skn;
     return gemm_f32(p, s);
   }
 };
@@ -80,151 +87,157 @@ struct Bufs {
 };
 }  // namespace
 
-// attention block: out = LN(resid + out_proj(attn(q_in Wq, k_in Wk, v_in Wv)))  (resid == nullptr: replace)
-static int attn_block(const L& l, const DecEngine::Attn& a, int heads, int C, const float* q_in, int Nq,
+// attention block over F frames: out = LN(resid + out_proj(attn(q_in Wq, k_in Wk, v_in Wv)))  (resid null: replace)
+static int attn_block(const L& l, const DecEngine::Attn& a, int heads, int C, int F, const float* q_in, int Nq,
                       const float* k_in, const float* v_in, int Nk, bool few_keys, Bufs& b, const float* resid,
                       float* out, const float* lnw, const float* lnb, hipStream_t s) {
-  SAMPT_TRY(l.lin(q_in, Nq, C, a.qw, a.qb, b.Q, a.inner));
-  SAMPT_TRY(l.lin(k_in, Nk, C, a.kw, a.kb, b.K, a.inner));
-  SAMPT_TRY(l.lin(v_in, Nk, C, a.vw, a.vb, b.V, a.inner));
+  SAMPT_TRY(l.lin(q_in, F * Nq, C, a.qw, a.qb, b.Q, a.inner));
+  SAMPT_TRY(l.lin(k_in, F * Nk, C, a.kw, a.kb, b.K, a.inner));
+  SAMPT_TRY(l.lin(v_in, F * Nk, C, a.vw, a.vb, b.V, a.inner));
   const int hd = a.inner / heads;
-  if (few_keys) SAMPT_TRY(attn_fewkeys(b.Q, b.K, b.V, b.att, Nq, Nk, heads, hd, s));
-  else SAMPT_TRY(attn_rowblock(b.Q, b.K, b.V, b.att, Nq, Nk, heads, hd, s));
-  SAMPT_TRY(l.lin(b.att, Nq, a.inner, a.ow, a.ob, out, C, ACT_NONE, resid));
-  return layernorm_rows(out, lnw, lnb, out, Nq, C, 1e-5f, nullptr, 0, ACT_NONE, s);
+  if (few_keys) SAMPT_TRY(attn_fewkeys(b.Q, b.K, b.V, b.att, F, Nq, Nk, heads, hd, s));
+  else SAMPT_TRY(attn_rowblock(b.Q, b.K, b.V, b.att, F, Nq, Nk, heads, hd, s));
+  SAMPT_TRY(l.lin(b.att, F * Nq, a.inner, a.ow, a.ob, out, C, ACT_NONE, resid));
+  return layernorm_rows(out, lnw, lnb, out, (long)F * Nq, C, 1e-5f, nullptr, 0, ACT_NONE, s);
 }
 
-int DecEngine::decode(const float* features, const float* pts, const int* labels, int k, const float* box,
-                      const float* mask_in, int in_h, int in_w, int oh, int ow, float* logits_out, float* iou_out,
-                      float* low_out, int* bbox_out, Arena& ws, hipStream_t s) {
+int DecEngine::decode(int F, const float* features, const float* pts, const int* labels, int k, int ld_pts,
+                      const float* box, const float* mask_in, int in_h, int in_w, int oh, int ow, float* logits_out,
+                      float* iou_out, float* low_out, int* bbox_out, Arena& ws, hipStream_t s) {
   const int g = c.grid, P = g * g, C = c.C, H = c.heads;
   const int nsparse = k + (box ? 2 : 1), Nt = 5 + nsparse;
-  if (Nt > 64 || k < 0) return SAMPT_ERR_UNSUPPORTED;
+  if (Nt > 64 || k < 0 || F <= 0 || F > max_frames) return SAMPT_ERR_UNSUPPORTED;
+  const size_t FP = (size_t)F * P, FT = (size_t)F * Nt;
   Bufs b;
-  b.tokens = ws.f32((size_t)Nt * C);
-  float* queries = ws.f32((size_t)Nt * C);
-  b.qin = ws.f32((size_t)Nt * C);
-  b.kin = ws.f32((size_t)P * C);
-  b.keys = ws.f32((size_t)P * C);
-  b.Q = ws.f32((size_t)P * C);
-  b.K = ws.f32((size_t)P * C);
-  b.V = ws.f32((size_t)P * C);
-  b.att = ws.f32((size_t)P * C);
-  b.hid = ws.f32((size_t)Nt * c.mlp);
-  b.up0 = ws.f32((size_t)4 * P * (C / 4));
-  b.up1 = ws.f32((size_t)16 * P * (C / 8));
-  b.t0 = ws.f32(C), b.t1 = ws.f32(C), b.t2 = ws.f32(C);
-  b.me0 = ws.f32((size_t)4 * P * 4), b.me1 = ws.f32((size_t)P * 16);
-  int* bbox_partial = (int*)ws.get(bbox_partial_ints(oh, ow) * sizeof(int));
+  b.tokens = ws.f32(FT * C);
+  float* queries = ws.f32(FT * C);
+  b.qin = ws.f32(FT * C);
+  b.kin = ws.f32(FP * C);
+  b.keys = ws.f32(FP * C);
+  b.Q = ws.f32(FP * C);
+  b.K = ws.f32(FP * C);
+  b.V = ws.f32(FP * C);
+  b.att = ws.f32(FP * C);
+  b.hid = ws.f32(FT * c.mlp);
+  b.up0 = ws.f32(4 * FP * (C / 4));
+  b.up1 = ws.f32(16 * FP * (C / 8));
+  b.t0 = ws.f32((size_t)F * C), b.t1 = ws.f32((size_t)F * C), b.t2 = ws.f32((size_t)F * C);
+  b.me0 = ws.f32(4 * FP * 4), b.me1 = ws.f32(FP * 16);
+  int* bbox_partial = (int*)ws.get((size_t)F * bbox_partial_ints(oh, ow) * sizeof(int));
+  const size_t skn = (size_t)16 * FT * C;
+  float* skws = ws.f32(skn);
   if (!ws.ok()) return SAMPT_ERR_WORKSPACE;
   if (ws.dry()) return SAMPT_OK;
-  L l{s};
+  L l{s, skws, skn};
 
   // ---- prompt encoder
-  if (hipMemcpyAsync(b.tokens, out_tokens, sizeof(float) * 5 * C, hipMemcpyDeviceToDevice, s) != hipSuccess)
-    return SAMPT_ERR_HIP;
-  SAMPT_TRY(sam_prompt_tokens(pts, labels, k, box, gauss, point_emb, not_a_point, (float)c.img, b.tokens + 5 * C, s));
-  if (mask_in) SAMPT_TRY(sam_mask_embed_src(mask_in, g, me, features, b.me0, b.me1, b.keys, s));
-  else SAMPT_TRY(add_bcast(features, no_mask, b.keys, (long)P * C, C, s));
+  SAMPT_TRY(sam_tokens(out_tokens, pts, labels, k, ld_pts, box, gauss, point_emb, not_a_point, (float)c.img, F, b.tokens, s));
+  if (mask_in) SAMPT_TRY(sam_mask_embed_src(mask_in, g, F, me, features, b.me0, b.me1, b.keys, s));
+  else SAMPT_TRY(add_bcast(features, no_mask, b.keys, (long)FP * C, C, s));
 
   // ---- two-way transformer: query PE = the prompt tokens, key PE = dense positional encoding
   const float* qpe = b.tokens;
+  const long nT = (long)FT * C, nP = (long)FP * C, pe_mod = (long)P * C;
   for (int i = 0; i < c.depth; ++i) {
     const Layer& Ly = layer[i];
     if (i == 0) {
-      SAMPT_TRY(attn_block(l, Ly.self, H, C, b.tokens, Nt, b.tokens, b.tokens, Nt, false, b, nullptr, queries, Ly.n1w,
+      SAMPT_TRY(attn_block(l, Ly.self, H, C, F, b.tokens, Nt, b.tokens, b.tokens, Nt, false, b, nullptr, queries, Ly.n1w,
                            Ly.n1b, s));
     } else {
-      SAMPT_TRY(add_bcast(queries, qpe, b.qin, (long)Nt * C, (long)Nt * C, s));
-      SAMPT_TRY(attn_block(l, Ly.self, H, C, b.qin, Nt, b.qin, queries, Nt, false, b, queries, queries, Ly.n1w, Ly.n1b, s));
+      SAMPT_TRY(add_bcast(queries, qpe, b.qin, nT, nT, s));
+      SAMPT_TRY(attn_block(l, Ly.self, H, C, F, b.qin, Nt, b.qin, queries, Nt, false, b, queries, queries, Ly.n1w, Ly.n1b, s));
     }
     // tokens -> image
-    SAMPT_TRY(add_bcast(queries, qpe, b.qin, (long)Nt * C, (long)Nt * C, s));
-    SAMPT_TRY(add_bcast(b.keys, dense_pe, b.kin, (long)P * C, (long)P * C, s));
-    SAMPT_TRY(attn_block(l, Ly.t2i, H, C, b.qin, Nt, b.kin, b.keys, P, false, b, queries, queries, Ly.n2w, Ly.n2b, s));
+    SAMPT_TRY(add_bcast(queries, qpe, b.qin, nT, nT, s));
+    SAMPT_TRY(add_bcast(b.keys, dense_pe, b.kin, nP, pe_mod, s));
+    SAMPT_TRY(attn_block(l, Ly.t2i, H, C, F, b.qin, Nt, b.kin, b.keys, P, false, b, queries, queries, Ly.n2w, Ly.n2b, s));
     // MLP (ReLU)
-    SAMPT_TRY(l.lin(queries, Nt, C, Ly.m1w, Ly.m1b, b.hid, c.mlp, ACT_RELU));
-    SAMPT_TRY(l.lin(b.hid, Nt, c.mlp, Ly.m2w, Ly.m2b, queries, C, ACT_NONE, queries));
-    SAMPT_TRY(layernorm_rows(queries, Ly.n3w, Ly.n3b, queries, Nt, C, 1e-5f, nullptr, 0, ACT_NONE, s));
+    SAMPT_TRY(l.lin(queries, (int)FT, C, Ly.m1w, Ly.m1b, b.hid, c.mlp, ACT_RELU));
+    SAMPT_TRY(l.lin(b.hid, (int)FT, c.mlp, Ly.m2w, Ly.m2b, queries, C, ACT_NONE, queries));
+    SAMPT_TRY(layernorm_rows(queries, Ly.n3w, Ly.n3b, queries, (long)FT, C, 1e-5f, nullptr, 0, ACT_NONE, s));
     // image -> tokens
-    SAMPT_TRY(add_bcast(queries, qpe, b.qin, (long)Nt * C, (long)Nt * C, s));
-    SAMPT_TRY(attn_block(l, Ly.i2t, H, C, b.kin, P, b.qin, queries, Nt, true, b, b.keys, b.keys, Ly.n4w, Ly.n4b, s));
+    SAMPT_TRY(add_bcast(queries, qpe, b.qin, nT, nT, s));
+    SAMPT_TRY(attn_block(l, Ly.i2t, H, C, F, b.kin, P, b.qin, queries, Nt, true, b, b.keys, b.keys, Ly.n4w, Ly.n4b, s));
   }
-  SAMPT_TRY(add_bcast(queries, qpe, b.qin, (long)Nt * C, (long)Nt * C, s));
-  SAMPT_TRY(add_bcast(b.keys, dense_pe, b.kin, (long)P * C, (long)P * C, s));
-  SAMPT_TRY(attn_block(l, fin, H, C, b.qin, Nt, b.kin, b.keys, P, false, b, queries, queries, nfw, nfb, s));
+  SAMPT_TRY(add_bcast(queries, qpe, b.qin, nT, nT, s));
+  SAMPT_TRY(add_bcast(b.keys, dense_pe, b.kin, nP, pe_mod, s));
+  SAMPT_TRY(attn_block(l, fin, H, C, F, b.qin, Nt, b.kin, b.keys, P, false, b, queries, queries, nfw, nfb, s));
 
-  // ---- upscaling: ConvT2x2s2 (C -> C/4) + LN2d + GELU ; ConvT2x2s2 (C/4 -> C/8) + GELU   (pixel shuffle via row maps)
+  // ---- upscaling: ConvT2x2s2 (C -> C/4) + LN2d + GELU ; ConvT2x2s2 (C/4 -> C/8) + GELU   (pixel shuffle via row maps
+  //      that cover max_frames frames: map[(dy,dx)][f*P + p] = f*4P + (2y+dy)*2g + 2x+dx)
   {
     GemmP p;
     p.A = b.keys, p.W = up0_w, p.bias = up0_b, p.C = b.up0, p.rowmap = up0_map;
-    p.M = P, p.N = C / 4, p.K = C, p.lda = C, p.ldw = C, p.ldc = C / 4;
-    p.nb1 = 4, p.sW1 = (long)(C / 4) * C, p.sRowmap1 = P;
+    p.M = (int)FP, p.N = C / 4, p.K = C, p.lda = C, p.ldw = C, p.ldc = C / 4;
+    p.nb1 = 4, p.sW1 = (long)(C / 4) * C, p.sRowmap1 = (long)max_frames * P;
     SAMPT_TRY(gemm_f32(p, s));
-    SAMPT_TRY(layernorm_rows(b.up0, upln_w, upln_b, b.up0, 4L * P, C / 4, 1e-6f, nullptr, 0, ACT_GELU, s));
+    SAMPT_TRY(layernorm_rows(b.up0, upln_w, upln_b, b.up0, 4L * FP, C / 4, 1e-6f, nullptr, 0, ACT_GELU, s));
     GemmP q;
     q.A = b.up0, q.W = up1_w, q.bias = up1_b, q.C = b.up1, q.rowmap = up1_map;
-    q.M = 4 * P, q.N = C / 8, q.K = C / 4, q.lda = C / 4, q.ldw = C / 4, q.ldc = C / 8, q.act = ACT_GELU;
-    q.nb1 = 4, q.sW1 = (long)(C / 8) * (C / 4), q.sRowmap1 = 4L * P;
+    q.M = (int)(4 * FP), q.N = C / 8, q.K = C / 4, q.lda = C / 4, q.ldw = C / 4, q.ldc = C / 8, q.act = ACT_GELU;
+    q.nb1 = 4, q.sW1 = (long)(C / 8) * (C / 4), q.sRowmap1 = 4L * max_frames * P;
     SAMPT_TRY(gemm_f32(q, s));
   }
-  // ---- hypernetwork MLP of mask token 0 (multimask_output=False keeps slice 0 only) and the IoU head
+  // ---- hypernetwork MLP of mask token 0 (multimask_output=False keeps slice 0 only) and the IoU head;
+  //      A = row 1 (mask token 0) / row 0 (iou token) of every frame's token matrix: lda = Nt*C
   const float* mask_tok = queries + 1 * C;
-  SAMPT_TRY(l.lin(mask_tok, 1, C, hyp_w[0], hyp_b[0], b.t0, C, ACT_RELU));
-  SAMPT_TRY(l.lin(b.t0, 1, C, hyp_w[1], hyp_b[1], b.t1, C, ACT_RELU));
-  SAMPT_TRY(l.lin(b.t1, 1, C, hyp_w[2], hyp_b[2], b.t2, C / 8, ACT_NONE));
-  SAMPT_TRY(sam_mask_dot(b.up1, b.t2, low_out, 16 * P, C / 8, s));
-  SAMPT_TRY(l.lin(queries, 1, C, iou_w[0], iou_b[0], b.t0, C, ACT_RELU));
-  SAMPT_TRY(l.lin(b.t0, 1, C, iou_w[1], iou_b[1], b.t1, C, ACT_RELU));
-  SAMPT_TRY(l.lin(b.t1, 1, C, iou_w[2], iou_b[2], iou_out, 1, ACT_NONE));  // N = 1: only IoU slot 0 is needed
-  // ---- Sam.postprocess_masks
-  SAMPT_TRY(sam_postprocess_bbox(low_out, 4 * g, c.img, in_h, in_w, logits_out, oh, ow, bbox_out, bbox_partial, s));
+  SAMPT_TRY(l.lin(mask_tok, F, C, hyp_w[0], hyp_b[0], b.t0, C, ACT_RELU, nullptr, Nt * C));
+  SAMPT_TRY(l.lin(b.t0, F, C, hyp_w[1], hyp_b[1], b.t1, C, ACT_RELU));
+  SAMPT_TRY(l.lin(b.t1, F, C, hyp_w[2], hyp_b[2], b.t2, C / 8, ACT_NONE));
+  SAMPT_TRY(sam_mask_dot(b.up1, b.t2, C / 8, low_out, F, 16 * P, C / 8, s));
+  SAMPT_TRY(l.lin(queries, F, C, iou_w[0], iou_b[0], b.t0, C, ACT_RELU, nullptr, Nt * C));
+  SAMPT_TRY(l.lin(b.t0, F, C, iou_w[1], iou_b[1], b.t1, C, ACT_RELU));
+  SAMPT_TRY(l.lin(b.t1, F, C, iou_w[2], iou_b[2], iou_out, 1, ACT_NONE));  // N = 1: only IoU slot 0 is needed
+  // ---- Sam.postprocess_masks (+ bbox of logits > 0)
+  SAMPT_TRY(sam_postprocess_bbox(low_out, 4 * g, c.img, in_h, in_w, logits_out, oh, ow, F, bbox_out, bbox_partial, s));
   return SAMPT_OK;
 }
 
-int DecEngine::track_decode(const float* features, const float* pts, const int* labels, int k, int n_pos_first, int R,
-                            float iou_thr, int in_h, int in_w, int oh, int ow, float* final_logits, float* score_out,
-                            Arena& ws, hipStream_t s) {
+int DecEngine::track_decode(int F, const float* features, const float* pts, const int* labels, int k, int ld_pts,
+                            int n_pos_first, int R, float iou_thr, int in_h, int in_w, int oh, int ow,
+                            float* final_logits, float* score_out, Arena& ws, hipStream_t s) {
   const int g = c.grid, Lr = 4 * g;
   const long nlog = (long)oh * ow, nlow = (long)Lr * Lr;
-  float* cur_logits = ws.f32(nlog);
-  float* cand_logits = ws.f32(nlog);
-  float* cur_low = ws.f32(nlow);
-  float* cand_low = ws.f32(nlow);
-  float* low0 = ws.f32(nlow);
-  float* scal = ws.f32(16);                 // [0] cur iou, [1] cand iou, [4..7] refinement box
-  int* ist = (int*)ws.get(16 * sizeof(int));  // [0..4] cur bbox, [5..9] cand bbox, [10] active
+  float* cur_logits = ws.f32((size_t)F * nlog);
+  float* cand_logits = ws.f32((size_t)F * nlog);
+  float* cur_low = ws.f32((size_t)F * nlow);
+  float* cand_low = ws.f32((size_t)F * nlow);
+  float* low0 = ws.f32((size_t)F * nlow);
+  float* cur_iou = ws.f32(F);
+  float* cand_iou = ws.f32(F);
+  float* boxf = ws.f32((size_t)F * 4);
+  int* cur_bb = (int*)ws.get((size_t)F * 5 * sizeof(int));
+  int* cand_bb = (int*)ws.get((size_t)F * 5 * sizeof(int));
+  int* active = (int*)ws.get((size_t)F * sizeof(int));
   size_t mark = ws.off;
-  // measure the per-pass scratch once (all passes reuse it)
-  if (ws.dry()) {
-    SAMPT_TRY(decode(features, pts, labels, k, pts, cur_low, in_h, in_w, oh, ow, cur_logits, scal, cur_low, ist, ws, s));
+  if (ws.dry()) {  // measure the per-pass scratch once (all passes reuse it); box + mask = the largest variant
+    SAMPT_TRY(decode(F, features, pts, labels, k, ld_pts, pts, cur_low, in_h, in_w, oh, ow, cur_logits, cur_iou, cur_low,
+                     cur_bb, ws, s));
     return SAMPT_OK;
   }
   if (!ws.ok()) return SAMPT_ERR_WORKSPACE;
-  float *cur_iou = scal, *cand_iou = scal + 1, *boxf = scal + 4;
-  int *cur_bb = ist, *cand_bb = ist + 5, *active = ist + 10;
   const float* mask_in = nullptr;
   if (n_pos_first >= 0) {  // negative_points_per_mask > 0 (sam_pt.py:791-807): positives only, then all + low-res mask
     ws.off = mark;
-    SAMPT_TRY(decode(features, pts, labels, n_pos_first, nullptr, nullptr, in_h, in_w, oh, ow, cand_logits, cand_iou,
-                     low0, nullptr, ws, s));
+    SAMPT_TRY(decode(F, features, pts, labels, n_pos_first, ld_pts, nullptr, nullptr, in_h, in_w, oh, ow, cand_logits,
+                     cand_iou, low0, nullptr, ws, s));
     mask_in = low0;
   }
   ws.off = mark;
-  SAMPT_TRY(decode(features, pts, labels, k, nullptr, mask_in, in_h, in_w, oh, ow, cur_logits, cur_iou, cur_low, cur_bb,
-                   ws, s));
+  SAMPT_TRY(decode(F, features, pts, labels, k, ld_pts, nullptr, mask_in, in_h, in_w, oh, ow, cur_logits, cur_iou, cur_low,
+                   cur_bb, ws, s));
   if (R > 0) {
-    if (hipMemsetAsync(active, 0xff, sizeof(int), s) != hipSuccess) return SAMPT_ERR_HIP;
+    if (hipMemsetAsync(active, 0xff, sizeof(int) * F, s) != hipSuccess) return SAMPT_ERR_HIP;
     for (int r = 0; r < R; ++r) {
-      SAMPT_TRY(sam_refine_gate(active, cur_bb, boxf, s));
+      SAMPT_TRY(sam_refine_gate(active, cur_bb, boxf, F, s));
       ws.off = mark;
-      SAMPT_TRY(decode(features, pts, labels, k, boxf, cur_low, in_h, in_w, oh, ow, cand_logits, cand_iou, cand_low,
-                       cand_bb, ws, s));
+      SAMPT_TRY(decode(F, features, pts, labels, k, ld_pts, boxf, cur_low, in_h, in_w, oh, ow, cand_logits, cand_iou,
+                       cand_low, cand_bb, ws, s));
       SAMPT_TRY(sam_commit(active, cand_logits, cur_logits, nlog, cand_low, cur_low, nlow, cand_iou, cur_iou, cand_bb,
-                           cur_bb, s));
+                           cur_bb, F, s));
     }
   }
-  return sam_finalize_mask(cur_logits, cur_iou, iou_thr, final_logits, score_out, nlog, s);
+  return sam_finalize_mask(cur_logits, cur_iou, iou_thr, final_logits, score_out, nlog, F, s);
 }
 
 }  // namespace sampt

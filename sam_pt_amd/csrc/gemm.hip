@@ -271,13 +271,14 @@ __global__ __launch_bounds__(256) void gemm_skinny_f32(GemmP p) {
   for (int m = 0; m < MT; ++m) acc0[m] = acc1[m] = 0.f;
   for (int k = lane * 4; k < p.K; k += 256) {
     float4 w0 = *(const float4*)(W0 + k), w1 = *(const float4*)(W1 + k);
+    // branch-free: rows beyond M re-read row M-1 (a per-row branch makes hipcc serialise the loads behind vmcnt(0))
+    float4 a[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) a[m] = *(const float4*)(A + (long)(m < p.M ? m : p.M - 1) * p.lda + k);
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-      if (m < p.M) {
-        float4 a = *(const float4*)(A + (long)m * p.lda + k);
-        acc0[m] += a.x * w0.x + a.y * w0.y + a.z * w0.z + a.w * w0.w;
-        acc1[m] += a.x * w1.x + a.y * w1.y + a.z * w1.z + a.w * w1.w;
-      }
+      acc0[m] += a[m].x * w0.x + a[m].y * w0.y + a[m].z * w0.z + a[m].w * w0.w;
+      acc1[m] += a[m].x * w1.x + a[m].y * w1.y + a[m].z * w1.z + a[m].w * w1.w;
     }
   }
 #pragma unroll
@@ -316,11 +317,11 @@ static int gemm_dispatch(const GemmP& p_in, hipStream_t s) {
 
   // ---- skinny path
   if constexpr (sizeof(T) == 4) {
-    if (plain && p.M <= 32) {
+    if (plain && p.M <= 16) {
       p.splitk = 1;
       dim3 grid(cdiv(p.N, 8)), block(256);
-      if (p.M <= 16) hipLaunchKernelGGL(gemm_skinny_f32<16>, grid, block, 0, s, p);
-      else hipLaunchKernelGGL(gemm_skinny_f32<32>, grid, block, 0, s, p);
+      if (p.M <= 4) hipLaunchKernelGGL(gemm_skinny_f32<4>, grid, block, 0, s, p);
+      else hipLaunchKernelGGL(gemm_skinny_f32<16>, grid, block, 0, s, p);
       SAMPT_CHECK_LAUNCH("gemm_skinny");
       return SAMPT_OK;
     }

@@ -77,44 +77,43 @@ int pips_update(const float* delta, const float* gn_w, const float* gn_b, const 
 int pips_finalize(const float* ffeats, const float* vis_w, const float* vis_b, const float* coords, float stride,
                   int S, int n, float* traj, float* vis, hipStream_t s);
 
-// ---- sam_decoder.hip --------------------------------------------------------------------------
-// sparse prompt tokens (App. A-4). points xy in input-frame px (device), labels i32 (device), box 4 f32 (device) or null.
-int sam_prompt_tokens(const float* pts, const int* labels, int k, const float* box, const float* gauss,
-                      const float* point_emb /*[4][256]*/, const float* not_a_point, float img_size, float* tokens_out,
-                      hipStream_t s);
-// small f32 attention, one workgroup per (query, head): q [Nq][H*hd], k,v [Nk][H*hd] -> out [Nq][H*hd]
-int attn_rowblock(const float* q, const float* k, const float* v, float* out, int Nq, int Nk, int heads, int hd,
+// ---- sam_decoder.hip (every launcher takes the frame batch F; tensors are [F][...] contiguous) ---------------
+// decoder tokens [F][Nt][256] (Nt = 5 + k + (box ? 2 : 1)): out tokens, then the sparse prompt tokens (App. A-4).
+// pts [F][ld_pts][2] input-frame px, labels [F][ld_pts] i32, box [F][4] or null.
+int sam_tokens(const float* out_tokens, const float* pts, const int* labels, int k, int ld_pts, const float* box,
+               const float* gauss, const float* point_emb /*[4][256]*/, const float* not_a_point, float img_size, int F,
+               float* tokens, hipStream_t s);
+// small f32 attention, one workgroup per (query, head, frame): q [F][Nq][H*hd], k,v [F][Nk][H*hd]
+int attn_rowblock(const float* q, const float* k, const float* v, float* out, int F, int Nq, int Nk, int heads, int hd,
                   hipStream_t s);
 // small f32 attention with few keys (Nk <= 64): one thread per (query, head)
-int attn_fewkeys(const float* q, const float* k, const float* v, float* out, int Nq, int Nk, int heads, int hd,
+int attn_fewkeys(const float* q, const float* k, const float* v, float* out, int F, int Nq, int Nk, int heads, int hd,
                  hipStream_t s);
-// low_res[p] = <hyper[32], up[p][32]>
-int sam_mask_dot(const float* up, const float* hyper, float* low_res, int npix, int C, hipStream_t s);
+// low_res[f][p] = <hyper[f][0:C], up[f][p][0:C]>
+int sam_mask_dot(const float* up, const float* hyper, int ld_hyper, float* low_res, int F, int npix, int C, hipStream_t s);
 // fused Sam.postprocess_masks: low (L x L) -> bilinear to (img x img) -> crop (in_h,in_w) -> bilinear to (oh,ow)
 int sam_postprocess(const float* low, int L, int img, int in_h, int in_w, float* out, int oh, int ow, hipStream_t s);
-// bbox state: int[5] = {xmin, ymin, xmax, ymax, count} of logits > 0 (the refinement box of sam_pt.py:809-820)
-int bbox_state_init(int* bbox, hipStream_t s);
-// bbox_partial: scratch of bbox_partial_ints(oh, ow) ints (deterministic two-stage reduction, no atomics)
+// bbox state per frame: int[5] = {xmin, ymin, xmax, ymax, count} of logits > 0 (refinement box of sam_pt.py:809-820);
+// bbox_partial: scratch of F * bbox_partial_ints(oh, ow) ints (deterministic two-stage reduction, no atomics)
 size_t bbox_partial_ints(int oh, int ow);
-int sam_postprocess_bbox(const float* low, int L, int img, int in_h, int in_w, float* out, int oh, int ow, int* bbox,
-                         int* bbox_partial, hipStream_t s);
-int bbox_from_logits_state(const float* logits, int h, int w, int* bbox_state, hipStream_t s);
-int bbox_to_float(const int* bbox, float* box_out, int* count_out, hipStream_t s);
+int sam_postprocess_bbox(const float* low, int L, int img, int in_h, int in_w, float* out, int oh, int ow, int F,
+                         int* bbox, int* bbox_partial, hipStream_t s);
+int bbox_from_logits_state(const float* logits, int h, int w, int* bbox_state, int* bbox_partial, hipStream_t s);
 // mask-input embedding (PromptEncoder.mask_downscaling, App. A-4) fused with "src = image_embedding + dense":
 //   mask (4g x 4g) -> conv2x2s2(1->c1) LN2d GELU -> conv2x2s2(c1->c2) LN2d GELU -> conv1x1(c2->256) ; src = feat + dense
 struct MaskEmbedW {
   const float *w0, *b0, *ln0w, *ln0b, *w1, *b1, *ln1w, *ln1b, *w2, *b2;  // torch layouts [out][in][kh][kw]
 };
-int sam_mask_embed_src(const float* mask, int g, const MaskEmbedW& w, const float* feat, float* tmp0, float* tmp1,
-                       float* src, hipStream_t s);
-// refinement gating (sam_pt.py:809-811): st = {active, ...}; active &= count(bbox_cur) >= 2 ; box_f = bbox_cur
-int sam_refine_gate(int* active, const int* bbox_cur, float* box_f, hipStream_t s);
-// if *active: cur <- cand for logits (n_logits), low-res (n_low), iou (1 float) and the bbox state (5 ints)
+int sam_mask_embed_src(const float* mask, int g, int F, const MaskEmbedW& w, const float* feat, float* tmp0,
+                       float* tmp1, float* src, hipStream_t s);
+// refinement gating (sam_pt.py:809-811): active[f] &= count(bbox_cur[f]) >= 2 ; box_f[f] = bbox_cur[f]
+int sam_refine_gate(int* active, const int* bbox_cur, float* box_f, int F, hipStream_t s);
+// where active[f]: cur <- cand for logits (n_logits), low-res (n_low), iou and the bbox state
 int sam_commit(const int* active, const float* cand_logits, float* cur_logits, long n_logits, const float* cand_low,
                float* cur_low, long n_low, const float* cand_iou, float* cur_iou, const int* cand_bbox, int* cur_bbox,
-               hipStream_t s);
-// out = (iou >= thr) ? logits : -inf ; score_out = iou   (sam_pt.py:830-837)
-int sam_finalize_mask(const float* logits, const float* iou, float thr, float* out, float* score_out, long n,
+               int F, hipStream_t s);
+// out[f] = (iou[f] >= thr) ? logits[f] : -inf ; score_out[f] = iou[f]   (sam_pt.py:830-837)
+int sam_finalize_mask(const float* logits, const float* iou, float thr, float* out, float* score_out, long n, int F,
                       hipStream_t s);
 
 }  // namespace sampt

@@ -1,31 +1,41 @@
-// Prompt encoder / mask decoder helper kernels (all fp32, latency-bound).
+// Prompt encoder / mask decoder helper kernels (all fp32).
+// Every kernel carries a frame-batch dimension F: the per-(frame, object) prompt chains of one clip are independent,
+// so the engine runs pass r of ALL frames as one launch (tokens [F][Nt][256], image tokens [F][4096][256]) instead of
+// F latency-bound single-frame launches.
 #include "ops.h"
 
 namespace sampt {
 
 // ---------------------------------------------------------------------------------------------
-// sparse prompt tokens: random-Fourier positional encoding + label embeddings.
-// rows: k points, then (no box) one "not a point" pad row | (box) two corner rows.
+// decoder token matrix [F][Nt][256]: rows 0..4 = iou token + 4 mask tokens, then the sparse prompt tokens:
+// k points (random-Fourier PE + label embedding), then (no box) one "not a point" pad row | (box) two corner rows.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void k_sam_prompt_tokens(const float* __restrict__ pts, const int* __restrict__ labels,
-                                                           int k, const float* __restrict__ box,
-                                                           const float* __restrict__ gauss,
-                                                           const float* __restrict__ point_emb,
-                                                           const float* __restrict__ not_a_point, float img_size,
-                                                           float* __restrict__ out) {
-  const int row = blockIdx.x, j = threadIdx.x;
+__global__ __launch_bounds__(128) void k_sam_tokens(const float* __restrict__ out_tokens, const float* __restrict__ pts,
+                                                    const int* __restrict__ labels, int k, int ld_pts,
+                                                    const float* __restrict__ box, const float* __restrict__ gauss,
+                                                    const float* __restrict__ point_emb,
+                                                    const float* __restrict__ not_a_point, float img_size, int Nt,
+                                                    float* __restrict__ tokens) {
+  const int trow = blockIdx.x, f = blockIdx.y, j = threadIdx.x;
+  float* out = tokens + ((long)f * Nt + trow) * 256;
+  if (trow < 5) {
+    out[j] = out_tokens[trow * 256 + j];
+    out[128 + j] = out_tokens[trow * 256 + 128 + j];
+    return;
+  }
+  const int row = trow - 5;
   float x, y;
   int label;
   const float* emb;
   if (row < k) {
-    x = pts[row * 2], y = pts[row * 2 + 1];
-    label = labels[row];
+    x = pts[((long)f * ld_pts + row) * 2], y = pts[((long)f * ld_pts + row) * 2 + 1];
+    label = labels[(long)f * ld_pts + row];
     emb = label == 0 ? point_emb : (label == 1 ? point_emb + 256 : not_a_point);
   } else if (box == nullptr) {
     x = 0.f, y = 0.f, label = -1, emb = not_a_point;
   } else {
     int c = row - k;  // corner 0 = (x0,y0), corner 1 = (x1,y1)
-    x = box[c * 2], y = box[c * 2 + 1];
+    x = box[f * 4 + c * 2], y = box[f * 4 + c * 2 + 1];
     label = 2 + c;
     emb = point_emb + (2 + c) * 256;
   }
@@ -39,31 +49,33 @@ __global__ __launch_bounds__(128) void k_sam_prompt_tokens(const float* __restri
     s = sinf(v);
     c = cosf(v);
   }
-  out[row * 256 + j] = s + emb[j];
-  out[row * 256 + 128 + j] = c + emb[128 + j];
+  out[j] = s + emb[j];
+  out[128 + j] = c + emb[128 + j];
 }
 
-int sam_prompt_tokens(const float* pts, const int* labels, int k, const float* box, const float* gauss,
-                      const float* point_emb, const float* not_a_point, float img_size, float* tokens_out,
-                      hipStream_t s) {
-  int rows = k + (box ? 2 : 1);
-  hipLaunchKernelGGL(k_sam_prompt_tokens, dim3(rows), dim3(128), 0, s, pts, labels, k, box, gauss, point_emb,
-                     not_a_point, img_size, tokens_out);
-  SAMPT_CHECK_LAUNCH("sam_prompt_tokens");
+int sam_tokens(const float* out_tokens, const float* pts, const int* labels, int k, int ld_pts, const float* box,
+               const float* gauss, const float* point_emb, const float* not_a_point, float img_size, int F,
+               float* tokens, hipStream_t s) {
+  int Nt = 5 + k + (box ? 2 : 1);
+  hipLaunchKernelGGL(k_sam_tokens, dim3(Nt, F), dim3(128), 0, s, out_tokens, pts, labels, k, ld_pts, box, gauss,
+                     point_emb, not_a_point, img_size, Nt, tokens);
+  SAMPT_CHECK_LAUNCH("sam_tokens");
   return SAMPT_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
-// attention with many keys and few queries: one workgroup per (query, head); scores stay in registers
+// attention with many keys and few queries: one workgroup per (query, head, frame); scores stay in registers
 // ---------------------------------------------------------------------------------------------
 template <int HD>
 __global__ __launch_bounds__(256) void k_attn_rowblock(const float* __restrict__ q, const float* __restrict__ k,
-                                                       const float* __restrict__ v, float* __restrict__ out, int Nk,
-                                                       int ld) {
+                                                       const float* __restrict__ v, float* __restrict__ out, int Nq,
+                                                       int Nk, int ld) {
   constexpr int KPT = 16;  // keys per thread (Nk <= 4096)
   __shared__ float red[8];
   __shared__ float accs[4][HD];
-  const int qi = blockIdx.x, h = blockIdx.y;
+  const int qi = blockIdx.x, h = blockIdx.y, f = blockIdx.z;
+  q += (long)f * Nq * ld, out += (long)f * Nq * ld;
+  k += (long)f * Nk * ld, v += (long)f * Nk * ld;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float qv[HD];
 #pragma unroll
@@ -127,12 +139,13 @@ __global__ __launch_bounds__(256) void k_attn_rowblock(const float* __restrict__
   }
 }
 
-int attn_rowblock(const float* q, const float* k, const float* v, float* out, int Nq, int Nk, int heads, int hd,
+int attn_rowblock(const float* q, const float* k, const float* v, float* out, int F, int Nq, int Nk, int heads, int hd,
                   hipStream_t s) {
-  if (Nk > 4096 || Nk <= 0 || Nq <= 0) return SAMPT_ERR_ARG;
+  if (Nk > 4096 || Nk <= 0 || Nq <= 0 || F <= 0) return SAMPT_ERR_ARG;
   int ld = heads * hd;
-  if (hd == 16) hipLaunchKernelGGL(k_attn_rowblock<16>, dim3(Nq, heads), dim3(256), 0, s, q, k, v, out, Nk, ld);
-  else if (hd == 32) hipLaunchKernelGGL(k_attn_rowblock<32>, dim3(Nq, heads), dim3(256), 0, s, q, k, v, out, Nk, ld);
+  dim3 grid(Nq, heads, F);
+  if (hd == 16) hipLaunchKernelGGL(k_attn_rowblock<16>, grid, dim3(256), 0, s, q, k, v, out, Nq, Nk, ld);
+  else if (hd == 32) hipLaunchKernelGGL(k_attn_rowblock<32>, grid, dim3(256), 0, s, q, k, v, out, Nq, Nk, ld);
   else return SAMPT_ERR_UNSUPPORTED;
   SAMPT_CHECK_LAUNCH("attn_rowblock");
   return SAMPT_OK;
@@ -146,7 +159,9 @@ __global__ __launch_bounds__(256) void k_attn_fewkeys(const float* __restrict__ 
                                                       const float* __restrict__ v, float* __restrict__ out, int Nq,
                                                       int Nk, int heads) {
   extern __shared__ float kv[];  // [2][Nk][ld]
-  const int ld = heads * HD;
+  const int ld = heads * HD, f = blockIdx.y;
+  q += (long)f * Nq * ld, out += (long)f * Nq * ld;
+  k += (long)f * Nk * ld, v += (long)f * Nk * ld;
   float* ks = kv;
   float* vs = kv + (long)Nk * ld;
   for (int i = threadIdx.x; i < Nk * ld; i += 256) {
@@ -194,43 +209,45 @@ __global__ __launch_bounds__(256) void k_attn_fewkeys(const float* __restrict__ 
     op[c] = make_float4(acc[4 * c] / sum, acc[4 * c + 1] / sum, acc[4 * c + 2] / sum, acc[4 * c + 3] / sum);
 }
 
-int attn_fewkeys(const float* q, const float* k, const float* v, float* out, int Nq, int Nk, int heads, int hd,
+int attn_fewkeys(const float* q, const float* k, const float* v, float* out, int F, int Nq, int Nk, int heads, int hd,
                  hipStream_t s) {
-  if (Nk <= 0 || Nk > 64 || hd != 16) return SAMPT_ERR_UNSUPPORTED;
+  if (Nk <= 0 || Nk > 64 || hd != 16 || F <= 0) return SAMPT_ERR_UNSUPPORTED;
   size_t sh = (size_t)2 * Nk * heads * hd * sizeof(float);
-  hipLaunchKernelGGL(k_attn_fewkeys<16>, dim3(cdiv((long)Nq * heads, 256)), dim3(256), sh, s, q, k, v, out, Nq, Nk,
+  hipLaunchKernelGGL(k_attn_fewkeys<16>, dim3(cdiv((long)Nq * heads, 256), F), dim3(256), sh, s, q, k, v, out, Nq, Nk,
                      heads);
   SAMPT_CHECK_LAUNCH("attn_fewkeys");
   return SAMPT_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
-// low_res[p] = <hyper, upscaled[p]>   (masks = hyper_in @ upscaled, App. A-4)
+// low_res[f][p] = <hyper[f], upscaled[f][p]>   (masks = hyper_in @ upscaled, App. A-4)
 // ---------------------------------------------------------------------------------------------
-__global__ void k_sam_mask_dot(const float* __restrict__ up, const float* __restrict__ hyper, float* __restrict__ low,
-                               int npix, int C) {
-  int p = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void k_sam_mask_dot(const float* __restrict__ up, const float* __restrict__ hyper, int ld_hyper,
+                               float* __restrict__ low, int npix, int C) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
   if (p >= npix) return;
-  const float4* u = (const float4*)(up + (long)p * C);
+  const float4* u = (const float4*)(up + ((long)f * npix + p) * C);
+  const float* hy = hyper + (long)f * ld_hyper;
   float a = 0.f;
   for (int c = 0; c < C / 4; ++c) {
     float4 t = u[c];
-    a += hyper[4 * c] * t.x + hyper[4 * c + 1] * t.y + hyper[4 * c + 2] * t.z + hyper[4 * c + 3] * t.w;
+    a += hy[4 * c] * t.x + hy[4 * c + 1] * t.y + hy[4 * c + 2] * t.z + hy[4 * c + 3] * t.w;
   }
-  low[p] = a;
+  low[(long)f * npix + p] = a;
 }
 
-int sam_mask_dot(const float* up, const float* hyper, float* low_res, int npix, int C, hipStream_t s) {
+int sam_mask_dot(const float* up, const float* hyper, int ld_hyper, float* low_res, int F, int npix, int C,
+                 hipStream_t s) {
   if (C % 4) return SAMPT_ERR_ARG;
-  hipLaunchKernelGGL(k_sam_mask_dot, dim3(cdiv(npix, 256)), dim3(256), 0, s, up, hyper, low_res, npix, C);
+  hipLaunchKernelGGL(k_sam_mask_dot, dim3(cdiv(npix, 256), F), dim3(256), 0, s, up, hyper, ld_hyper, low_res, npix, C);
   SAMPT_CHECK_LAUNCH("sam_mask_dot");
   return SAMPT_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
 // Sam.postprocess_masks fused: low (LxL) --bilinear--> (img x img) --crop (in_h,in_w)--> bilinear --> (oh,ow),
-// both align_corners=False.  Optionally accumulates the bounding box / count of logits > 0 (sam_pt.py:809-820).
-// bbox state: int[5] = {xmin, ymin, xmax, ymax, count}, must be initialised with bbox_state_init.
+// both align_corners=False.  Optionally reduces the bounding box / count of logits > 0 (sam_pt.py:809-820) in two
+// deterministic stages (per-workgroup partials, then k_bbox_final): state int[5] = {xmin, ymin, xmax, ymax, count}.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void src_index(int d, float scale, int in, int& i0, int& i1, float& l1) {
   float src = scale * ((float)d + 0.5f) - 0.5f;
@@ -250,10 +267,38 @@ __device__ __forceinline__ float up_sample(const float* __restrict__ low, int L,
   return hy * (hx * low[y0 * L + x0] + lx * low[y0 * L + x1]) + ly * (hx * low[y1 * L + x0] + lx * low[y1 * L + x1]);
 }
 
+__device__ __forceinline__ void bbox_block_reduce(bool pos, int x, int y, int (*red)[5], int* out5) {
+  int xmin = pos ? x : 0x7fffffff, xmax = pos ? x : -1, ymin = pos ? y : 0x7fffffff, ymax = pos ? y : -1;
+  int cnt = pos ? 1 : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    xmin = min(xmin, __shfl_xor(xmin, o, 64));
+    xmax = max(xmax, __shfl_xor(xmax, o, 64));
+    ymin = min(ymin, __shfl_xor(ymin, o, 64));
+    ymax = max(ymax, __shfl_xor(ymax, o, 64));
+    cnt += __shfl_xor(cnt, o, 64);
+  }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    red[wave][0] = xmin, red[wave][1] = ymin, red[wave][2] = xmax, red[wave][3] = ymax, red[wave][4] = cnt;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out5[0] = min(min(red[0][0], red[1][0]), min(red[2][0], red[3][0]));
+    out5[1] = min(min(red[0][1], red[1][1]), min(red[2][1], red[3][1]));
+    out5[2] = max(max(red[0][2], red[1][2]), max(red[2][2], red[3][2]));
+    out5[3] = max(max(red[0][3], red[1][3]), max(red[2][3], red[3][3]));
+    out5[4] = red[0][4] + red[1][4] + red[2][4] + red[3][4];
+  }
+}
+
 __global__ __launch_bounds__(256) void k_sam_postprocess(const float* __restrict__ low, int L, int img, int in_h,
                                                          int in_w, float* __restrict__ out, int oh, int ow,
-                                                         int* __restrict__ bbox) {
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+                                                         int* __restrict__ partial) {
+  __shared__ int red[4][5];
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), f = blockIdx.z;
+  low += (long)f * L * L;
+  out += (long)f * oh * ow;
   bool pos = false;
   if (x < ow && y < oh) {
     const float s1 = (float)L / (float)img;
@@ -274,37 +319,17 @@ __global__ __launch_bounds__(256) void k_sam_postprocess(const float* __restrict
     out[(long)y * ow + x] = v;
     pos = v > 0.f;
   }
-  if (bbox) {
-    // deterministic two-stage reduction: per-workgroup partial {xmin,ymin,xmax,ymax,count} -> k_bbox_final
-    __shared__ int red[4][5];
-    int xmin = pos ? x : 0x7fffffff, xmax = pos ? x : -1, ymin = pos ? y : 0x7fffffff, ymax = pos ? y : -1;
-    int cnt = pos ? 1 : 0;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      xmin = min(xmin, __shfl_xor(xmin, o, 64));
-      xmax = max(xmax, __shfl_xor(xmax, o, 64));
-      ymin = min(ymin, __shfl_xor(ymin, o, 64));
-      ymax = max(ymax, __shfl_xor(ymax, o, 64));
-      cnt += __shfl_xor(cnt, o, 64);
-    }
-    const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) {
-      red[wave][0] = xmin, red[wave][1] = ymin, red[wave][2] = xmax, red[wave][3] = ymax, red[wave][4] = cnt;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      int* o = bbox + 5 * (blockIdx.y * gridDim.x + blockIdx.x);
-      o[0] = min(min(red[0][0], red[1][0]), min(red[2][0], red[3][0]));
-      o[1] = min(min(red[0][1], red[1][1]), min(red[2][1], red[3][1]));
-      o[2] = max(max(red[0][2], red[1][2]), max(red[2][2], red[3][2]));
-      o[3] = max(max(red[0][3], red[1][3]), max(red[2][3], red[3][3]));
-      o[4] = red[0][4] + red[1][4] + red[2][4] + red[3][4];
-    }
+  if (partial) {
+    const int nb = gridDim.x * gridDim.y;
+    bbox_block_reduce(pos, x, y, red, partial + 5 * ((long)f * nb + blockIdx.y * gridDim.x + blockIdx.x));
   }
 }
 
-__global__ __launch_bounds__(256) void k_bbox_final(const int* __restrict__ partial, int nblocks, int* __restrict__ bbox) {
+__global__ __launch_bounds__(256) void k_bbox_final(const int* __restrict__ partial, int nblocks, int* __restrict__ bbox,
+                                                    int ld_bbox) {
   __shared__ int red[4][5];
+  const int f = blockIdx.x;
+  partial += (long)f * nblocks * 5;
   int xmin = 0x7fffffff, ymin = 0x7fffffff, xmax = -1, ymax = -1, cnt = 0;
   for (int i = threadIdx.x; i < nblocks; i += 256) {
     const int* o = partial + 5 * i;
@@ -324,107 +349,68 @@ __global__ __launch_bounds__(256) void k_bbox_final(const int* __restrict__ part
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    bbox[0] = min(min(red[0][0], red[1][0]), min(red[2][0], red[3][0]));
-    bbox[1] = min(min(red[0][1], red[1][1]), min(red[2][1], red[3][1]));
-    bbox[2] = max(max(red[0][2], red[1][2]), max(red[2][2], red[3][2]));
-    bbox[3] = max(max(red[0][3], red[1][3]), max(red[2][3], red[3][3]));
-    bbox[4] = red[0][4] + red[1][4] + red[2][4] + red[3][4];
+    int* b = bbox + (long)f * ld_bbox;
+    b[0] = min(min(red[0][0], red[1][0]), min(red[2][0], red[3][0]));
+    b[1] = min(min(red[0][1], red[1][1]), min(red[2][1], red[3][1]));
+    b[2] = max(max(red[0][2], red[1][2]), max(red[2][2], red[3][2]));
+    b[3] = max(max(red[0][3], red[1][3]), max(red[2][3], red[3][3]));
+    b[4] = red[0][4] + red[1][4] + red[2][4] + red[3][4];
   }
 }
 
 size_t bbox_partial_ints(int oh, int ow) { return (size_t)5 * cdiv(ow, 64) * cdiv(oh, 4); }
 
-__global__ void k_bbox_state_init(int* bbox) {
-  bbox[0] = 0x7fffffff;
-  bbox[1] = 0x7fffffff;
-  bbox[2] = -1;
-  bbox[3] = -1;
-  bbox[4] = 0;
-}
-
-int bbox_state_init(int* bbox, hipStream_t s) {
-  hipLaunchKernelGGL(k_bbox_state_init, dim3(1), dim3(1), 0, s, bbox);
-  SAMPT_CHECK_LAUNCH("bbox_state_init");
-  return SAMPT_OK;
-}
-
-int sam_postprocess_bbox(const float* low, int L, int img, int in_h, int in_w, float* out, int oh, int ow, int* bbox,
-                         int* bbox_partial, hipStream_t s) {
-  if (in_h > img || in_w > img || (bbox && !bbox_partial)) return SAMPT_ERR_ARG;
-  dim3 grid(cdiv(ow, 64), cdiv(oh, 4));
+int sam_postprocess_bbox(const float* low, int L, int img, int in_h, int in_w, float* out, int oh, int ow, int F,
+                         int* bbox, int* bbox_partial, hipStream_t s) {
+  if (in_h > img || in_w > img || (bbox && !bbox_partial) || F <= 0) return SAMPT_ERR_ARG;
+  dim3 grid(cdiv(ow, 64), cdiv(oh, 4), F);
   hipLaunchKernelGGL(k_sam_postprocess, grid, dim3(256), 0, s, low, L, img, in_h, in_w, out, oh, ow,
                      bbox ? bbox_partial : nullptr);
   SAMPT_CHECK_LAUNCH("sam_postprocess");
   if (bbox) {
-    hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(256), 0, s, bbox_partial, (int)(grid.x * grid.y), bbox);
+    hipLaunchKernelGGL(k_bbox_final, dim3(F), dim3(256), 0, s, bbox_partial, (int)(grid.x * grid.y), bbox, 5);
     SAMPT_CHECK_LAUNCH("bbox_final");
   }
   return SAMPT_OK;
 }
 
 int sam_postprocess(const float* low, int L, int img, int in_h, int in_w, float* out, int oh, int ow, hipStream_t s) {
-  return sam_postprocess_bbox(low, L, img, in_h, in_w, out, oh, ow, nullptr, nullptr, s);
+  return sam_postprocess_bbox(low, L, img, in_h, in_w, out, oh, ow, 1, nullptr, nullptr, s);
 }
 
-// standalone bbox of logits > 0
+// standalone bbox of logits > 0 (one image)
 __global__ __launch_bounds__(256) void k_bbox_from_logits(const float* __restrict__ logits, int h, int w,
-                                                          int* __restrict__ bbox) {
+                                                          int* __restrict__ partial) {
+  __shared__ int red[4][5];
   const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
   bool pos = x < w && y < h && logits[(long)y * w + x] > 0.f;
-  int xmin = pos ? x : 0x7fffffff, xmax = pos ? x : -1, ymin = pos ? y : 0x7fffffff, ymax = pos ? y : -1;
-  int cnt = pos ? 1 : 0;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    xmin = min(xmin, __shfl_xor(xmin, o, 64));
-    xmax = max(xmax, __shfl_xor(xmax, o, 64));
-    ymin = min(ymin, __shfl_xor(ymin, o, 64));
-    ymax = max(ymax, __shfl_xor(ymax, o, 64));
-    cnt += __shfl_xor(cnt, o, 64);
-  }
-  if ((threadIdx.x & 63) == 0 && cnt > 0) {
-    atomicMin(&bbox[0], xmin);
-    atomicMin(&bbox[1], ymin);
-    atomicMax(&bbox[2], xmax);
-    atomicMax(&bbox[3], ymax);
-    atomicAdd(&bbox[4], cnt);
-  }
+  bbox_block_reduce(pos, x, y, red, partial + 5 * (blockIdx.y * gridDim.x + blockIdx.x));
 }
 
-__global__ void k_bbox_to_float(const int* __restrict__ bbox, float* __restrict__ box_out, int* __restrict__ count_out) {
-  int i = threadIdx.x;
-  if (i < 4) box_out[i] = (float)bbox[i];
-  if (i == 4 && count_out) count_out[0] = bbox[4];
-}
-
-int bbox_to_float(const int* bbox, float* box_out, int* count_out, hipStream_t s) {
-  hipLaunchKernelGGL(k_bbox_to_float, dim3(1), dim3(64), 0, s, bbox, box_out, count_out);
-  SAMPT_CHECK_LAUNCH("bbox_to_float");
-  return SAMPT_OK;
-}
-
-int bbox_from_logits_state(const float* logits, int h, int w, int* bbox_state, hipStream_t s) {
-  SAMPT_TRY(bbox_state_init(bbox_state, s));
-  hipLaunchKernelGGL(k_bbox_from_logits, dim3(cdiv(w, 64), cdiv(h, 4)), dim3(256), 0, s, logits, h, w, bbox_state);
+int bbox_from_logits_state(const float* logits, int h, int w, int* bbox_state, int* bbox_partial, hipStream_t s) {
+  dim3 grid(cdiv(w, 64), cdiv(h, 4));
+  hipLaunchKernelGGL(k_bbox_from_logits, grid, dim3(256), 0, s, logits, h, w, bbox_partial);
   SAMPT_CHECK_LAUNCH("bbox_from_logits");
+  hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(256), 0, s, bbox_partial, (int)(grid.x * grid.y), bbox_state, 5);
+  SAMPT_CHECK_LAUNCH("bbox_final");
   return SAMPT_OK;
 }
-
-}  // namespace sampt
 
 // =============================================================================================
 // mask-input embedding, refinement gating, commit and IoU-threshold finalisation
 // =============================================================================================
-namespace sampt {
 
 // stage A: conv2x2 s2 (1 -> C1) + LayerNorm2d(C1) + GELU ; stage B: conv2x2 s2 (C1 -> C2) + LayerNorm2d + GELU
 template <int CIN, int COUT>
 __global__ void k_mask_down(const float* __restrict__ in, int ih, int iw, const float* __restrict__ w,
                             const float* __restrict__ b, const float* __restrict__ lnw, const float* __restrict__ lnb,
                             float* __restrict__ out) {
-  // in: [ih][iw][CIN] NHWC ; out: [ih/2][iw/2][COUT] ; w: [COUT][CIN][2][2]
+  // in: [F][ih][iw][CIN] NHWC ; out: [F][ih/2][iw/2][COUT] ; w: [COUT][CIN][2][2]
   int oh = ih / 2, ow = iw / 2;
-  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  int p = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
   if (p >= oh * ow) return;
+  in += (long)f * ih * iw * CIN;
+  out += (long)f * oh * ow * COUT;
   int y = p / ow, x = p - y * ow;
   float v[COUT];
 #pragma unroll
@@ -452,39 +438,62 @@ __global__ void k_mask_down(const float* __restrict__ in, int ih, int iw, const 
   for (int co = 0; co < COUT; ++co) out[(long)p * COUT + co] = gelu_erf((v[co] - mean) * rstd * lnw[co] + lnb[co]);
 }
 
-// stage C: src[p][c] = feat[p][c] + b2[c] + sum_k w2[c][k] * e[p][k]
+// stage C: src[f][p][c] = feat[f][p][c] + b2[c] + sum_k w2[c][k] * e[f][p][k]
 __global__ void k_mask_embed_out(const float* __restrict__ e, int C2, const float* __restrict__ w2,
                                  const float* __restrict__ b2, const float* __restrict__ feat, float* __restrict__ src,
-                                 int npix) {
-  int p = blockIdx.x, c = threadIdx.x;  // 256 threads = output channels
-  if (p >= npix) return;
-  float a = b2[c];
-  for (int k = 0; k < C2; ++k) a += w2[c * C2 + k] * e[(long)p * C2 + k];
-  src[(long)p * 256 + c] = feat[(long)p * 256 + c] + a;
+                                 long npix_total) {
+  // 256 threads = output channels; 4 pixels per workgroup
+  __shared__ float es[4][16];
+  const int c = threadIdx.x;
+  const long p0 = (long)blockIdx.x * 4;
+  if (c < 4 * C2) {
+    long p = p0 + c / C2;
+    es[c / C2][c % C2] = p < npix_total ? e[p * C2 + c % C2] : 0.f;
+  }
+  __syncthreads();
+  float wr[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) wr[k] = k < C2 ? w2[c * C2 + k] : 0.f;
+  const float bb = b2[c];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    long p = p0 + i;
+    if (p >= npix_total) break;
+    float a = bb;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a += wr[k] * es[i][k];
+    src[p * 256 + c] = feat[p * 256 + c] + a;
+  }
 }
 
-int sam_mask_embed_src(const float* mask, int g, const MaskEmbedW& w, const float* feat, float* tmp0, float* tmp1,
-                       float* src, hipStream_t s) {
+int sam_mask_embed_src(const float* mask, int g, int F, const MaskEmbedW& w, const float* feat, float* tmp0,
+                       float* tmp1, float* src, hipStream_t s) {
   int L = 4 * g;
-  hipLaunchKernelGGL((k_mask_down<1, 4>), dim3(cdiv((L / 2) * (L / 2), 256)), dim3(256), 0, s, mask, L, L, w.w0, w.b0,
-                     w.ln0w, w.ln0b, tmp0);
+  hipLaunchKernelGGL((k_mask_down<1, 4>), dim3(cdiv((L / 2) * (L / 2), 256), F), dim3(256), 0, s, mask, L, L, w.w0,
+                     w.b0, w.ln0w, w.ln0b, tmp0);
   SAMPT_CHECK_LAUNCH("mask_down0");
-  hipLaunchKernelGGL((k_mask_down<4, 16>), dim3(cdiv(g * g, 256)), dim3(256), 0, s, tmp0, L / 2, L / 2, w.w1, w.b1,
+  hipLaunchKernelGGL((k_mask_down<4, 16>), dim3(cdiv(g * g, 256), F), dim3(256), 0, s, tmp0, L / 2, L / 2, w.w1, w.b1,
                      w.ln1w, w.ln1b, tmp1);
   SAMPT_CHECK_LAUNCH("mask_down1");
-  hipLaunchKernelGGL(k_mask_embed_out, dim3(g * g), dim3(256), 0, s, tmp1, 16, w.w2, w.b2, feat, src, g * g);
+  long npix = (long)F * g * g;
+  hipLaunchKernelGGL(k_mask_embed_out, dim3(cdiv(npix, 4)), dim3(256), 0, s, tmp1, 16, w.w2, w.b2, feat, src, npix);
   SAMPT_CHECK_LAUNCH("mask_embed_out");
   return SAMPT_OK;
 }
 
-__global__ void k_sam_refine_gate(int* active, const int* __restrict__ bbox_cur, float* __restrict__ box_f) {
-  int i = threadIdx.x;
-  if (i < 4) box_f[i] = (float)bbox_cur[i];
-  if (i == 0) active[0] = (active[0] != 0 && bbox_cur[4] >= 2) ? 1 : 0;
+// active[f] &= count(bbox_cur[f]) >= 2 ; box_f[f] = bbox_cur[f]     (sam_pt.py:809-820)
+__global__ void k_sam_refine_gate(int* __restrict__ active, const int* __restrict__ bbox_cur, float* __restrict__ box_f,
+                                  int F) {
+  int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= F) return;
+  const int* b = bbox_cur + f * 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) box_f[f * 4 + i] = (float)b[i];
+  active[f] = (active[f] != 0 && b[4] >= 2) ? 1 : 0;
 }
 
-int sam_refine_gate(int* active, const int* bbox_cur, float* box_f, hipStream_t s) {
-  hipLaunchKernelGGL(k_sam_refine_gate, dim3(1), dim3(64), 0, s, active, bbox_cur, box_f);
+int sam_refine_gate(int* active, const int* bbox_cur, float* box_f, int F, hipStream_t s) {
+  hipLaunchKernelGGL(k_sam_refine_gate, dim3(cdiv(F, 64)), dim3(64), 0, s, active, bbox_cur, box_f, F);
   SAMPT_CHECK_LAUNCH("sam_refine_gate");
   return SAMPT_OK;
 }
@@ -493,19 +502,20 @@ __global__ void k_sam_commit(const int* __restrict__ active, const float* __rest
                              float* __restrict__ cur_logits, long n_logits, const float* __restrict__ cand_low,
                              float* __restrict__ cur_low, long n_low, const float* __restrict__ cand_iou,
                              float* __restrict__ cur_iou, const int* __restrict__ cand_bbox, int* __restrict__ cur_bbox) {
-  if (active[0] == 0) return;
+  const int f = blockIdx.y;
+  if (active[f] == 0) return;
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n_logits) cur_logits[i] = cand_logits[i];
-  if (i < n_low) cur_low[i] = cand_low[i];
-  if (i == 0) cur_iou[0] = cand_iou[0];
-  if (i < 5) cur_bbox[i] = cand_bbox[i];
+  if (i < n_logits) cur_logits[f * n_logits + i] = cand_logits[f * n_logits + i];
+  if (i < n_low) cur_low[f * n_low + i] = cand_low[f * n_low + i];
+  if (i == 0) cur_iou[f] = cand_iou[f];
+  if (i < 5) cur_bbox[f * 5 + i] = cand_bbox[f * 5 + i];
 }
 
 int sam_commit(const int* active, const float* cand_logits, float* cur_logits, long n_logits, const float* cand_low,
                float* cur_low, long n_low, const float* cand_iou, float* cur_iou, const int* cand_bbox, int* cur_bbox,
-               hipStream_t s) {
+               int F, hipStream_t s) {
   long n = n_logits > n_low ? n_logits : n_low;
-  hipLaunchKernelGGL(k_sam_commit, dim3(cdiv(n, 256)), dim3(256), 0, s, active, cand_logits, cur_logits, n_logits,
+  hipLaunchKernelGGL(k_sam_commit, dim3(cdiv(n, 256), F), dim3(256), 0, s, active, cand_logits, cur_logits, n_logits,
                      cand_low, cur_low, n_low, cand_iou, cur_iou, cand_bbox, cur_bbox);
   SAMPT_CHECK_LAUNCH("sam_commit");
   return SAMPT_OK;
@@ -513,15 +523,16 @@ int sam_commit(const int* active, const float* cand_logits, float* cur_logits, l
 
 __global__ void k_sam_finalize_mask(const float* __restrict__ logits, const float* __restrict__ iou, float thr,
                                     float* __restrict__ out, float* __restrict__ score_out, long n) {
+  const int f = blockIdx.y;
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  float sc = iou[0];
-  if (i < n) out[i] = sc < thr ? -INFINITY : logits[i];
-  if (i == 0) score_out[0] = sc;
+  float sc = iou[f];
+  if (i < n) out[f * n + i] = sc < thr ? -INFINITY : logits[f * n + i];
+  if (i == 0) score_out[f] = sc;
 }
 
-int sam_finalize_mask(const float* logits, const float* iou, float thr, float* out, float* score_out, long n,
+int sam_finalize_mask(const float* logits, const float* iou, float thr, float* out, float* score_out, long n, int F,
                       hipStream_t s) {
-  hipLaunchKernelGGL(k_sam_finalize_mask, dim3(cdiv(n, 256)), dim3(256), 0, s, logits, iou, thr, out, score_out, n);
+  hipLaunchKernelGGL(k_sam_finalize_mask, dim3(cdiv(n, 256), F), dim3(256), 0, s, logits, iou, thr, out, score_out, n);
   SAMPT_CHECK_LAUNCH("sam_finalize_mask");
   return SAMPT_OK;
 }

@@ -102,15 +102,17 @@ def _convt_pack(w: torch.Tensor) -> torch.Tensor:
     return w.permute(2, 3, 1, 0).reshape(4, w.shape[1], w.shape[0]).contiguous()
 
 
-def _shuffle_map(side: int) -> torch.Tensor:
-    # input pixel p = y*side + x of a (side x side) map -> output row (2y+dy)*(2*side) + 2x+dx, for (dy,dx) in order
+def _shuffle_map(side: int, frames: int = 1) -> torch.Tensor:
+    """Pixel-shuffle row maps of a stride-2 ConvTranspose2d for a batch of `frames` maps: [4][frames*side*side];
+    input pixel p = y*side + x of frame f -> output row f*4*side^2 + (2y+dy)*(2*side) + 2x+dx, (dy,dx) in order."""
     y = torch.arange(side).view(side, 1).expand(side, side)
     x = torch.arange(side).view(1, side).expand(side, side)
-    maps = [((2 * y + dy) * (2 * side) + 2 * x + dx).reshape(-1) for dy in range(2) for dx in range(2)]
+    off = (torch.arange(frames) * 4 * side * side).view(frames, 1)
+    maps = [(((2 * y + dy) * (2 * side) + 2 * x + dx).reshape(1, -1) + off).reshape(-1) for dy in range(2) for dx in range(2)]
     return torch.stack(maps).to(torch.int32).contiguous()
 
 
-def pack_decoder(sd: Dict[str, torch.Tensor], cfg: SamConfig, device) -> Dict[str, torch.Tensor]:
+def pack_decoder(sd: Dict[str, torch.Tensor], cfg: SamConfig, device, max_frames: int = 1) -> Dict[str, torch.Tensor]:
     out: Dict[str, torch.Tensor] = {}
     for k, v in sd.items():
         if k.startswith("mask_decoder.") or k.startswith("prompt_encoder."):
@@ -123,6 +125,6 @@ def pack_decoder(sd: Dict[str, torch.Tensor], cfg: SamConfig, device) -> Dict[st
     out["prompt_encoder.__dense_pe"] = dense_pe(g, cfg.grid)
     out["mask_decoder.output_upscaling.0.weight_packed"] = _convt_pack(sd["mask_decoder.output_upscaling.0.weight"].float())
     out["mask_decoder.output_upscaling.3.weight_packed"] = _convt_pack(sd["mask_decoder.output_upscaling.3.weight"].float())
-    out["mask_decoder.__up0_map"] = _shuffle_map(cfg.grid)
-    out["mask_decoder.__up1_map"] = _shuffle_map(2 * cfg.grid)
+    out["mask_decoder.__up0_map"] = _shuffle_map(cfg.grid, max_frames)
+    out["mask_decoder.__up1_map"] = _shuffle_map(2 * cfg.grid, max_frames)
     return {k: v.to(device) for k, v in out.items()}

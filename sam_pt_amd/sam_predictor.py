@@ -63,7 +63,8 @@ class SamHip(nn.Module):
     image_format: str = "RGB"
 
     def __init__(self, variant: str = "vit_h", checkpoint: Optional[str] = None, state_dict=None, seed: int = 72,
-                 precision: str = "f16", config: Optional[SamConfig] = None, max_batch: int = 8, **hydra_kwargs):
+                 precision: str = "f16", config: Optional[SamConfig] = None, max_batch: int = 8,
+                 max_decode_batch: int = 32, **hydra_kwargs):
         super().__init__()
         self.cfg = config if config is not None else SAM_CONFIGS[variant]
         if state_dict is None and checkpoint is not None:
@@ -73,6 +74,7 @@ class SamHip(nn.Module):
         assert precision in ("f16", "f32")
         self.precision = precision
         self.max_batch = max_batch
+        self.max_decode_batch = max_decode_batch
         self.register_buffer("pixel_mean", torch.tensor(self.cfg.pixel_mean).view(-1, 1, 1), persistent=False)
         self.prompt_embed_dim, self.image_size = self.cfg.out_chans, self.cfg.img_size
         self.vit_patch_size, self.image_embedding_size = self.cfg.patch_size, self.cfg.grid
@@ -121,10 +123,11 @@ class SamPredictor:
         h = C.c_void_p()
         _lib.check(lib.sampt_vit_create(C.byref(c), names, ptrs, n, m.max_batch, C.byref(h)), "sampt_vit_create")
         self._vit = h
-        self._wd = pack_decoder(m.sd, cfg, dev)
+        self._wd = pack_decoder(m.sd, cfg, dev, m.max_decode_batch)
         names, ptrs, n = _lib.name_table(self._wd)
         h2 = C.c_void_p()
-        _lib.check(lib.sampt_dec_create(names, ptrs, n, cfg.grid, cfg.img_size, C.byref(h2)), "sampt_dec_create")
+        _lib.check(lib.sampt_dec_create(names, ptrs, n, cfg.grid, cfg.img_size, m.max_decode_batch, C.byref(h2)),
+                   "sampt_dec_create")
         self._dec, self._dev, self._lib = h2, dev, lib
 
     def __del__(self):
@@ -143,12 +146,14 @@ class SamPredictor:
             self._ws_vit = {B: torch.empty(n.value, dtype=torch.uint8, device=self._dev)}  # keep only the latest size
         return self._ws_vit[B]
 
-    def _dec_ws(self, oh: int, ow: int) -> torch.Tensor:
-        if (oh, ow) not in self._ws_dec:
+    def _dec_ws(self, oh: int, ow: int, frames: int = 1) -> torch.Tensor:
+        key = (oh, ow)
+        have = self._ws_dec.get(key)
+        if have is None or have[0] < frames:
             n = C.c_size_t()
-            _lib.check(self._lib.sampt_dec_workspace_bytes(self._dec, oh, ow, C.byref(n)), "dec_workspace")
-            self._ws_dec = {(oh, ow): torch.empty(n.value, dtype=torch.uint8, device=self._dev)}
-        return self._ws_dec[(oh, ow)]
+            _lib.check(self._lib.sampt_dec_workspace_bytes(self._dec, frames, oh, ow, C.byref(n)), "dec_workspace")
+            self._ws_dec = {key: (frames, torch.empty(n.value, dtype=torch.uint8, device=self._dev))}
+        return self._ws_dec[key][1]
 
     # -- image encoder -------------------------------------------------------------------------------
     @torch.no_grad()
@@ -239,15 +244,19 @@ class SamPredictor:
         return m[0].cpu().numpy(), i[0].cpu().numpy(), l[0].cpu().numpy()
 
     @torch.no_grad()
-    def track_decode(self, feat_tokens: torch.Tensor, pts: torch.Tensor, labels: torch.Tensor, n_pos_first: int,
+    def track_decode(self, feat_tokens: torch.Tensor, pts: torch.Tensor, labels: torch.Tensor, k: int, n_pos_first: int,
                      refine_iters: int, iou_thr: float, size_hw, out_logits: torch.Tensor, out_score: torch.Tensor):
-        """SamPt.predict_mask (sam_pt.py:760-837) for one (frame, object), on device, no host sync.
-        pts (k,2) f32 in input-frame px, labels (k,) i32 (positives first); results written into the given
-        (H,W) logits slice and 1-element score tensor."""
+        """SamPt.predict_mask (sam_pt.py:760-837) for F independent (frame, object) items that share the visible-point
+        count k, as ONE batched device-side chain without host syncs.  feat_tokens (F,g*g,256); pts (F,ld,2) f32 in
+        input-frame px and labels (F,ld) i32 with the first k entries valid (positives first); n_pos_first = -1 for
+        the single-pass case, else the number of leading positives used by the positives-only first pass.
+        Results are written into out_logits (F,H,W) and out_score (F,)."""
         self._ensure()
         oh, ow = size_hw
-        ws = self._dec_ws(oh, ow)
-        _lib.check(self._lib.sampt_sam_track_decode(self._dec, _lib.ptr(feat_tokens), _lib.ptr(pts), _lib.ptr(labels),
-                                                    pts.shape[0], n_pos_first, refine_iters, float(iou_thr), oh, ow, oh, ow,
-                                                    _lib.ptr(out_logits), _lib.ptr(out_score), _lib.ptr(ws), ws.numel(),
-                                                    _lib.stream_ptr()), "sampt_sam_track_decode")
+        F = feat_tokens.shape[0]
+        assert F <= self.model.max_decode_batch
+        ws = self._dec_ws(oh, ow, F)
+        _lib.check(self._lib.sampt_sam_track_decode(self._dec, F, _lib.ptr(feat_tokens), _lib.ptr(pts), _lib.ptr(labels),
+                                                    k, pts.shape[1], n_pos_first, refine_iters, float(iou_thr), oh, ow,
+                                                    oh, ow, _lib.ptr(out_logits), _lib.ptr(out_score), _lib.ptr(ws),
+                                                    ws.numel(), _lib.stream_ptr()), "sampt_sam_track_decode")

@@ -208,17 +208,27 @@ class SamPt(nn.Module):
         logits = torch.full((n_masks, n_frames, height, width), -float("inf"), dtype=torch.float32, device=dev)
         scores = torch.full((n_frames * n_masks,), -float("inf"), dtype=torch.float32, device=dev)
         two_pass = self.negative_points_per_mask > 0
-        for t in range(n_frames):
-            for m in range(n_masks):
-                i = t * n_masks + m
-                c, l = prompts[i]
-                k = len(c)
-                if k == 0:
-                    continue                                                     # sam_pt.py:766-767
-                n_pos_first = int((l == 1).sum()) if two_pass else -1
-                pred.track_decode(feats[t], xy_d[i, :k], lab_d[i, :k], n_pos_first,
+        # group the (frame, object) items by prompt shape: items of one group run as ONE batched device-side chain
+        groups = {}
+        for i, (c, l) in enumerate(prompts):
+            if len(c) == 0:
+                continue                                                         # sam_pt.py:766-767
+            key = (len(c), int((l == 1).sum()) if two_pass else -1)
+            groups.setdefault(key, []).append(i)
+        Fmax = getattr(pred.model, "max_decode_batch", 1)
+        for (k, n_pos_first), items in groups.items():
+            for s0 in range(0, len(items), Fmax):
+                idx = torch.tensor(items[s0:s0 + Fmax], dtype=torch.long, device=dev)
+                t_idx, m_idx = idx // n_masks, idx % n_masks
+                F_ = idx.numel()
+                out_l = torch.empty((F_, height, width), dtype=torch.float32, device=dev)
+                out_s = torch.empty((F_,), dtype=torch.float32, device=dev)
+                pred.track_decode(feats.index_select(0, t_idx), xy_d.index_select(0, idx).contiguous(),
+                                  lab_d.index_select(0, idx).contiguous(), k, n_pos_first,
                                   int(self.iterative_refinement_iterations), float(self.sam_iou_threshold), size,
-                                  logits[m, t], scores[i:i + 1])
+                                  out_l, out_s)
+                logits[m_idx, t_idx] = out_l
+                scores[idx] = out_s
         scores_cpu = scores.cpu().view(n_frames, n_masks)                        # the only sync of the SAM stage
         pred_scores = self._mean_scores(scores_cpu)
         return pred_scores, logits, scores_cpu

@@ -206,7 +206,9 @@ def test_postprocess_and_bbox(lib, dev, in_h, in_w, oh, ow):
     ok(lib.sampt_postprocess_masks(P(low_d), 256, 1024, in_h, in_w, P(out), oh, ow, S()), "postprocess")
     assert max_abs(out, ref) < 1e-5
     bb = torch.zeros(5, dtype=torch.int32, device=dev)
-    ok(lib.sampt_bbox_from_logits(P(out), oh, ow, P(bb), S()), "bbox")
+    nb = lib.sampt_bbox_workspace_bytes(oh, ow)
+    bws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    ok(lib.sampt_bbox_from_logits(P(out), oh, ow, P(bb), P(bws), nb, S()), "bbox")
     m = out.cpu() > 0
     yx = m.nonzero()
     exp = [int(yx[:, 1].min()), int(yx[:, 0].min()), int(yx[:, 1].max()), int(yx[:, 0].max()), int(m.sum())]
