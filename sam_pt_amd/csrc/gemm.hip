@@ -298,10 +298,18 @@ __global__ __launch_bounds__(256) void gemm_skinny_f32(GemmP p) {
   }
 }
 
+int gemm_f16_glds_launch(const GemmP& p, hipStream_t s);  // gemm_f16.hip
+
 template <typename T>
 static int gemm_dispatch(const GemmP& p_in, hipStream_t s) {
   constexpr int VEC = GT<T>::VEC;
   GemmP p = p_in;
+  if constexpr (sizeof(T) == 2) {
+    if (!p.force_generic) {
+      int rc = gemm_f16_glds_launch(p, s);  // LDS-DMA kernel for the big ViT GEMMs
+      if (rc != SAMPT_ERR_UNSUPPORTED) return rc;
+    }
+  }
   if (!p.A || !p.W || !p.C || p.M <= 0 || p.N <= 0 || p.K <= 0) return SAMPT_ERR_ARG;
   if (p.K % VEC) return SAMPT_ERR_ARG;
   if (p.conv) {

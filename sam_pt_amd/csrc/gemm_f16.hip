@@ -1,0 +1,139 @@
+// fp16 MFMA GEMM for the ViT image encoder, LDS-DMA version (the dominant kernel of the SAM-PT hot path).
+//
+//   C[M][N] = epi(A[M][K] . W[N][K]^T + bias) (+ residual)        A, W fp16 K-contiguous; fp32 accumulate
+//
+// 128 x 128 x 64 block tile, 256 threads = 4 waves (2 x 2), each wave 64 x 64 = 4 x 4 fragments of
+// v_mfma_f32_16x16x32_f16.  Both operand slabs go HBM -> LDS with `global_load_lds_dwordx4` (no VGPR staging, no
+// ds_write pass): each wave-instruction lands 8 rows x 128 B.  The LDS image is linear per instruction (hardware
+// rule: M0 base + lane*16), so the bank-conflict swizzle is applied on the SOURCE side: the 16-byte chunk that lane l
+// fetches for tile row r is chunk (l&7) ^ (r&7), and fragment reads apply the same XOR.  Two LDS buffers (64 KiB
+// total, 2 workgroups per CU) and ONE barrier per K-slab: the DMA of slab k+1 is issued right after the barrier
+// that retires slab k and overlaps its 32 MFMAs per wave.
+//
+// Edge handling: rows beyond M / N are clamped to the last valid row (their products land in accumulator rows /
+// columns the epilogue never stores); K must be a multiple of 64 (true for every ViT GEMM: 768..5120).
+#include "common.h"
+
+namespace sampt {
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void gemm_f16_glds(GemmP p) {
+  constexpr int BK = 64;
+  constexpr int A_IT = BM / 32, B_IT = BN / 32;           // 8-row DMA pieces per wave
+  constexpr int WTM = BM / 2, WTN = BN / 2, FM = WTM / 16, FN = WTN / 16;
+  __shared__ __attribute__((aligned(1024))) half_t lds[2 * (BM + BN) * BK];  // ONE object: [buf][A rows | B rows][64]
+  half_t* As0 = lds;
+  half_t* Bs0 = lds + BM * BK;
+  constexpr int BUF = (BM + BN) * BK;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const half_t* __restrict__ A = (const half_t*)p.A;
+  const half_t* __restrict__ W = (const half_t*)p.W;
+
+  // per-lane DMA source pointers (row clamped, chunk XOR-swizzled); piece i of this wave = tile rows (wave*IT+i)*8..+8
+  const int sub = lane >> 3, chunk = (lane & 7) ^ sub;
+  const half_t* a_src[A_IT];
+  const half_t* b_src[B_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    int row = m0 + (wave * A_IT + i) * 8 + sub;
+    if (row > p.M - 1) row = p.M - 1;
+    a_src[i] = A + (long)row * p.lda + chunk * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < B_IT; ++i) {
+    int row = n0 + (wave * B_IT + i) * 8 + sub;
+    if (row > p.N - 1) row = p.N - 1;
+    b_src[i] = W + (long)row * p.ldw + chunk * 8;
+  }
+  auto issue = [&](int kt, int buf) {
+    half_t* ab = As0 + buf * BUF + wave * A_IT * 8 * BK;
+    half_t* bb = Bs0 + buf * BUF + wave * B_IT * 8 * BK;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i)
+      __builtin_amdgcn_global_load_lds((glb_void*)(a_src[i] + kt * BK), (lds_void*)(ab + i * 8 * BK), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i)
+      __builtin_amdgcn_global_load_lds((glb_void*)(b_src[i] + kt * BK), (lds_void*)(bb + i * 8 * BK), 16, 0, 0);
+  };
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / BK;
+  const int lr = lane & 15, lq = lane >> 4;
+  // fragment read offsets (halfs) inside a buffer: row*64 + ((kk*4+lq) ^ (row&7))*8 ; row&7 == lr&7 for every fragment
+  int a_off[FM], b_off[FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) a_off[i] = (wm * WTM + i * 16 + lr) * BK;
+#pragma unroll
+  for (int j = 0; j < FN; ++j) b_off[j] = BM * BK + (wn * WTN + j * 16 + lr) * BK;
+  const int sw = lr & 7;
+
+  issue(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < nk) issue(kt + 1, buf ^ 1);
+    const half_t* base = lds + buf * BUF;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int pos = ((kk * 4 + lq) ^ sw) * 8;
+      h8 a[FM], b[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) a[i] = *(const h8*)(base + a_off[i] + pos);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) b[j] = *(const h8*)(base + b_off[j] + pos);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue (same contract as gemm_kernel): bias, activation, residual at the (row-mapped) destination row
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int row = m0 + wm * WTM + i * 16 + lq * 4 + r;
+      if (row >= p.M) continue;
+      int drow = p.rowmap ? p.rowmap[row] : row;
+      if (drow < 0) continue;
+      int rrow = p.res_mod > 0 ? drow % p.res_mod : drow;
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        int col = n0 + wn * WTN + j * 16 + lr;
+        if (col >= p.N) continue;
+        float v = acc[i][j][r] * p.alpha;
+        if (p.bias) v += p.bias[col];
+        v = apply_act(v, p.act);
+        if (p.res) v += p.res[(long)rrow * p.ldr + col];
+        if (p.out_f16) ((half_t*)p.C)[(long)drow * p.ldc + col] = (half_t)v;
+        else ((float*)p.C)[(long)drow * p.ldc + col] = v;
+      }
+    }
+  }
+}
+
+// returns SAMPT_ERR_UNSUPPORTED when the shape does not fit this kernel (caller falls back to gemm_kernel)
+int gemm_f16_glds_launch(const GemmP& p, hipStream_t s) {
+  if (p.conv || p.w_kn || p.nb1 * p.nb2 != 1 || p.K % 64 || p.M < 128 || p.N < 128) return SAMPT_ERR_UNSUPPORTED;
+  if ((p.lda % 8) || (p.ldw % 8) || (((uintptr_t)p.A | (uintptr_t)p.W) & 15)) return SAMPT_ERR_UNSUPPORTED;
+  dim3 grid(cdiv(p.N, 128), cdiv(p.M, 128), 1), block(256);
+  hipLaunchKernelGGL((gemm_f16_glds<128, 128>), grid, block, 0, s, p);
+  SAMPT_CHECK_LAUNCH("gemm_f16_glds");
+  return SAMPT_OK;
+}
+
+}  // namespace sampt

@@ -49,7 +49,8 @@ def test_gemm_f32(lib, dev, M, N, K, act):
     assert rel_err(Cd, ref) < 2e-6
 
 
-@pytest.mark.parametrize("M,N,K,dtype", [(256, 256, 128, 1), (4900, 3840, 1280, 2), (100, 72, 64, 1), (4096, 768, 768, 2)])
+@pytest.mark.parametrize("M,N,K,dtype", [(256, 256, 128, 1), (4900, 3840, 1280, 2), (100, 72, 64, 1), (4096, 768, 768, 2),
+                                           (300, 200, 192, 1), (129, 129, 64, 2)])
 def test_gemm_f16(lib, dev, M, N, K, dtype):
     g = torch.Generator().manual_seed(M + N)
     A = torch.randn(M, K, generator=g).half()
