@@ -61,7 +61,7 @@ def one_step(model, video, max_frames):
 
 
 def gemm_roofline(args, dev):
-    """Dominant kernel = the fp16 MFMA GEMM of the ViT encoder (gemm_kernel<_Float16,128,128>).  Each distinct launch
+    """Dominant kernel = the fp16 MFMA GEMM of the ViT encoder (gemm_f16_glds<128,128,1>).  Each distinct launch
     shape of one encode call is timed with HIP events on the launching stream; achieved = algorithmic FLOP of all those
     launches / their total duration."""
     from sam_pt_amd import _lib
@@ -99,7 +99,7 @@ def gemm_roofline(args, dev):
         launches += cnt
         del A, W, Cc
     ach = tot_flop / tot_t / 1e12
-    return {"bound": "mfma", "kernel": "gemm_kernel<_Float16,128,128> (ViT qkv/proj/MLP/patch/neck GEMMs)",
+    return {"bound": "mfma", "kernel": "gemm_f16_glds<128,128,1> (ViT qkv/proj/MLP/patch/neck GEMMs, LDS-DMA fp16 MFMA)",
             "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
             "traffic": None, "launches_per_encode_call": launches,
             "avg_launch_us": round(tot_t / launches * 1e6, 1), "encode_batch": B}

@@ -12,6 +12,8 @@
 //
 // Edge handling: rows beyond M / N are clamped to the last valid row (their products land in accumulator rows /
 // columns the epilogue never stores); K must be a multiple of 64 (true for every ViT GEMM: 768..5120).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace sampt {
@@ -19,12 +21,12 @@ namespace sampt {
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
-template <int BM, int BN>
-__global__ __launch_bounds__(256, 2) void gemm_f16_glds(GemmP p) {
+template <int BM, int BN, int NBUF>
+__global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void gemm_f16_glds(GemmP p) {
   constexpr int BK = 64;
   constexpr int A_IT = BM / 32, B_IT = BN / 32;           // 8-row DMA pieces per wave
   constexpr int WTM = BM / 2, WTN = BN / 2, FM = WTM / 16, FN = WTN / 16;
-  __shared__ __attribute__((aligned(1024))) half_t lds[2 * (BM + BN) * BK];  // ONE object: [buf][A rows | B rows][64]
+  __shared__ __attribute__((aligned(1024))) half_t lds[NBUF * (BM + BN) * BK];  // ONE object: [buf][A rows | B rows][64]
   half_t* As0 = lds;
   half_t* Bs0 = lds + BM * BK;
   constexpr int BUF = (BM + BN) * BK;
@@ -78,12 +80,17 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_glds(GemmP p) {
   for (int j = 0; j < FN; ++j) b_off[j] = BM * BK + (wn * WTN + j * 16 + lr) * BK;
   const int sw = lr & 7;
 
-  issue(0, 0);
+  if (NBUF == 2) issue(0, 0);
   for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
+    const int buf = NBUF == 2 ? (kt & 1) : 0;
+    if (NBUF == 1) {
+      // single buffer, 4 workgroups per CU: the other resident workgroups compute while this one waits for its DMA
+      if (kt > 0) __syncthreads();      // everyone done reading the previous slab
+      issue(kt, 0);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (kt + 1 < nk) issue(kt + 1, buf ^ 1);
+    if (NBUF == 2 && kt + 1 < nk) issue(kt + 1, buf ^ 1);
     const half_t* base = lds + buf * BUF;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -97,30 +104,57 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_glds(GemmP p) {
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[j], a[i], acc[i][j], 0, 0, 0);  // D^T: see epilogue
     }
   }
 
-  // ---- epilogue (same contract as gemm_kernel): bias, activation, residual at the (row-mapped) destination row
+  // ---- epilogue.  The MFMAs were issued with swapped operands (W fragment as A, A fragment as B), so each accumulator
+  // fragment holds C^T: lane (lr, lq) owns row m = lr and the 4 CONSECUTIVE columns lq*4..+3 -> one 16-byte (f32) or
+  // 8-byte (f16) store per fragment instead of four scattered scalar stores.  Same contract as gemm_kernel: bias,
+  // activation, residual at the (row-mapped) destination row.
+  const bool vec_ok = (p.N % 4 == 0) && (p.ldc % 4 == 0) && (!p.res || p.ldr % 4 == 0);
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
+    int row = m0 + wm * WTM + i * 16 + lr;
+    if (row >= p.M) continue;
+    int drow = p.rowmap ? p.rowmap[row] : row;
+    if (drow < 0) continue;
+    int rrow = p.res_mod > 0 ? drow % p.res_mod : drow;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      int row = m0 + wm * WTM + i * 16 + lq * 4 + r;
-      if (row >= p.M) continue;
-      int drow = p.rowmap ? p.rowmap[row] : row;
-      if (drow < 0) continue;
-      int rrow = p.res_mod > 0 ? drow % p.res_mod : drow;
+    for (int j = 0; j < FN; ++j) {
+      int col = n0 + wn * WTN + j * 16 + lq * 4;
+      if (col >= p.N) continue;
+      float v[4];
 #pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        int col = n0 + wn * WTN + j * 16 + lr;
-        if (col >= p.N) continue;
-        float v = acc[i][j][r] * p.alpha;
-        if (p.bias) v += p.bias[col];
-        v = apply_act(v, p.act);
-        if (p.res) v += p.res[(long)rrow * p.ldr + col];
-        if (p.out_f16) ((half_t*)p.C)[(long)drow * p.ldc + col] = (half_t)v;
-        else ((float*)p.C)[(long)drow * p.ldc + col] = v;
+      for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * p.alpha;
+      if (vec_ok) {
+        if (p.bias) {
+          float4 bv = *(const float4*)(p.bias + col);
+          v[0] += bv.x, v[1] += bv.y, v[2] += bv.z, v[3] += bv.w;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act);
+        if (p.res) {
+          float4 rv = *(const float4*)(p.res + (long)rrow * p.ldr + col);
+          v[0] += rv.x, v[1] += rv.y, v[2] += rv.z, v[3] += rv.w;
+        }
+        if (p.out_f16) {
+          h4 o = (h4){(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+          *(h4*)((half_t*)p.C + (long)drow * p.ldc + col) = o;
+        } else {
+          *(float4*)((float*)p.C + (long)drow * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (col + r >= p.N) continue;
+          float x = v[r];
+          if (p.bias) x += p.bias[col + r];
+          x = apply_act(x, p.act);
+          if (p.res) x += p.res[(long)rrow * p.ldr + col + r];
+          if (p.out_f16) ((half_t*)p.C)[(long)drow * p.ldc + col + r] = (half_t)x;
+          else ((float*)p.C)[(long)drow * p.ldc + col + r] = x;
+        }
       }
     }
   }
@@ -131,7 +165,9 @@ int gemm_f16_glds_launch(const GemmP& p, hipStream_t s) {
   if (p.conv || p.w_kn || p.nb1 * p.nb2 != 1 || p.K % 64 || p.M < 128 || p.N < 128) return SAMPT_ERR_UNSUPPORTED;
   if ((p.lda % 8) || (p.ldw % 8) || (((uintptr_t)p.A | (uintptr_t)p.W) & 15)) return SAMPT_ERR_UNSUPPORTED;
   dim3 grid(cdiv(p.N, 128), cdiv(p.M, 128), 1), block(256);
-  hipLaunchKernelGGL((gemm_f16_glds<128, 128>), grid, block, 0, s, p);
+  static const int variant = getenv("SAMPT_GEMM_VARIANT") ? atoi(getenv("SAMPT_GEMM_VARIANT")) : 1;
+  if (variant == 1) hipLaunchKernelGGL((gemm_f16_glds<128, 128, 1>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((gemm_f16_glds<128, 128, 2>), grid, block, 0, s, p);
   SAMPT_CHECK_LAUNCH("gemm_f16_glds");
   return SAMPT_OK;
 }
