@@ -64,8 +64,10 @@ def load_sam_pt():
 
     def stub(name, **attrs):
         if name not in sys.modules:
+            import importlib.machinery
             m = types.ModuleType(name)
             m.__path__ = []
+            m.__spec__ = importlib.machinery.ModuleSpec(name, None)  # keeps importlib.util.find_spec() working
             sys.modules[name] = m
         for k, v in attrs.items():
             setattr(sys.modules[name], k, v)

@@ -1,0 +1,142 @@
+"""CPU tests of the host logic and the C-ABI surface (no GPU compute calls)."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """libsampt_hip.so loads and exports exactly the functions declared in include/sampt_hip.h."""
+    from sam_pt_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "sampt_hip.h")).read()
+    declared = set(re.findall(r"\b(sampt_[a-z0-9_]+)\s*\(", hdr)) - {"sampt_vit_config"}
+    lib = _lib.load()                       # AttributeError here if a bound symbol is missing from the .so
+    assert lib.sampt_version() >= 1
+    bound = set(_lib.exported_symbols())
+    assert declared == bound, f"header vs ctypes binding mismatch: {declared ^ bound}"
+    for name in declared:
+        assert hasattr(lib, name)
+
+
+def test_product_fails_loudly_without_gpu():
+    """No CPU / PyTorch fallback on the product path."""
+    from sam_pt_amd import _lib
+    from sam_pt_amd.point_tracker import PipsPointTracker
+    from sam_pt_amd.sam_predictor import SamHip, SamPredictor
+    from sam_pt_amd.weights import SAM_CONFIGS, init_pips_state_dict
+    trk = PipsPointTracker(state_dict=init_pips_state_dict(1))
+    rgbs = torch.zeros(1, 9, 3, 64, 96, dtype=torch.uint8)
+    with pytest.raises(_lib.SamptError):
+        trk(rgbs, torch.tensor([[[0.0, 10.0, 10.0]]]))
+    pred = SamPredictor(SamHip(config=SAM_CONFIGS["vit_test"]))
+    with pytest.raises(_lib.SamptError):
+        pred.set_image(np.zeros((144, 256, 3), dtype=np.uint8))
+    with pytest.raises(RuntimeError):
+        pred.predict_torch(torch.zeros(1, 1, 2), torch.ones(1, 1, dtype=torch.int), multimask_output=False)
+
+
+def test_product_does_not_import_oracle():
+    for root, _, files in os.walk(os.path.join(ROOT, "sam_pt_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f"{f} imports the oracle"
+
+
+def test_window_row_map_matches_window_partition():
+    """pack.window_row_map == the row permutation of SAM's window_partition (zero padding -> -1)."""
+    from oracle import sam_ref as R
+    from sam_pt_amd.pack import window_row_map
+    for grid, ws, B in [(16, 6, 2), (64, 14, 1), (8, 4, 3)]:
+        tok = torch.arange(1, B * grid * grid + 1, dtype=torch.float32).view(B, grid, grid, 1)
+        win, _ = R._window_partition(tok, ws)              # (B*nwin, ws, ws, 1); padding = 0
+        expect = win.reshape(-1).long() - 1                # token row, -1 on padding
+        assert torch.equal(window_row_map(grid, ws, B).long(), expect)
+
+
+def test_pixel_shuffle_maps_match_conv_transpose():
+    from sam_pt_amd.pack import _convt_pack, _shuffle_map
+    g = torch.Generator().manual_seed(0)
+    side, cin, cout, F = 4, 8, 6, 3
+    x = torch.randn(F, cin, side, side, generator=g)
+    w = torch.randn(cin, cout, 2, 2, generator=g)
+    ref = torch.nn.functional.conv_transpose2d(x, w, stride=2).permute(0, 2, 3, 1).reshape(F * 4 * side * side, cout)
+    rows = x.permute(0, 2, 3, 1).reshape(F * side * side, cin)
+    maps, wp = _shuffle_map(side, F), _convt_pack(w)
+    out = torch.zeros_like(ref)
+    for z in range(4):
+        out[maps[z].long()] = rows @ wp[z].t()
+    assert torch.allclose(out, ref, atol=1e-5)
+
+
+def test_weight_layouts_and_packing():
+    from sam_pt_amd.pack import pack_pips
+    from sam_pt_amd.weights import SAM_CONFIGS, init_pips_state_dict, init_sam_state_dict
+    sd = init_pips_state_dict(72)
+    assert len(sd) == 200 and sd["delta_block.to_delta.0.weight"].shape == (512, 519)
+    assert sd["delta_block.to_delta.3.0.fn.0.weight"].shape == (32, 8, 1)
+    p = pack_pips(sd, "cpu")
+    assert p["fnet.conv1.weight"].shape == (64, 7 * 7 * 4) and p["delta_block.to_delta.0.weight"].shape == (512, 520)
+    w = sd["fnet.layer2.0.conv1.weight"]
+    assert torch.equal(p["fnet.layer2.0.conv1.weight"].view(96, 3, 3, 64)[5, 1, 2], w[5, :, 1, 2])
+    s = init_sam_state_dict(SAM_CONFIGS["vit_b"], 72)
+    assert s["image_encoder.blocks.2.attn.rel_pos_h"].shape == (127, 64)   # global block: 2*64-1
+    assert s["image_encoder.blocks.0.attn.rel_pos_h"].shape == (27, 64)    # windowed: 2*14-1
+    assert s["mask_decoder.output_upscaling.0.weight"].shape == (256, 64, 2, 2)
+
+
+def test_sharding_helpers():
+    from sam_pt_amd.dist import frame_batches, index_masks, lpt_assign
+    lengths = [104, 34, 50, 80, 69, 40, 90, 75, 60, 45]
+    parts = lpt_assign(lengths, 4)
+    assert sorted(i for p in parts for i in p) == list(range(10))
+    loads = [sum(lengths[i] for i in p) for p in parts]
+    assert max(loads) - min(loads) <= max(lengths)
+    fb = [frame_batches(50, 4, r, 8) for r in range(4)]
+    assert sorted(t for r in fb for b in r for t in b) == list(range(50))
+    logits = torch.full((2, 3, 4, 5), -1.0)
+    logits[1, :, 1, 2] = 3.0
+    m = index_masks(logits)
+    assert m.dtype == torch.uint8 and m[:, 1, 2].tolist() == [2, 2, 2] and int(m.sum()) == 6
+
+
+def test_gather_masks_two_ranks_gloo():
+    """The N > 1 path of bench.py (sequence sharding + final uint8 mask gather) with 2 processes on the gloo backend."""
+    code = r"""
+import os, sys, torch
+sys.path.insert(0, %r)
+import torch.distributed as dist
+from sam_pt_amd.dist import init_from_env, gather_masks, lpt_assign
+rank, world, local = init_from_env("gloo")
+assert world == 2
+mine = lpt_assign([5, 3, 4, 2], world)[rank]
+T = 2 + rank
+masks = torch.full((T, 4, 6), rank + 1, dtype=torch.uint8)
+out = gather_masks(masks, max_frames=3)
+if rank == 0:
+    assert out.shape == (2, 3, 4, 6)
+    assert out[0, :2].eq(1).all() and out[0, 2].eq(0).all() and out[1].eq(2).all()
+    print("GATHER_OK", mine)
+else:
+    assert out is None
+dist.barrier(); dist.destroy_process_group()
+""" % ROOT
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    import tempfile  # torch.distributed.run needs a script file
+    with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:
+        f.write(code)
+        path = f.name
+    try:
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                            "--master-addr", "127.0.0.1", "--master-port", "29533", path], env=env, capture_output=True,
+                           text=True, timeout=240)
+    finally:
+        os.unlink(path)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "GATHER_OK" in r.stdout
