@@ -198,3 +198,36 @@ def test_sampt_end_to_end_vs_oracle(dev, neg):
         for t in range(10):
             assert iou(a[t] > 0, b[t] > 0) >= 1 - 1e-3, f"mask IoU object {m} frame {t}"
     assert np.allclose(np.array(out["scores_per_frame"]), np.array(ref["scores_per_frame"]), atol=1e-3)
+
+
+# ------------------------------------------------------------------------------------------ golden fixtures
+def test_hip_tracker_vs_reference_golden(dev, pips_sd, clip):
+    """HIP PipsPointTracker against the committed output of the REFERENCE's PipsPointTracker (tests/golden)."""
+    import os
+    from oracle.make_golden import golden_queries
+    from sam_pt_amd.point_tracker import PipsPointTracker
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pips_tracker.npz"))
+    frames, centres = clip
+    q = golden_queries(centres)
+    tr, vi = PipsPointTracker(state_dict=pips_sd)(frames[None].to(dev), q.to(dev))
+    assert np.array_equal(vi.cpu().numpy(), g["vis"])
+    assert np.abs(tr.cpu().numpy() - g["traj"]).max() < 5e-3
+    assert np.array_equal(np.round(tr.cpu().numpy()), np.round(g["traj"]))
+
+
+def test_hip_sam_vs_hf_golden(dev):
+    """HIP decoder (exact fp32) against the committed HuggingFace SamModel outputs for the same weights."""
+    import os
+    from sam_pt_amd.sam_predictor import SamHip, SamPredictor
+    from sam_pt_amd.weights import SAM_CONFIGS
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sam_hf.npz"))
+    cfg = SAM_CONFIGS["vit_test"]
+    pred = SamPredictor(SamHip(config=cfg, seed=72, precision="f32").cuda())
+    emb = torch.from_numpy(g["emb"])                                   # (1,256,16,16) from HF
+    pred.set_features(emb[0].permute(1, 2, 0).reshape(256, 256).contiguous().to(dev), (256, 256))
+    pts, lab = torch.from_numpy(g["pts"]).to(dev), torch.from_numpy(g["lab"]).int().to(dev)
+    m, iou, low = pred.predict_torch(pts, lab, None, None, False, True)
+    assert np.abs(low.cpu().numpy()[0] - g["low"]).max() < 2e-4 and np.abs(iou.cpu().numpy() - g["iou"]).max() < 1e-4
+    box = torch.from_numpy(g["box"]).to(dev)
+    m2, iou2, low2 = pred.predict_torch(pts, lab, box[None], torch.from_numpy(g["low"])[None].to(dev), False, True)
+    assert np.abs(low2.cpu().numpy()[0] - g["low2"]).max() < 2e-4 and np.abs(iou2.cpu().numpy() - g["iou2"]).max() < 1e-4
