@@ -54,12 +54,14 @@ int sampt_pips_fnet_f32(sampt_pips_t h, const uint8_t* frames_dev, int nf, int H
                         void* workspace_dev, size_t workspace_bytes, sampt_stream_t stream);
 
 /* Initial point features: bilinear_sample2d(fmaps[:,0], xy/stride) (pips.py:469-475, utils/samp.py:6-80).
- * fmap_dev: one level-0 frame [H0][W0][128]; xy_dev: [n][2] in feature-map pixels; out_dev: [n][128]. */
-int sampt_pips_sample_feat_f32(const float* fmap_dev, int H0, int W0, const float* xy_dev, int n, float* out_dev,
-                               sampt_stream_t stream);
+ * fmap_dev: level-0 maps [frames][H0][W0][128]; frame_idx_dev: int32 [n] frame of each point (NULL: frame 0);
+ * xy_dev: [n][2] in feature-map pixels; out_dev: [n][128]. */
+int sampt_pips_sample_feat_f32(const float* fmap_dev, int H0, int W0, const int32_t* frame_idx_dev, const float* xy_dev,
+                               int n, float* out_dev, sampt_stream_t stream);
 
 /* One 8-frame window of Pips.forward's iterative update (pips.py:458-476, 507-568) + sigmoid (pips/tracker.py:102).
- * frame_idx_dev: int32 [S] indices into the pyramid's frame axis (window frames, tail repeated: tracker.py:73-78);
+ * frame_idx_dev: int32 [n][S] — per POINT, the indices of its window frames in the pyramid (tail repeated as
+ * tracker.py:73-78).  Points are independent in PIPS, so points anchored at different frames share one call;
  * xys_dev: [n][2] pixels at the window's first frame; feat_init_dev: [n][128].
  * traj_out_dev: [S][n][2] pixels (last iteration); vis_out_dev: [S][n] in (0,1). */
 int sampt_pips_update_workspace_bytes(sampt_pips_t h, int n, size_t* bytes);

@@ -68,9 +68,9 @@ int sampt_pips_fnet_f32(sampt_pips_t h, const uint8_t* frames, int nf, int H, in
   return h->e.fnet(frames, nf, H, W, pyr, a, (hipStream_t)stream);
 }
 
-int sampt_pips_sample_feat_f32(const float* fmap, int H0, int W0, const float* xy, int n, float* out,
-                               sampt_stream_t stream) {
-  return pips_sample_feat(fmap, H0, W0, 128, xy, n, out, (hipStream_t)stream);
+int sampt_pips_sample_feat_f32(const float* fmap, int H0, int W0, const int32_t* frame_idx, const float* xy, int n,
+                               float* out, sampt_stream_t stream) {
+  return pips_sample_feat(fmap, H0, W0, 128, (const int*)frame_idx, xy, n, out, (hipStream_t)stream);
 }
 
 int sampt_pips_update_workspace_bytes(sampt_pips_t h, int n, size_t* bytes) {

@@ -67,7 +67,7 @@ struct PipsEngine {
   int init(const WeightMap& w);
   // frames: uint8 (nf,3,H,W).  out[l]: level-l feature maps [nf][H_l][W_l][128] f32 (H_0 = H/stride).
   int fnet(const uint8_t* frames, int nf, int H, int W, float* const out[4], Arena& ws, hipStream_t s);
-  // one PIPS window: frame_idx (device, [S] ints into the pyramid), xys (device [n][2], px at window frame 0),
+  // one PIPS window per point: frame_idx (device, [n][S] ints into the pyramid), xys (device [n][2], px at frame 0),
   // feat_init (device [n][128]).  traj_out [S][n][2] px, vis_out [S][n] = sigmoid(logit).
   int update(const PyramidLevels& pyr, const int* frame_idx, int n, const float* xys, const float* feat_init, int iters,
              float* traj_out, float* vis_out, Arena& ws, hipStream_t s);

@@ -52,7 +52,9 @@ struct PyramidLevels {
   int H[4], W[4];
 };
 // ffeat[n][c] = bilinear_sample2d(fmap[frame], x/stride..)   (samp.py:6-80)
-int pips_sample_feat(const float* fmap, int H, int W, int C, const float* xy, int n, float* out, hipStream_t s);
+// frame_idx: optional per-point frame index into fmap [frames][H][W][C]
+int pips_sample_feat(const float* fmap, int H, int W, int C, const int* frame_idx, const float* xy, int n, float* out,
+                     hipStream_t s);
 // fused correlation + 7x7 window sampler (pips.py:364-407): writes x[n][s][xoff + lvl*49 + i*7+j]
 int pips_corr_sample(const PyramidLevels& pyr, const int* frame_idx, int S, int n, int C, const float* ffeats,
                      const float* coords, float* x, int ldx, int xoff, hipStream_t s);

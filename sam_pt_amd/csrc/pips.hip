@@ -13,10 +13,12 @@ namespace sampt {
 // ---------------------------------------------------------------------------------------------
 // K7: bilinear_sample2d (utils/samp.py:6-80): clamped indices, weights from the un-clamped floor
 // ---------------------------------------------------------------------------------------------
-__global__ void k_pips_sample_feat(const float* __restrict__ fmap, int H, int W, int C, const float* __restrict__ xy,
+__global__ void k_pips_sample_feat(const float* __restrict__ fmap, int H, int W, int C,
+                                   const int* __restrict__ frame_idx, const float* __restrict__ xy,
                                    float* __restrict__ out) {
   int pt = blockIdx.x, c = threadIdx.x;
   if (c >= C) return;
+  if (frame_idx) fmap += (long)frame_idx[pt] * H * W * C;
   float x = xy[pt * 2], y = xy[pt * 2 + 1];
   float x0f = floorf(x), y0f = floorf(y);
   float x1f = x0f + 1.f, y1f = y0f + 1.f;
@@ -30,9 +32,10 @@ __global__ void k_pips_sample_feat(const float* __restrict__ fmap, int H, int W,
   out[pt * C + c] = w00 * v00 + w01 * v01 + w10 * v10 + w11 * v11;
 }
 
-int pips_sample_feat(const float* fmap, int H, int W, int C, const float* xy, int n, float* out, hipStream_t s) {
+int pips_sample_feat(const float* fmap, int H, int W, int C, const int* frame_idx, const float* xy, int n, float* out,
+                     hipStream_t s) {
   if (n <= 0 || C > 1024) return SAMPT_ERR_ARG;
-  hipLaunchKernelGGL(k_pips_sample_feat, dim3(n), dim3(C), 0, s, fmap, H, W, C, xy, out);
+  hipLaunchKernelGGL(k_pips_sample_feat, dim3(n), dim3(C), 0, s, fmap, H, W, C, frame_idx, xy, out);
   SAMPT_CHECK_LAUNCH("pips_sample_feat");
   return SAMPT_OK;
 }
@@ -55,7 +58,7 @@ __global__ __launch_bounds__(64) void k_pips_corr_sample(PyramidLevels pyr, cons
   const int unit = blockIdx.x, lvl = blockIdx.y;
   const int s = unit / n, pt = unit - s * n;
   const int H = pyr.H[lvl], W = pyr.W[lvl];
-  const float* fmap = pyr.base[lvl] + (long)frame_idx[s] * H * W * C;
+  const float* fmap = pyr.base[lvl] + (long)frame_idx[pt * S + s] * H * W * C;  // per-point window frames
   const float scale = (float)(1 << lvl);
   const float cx = coords[(s * n + pt) * 2] / scale, cy = coords[(s * n + pt) * 2 + 1] / scale;
   const int bx = (int)floorf(cx) - 3, by = (int)floorf(cy) - 3;

@@ -131,12 +131,22 @@ class PipsPointTracker(PointTracker):
         self.stats["fnet_frames"] += T
         return pyr
 
-    # -- one direction (pips/tracker.py:42-153) ----------------------------------------------------
-    def _one_direction(self, pyr, T: int, query_points: torch.Tensor, index_of, ws):
-        """query_points (N,3) CPU float (t in this direction's time).  Returns CPU (T,N,2), (T,N) bool."""
+    # -- chained windows for a set of independent point chains (pips/tracker.py:42-153) --------------------------
+    def _run_chains(self, pyr, T: int, query_points: torch.Tensor, flipped: torch.Tensor, ws):
+        """query_points (N,3) CPU float = (t, x, y) in each chain's OWN time axis; ``flipped[i]`` marks chains that run on
+        the time-reversed clip (direction frame d = original frame T-1-d).  Returns CPU (T,N,2), (T,N) bool in each
+        chain's own time axis.
+
+        The reference walks ``current_frame`` upwards and runs one ``Pips.forward`` per distinct anchor frame with the
+        points anchored there (tracker.py:67-109).  PIPS treats points independently (the mixer batch is per point,
+        pips.py:525-532), so the same per-point window sequence can be executed in ROUNDS: every unfinished chain
+        advances by one window per round, all of them batched into one ``sampt_pips_update_f32`` call with per-point
+        window frames.  Results are identical per point; the number of device calls drops from one per distinct anchor
+        to max-windows-per-chain, and the MFMA GEMMs of the mixer always see all active points."""
         dev = pyr[0].device
         N = query_points.shape[0]
         H0, W0 = pyr[0].shape[1:3]
+        S = self.s
         traj = torch.zeros(T, N, 2)
         vis = torch.zeros(T, N)
         start = query_points[:, 0].long()
@@ -144,47 +154,59 @@ class PipsPointTracker(PointTracker):
         vis[start, ar] = 1.0
         traj[start, ar] = query_points[:, 1:]
         feat_init = torch.zeros(N, 128, device=dev)
+        have_feat = torch.zeros(N, dtype=torch.bool)
         cur = start.clone()
+        thr0 = float(self.initial_next_frame_visibility_threshold)
         pyr_ptrs = _lib.ptr_array(pyr)
-        for f in range(T - 1):
-            active = cur == f
-            if active.sum() == 0:
-                continue
-            idx = list(range(f, min(f + self.s, T)))
-            n_missing = self.s - len(idx)
-            idx = idx + [idx[-1]] * n_missing                                   # tracker.py:73-78
-            fidx = torch.tensor([index_of(i) for i in idx], dtype=torch.int32, device=dev)
-            fresh = start == f
-            if fresh.any():                                                       # tracker.py:81-90 == App. B-6
-                xy = (traj[f, fresh] / float(self.stride)).to(dev).contiguous()
-                out = torch.empty(int(fresh.sum()), 128, device=dev)
-                _lib.check(self._lib.sampt_pips_sample_feat_f32(_lib.ptr(pyr[0][index_of(f)]), H0, W0, _lib.ptr(xy),
-                                                                xy.shape[0], _lib.ptr(out), _lib.stream_ptr()),
+
+        def orig(d, fl):                       # direction frame -> original frame index
+            return torch.where(fl, T - 1 - d, d)
+
+        while True:
+            act = (cur < T - 1).nonzero().flatten()            # tracker.py:67: anchors range over n_frames-1
+            if act.numel() == 0:
+                break
+            n = act.numel()
+            f = cur[act]                                        # (n,) anchor frame of each active chain
+            hi = torch.clamp(T - f, max=S)                      # frames available in the window (S - n_missing)
+            win = f[:, None] + torch.arange(S)[None, :]
+            win = torch.minimum(win, (f + hi - 1)[:, None])    # repeat the last frame (tracker.py:73-78)
+            fidx = orig(win, flipped[act][:, None]).to(torch.int32).to(dev).contiguous()        # [n][S]
+            xys_cpu = traj[f, act]                              # (n,2)
+            xys = xys_cpu.to(dev).contiguous()
+            fresh = ~have_feat[act]
+            if fresh.any():                                     # tracker.py:81-90 == App. B-6: feature at the query frame
+                fa = act[fresh]
+                xy = (xys_cpu[fresh] / float(self.stride)).to(dev).contiguous()
+                fr = fidx[fresh.to(dev), 0].contiguous()
+                out = torch.empty(fa.numel(), 128, device=dev)
+                _lib.check(self._lib.sampt_pips_sample_feat_f32(_lib.ptr(pyr[0]), H0, W0, _lib.ptr(fr), _lib.ptr(xy),
+                                                                fa.numel(), _lib.ptr(out), _lib.stream_ptr()),
                            "sampt_pips_sample_feat_f32")
-                feat_init[fresh.to(dev)] = out
-            n = int(active.sum())
-            xys = traj[f, active].to(dev).contiguous()
-            fi = feat_init[active.to(dev)].contiguous()
-            tr_o = torch.empty(self.s, n, 2, device=dev)
-            vi_o = torch.empty(self.s, n, device=dev)
+                feat_init[fa.to(dev)] = out
+                have_feat[fa] = True
+            fi = feat_init[act.to(dev)].contiguous()
+            tr_o = torch.empty(S, n, 2, device=dev)
+            vi_o = torch.empty(S, n, device=dev)
             _lib.check(self._lib.sampt_pips_update_f32(self._h, pyr_ptrs, H0, W0, _lib.ptr(fidx), n, _lib.ptr(xys),
                                                        _lib.ptr(fi), 6, _lib.ptr(tr_o), _lib.ptr(vi_o), _lib.ptr(ws),
                                                        ws.numel(), _lib.stream_ptr()), "sampt_pips_update_f32")
             self.stats["windows"] += 1
-            tr_c, vi_c = tr_o.cpu(), vi_o.cpu()       # the linking below is data-dependent host control flow
-            hi = self.s - n_missing
-            vis[f + 1:f + hi, active] = vi_c[1:hi]
-            traj[f + 1:f + hi, active] = tr_c[1:hi]
-            # trajectory linking (tracker.py:111-148)
-            thr = torch.where(active, torch.full((N,), float(self.initial_next_frame_visibility_threshold)), torch.zeros(N))
-            earliest = torch.where(active, cur + 1, cur)
-            last = torch.where(active, cur + hi - 1, cur)
-            nxt = last
-            while (vis[nxt, ar] <= thr).any():
-                nxt = torch.where(vis[nxt, ar] <= thr, nxt - 1, nxt)
+            self.stats["point_windows"] = self.stats.get("point_windows", 0) + n
+            tr_c, vi_c = tr_o.cpu(), vi_o.cpu()                 # linking below is data-dependent host control flow
+            for j in range(n):                                  # write frames 1..hi-1 of each chain (tracker.py:104-109)
+                p, fj, hj = int(act[j]), int(f[j]), int(hi[j])
+                vis[fj + 1:fj + hj, p] = vi_c[1:hj, j]
+                traj[fj + 1:fj + hj, p] = tr_c[1:hj, j]
+            # trajectory linking per chain (tracker.py:111-148)
+            thr = torch.full((n,), thr0)
+            earliest, last = f + 1, f + hi - 1
+            nxt = last.clone()
+            while (vis[nxt, act] <= thr).any():
+                nxt = torch.where(vis[nxt, act] <= thr, nxt - 1, nxt)
                 thr = torch.where(nxt < earliest, thr - 0.02, thr)
                 nxt = torch.where(nxt < earliest, last, nxt)
-            cur = torch.where(active, nxt, cur)
+            cur[act] = nxt
         return traj, vis > 0.5
 
     @torch.no_grad()
@@ -200,13 +222,15 @@ class PipsPointTracker(PointTracker):
         N = q.shape[0]
         pyr = self.compute_pyramid(frames)
         nbytes = C.c_size_t()
-        _lib.check(self._lib.sampt_pips_update_workspace_bytes(self._h, N, C.byref(nbytes)), "update_workspace")
+        _lib.check(self._lib.sampt_pips_update_workspace_bytes(self._h, 2 * N, C.byref(nbytes)), "update_workspace")
         ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
-        tr_r, vi_r = self._one_direction(pyr, T, q, lambda i: i, ws)
+        # both temporal directions are independent chains too: run them in the same rounds (tracker.py:159-167)
         qf = q.clone()
         qf[:, 0] = T - qf[:, 0] - 1
-        tr_l, vi_l = self._one_direction(pyr, T, qf, lambda i: T - 1 - i, ws)   # time-flipped pass on the same pyramid
-        tr_l, vi_l = tr_l.flip(0), vi_l.flip(0)
+        flipped = torch.cat([torch.zeros(N, dtype=torch.bool), torch.ones(N, dtype=torch.bool)])
+        tr_all, vi_all = self._run_chains(pyr, T, torch.cat([q, qf]), flipped, ws)
+        tr_r, vi_r = tr_all[:, :N], vi_all[:, :N]
+        tr_l, vi_l = tr_all[:, N:].flip(0), vi_all[:, N:].flip(0)
         traj, vis = tr_r.clone(), vi_r.clone()
         for n in range(N):                                                       # tracker.py:173-199
             s = int(q[n, 0].item())

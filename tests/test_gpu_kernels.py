@@ -159,7 +159,7 @@ def test_corr_sample_vs_oracle(lib, dev):
     coords[:, 2] = torch.tensor([10.0, 7.0])          # exactly integral
     ref = O.sample_corr(O.corr_volumes(pyr, ffeats), coords)           # S,N,196
     pyr_d = [p.permute(0, 2, 3, 1).contiguous().to(dev) for p in pyr]
-    fidx = torch.arange(S_, dtype=torch.int32, device=dev)
+    fidx = torch.arange(S_, dtype=torch.int32, device=dev).repeat(n, 1).contiguous()    # [n][S]
     ff_d = ffeats.permute(1, 0, 2).contiguous().to(dev)                # [n][S][128]
     out = torch.empty(n, S_, 196, device=dev)
     co_d = coords.contiguous().to(dev)

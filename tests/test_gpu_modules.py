@@ -58,9 +58,9 @@ def test_update_window_vs_oracle(dev, pips_sd, clip):
     ws = torch.empty(nb.value, dtype=torch.uint8, device=dev)
     fi = torch.empty(5, 128, device=dev)
     xy0 = (xys / 4.0).contiguous().to(dev)
-    _lib.check(lib.sampt_pips_sample_feat_f32(_lib.ptr(pyr[0][0]), 32, 64, _lib.ptr(xy0), 5, _lib.ptr(fi), _lib.stream_ptr()), "feat")
+    _lib.check(lib.sampt_pips_sample_feat_f32(_lib.ptr(pyr[0]), 32, 64, None, _lib.ptr(xy0), 5, _lib.ptr(fi), _lib.stream_ptr()), "feat")
     assert max_abs(fi, ffeat) < 1e-5
-    fidx = torch.arange(8, dtype=torch.int32, device=dev)
+    fidx = torch.arange(8, dtype=torch.int32, device=dev).repeat(5, 1).contiguous()   # per-point window frames [n][S]
     tr = torch.empty(8, 5, 2, device=dev)
     vi = torch.empty(8, 5, device=dev)
     xys_d = xys.contiguous().to(dev)
