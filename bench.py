@@ -157,6 +157,8 @@ def main():
         assert world == 1 and args.gpus == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch through torch.distributed.run"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    # host-side weight generation / packing: keep N ranks from oversubscribing the host cores
+    torch.set_num_threads(max(1, min(32, (os.cpu_count() or 8) // max(world, 1))))
     frames, qp = bench_clip(T=args.frames, seed=72 + rank, n_pos=args.points)
     H, W = frames.shape[-2:]
     model = build_model(args, dev)

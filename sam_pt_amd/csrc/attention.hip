@@ -106,8 +106,8 @@ int softmax_rel_rows(float* scores, const float* relh, const float* relw, long B
 // the A operand uses the same one, and V^T is read from LDS with exactly that permutation).
 // ---------------------------------------------------------------------------------------------
 template <int HD, int NW, int SG>
-__global__ __launch_bounds__(NW * 64) void k_flash_f16(const half_t* __restrict__ qkv, const float* __restrict__ relhT,
-                                                       const float* __restrict__ relwT, half_t* __restrict__ out, int N,
+__global__ __launch_bounds__(NW * 64) void k_flash_f16(const half_t* __restrict__ qkv, const float* __restrict__ rel_h,
+                                                       const float* __restrict__ rel_w, half_t* __restrict__ out, int N,
                                                        int heads, float scale) {
   constexpr int KS = HD / 16;            // k-steps of QK^T
   constexpr int DT = (HD + 31) / 32;     // 32-row tiles of O^T
@@ -127,28 +127,60 @@ __global__ __launch_bounds__(NW * 64) void k_flash_f16(const half_t* __restrict_
   const int qblk = blockIdx.x * QT;
   const int ql = wave * 32 + li;
   const int q = qblk + ql;
-  const long bh = (long)b * heads + h;
-
-  // ---- prologue: bias tables (fp16 in LDS), zero the unused V^T rows, Q fragments
-  for (int i = tid; i < SG * QT; i += NT) {
-    int kk = i / QT, qq = i - kk * QT;
-    int gq = qblk + qq;
-    float vh = 0.f, vw = 0.f;
-    if (gq < N) {
-      vh = relhT[(bh * SG + kk) * N + gq];
-      vw = relwT[(bh * SG + kk) * N + gq];
-    }
-    relh_s[kk][qq] = (half_t)vh;
-    relw_s[kk][qq] = (half_t)vw;
-  }
+  // ---- prologue: zero the unused V^T rows, Q fragments, then the decomposed rel-pos tables of THIS wave's 32 queries
+  //      computed with MFMA straight into LDS (fp16): G[rho][q] = <rel_pos[rho], q_vec> for all 2*SG-1 table rows, and
+  //      rel_h[q][kh] = G_h[qh - kh + SG-1][q], rel_w[q][kw] = G_w[qw - kw + SG-1][q]   (App. A-3) — no HBM round trip.
   if (DT * 32 > HD) {
     for (int i = tid; i < (DT * 32 - HD) * VLD; i += NT) Vt[HD + i / VLD][i % VLD] = (half_t)0.f;
+  }
+  for (int i = tid; i < SG * RLD; i += NT) {
+    (&relh_s[0][0])[i] = (half_t)0.f;
+    (&relw_s[0][0])[i] = (half_t)0.f;
   }
   h8 qf[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
     if (q < N) qf[ks] = *(const h8*)(qkv + (tok0 + q) * 3 * D + h * HD + ks * 16 + hi * 8);
     else qf[ks] = (h8){0, 0, 0, 0, 0, 0, 0, 0};
+  }
+  __syncthreads();
+  {
+    constexpr int NR = 2 * SG - 1, NTIL = (NR + 31) / 32;
+    const int qh = q / SG, qw = q - qh * SG;
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb) {
+      const float* tab = tb == 0 ? rel_h : rel_w;
+      const int qpos = tb == 0 ? qh : qw;
+#pragma unroll
+      for (int t = 0; t < NTIL; ++t) {
+        f32x16 g;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[r] = 0.f;
+        const int row = 32 * t + li;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          h8 tf = (h8){0, 0, 0, 0, 0, 0, 0, 0};
+          if (row < NR) {
+            const float4* tp = (const float4*)(tab + (long)row * HD + ks * 16 + hi * 8);
+            float4 t0 = tp[0], t1 = tp[1];
+            tf = (h8){(half_t)t0.x, (half_t)t0.y, (half_t)t0.z, (half_t)t0.w,
+                      (half_t)t1.x, (half_t)t1.y, (half_t)t1.z, (half_t)t1.w};
+          }
+          g = __builtin_amdgcn_mfma_f32_32x32x16_f16(tf, qf[ks], g, 0, 0, 0);
+        }
+        if (q < N) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int rho = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const int kx = qpos - rho + SG - 1;
+            if (kx >= 0 && kx < SG) {
+              if (tb == 0) relh_s[kx][ql] = (half_t)g[r];
+              else relw_s[kx][ql] = (half_t)g[r];
+            }
+          }
+        }
+      }
+    }
   }
 
   f32x16 o[DT];
@@ -259,6 +291,7 @@ __global__ __launch_bounds__(NW * 64) void k_flash_f16(const half_t* __restrict_
   }
 }
 
+// rel_h / rel_w: the block's rel_pos tables, f32 [2S-1][hd]
 int vit_flash_attention_f16(const half_t* qkv, const float* relh, const float* relw, half_t* out, int B, int S,
                             int heads, int hd, hipStream_t s) {
   const int N = S * S;

@@ -263,12 +263,8 @@ int sampt_corr_sample_f32(const float* const pyr[4], int H0, int W0, const int32
 
 int sampt_vit_attention_f16(const void* qkv, const float* rel_h, const float* rel_w, void* out, int B, int S, int heads,
                             int hd, void* ws, size_t ws_bytes, sampt_stream_t stream) {
-  size_t n = (size_t)B * heads * S * S * S;
-  if (ws_bytes < 2 * n * sizeof(float)) return SAMPT_ERR_WORKSPACE;
-  float* relh = (float*)ws;
-  float* relw = relh + n;
-  SAMPT_TRY(vit_rel_bias(qkv, 1, rel_h, rel_w, B, S, heads, hd, relh, relw, (hipStream_t)stream));
-  return vit_flash_attention_f16((const half_t*)qkv, relh, relw, (half_t*)out, B, S, heads, hd, (hipStream_t)stream);
+  (void)ws, (void)ws_bytes;  // the decomposed rel-pos bias is computed inside the kernel: no scratch needed any more
+  return vit_flash_attention_f16((const half_t*)qkv, rel_h, rel_w, (half_t*)out, B, S, heads, hd, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -74,8 +74,8 @@ int VitEngine::encode(const uint8_t* frames, int chw, int B, int H, int W, float
   const long BHg = (long)B * c.heads, BHw = (long)B * nwin * c.heads;
   size_t rel_elems = (size_t)BHg * g * T;
   if ((size_t)BHw * ws_ * wt > rel_elems) rel_elems = (size_t)BHw * ws_ * wt;
-  float* relh = ws.f32(rel_elems);
-  float* relw = ws.f32(rel_elems);
+  float* relh = c.f16 ? nullptr : ws.f32(rel_elems);   // materialised bias tables: exact-fp32 mode only
+  float* relw = c.f16 ? nullptr : ws.f32(rel_elems);
   float* scores = nullptr;
   if (!c.f16) {
     size_t sg = (size_t)BHg * T * T, sw2 = (size_t)BHw * wt * wt;
@@ -103,10 +103,10 @@ int VitEngine::encode(const uint8_t* frames, int chw, int B, int H, int W, float
     // norm1 (+ window partition with zero padding AFTER the norm)
     SAMPT_TRY(layernorm_rows(x, b.ln1w, b.ln1b, xn, M, D, 1e-6f, map, c.f16, ACT_NONE, s));
     SAMPT_TRY(gm.run(xn, (int)M, D, b.qkv_w, b.qkv_b, qkv, 3 * D, ACT_NONE, c.f16 != 0, nullptr, 0, nullptr, 0));
-    SAMPT_TRY(vit_rel_bias(qkv, c.f16, b.rel_h, b.rel_w, Bw, S, c.heads, hd, relh, relw, s));
     if (c.f16) {
-      SAMPT_TRY(vit_flash_attention_f16((const half_t*)qkv, relh, relw, (half_t*)att, Bw, S, c.heads, hd, s));
+      SAMPT_TRY(vit_flash_attention_f16((const half_t*)qkv, b.rel_h, b.rel_w, (half_t*)att, Bw, S, c.heads, hd, s));
     } else {
+      SAMPT_TRY(vit_rel_bias(qkv, 0, b.rel_h, b.rel_w, Bw, S, c.heads, hd, relh, relw, s));
       const float* q = (const float*)qkv;
       GemmP p;  // scores[bw][h] = scale * Q K^T
       p.A = q, p.W = q + D, p.C = scores;

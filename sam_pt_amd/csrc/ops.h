@@ -42,8 +42,9 @@ int vit_rel_bias(const void* qkv, int qkv_f16, const float* rel_h, const float* 
                  int hd, float* relh, float* relw, hipStream_t s);
 // scores[bh][q][k] (already scaled) += relh[bh][q][k/S] + relw[bh][q][k%S]; softmax over k, in place (f32).
 int softmax_rel_rows(float* scores, const float* relh, const float* relw, long BH, int Nq, int S, hipStream_t s);
-// Fused flash-style attention, f16 operands, fp32 softmax/accumulate.  qkv f16 [B*S*S][3*D]; out f16 [B*S*S][D].
-int vit_flash_attention_f16(const half_t* qkv, const float* relh, const float* relw, half_t* out, int B, int S,
+// Fused flash-style attention, f16 operands, fp32 softmax/accumulate.  qkv f16 [B*S*S][3*D]; out f16 [B*S*S][D];
+// rel_h / rel_w: rel_pos tables f32 [2S-1][hd] (the decomposed bias is computed inside the kernel).
+int vit_flash_attention_f16(const half_t* qkv, const float* rel_h, const float* rel_w, half_t* out, int B, int S,
                             int heads, int hd, hipStream_t s);
 
 // ---- pips.hip ---------------------------------------------------------------------------------
