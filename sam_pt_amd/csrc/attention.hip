@@ -106,7 +106,7 @@ int softmax_rel_rows(float* scores, const float* relh, const float* relw, long B
 // the A operand uses the same one, and V^T is read from LDS with exactly that permutation).
 // ---------------------------------------------------------------------------------------------
 template <int HD, int NW, int SG>
-__global__ __launch_bounds__(NW * 64) void k_flash_f16(const half_t* __restrict__ qkv, const float* __restrict__ rel_h,
+__global__ __launch_bounds__(NW * 64, 2) void k_flash_f16(const half_t* __restrict__ qkv, const float* __restrict__ rel_h,
                                                        const float* __restrict__ rel_w, half_t* __restrict__ out, int N,
                                                        int heads, float scale) {
   constexpr int KS = HD / 16;            // k-steps of QK^T
@@ -190,23 +190,55 @@ __global__ __launch_bounds__(NW * 64) void k_flash_f16(const half_t* __restrict_
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
+  // ---- register-staged K/V pipeline: the global loads of tile t+1 are issued before tile t is multiplied and written
+  //      to LDS (K row-major, V transposed) only after the barrier that retires tile t
+  constexpr int TV = 64 * (HD / 8);                 // 16-byte vectors per K (or V) tile
+  constexpr int LI = (TV + NT - 1) / NT;            // vectors per thread
+  h8 kreg[LI], vreg[LI];
+  auto load_tile = [&](int kt0) {
+#pragma unroll
+    for (int i = 0; i < LI; ++i) {
+      const int v = tid + i * NT;
+      kreg[i] = (h8){0, 0, 0, 0, 0, 0, 0, 0};
+      vreg[i] = (h8){0, 0, 0, 0, 0, 0, 0, 0};
+      if (v < TV) {
+        const int kr = v / (HD / 8), kv = v - kr * (HD / 8);
+        if (kt0 + kr < N) kreg[i] = *(const h8*)(qkv + (tok0 + kt0 + kr) * 3 * D + D + h * HD + kv * 8);
+        const int vr = v & 63, dv = v >> 6;
+        if (kt0 + vr < N) vreg[i] = *(const h8*)(qkv + (tok0 + kt0 + vr) * 3 * D + 2 * D + h * HD + dv * 8);
+      }
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < LI; ++i) {
+      const int v = tid + i * NT;
+      if (v < TV) {
+        const int kr = v / (HD / 8), kv = v - kr * (HD / 8);
+        *(h8*)&Ks[kr][kv * 8] = kreg[i];
+        const int vr = v & 63, dv = v >> 6;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) Vt[dv * 8 + e][vr] = vreg[i][e];
+      }
+    }
+  };
+  // global blocks (SG == 64): one key tile == one grid row, so the rel_w bias of a lane's 32 score slots is the same
+  // for every tile (kept in registers) and rel_h is one value per tile
+  float relw_r[SG == 64 ? 32 : 1];
+  if constexpr (SG == 64) {
+    __syncthreads();
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) relw_r[kt * 16 + r] = (float)relw_s[kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi][ql];
+  }
+
+  load_tile(0);
   for (int kt0 = 0; kt0 < N; kt0 += 64) {
     __syncthreads();  // previous tile fully consumed (also orders the prologue LDS writes)
-    // ---- stage K tile [64][HD] and V^T tile [HD][64]
-    for (int v = tid; v < 64 * (HD / 8); v += NT) {
-      int kr = v / (HD / 8), kv = v - kr * (HD / 8);
-      h8 val = (h8){0, 0, 0, 0, 0, 0, 0, 0};
-      if (kt0 + kr < N) val = *(const h8*)(qkv + (tok0 + kt0 + kr) * 3 * D + D + h * HD + kv * 8);
-      *(h8*)&Ks[kr][kv * 8] = val;
-    }
-    for (int v = tid; v < 64 * (HD / 8); v += NT) {
-      int kr = v & 63, dv = v >> 6;
-      h8 val = (h8){0, 0, 0, 0, 0, 0, 0, 0};
-      if (kt0 + kr < N) val = *(const h8*)(qkv + (tok0 + kt0 + kr) * 3 * D + 2 * D + h * HD + dv * 8);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) Vt[dv * 8 + e][kr] = val[e];
-    }
+    store_tile();
     __syncthreads();
+    if (kt0 + 64 < N) load_tile(kt0 + 64);
 
     // ---- S^T = K . Q^T  (two 32-key tiles)
     f32x16 st[2];
@@ -222,13 +254,16 @@ __global__ __launch_bounds__(NW * 64) void k_flash_f16(const half_t* __restrict_
     }
     // ---- scale + decomposed rel-pos bias + key mask, running max
     float mloc = -INFINITY;
+    const float relh_t = SG == 64 ? (float)relh_s[(kt0 >> 6) & (SG - 1)][ql] : 0.f;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         int key = kt0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
         float sv;
-        if (key < N) {
+        if constexpr (SG == 64) {
+          sv = key < N ? st[kt][r] * scale + relh_t + relw_r[kt * 16 + r] : -INFINITY;
+        } else if (key < N) {
           int kh = key / SG, kw = key - kh * SG;
           sv = st[kt][r] * scale + (float)relh_s[kh][ql] + (float)relw_s[kw][ql];
         } else {
