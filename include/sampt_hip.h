@@ -126,6 +126,12 @@ size_t sampt_bbox_workspace_bytes(int h, int w);
 int sampt_bbox_from_logits(const float* logits_dev, int h, int w, int32_t* bbox_state_dev, void* workspace_dev,
                            size_t workspace_bytes, sampt_stream_t stream);
 
+/* VOS post-processing.  sampt_resize_logits: F.interpolate(logits, target_hw, bilinear, align_corners=False) of
+ * sam_pt.py:205-206 for n single-channel maps.  sampt_index_masks: uint8 object index per pixel = argmax over
+ * {background logit 0, logits_dev[M][npix]}, i.e. the bg-stack + softmax + argmax of vos_eval/eval.py:304, 326, 355. */
+int sampt_resize_logits(const float* src_dev, int n, int sh, int sw, float* dst_dev, int dh, int dw, sampt_stream_t stream);
+int sampt_index_masks(const float* logits_dev, int M, long npix, uint8_t* out_dev, sampt_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Kernel-level entry points (used by the parity tests and the roofline bench; same kernels the engines launch).
  * --------------------------------------------------------------------------------------------------------- */

@@ -51,6 +51,8 @@ _SIGS = {
     "sampt_postprocess_masks": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P]),
     "sampt_bbox_workspace_bytes": (c_size_t, [c_int, c_int]),
     "sampt_bbox_from_logits": (c_int, [_P, c_int, c_int, _P, _P, c_size_t, _P]),
+    "sampt_resize_logits": (c_int, [_P, c_int, c_int, c_int, _P, c_int, c_int, _P]),
+    "sampt_index_masks": (c_int, [_P, c_int, C.c_long, _P, _P]),
     "sampt_gemm": (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     "sampt_conv2d_nhwc": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "sampt_instance_norm_nhwc": (c_int, [_P, c_int, c_int, c_int, c_float, c_int, _P, _P, c_size_t, _P]),

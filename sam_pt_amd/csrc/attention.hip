@@ -336,8 +336,8 @@ int vit_flash_attention_f16(const half_t* qkv, const float* relh, const float* r
                      relh, relw, out, N, heads, scale)
   if (S == 64 && hd == 80) FL(80, 4, 64);
   else if (S == 64 && hd == 64) FL(64, 4, 64);
-  else if (S == 14 && hd == 80) FL(80, 7, 14);
-  else if (S == 14 && hd == 64) FL(64, 7, 14);
+  else if (S == 14 && hd == 80) FL(80, 4, 14);
+  else if (S == 14 && hd == 64) FL(64, 4, 14);
   else if (S == 16 && hd == 32) FL(32, 4, 16);   // reduced test geometry (vit_test)
   else if (S == 6 && hd == 32) FL(32, 2, 6);
   else return SAMPT_ERR_UNSUPPORTED;

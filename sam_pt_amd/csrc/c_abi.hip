@@ -256,6 +256,16 @@ int sampt_avgpool2x2_nhwc(const float* src, int n, int h, int w, int C, float* d
   return avgpool2x2_nhwc(src, n, h, w, C, dst, (hipStream_t)stream);
 }
 
+int sampt_resize_logits(const float* src, int n, int sh, int sw, float* dst, int dh, int dw, sampt_stream_t stream) {
+  if (!src || !dst || n <= 0) return SAMPT_ERR_ARG;
+  return resize_logits(src, n, sh, sw, dst, dh, dw, (hipStream_t)stream);
+}
+
+int sampt_index_masks(const float* logits, int M, long npix, uint8_t* out, sampt_stream_t stream) {
+  if (!logits || !out || npix <= 0) return SAMPT_ERR_ARG;
+  return index_masks(logits, M, npix, out, (hipStream_t)stream);
+}
+
 int sampt_corr_sample_f32(const float* const pyr[4], int H0, int W0, const int32_t* frame_idx, int S, int n,
                           const float* ffeats, const float* coords, float* out, sampt_stream_t stream) {
   return pips_corr_sample(make_pyr(pyr, H0, W0), frame_idx, S, n, 128, ffeats, coords, out, 196, 0, (hipStream_t)stream);

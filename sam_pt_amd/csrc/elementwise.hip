@@ -268,10 +268,72 @@ __global__ __launch_bounds__(256) void k_layernorm_rows(const float* __restrict_
   }
 }
 
+// vectorised variant for D % 256 == 0: every lane owns NV float4 chunks (16-byte loads, 8/16-byte stores)
+template <int NV>
+__global__ __launch_bounds__(256) void k_layernorm_rows_v4(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ b, void* __restrict__ y, long M,
+                                                           int D, float eps, const int* __restrict__ src_rows,
+                                                           int out_f16, int act) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  long srow = src_rows ? (long)src_rows[row] : row;
+  if (srow < 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int c = (lane + 64 * i) * 4;
+      if (out_f16) *(h4*)((half_t*)y + row * D + c) = (h4){0, 0, 0, 0};
+      else *(float4*)((float*)y + row * D + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    return;
+  }
+  const float4* xr = (const float4*)(x + srow * D);
+  float4 v[NV];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    v[i] = xr[lane + 64 * i];
+    sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  const float mean = wave_sum(sum) / (float)D;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    float d0 = v[i].x - mean, d1 = v[i].y - mean, d2 = v[i].z - mean, d3 = v[i].w - mean;
+    sq += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)D + eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    const float4 wv = *(const float4*)(w + c), bv = *(const float4*)(b + c);
+    float o0 = apply_act((v[i].x - mean) * rstd * wv.x + bv.x, act);
+    float o1 = apply_act((v[i].y - mean) * rstd * wv.y + bv.y, act);
+    float o2 = apply_act((v[i].z - mean) * rstd * wv.z + bv.z, act);
+    float o3 = apply_act((v[i].w - mean) * rstd * wv.w + bv.w, act);
+    if (out_f16) *(h4*)((half_t*)y + row * D + c) = (h4){(half_t)o0, (half_t)o1, (half_t)o2, (half_t)o3};
+    else *(float4*)((float*)y + row * D + c) = make_float4(o0, o1, o2, o3);
+  }
+}
+
 int layernorm_rows(const float* x, const float* w, const float* b, void* y, long M, int D, float eps,
                    const int* src_rows, int out_f16, int act, hipStream_t s) {
   if (D <= 0 || D > 2048 || M <= 0) return SAMPT_ERR_ARG;
   dim3 grid(cdiv(M, 4)), block(256);
+  if (D % 256 == 0 && D <= 1536 && ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)w | (uintptr_t)b) & 15) == 0)) {
+#define LNV(NVv) hipLaunchKernelGGL(k_layernorm_rows_v4<NVv>, grid, block, 0, s, x, w, b, y, M, D, eps, src_rows, out_f16, act)
+    switch (D / 256) {
+      case 1: LNV(1); break;
+      case 2: LNV(2); break;
+      case 3: LNV(3); break;
+      case 4: LNV(4); break;
+      case 5: LNV(5); break;
+      default: LNV(6); break;
+    }
+#undef LNV
+    SAMPT_CHECK_LAUNCH("layernorm_rows_v4");
+    return SAMPT_OK;
+  }
   int ni = cdiv(D, 64);
 #define LN(NIv) hipLaunchKernelGGL(k_layernorm_rows<NIv>, grid, block, 0, s, x, w, b, y, M, D, eps, src_rows, out_f16, act)
   if (ni <= 1) LN(1);
@@ -359,6 +421,64 @@ int sam_patchify(const uint8_t* frames, int chw, int B, int H, int W, int img, i
     hipLaunchKernelGGL(k_sam_patchify<float>, grid, block, 0, s, frames, B, H, W, img, P, chw, mean[0], mean[1], mean[2],
                        stdv[0], stdv[1], stdv[2], (float*)A);
   SAMPT_CHECK_LAUNCH("sam_patchify");
+  return SAMPT_OK;
+}
+
+}  // namespace sampt
+
+// =============================================================================================
+// VOS post-processing: logits resize to target_hw (sam_pt.py:205-206) and the background-stack
+// softmax/argmax over objects (vos_eval/eval.py:304, 326, 355; demo.py:140)
+// =============================================================================================
+namespace sampt {
+
+// bilinear, align_corners=False, single channel, batch of n images (torch F.interpolate semantics)
+__global__ void k_resize_logits(const float* __restrict__ src, int sh, int sw, float* __restrict__ dst, int dh, int dw,
+                                long total) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int x = (int)(i % dw);
+  long r = i / dw;
+  int y = (int)(r % dh);
+  long n = r / dh;
+  int y0, y1, x0, x1;
+  float ly, lx;
+  bilinear_src(y, sh, dh, 0, y0, y1, ly);
+  bilinear_src(x, sw, dw, 0, x0, x1, lx);
+  const float* b = src + n * sh * sw;
+  float v00 = b[(long)y0 * sw + x0], v01 = b[(long)y0 * sw + x1], v10 = b[(long)y1 * sw + x0], v11 = b[(long)y1 * sw + x1];
+  float hy = 1.f - ly, hx = 1.f - lx;
+  dst[i] = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+}
+
+int resize_logits(const float* src, int n, int sh, int sw, float* dst, int dh, int dw, hipStream_t s) {
+  long total = (long)n * dh * dw;
+  hipLaunchKernelGGL(k_resize_logits, dim3(cdiv(total, 256)), dim3(256), 0, s, src, sh, sw, dst, dh, dw, total);
+  SAMPT_CHECK_LAUNCH("resize_logits");
+  return SAMPT_OK;
+}
+
+// index mask: argmax over {background logit 0, object logits 1..M} == argmax(softmax(cat(0, logits))) (softmax is
+// monotonic; first maximum wins like torch.argmax; -inf objects never win; NaN is treated as -inf)
+__global__ void k_index_masks(const float* __restrict__ logits, int M, long npix, uint8_t* __restrict__ out) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix) return;
+  float best = 0.f;
+  int arg = 0;
+  for (int m = 0; m < M; ++m) {
+    float v = logits[(long)m * npix + i];
+    if (v > best) {
+      best = v;
+      arg = m + 1;
+    }
+  }
+  out[i] = (uint8_t)arg;
+}
+
+int index_masks(const float* logits, int M, long npix, uint8_t* out, hipStream_t s) {
+  if (M <= 0 || M > 254) return SAMPT_ERR_ARG;
+  hipLaunchKernelGGL(k_index_masks, dim3(cdiv(npix, 256)), dim3(256), 0, s, logits, M, npix, out);
+  SAMPT_CHECK_LAUNCH("index_masks");
   return SAMPT_OK;
 }
 

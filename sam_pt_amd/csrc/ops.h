@@ -34,6 +34,11 @@ int cast_f32_f16(const float* x, half_t* y, long n, hipStream_t s);
 int sam_patchify(const uint8_t* frames, int chw, int B, int H, int W, int img, int P, const float* mean,
                  const float* stdv, void* A, int out_f16, hipStream_t s);
 
+// single-channel bilinear resize (align_corners=False) of n maps: the target_hw resize of sam_pt.py:205-206
+int resize_logits(const float* src, int n, int sh, int sw, float* dst, int dh, int dw, hipStream_t s);
+// uint8 index mask = argmax over {background 0, object logits [M][npix]} (vos_eval/eval.py:304-355)
+int index_masks(const float* logits, int M, long npix, uint8_t* out, hipStream_t s);
+
 // ---- attention.hip --------------------------------------------------------------------------
 // Decomposed relative-position terms of SAM's ViT attention (App. A-3):
 //   relh[bh][q][kh] = <q_vec, rel_pos_h[qh - kh + S-1]>, relw likewise.  qkv: [B*S*S][3*D] (f32 or f16),

@@ -53,7 +53,14 @@ def index_masks(logits: torch.Tensor) -> torch.Tensor:
     """(M,T,H,W) per-object logits -> uint8 (T,H,W) object index map with background 0 (bg logit 0 stacked in front,
     softmax/argmax over objects: sam_pt/vos_eval/eval.py:304, 326, 355)."""
     M, T, H, W = logits.shape
-    bg = torch.zeros((1, T, H, W), dtype=logits.dtype, device=logits.device)
+    if logits.is_cuda:
+        from . import _lib
+        lib = _lib.load()
+        logits = logits.contiguous()
+        out = torch.empty((T, H, W), dtype=torch.uint8, device=logits.device)
+        _lib.check(lib.sampt_index_masks(_lib.ptr(logits), M, T * H * W, _lib.ptr(out), _lib.stream_ptr()), "sampt_index_masks")
+        return out
+    bg = torch.zeros((1, T, H, W), dtype=logits.dtype, device=logits.device)      # host-side helper for CPU tests
     prob = torch.softmax(torch.cat([bg, logits], dim=0), dim=0)
     return prob.argmax(dim=0).to(torch.uint8)
 

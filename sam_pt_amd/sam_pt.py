@@ -104,13 +104,26 @@ class SamPt(nn.Module):
         resize_factor = torch.tensor(target_hw) / torch.tensor(logits.shape[-2:])
         assert (resize_factor[0] - resize_factor[1]).abs().item() < 0.01, "The resizing should have been isotropic"
         if tuple(logits.shape[-2:]) != target_hw:
-            logits = F.interpolate(logits, size=target_hw, mode="bilinear", align_corners=False)
+            logits = self._resize_logits(logits, target_hw)
         trajectories = trajectories * resize_factor
         assert logits.shape == (n_masks, n_frames, target_hw[0], target_hw[1])
         assert trajectories.shape == (n_frames, n_masks, n_points_per_mask, 2)
         assert visibilities.shape == (n_frames, n_masks, n_points_per_mask)
         return {"logits": [m for m in logits], "scores": scores.tolist(), "scores_per_frame": scores_per_frame.tolist(),
                 "trajectories": trajectories, "visibilities": visibilities}
+
+    @staticmethod
+    def _resize_logits(logits, target_hw):
+        """Bilinear (align_corners=False) resize of the (M,T,H,W) logits to target_hw (sam_pt.py:205-206)."""
+        if not logits.is_cuda:
+            return F.interpolate(logits, size=target_hw, mode="bilinear", align_corners=False)   # reference protocol on CPU
+        from . import _lib
+        lib = _lib.load()
+        M, T, H, W = logits.shape
+        out = torch.empty((M, T, target_hw[0], target_hw[1]), dtype=torch.float32, device=logits.device)
+        _lib.check(lib.sampt_resize_logits(_lib.ptr(logits.contiguous()), M * T, H, W, _lib.ptr(out), target_hw[0],
+                                           target_hw[1], _lib.stream_ptr()), "sampt_resize_logits")
+        return out
 
     # ------------------------------------------------------------------------------------------------
     def extract_query_masks(self, images, query_points, feats=None):

@@ -214,3 +214,23 @@ def test_postprocess_and_bbox(lib, dev, in_h, in_w, oh, ow):
     yx = m.nonzero()
     exp = [int(yx[:, 1].min()), int(yx[:, 0].min()), int(yx[:, 1].max()), int(yx[:, 0].max()), int(m.sum())]
     assert bb.cpu().tolist() == exp
+
+
+def test_resize_logits_and_index_masks(lib, dev):
+    """VOS post-processing kernels vs torch: F.interpolate(align_corners=False) incl. -inf maps, and
+    argmax(softmax(cat(bg=0, logits)))."""
+    g = torch.Generator().manual_seed(11)
+    logits = torch.randn(3, 4, 36, 64, generator=g) * 2
+    logits[1, 2] = -float("inf")                                   # a rejected mask (sam_pt.py:834-835)
+    ref = F.interpolate(logits, size=(30, 53), mode="bilinear", align_corners=False)
+    ld = logits.to(dev)
+    out = torch.empty(3, 4, 30, 53, device=dev)
+    ok(lib.sampt_resize_logits(P(ld), 12, 36, 64, P(out), 30, 53, S()), "resize_logits")
+    o, r = out.cpu(), ref
+    fin = torch.isfinite(r)
+    assert (torch.isfinite(o) == fin).all() and max_abs(o[fin], r[fin]) < 1e-5
+    bg = torch.zeros(1, 4, 36, 64)
+    exp = torch.softmax(torch.cat([bg, logits]), dim=0).argmax(dim=0).to(torch.uint8)
+    idx = torch.empty(4, 36, 64, dtype=torch.uint8, device=dev)
+    ok(lib.sampt_index_masks(P(ld), 3, 4 * 36 * 64, P(idx), S()), "index_masks")
+    assert torch.equal(idx.cpu(), exp)
