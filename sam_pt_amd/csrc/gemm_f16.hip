@@ -33,7 +33,27 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void gemm_f16_glds(GemmP p)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  int tile_m, tile_n;
+  if (p.xcd_swizzle) {
+    // XCD-aware tile order (blocks are dispatched round-robin over the 8 XCDs, each with a private 4 MiB L2): XCD x
+    // owns the strips {x, x+8, ...} of 8 consecutive row panels and walks a strip column-major, so the ~128 tiles
+    // resident on one XCD form an 8 x 16 patch that shares A panels and W tiles through that XCD's L2.  Pure speed:
+    // the mapping is a bijection over the tiles whatever the real placement is.
+    const int nt_m = (p.M + BM - 1) / BM, nt_n = (p.N + BN - 1) / BN;
+    const int R = p.xcd_swizzle;                    // strip height in row panels (8, or less for small M)
+    const int nstrips = (nt_m + R - 1) / R, per_strip = R * nt_n;
+    const int id = blockIdx.x, xcd = id & 7, idx = id >> 3;
+    const int j = idx / per_strip, t = idx - j * per_strip;
+    const int strip = xcd + 8 * j;
+    if (strip >= nstrips) return;
+    const int rows = min(R, nt_m - R * strip);
+    tile_n = t / rows;
+    if (tile_n >= nt_n) return;
+    tile_m = strip * R + (t - tile_n * rows);
+  } else {
+    tile_m = blockIdx.y, tile_n = blockIdx.x;
+  }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
   const half_t* __restrict__ A = (const half_t*)p.A;
   const half_t* __restrict__ W = (const half_t*)p.W;
 
@@ -164,10 +184,21 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void gemm_f16_glds(GemmP p)
 int gemm_f16_glds_launch(const GemmP& p, hipStream_t s) {
   if (p.conv || p.w_kn || p.nb1 * p.nb2 != 1 || p.K % 64 || p.M < 128 || p.N < 128) return SAMPT_ERR_UNSUPPORTED;
   if ((p.lda % 8) || (p.ldw % 8) || (((uintptr_t)p.A | (uintptr_t)p.W) & 15)) return SAMPT_ERR_UNSUPPORTED;
+  GemmP q = p;
+  static const int swz = getenv("SAMPT_GEMM_SWZ") ? atoi(getenv("SAMPT_GEMM_SWZ")) : 1;
+  q.xcd_swizzle = swz;
   dim3 grid(cdiv(p.N, 128), cdiv(p.M, 128), 1), block(256);
+  if (swz) {
+    const int nt_m = cdiv(p.M, 128), nt_n = cdiv(p.N, 128);
+    int R = 8;
+    while (R > 1 && cdiv(nt_m, R) < 16) R /= 2;     // keep >= 2 strips per XCD so that all 8 XCDs get work
+    const int nstrips = cdiv(nt_m, R), per_xcd = cdiv(nstrips, 8);
+    q.xcd_swizzle = R;
+    grid = dim3(8 * per_xcd * R * nt_n, 1, 1);
+  }
   static const int variant = getenv("SAMPT_GEMM_VARIANT") ? atoi(getenv("SAMPT_GEMM_VARIANT")) : 1;
-  if (variant == 1) hipLaunchKernelGGL((gemm_f16_glds<128, 128, 1>), grid, block, 0, s, p);
-  else hipLaunchKernelGGL((gemm_f16_glds<128, 128, 2>), grid, block, 0, s, p);
+  if (variant == 1) hipLaunchKernelGGL((gemm_f16_glds<128, 128, 1>), grid, block, 0, s, q);
+  else hipLaunchKernelGGL((gemm_f16_glds<128, 128, 2>), grid, block, 0, s, q);
   SAMPT_CHECK_LAUNCH("gemm_f16_glds");
   return SAMPT_OK;
 }
