@@ -231,3 +231,57 @@ def test_hip_sam_vs_hf_golden(dev):
     box = torch.from_numpy(g["box"]).to(dev)
     m2, iou2, low2 = pred.predict_torch(pts, lab, box[None], torch.from_numpy(g["low"])[None].to(dev), False, True)
     assert np.abs(low2.cpu().numpy()[0] - g["low2"]).max() < 2e-4 and np.abs(iou2.cpu().numpy() - g["iou2"]).max() < 1e-4
+
+
+# ------------------------------------------------------------------------------------------ edge cases
+@pytest.mark.parametrize("neg", [0, 1])
+def test_ragged_prompts_fused_vs_stepwise(dev, neg):
+    """Ragged prompts: frames with different numbers of visible points (incl. none -> -inf mask, a single point, points
+    marked OUTSIDE_FRAME) and 3 objects feeding each other's positives as negatives.  The batched device-side chain
+    (groups by prompt shape) must equal the reference call-by-call protocol run with the SAME HIP predictor."""
+    from sam_pt_amd.point_tracker import PipsPointTracker
+    from sam_pt_amd.sam_predictor import SamHip, SamPredictor
+    from sam_pt_amd.sam_pt import SamPt
+    from sam_pt_amd.weights import SAM_CONFIGS
+    cfg = SAM_CONFIGS["vit_test"]
+    T, M, P = 6, 3, 3 + neg
+    frames, centres = synthetic_clip(T=T, H=128, W=256, seed=3)
+    g = torch.Generator().manual_seed(7)
+    traj = torch.rand(T, M, P, 2, generator=g) * torch.tensor([250.0, 120.0]) + 3.0
+    vis = torch.ones(T, M, P)
+    vis[1, :, :] = 0                       # nothing visible in frame 1 -> empty prompts: -inf logits, -inf scores
+    vis[2, 1, 1:] = 0                      # a single visible point
+    vis[3, 2, 0] = -2                      # OUTSIDE_FRAME code is not a visible point (sam_pt.py:734-735)
+    vis[4, :, :] = torch.tensor([[1, 0, 1], [0, 1, 1], [1, 1, 0]])[:, :P] if P == 3 else vis[4]
+    pred = SamPredictor(SamHip(config=cfg, seed=72, precision="f32", max_decode_batch=4).to(dev))   # forces batch splits
+    model = SamPt(PipsPointTracker(seed=72), pred, sam_iou_threshold=0.0, positive_points_per_mask=3,
+                  negative_points_per_mask=neg, iterative_refinement_iterations=2).eval()
+    images = frames.to(dev)
+    feats = pred.encode_frames(images)
+    s_f, l_f, spf_f = model._apply_sam_to_trajectories(images, traj, vis, feats)          # fused, batched
+    s_s, l_s, spf_s = model._apply_sam_to_trajectories(images, traj, vis, None)           # set_image / predict_torch
+    assert torch.equal(torch.isfinite(l_f).cpu(), torch.isfinite(l_s))
+    assert not torch.isfinite(l_f[:, 1]).any() and (spf_f[1] == -float("inf")).all()
+    fin = torch.isfinite(l_s)
+    assert fin.any() and max_abs(l_f.cpu()[fin], l_s[fin]) < 2e-3
+    for m in range(M):
+        for t in range(T):
+            assert iou(l_f[m, t].cpu() > 0, l_s[m, t] > 0) >= 1 - 1e-3
+    assert np.allclose(spf_f.numpy(), spf_s.numpy(), atol=1e-4)
+
+
+def test_tracker_short_clip_and_late_queries(dev, pips_sd):
+    """Clips shorter than one PIPS window (tail frames repeated, pips/tracker.py:73-78), a query on the last frame
+    (never anchors a window) and a single point."""
+    from oracle import pips_ref as O
+    from sam_pt_amd.point_tracker import PipsPointTracker
+    frames, centres = synthetic_clip(T=5, H=128, W=256, seed=21)
+    q = torch.cat([disc_queries(centres, n_pos=2, r=8.0, t=0), disc_queries(centres, n_pos=1, r=4.0, t=4),
+                   disc_queries(centres, n_pos=1, r=2.0, t=2)])[None]
+    tr_ref, vi_ref = O.PipsTrackerRef(pips_sd).forward(frames[None], q)
+    tr, vi = PipsPointTracker(state_dict=pips_sd)(frames[None].to(dev), q.to(dev))
+    assert (vi.cpu() == vi_ref).all() and (tr.cpu().round() == tr_ref.round()).all() and max_abs(tr, tr_ref) < 5e-3
+    q1 = disc_queries(centres, n_pos=1, r=0.0, t=1)[None]
+    tr_ref, vi_ref = O.PipsTrackerRef(pips_sd).forward(frames[None], q1)
+    tr, vi = PipsPointTracker(state_dict=pips_sd)(frames[None].to(dev), q1.to(dev))
+    assert (vi.cpu() == vi_ref).all() and (tr.cpu().round() == tr_ref.round()).all()
