@@ -32,6 +32,7 @@ def parse():
     ap.add_argument("--model", default="vit_h", choices=["vit_h", "vit_l", "vit_b"])
     ap.add_argument("--frames", type=int, default=24)
     ap.add_argument("--points", type=int, default=8)
+    ap.add_argument("--objects", type=int, default=1, help="number of tracked objects (BASELINE config #4 uses 3)")
     ap.add_argument("--refine", type=int, default=12)
     ap.add_argument("--precision", default="f16", choices=["f16", "f32"])
     ap.add_argument("--encode-batch", type=int, default=8)
@@ -159,7 +160,7 @@ def main():
     torch.cuda.set_device(dev)
     # host-side weight generation / packing: keep N ranks from oversubscribing the host cores
     torch.set_num_threads(max(1, min(32, (os.cpu_count() or 8) // max(world, 1))))
-    frames, qp = bench_clip(T=args.frames, seed=72 + rank, n_pos=args.points)
+    frames, qp = bench_clip(T=args.frames, seed=72 + rank, n_pos=args.points, n_objects=args.objects)
     H, W = frames.shape[-2:]
     model = build_model(args, dev)
     frames_dev = frames.to(dev)
@@ -190,7 +191,7 @@ def main():
                "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None,
                "dtype": "f16" if args.precision == "f16" else "f32", "data": "synthetic",
-               "config": {"workload": f"SAM {args.model} + PIPS, {args.points} query points, 1 object, "
+               "config": {"workload": f"SAM {args.model} + PIPS, {args.points} query points, {args.objects} object(s), "
                                       f"{args.frames}x 480p synthetic frames upscaled to {H}x{W}, "
                                       f"{args.refine} refinement iterations, random-init weights (seed 72)",
                           "frames_per_step": args.frames, "parallelism": f"sequence-sharded x{world}",

@@ -22,10 +22,11 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
 template <int BM, int BN, int NBUF>
-__global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void gemm_f16_glds(GemmP p) {
+__global__ __launch_bounds__(BM * 2, NBUF == 1 ? 4 : 2) void gemm_f16_glds(GemmP p) {
   constexpr int BK = 64;
-  constexpr int A_IT = BM / 32, B_IT = BN / 32;           // 8-row DMA pieces per wave
-  constexpr int WTM = BM / 2, WTN = BN / 2, FM = WTM / 16, FN = WTN / 16;
+  constexpr int NWM = BM / 64, NWAVES = NWM * 2;          // waves: NWM x 2, each owning a 64 x (BN/2) sub-tile
+  constexpr int A_IT = BM / (8 * NWAVES), B_IT = BN / (8 * NWAVES);   // 8-row DMA pieces per wave
+  constexpr int WTM = 64, WTN = BN / 2, FM = WTM / 16, FN = WTN / 16;
   __shared__ __attribute__((aligned(1024))) half_t lds[NBUF * (BM + BN) * BK];  // ONE object: [buf][A rows | B rows][64]
   half_t* As0 = lds;
   half_t* Bs0 = lds + BM * BK;
@@ -197,7 +198,14 @@ int gemm_f16_glds_launch(const GemmP& p, hipStream_t s) {
     grid = dim3(8 * per_xcd * R * nt_n, 1, 1);
   }
   static const int variant = getenv("SAMPT_GEMM_VARIANT") ? atoi(getenv("SAMPT_GEMM_VARIANT")) : 1;
-  if (variant == 1) hipLaunchKernelGGL((gemm_f16_glds<128, 128, 1>), grid, block, 0, s, q);
+  if (variant == 3 && swz && p.M >= 256) {
+    const int nt_m = cdiv(p.M, 256), nt_n = cdiv(p.N, 128);
+    int R = 4;
+    while (R > 1 && cdiv(nt_m, R) < 16) R /= 2;
+    q.xcd_swizzle = R;
+    grid = dim3(8 * cdiv(cdiv(nt_m, R), 8) * R * nt_n, 1, 1);
+    hipLaunchKernelGGL((gemm_f16_glds<256, 128, 1>), grid, dim3(512), 0, s, q);
+  } else if (variant == 1 || variant == 3) hipLaunchKernelGGL((gemm_f16_glds<128, 128, 1>), grid, block, 0, s, q);
   else hipLaunchKernelGGL((gemm_f16_glds<128, 128, 2>), grid, block, 0, s, q);
   SAMPT_CHECK_LAUNCH("gemm_f16_glds");
   return SAMPT_OK;

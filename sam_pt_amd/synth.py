@@ -55,12 +55,17 @@ def upscale_to_longest_side(frames: torch.Tensor, centres: torch.Tensor, long_si
     return out, centres * s
 
 
-def bench_clip(T: int = 24, seed: int = 72, n_pos: int = 8):
+def bench_clip(T: int = 24, seed: int = 72, n_pos: int = 8, n_objects: int = 1):
     """The benchmark workload: a 480x854 synthetic clip upscaled to 576x1024, 8 positive query points on one object at
     t = 0 (BASELINE.json metric: ViT-H + PIPS, 480p, 8 pts, 1 obj)."""
     frames, centres = synthetic_clip(T=T, H=480, W=854, seed=seed, disc_r=60.0)
     frames, centres = upscale_to_longest_side(frames, centres, 1024)
     H, W = frames.shape[-2:]
     # PIPS needs H/4 and W/4 divisible by 8 for the 4-level pyramid; 576x1024 satisfies it
-    q = disc_queries(centres, n_pos=n_pos, r=36.0, t=0)
-    return frames, q[None]
+    qs = []
+    for m in range(n_objects):           # object 0 = the moving disc; further objects = background patches
+        q = disc_queries(centres, n_pos=n_pos, r=36.0, t=0)
+        q[:, 1] += 260.0 * m
+        q[:, 2] += (-120.0 if m % 2 else 90.0) * (m > 0)
+        qs.append(q)
+    return frames, torch.stack(qs)
