@@ -55,6 +55,28 @@ def sampt_video(frames, centres, npos, neg):
     return {"image": [f for f in frames], "target_hw": tuple(frames.shape[-2:]), "query_points": torch.stack([q, q2])}
 
 
+def reinit_kwargs(variant, neg):
+    kw = sampt_kwargs(4, neg)
+    kw.update(use_point_reinit=True, reinit_horizon=5, reinit_point_tracker_horizon=6, reinit_variant=variant,
+              positive_point_selection_method="random", negative_point_selection_method="random", sam_iou_threshold=-1e9)
+    return kw
+
+
+def reinit_video(frames, centres, neg):
+    video = sampt_video(frames, centres, 4, neg)
+    video["query_points"][1, :, 0] = 2           # the second object starts later
+    return video
+
+
+def query_mask_video(frames, centres):
+    H, W = frames.shape[-2:]
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    m0 = (((xx - centres[0, 0]) ** 2 + (yy - centres[0, 1]) ** 2) <= 15 ** 2).float()
+    m1 = ((xx > 150) & (xx < 190) & (yy > 20) & (yy < 50)).float()
+    return {"image": [f for f in frames], "target_hw": (H, W), "query_masks": torch.stack([m0, m1]),
+            "query_point_timestep": torch.tensor([0.0, 3.0])}
+
+
 def main():
     assert RL.available(), "the reference tree is required to (re)generate goldens"
     os.makedirs(OUT, exist_ok=True)
@@ -102,6 +124,25 @@ def main():
         out[f"vis_neg{neg}"] = res["visibilities"].numpy()
         out[f"predict_calls_neg{neg}"] = np.array([pred.n_set_image, pred.n_predict])
     np.savez_compressed(os.path.join(OUT, "sampt_ref.npz"), **out)
+
+    # ---- reference SamPt with point re-initialisation and in query_masks mode (random point selection, seeded RNG)
+    out = {}
+    for name, kw, video in [("reinit_median", reinit_kwargs("reinit-at-median-of-area-diff", 0), reinit_video(frames, centres, 0)),
+                            ("reinit_sync", reinit_kwargs("reinit-on-similar-mask-area-and-sync-masks", 1), reinit_video(frames, centres, 1)),
+                            ("qmasks", dict(sampt_kwargs(4, 1), positive_point_selection_method="random",
+                                            negative_point_selection_method="random", sam_iou_threshold=-1e9),
+                             query_mask_video(frames[:8], centres))]:
+        pred = R.SamPredictorRef(sd, cfg)
+        pred.model = torch.nn.Module()
+        pred.model.device, pred.model.mask_threshold = torch.device("cpu"), 0.0
+        torch.manual_seed(5)
+        res = RefSamPt(trk, pred, **kw).eval()(video)
+        masks = torch.stack([l > 0 for l in res["logits"]])
+        out[f"{name}_masks"] = np.packbits(masks.numpy(), axis=-1)
+        out[f"{name}_traj"] = res["trajectories"].numpy()
+        out[f"{name}_vis"] = res["visibilities"].numpy()
+        out[f"{name}_scores_per_frame"] = np.array(res["scores_per_frame"], dtype=np.float32)
+    np.savez_compressed(os.path.join(OUT, "sampt_reinit.npz"), **out)
 
     # ---- HF SamModel on the reduced geometry
     hf = H.build_hf_model(cfg, sd)

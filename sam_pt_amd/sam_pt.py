@@ -80,25 +80,28 @@ class SamPt(nn.Module):
         images = torch.stack(video["image"], dim=0) if isinstance(video["image"], (list, tuple)) else video["image"]
         n_frames, channels, height, width = images.shape
         assert images.dtype == torch.uint8, "Input images must be in uint8 format (0-255)"
-        if video.get("query_masks") is not None:
-            raise NotImplementedError("query_masks mode needs query-point selection (sam_pt/utils/query_points.py): "
-                                      "SURVEY.md §8 row f2, not built yet")
-        if video.get("query_points") is None:
-            raise ValueError("No query points or masks provided")
-        query_points = video["query_points"]
-        n_masks, n_points_per_mask, _ = query_points.shape
-        if self.use_point_reinit:
-            raise NotImplementedError("point re-initialisation (sam_pt.py:355-543): SURVEY.md §8 row f3, not built yet")
         fused = hasattr(self.sam_predictor, "encode_frames") and hasattr(self.sam_predictor, "track_decode")
         feats = None
         if fused:
             images = images.to(self.device)
             feats = self.sam_predictor.encode_frames(images, chw=True)   # every frame exactly once, embeddings in HBM
-        query_masks = self.extract_query_masks(images, query_points, feats)
+        if video.get("query_masks") is not None:                         # VOS task (sam_pt.py:171-177)
+            assert video.get("query_points") is None
+            query_masks = video["query_masks"].float()
+            query_points = self.extract_query_points(images, query_masks, video["query_point_timestep"])
+        elif video.get("query_points") is not None:                      # demo (sam_pt.py:178-182)
+            query_points = video["query_points"]
+            query_masks = self.extract_query_masks(images, query_points, feats)
+        else:
+            raise ValueError("No query points or masks provided")
+        n_masks, n_points_per_mask, _ = query_points.shape
         assert query_masks.shape == (n_masks, height, width)
-        trajectories, visibilities = self._track_points(images, query_points)
-        _, logits, scores_per_frame = self._apply_sam_to_trajectories(images, trajectories, visibilities, feats)
-        scores = scores_per_frame.mean(dim=0)
+        if not self.use_point_reinit:
+            trajectories, visibilities = self._track_points(images, query_points)
+            _, logits, scores_per_frame = self._apply_sam_to_trajectories(images, trajectories, visibilities, feats)
+            scores = scores_per_frame.mean(dim=0)
+        else:
+            trajectories, visibilities, logits, scores, scores_per_frame = self._forward_w_reinit(images, query_points, feats)
 
         target_hw = tuple(video["target_hw"])
         resize_factor = torch.tensor(target_hw) / torch.tensor(logits.shape[-2:])
@@ -111,6 +114,128 @@ class SamPt(nn.Module):
         assert visibilities.shape == (n_frames, n_masks, n_points_per_mask)
         return {"logits": [m for m in logits], "scores": scores.tolist(), "scores_per_frame": scores_per_frame.tolist(),
                 "trajectories": trajectories, "visibilities": visibilities}
+
+    def extract_query_points(self, images, query_masks, query_points_timestep):
+        """Query points (M, P+ + P-, 3) = (t, x, y) from masks: positives from the mask, negatives from its complement
+        (sam_pt.py:238-288).  Host-side selection, see sam_pt_amd/query_points.py."""
+        from .query_points import extract_query_points_xy
+        query_masks = query_masks.cpu()
+        query_points_timestep = query_points_timestep.cpu()
+        xy = extract_query_points_xy(images, query_masks, query_points_timestep, self.positive_point_selection_method,
+                                     self.positive_points_per_mask)
+        if self.negative_points_per_mask > 0:
+            neg = extract_query_points_xy(images, [1 - qm for qm in query_masks], query_points_timestep,
+                                          self.negative_point_selection_method, self.negative_points_per_mask)
+            xy = [torch.cat(x, dim=0) for x in zip(xy, neg)]
+        xy = torch.stack(xy, dim=0)
+        t = query_points_timestep[:, None, None].repeat(1, xy.shape[1], 1)
+        return torch.concat([t, xy], dim=2)
+
+    # ------------------------------------------------------------------------------------------------
+    # point re-initialisation (SURVEY.md §8 row f3; sam_pt.py:355-543).  The image embeddings of the clip are computed
+    # once and re-used by every re-initialisation segment (the reference re-encodes frames each time).
+    def _forward_w_reinit(self, images, query_points, feats=None):
+        n_frames = images.shape[0]
+        tr_r, vi_r, lg_r, _, sc_r = self._forward_w_reinit_inner(images, query_points, feats)
+        qf = query_points.clone()
+        qf[:, :, 0] = n_frames - query_points[:, :, 0] - 1
+        tr_l, vi_l, lg_l, _, sc_l = self._forward_w_reinit_inner(images.flip(0), qf, feats.flip(0) if feats is not None else None)
+        tr_l, vi_l, lg_l = tr_l.flip(0), vi_l.flip(0), lg_l.flip(1)
+        # NOTE: like the reference (sam_pt.py:380-384) the scores of the flipped pass are NOT flipped back
+        ts = query_points[:, 0, 0].int()
+        trajectories = torch.full_like(tr_r, torch.nan)
+        visibilities = torch.full_like(vi_r, False)
+        logits = torch.full_like(lg_r, torch.nan)
+        scores_per_frame = torch.full_like(sc_r, torch.nan)
+        for m, t in enumerate(ts):
+            trajectories[t:, m], trajectories[:t, m] = tr_r[t:, m], tr_l[:t, m]
+            visibilities[t:, m], visibilities[:t, m] = vi_r[t:, m], vi_l[:t, m]
+            logits[m, t:], logits[m, :t] = lg_r[m, t:], lg_l[m, :t]
+            scores_per_frame[t:, m], scores_per_frame[:t, m] = sc_r[t:, m], sc_l[:t, m]
+        assert not torch.isnan(trajectories).any()
+        assert not torch.isnan(logits).any()
+        return trajectories, visibilities, logits, scores_per_frame.nanmean(dim=0), scores_per_frame
+
+    def _forward_w_reinit_inner(self, images, query_points, feats=None):
+        n_frames, _, height, width = images.shape
+        n_masks, points_per_mask, _ = query_points.shape
+        assert self.reinit_point_tracker_horizon >= self.reinit_horizon
+        H = self.reinit_horizon
+        dev = images.device if feats is not None else torch.device("cpu")
+        trajectories = torch.full((n_frames, n_masks, points_per_mask, 2), torch.nan, dtype=torch.float32)
+        visibilities = torch.full((n_frames, n_masks, points_per_mask), False, dtype=torch.float32)
+        scores_per_frame = torch.full((n_frames, n_masks), torch.nan, dtype=torch.float32)
+        logits = torch.full((n_masks, n_frames, height, width), torch.nan, dtype=torch.float32, device=dev)
+        current = query_points.clone()
+        for start in range(int(query_points[:, 0, 0].int().min()), n_frames):
+            end = min(start + H, n_frames)
+            end_trk = min(start + self.reinit_point_tracker_horizon, n_frames)
+            cur_t = current[:, 0, 0].int()
+            tracked = cur_t == start
+            if tracked.sum() == 0:
+                continue
+            q_i = current[tracked].clone()
+            q_i[:, :, 0] -= start
+            assert (q_i[:, :, 0] == 0).all()
+            traj_i, vis_i = self._track_points(images[start:end_trk], q_i)
+            traj_i, vis_i = traj_i[:H], vis_i[:H]
+            _, logits_i, spf_i = self._apply_sam_to_trajectories(images[start:end], traj_i, vis_i,
+                                                                 feats[start:end] if feats is not None else None)
+            logits_i = logits_i.type(torch.float32)
+            logits[tracked.to(logits.device), start:end] = logits_i
+            pred = (logits_i > 0).cpu()
+            trajectories[start:end, tracked] = traj_i
+            visibilities[start:end, tracked] = vis_i
+            scores_per_frame[start:end, tracked] = spf_i
+            if end == n_frames:
+                continue
+            # choose the frame to re-initialise from (sam_pt.py:467-505)
+            area = pred[:, 1:, :, :].sum([2, 3]).float()
+            area[area <= 25] = torch.nan
+            if H // 4 < area.shape[1]:
+                area[:, :H // 4] = torch.nan
+            n_i = pred.shape[0]
+            if self.reinit_variant == "reinit-on-horizon-and-sync-masks":
+                nxt = H - 1 - 1
+                others = cur_t[cur_t > start]
+                if len(others) > 0:
+                    nxt = min(nxt, others.min() - start - 1)
+                q_t = torch.full((n_i,), nxt, dtype=torch.int64)
+            elif self.reinit_variant == "reinit-at-median-of-area-diff":
+                q_t = area.nanmedian(dim=1).indices
+            elif self.reinit_variant == "reinit-on-similar-mask-area":
+                target = pred[:, 0, :, :].sum([1, 2])
+                diff = torch.abs(area - target[:, None])
+                diff[diff.isnan()] = torch.inf
+                q_t = diff.argmin(dim=1)
+            elif self.reinit_variant == "reinit-on-similar-mask-area-and-sync-masks":
+                target = pred[:, 0, :, :].sum([1, 2])
+                diff = torch.abs(area - target[:, None]) / target[:, None]
+                diff[diff.isnan()] = 720
+                per_frame = diff.sum(dim=0)
+                others = cur_t[cur_t > start]
+                if len(others) > 0:
+                    per_frame[others.min().item() - start - 1] -= 36
+                q_t = torch.full((n_i,), per_frame.argmin(dim=0), dtype=torch.int64)
+            else:
+                raise ValueError(f"Unknown reinit variant: {self.reinit_variant}")
+            invalid = area[torch.arange(n_i), q_t] <= 0          # NaN area (tiny / empty mask) compares False, as upstream
+            if (~invalid).sum() > 0:
+                q_masks = pred[:, 1:, :, :][torch.arange(n_i), q_t].type(torch.float32)
+                upd = self.extract_query_points(images[start + 1:end], q_masks[~invalid], q_t[~invalid])
+                valid_tracked = tracked.clone()
+                valid_tracked[tracked] = ~invalid
+                current[valid_tracked] = upd.to(current.device)
+                current[valid_tracked, :, 0] += start + 1
+            if invalid.sum() > 0:
+                invalid_tracked = tracked.clone()
+                invalid_tracked[tracked] = invalid
+                current[invalid_tracked, :, 0] = n_frames
+                current[invalid_tracked, :, 1:] = 0
+                trajectories[end:, invalid_tracked] = -72
+                visibilities[end:, tracked] = PointVisibilityType.REINIT_FAILED.value
+                logits[invalid_tracked.to(logits.device), end:] = -float("inf")
+        return trajectories, visibilities, logits, scores_per_frame.nanmean(dim=1), scores_per_frame
 
     @staticmethod
     def _resize_logits(logits, target_hw):

@@ -285,3 +285,36 @@ def test_tracker_short_clip_and_late_queries(dev, pips_sd):
     tr_ref, vi_ref = O.PipsTrackerRef(pips_sd).forward(frames[None], q1)
     tr, vi = PipsPointTracker(state_dict=pips_sd)(frames[None].to(dev), q1.to(dev))
     assert (vi.cpu() == vi_ref).all() and (tr.cpu().round() == tr_ref.round()).all()
+
+
+@pytest.mark.parametrize("name", ["reinit_median", "qmasks"])
+def test_reinit_and_query_masks_device_path_vs_reference_golden(dev, pips_sd, clip, name):
+    """Rows f2/f3: point re-initialisation and query_masks mode through the fused device path (cached embeddings,
+    batched decoder) against the REFERENCE SamPt's committed outputs."""
+    import os
+    from oracle.make_golden import query_mask_video, reinit_kwargs, reinit_video, sampt_kwargs
+    from sam_pt_amd.point_tracker import PipsPointTracker
+    from sam_pt_amd.sam_predictor import SamHip, SamPredictor
+    from sam_pt_amd.sam_pt import SamPt
+    from sam_pt_amd.weights import SAM_CONFIGS
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sampt_reinit.npz"))
+    frames, centres = clip
+    cfg = SAM_CONFIGS["vit_test"]
+    if name == "reinit_median":
+        kw, video = reinit_kwargs("reinit-at-median-of-area-diff", 0), reinit_video(frames, centres, 0)
+    else:
+        kw = dict(sampt_kwargs(4, 1), positive_point_selection_method="random", negative_point_selection_method="random",
+                  sam_iou_threshold=-1e9)
+        video = query_mask_video(frames[:8], centres)
+    model = SamPt(PipsPointTracker(state_dict=pips_sd), SamPredictor(SamHip(config=cfg, seed=72, precision="f32").to(dev)),
+                  **kw).eval()
+    torch.manual_seed(5)
+    out = model({**video, "image": [f.to(dev) for f in video["image"]]})
+    assert np.array_equal(out["visibilities"].numpy(), g[f"{name}_vis"])
+    assert np.array_equal(np.round(out["trajectories"].numpy()), np.round(g[f"{name}_traj"]))
+    masks = torch.stack([l > 0 for l in out["logits"]]).cpu().numpy()
+    ref = np.unpackbits(g[f"{name}_masks"], axis=-1)[..., :masks.shape[-1]].astype(bool)
+    inter, union = (masks & ref).sum(axis=(-1, -2)), (masks | ref).sum(axis=(-1, -2))
+    assert np.where(union > 0, inter / np.maximum(union, 1), 1.0).min() >= 1 - 1e-3
+    assert np.allclose(np.array(out["scores_per_frame"], dtype=np.float32), g[f"{name}_scores_per_frame"], atol=1e-3,
+                       equal_nan=True)
