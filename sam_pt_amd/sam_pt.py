@@ -15,8 +15,11 @@ With a predictor that lacks ``encode_frames``/``track_decode`` (e.g. the CPU ora
 ``SamPredictor``) the same class falls back to the reference's call-by-call protocol (``set_image`` /
 ``predict_torch``), which is also what the unchanged reference ``SamPt`` does with our predictor.
 
-Not implemented in this round (raise ``NotImplementedError``): point re-initialisation (sam_pt.py:355-543, §8 row f3),
-``query_masks`` mode point selection (sam_pt/utils/query_points.py, row f2), patch-similarity filtering (default off).
+Also built: ``query_masks`` mode with host-side query-point selection
+(``sam_pt_amd/query_points.py``: random and k-medoids) and point re-initialisation with all four ``reinit_variant``s
+(sam_pt.py:355-543), re-using the cached image embeddings across re-initialisation segments.
+Not implemented (raise ``NotImplementedError``): Shi-Tomasi / "mixed" point selection (needs cv2) and patch-similarity
+filtering (default off).
 """
 from __future__ import annotations
 
