@@ -89,3 +89,58 @@ def hf_decode(model, image_embeddings, points=None, labels=None, boxes=None, mas
         kw["input_masks"] = masks
     out = model(image_embeddings=image_embeddings, multimask_output=multimask_output, **kw)
     return out.pred_masks[:, 0], out.iou_scores[:, 0]
+
+
+def build_hf_hq_model(cfg: SamConfig, sd: Dict[str, torch.Tensor]):
+    """HuggingFace ``SamHQModel`` carrying the same weights (HQ-SAM = SAM + MaskDecoderHQ extras, App. A-5)."""
+    from transformers.models.sam_hq.configuration_sam_hq import (SamHQConfig, SamHQMaskDecoderConfig,
+                                                                 SamHQPromptEncoderConfig, SamHQVisionConfig)
+    from transformers.models.sam_hq.modeling_sam_hq import SamHQModel
+    vc = SamHQVisionConfig(hidden_size=cfg.embed_dim, output_channels=cfg.out_chans, num_hidden_layers=cfg.depth,
+                           num_attention_heads=cfg.num_heads, image_size=cfg.img_size, patch_size=cfg.patch_size,
+                           window_size=cfg.window_size, global_attn_indexes=list(cfg.global_attn_indexes),
+                           mlp_dim=cfg.mlp_ratio * cfg.embed_dim, layer_norm_eps=1e-6, attn_implementation="eager")
+    pc = SamHQPromptEncoderConfig(hidden_size=cfg.out_chans, image_size=cfg.img_size, patch_size=cfg.patch_size,
+                                  mask_input_channels=cfg.mask_in_chans)
+    mc = SamHQMaskDecoderConfig(hidden_size=cfg.out_chans, mlp_dim=cfg.dec_mlp_dim, num_hidden_layers=cfg.dec_depth,
+                                num_attention_heads=cfg.dec_heads, iou_head_depth=cfg.iou_head_depth,
+                                iou_head_hidden_dim=cfg.iou_head_hidden_dim,
+                                num_multimask_outputs=cfg.num_multimask_outputs, vit_dim=cfg.embed_dim)
+    model = SamHQModel(SamHQConfig(vision_config=vc, prompt_encoder_config=pc, mask_decoder_config=mc)).eval()
+    hq_keys = ("hf_token", "hf_mlp", "compress_vit_feat", "embedding_encoder", "embedding_maskfeature")
+    base = build_hf_model(cfg, {k: v for k, v in sd.items() if not any(h in k for h in hq_keys)})   # SAM key mapping
+    hf = {k: v.clone() for k, v in base.state_dict().items()}
+    M = "mask_decoder."
+    hf[M + "hq_token.weight"] = sd[M + "hf_token.weight"].clone()
+    for i, name in enumerate(["proj_in", "layers.0", "proj_out"]):
+        hf[f"{M}hq_mask_mlp.{name}.weight"] = sd[f"{M}hf_mlp.layers.{i}.weight"].clone()
+        hf[f"{M}hq_mask_mlp.{name}.bias"] = sd[f"{M}hf_mlp.layers.{i}.bias"].clone()
+    for src, dst in [("compress_vit_feat", ("compress_vit_conv1", "compress_vit_norm", "compress_vit_conv2")),
+                     ("embedding_encoder", ("encoder_conv1", "encoder_norm", "encoder_conv2")),
+                     ("embedding_maskfeature", ("mask_conv1", "mask_norm", "mask_conv2"))]:
+        for idx, d in zip((0, 1, 3), dst):
+            hf[f"{M}{d}.weight"] = sd[f"{M}{src}.{idx}.weight"].clone()
+            hf[f"{M}{d}.bias"] = sd[f"{M}{src}.{idx}.bias"].clone()
+    model.load_state_dict(hf, strict=True)
+    return model
+
+
+@torch.no_grad()
+def hf_hq_embed(model, pixel_values):
+    out = model.vision_encoder(pixel_values)
+    return out.last_hidden_state, out.intermediate_embeddings
+
+
+@torch.no_grad()
+def hf_hq_decode(model, image_embeddings, interm, points=None, labels=None, boxes=None, masks=None):
+    kw = {}
+    if points is not None:
+        kw["input_points"] = points[:, None]
+        kw["input_labels"] = labels[:, None].long()
+    if boxes is not None:
+        kw["input_boxes"] = boxes[:, None].reshape(1, 1, 4)
+    if masks is not None:
+        kw["input_masks"] = masks
+    out = model(image_embeddings=image_embeddings, intermediate_embeddings=interm, multimask_output=False,
+                hq_token_only=False, **kw)
+    return out.pred_masks[:, 0], out.iou_scores[:, 0]

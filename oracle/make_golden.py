@@ -9,6 +9,7 @@ reference's own code run in place from /root/reference (never copied):
   sampt_ref.npz     sam_pt.modeling.sam_pt.SamPt.forward                  (reference orchestration; predictor = the
                                                                            SAM oracle, tracker = reference PIPS)
   sam_hf.npz        HuggingFace transformers SamModel                     (secondary pin of the absent third-party SAM)
+  sam_hq_hf.npz     HuggingFace transformers SamHQModel                   (secondary pin of the absent HQ-SAM decoder)
 
 Weights are NOT stored: they are regenerated from the seed (sam_pt_amd/weights.py), inputs from
 sam_pt_amd/synth.py.  Usage:  PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py
@@ -75,6 +76,23 @@ def query_mask_video(frames, centres):
     m1 = ((xx > 150) & (xx < 190) & (yy > 20) & (yy < 50)).float()
     return {"image": [f for f in frames], "target_hw": (H, W), "query_masks": torch.stack([m0, m1]),
             "query_point_timestep": torch.tensor([0.0, 3.0])}
+
+
+def make_hq_golden():
+    """HF SamHQModel on the reduced geometry (secondary pin of the absent third-party HQ-SAM decoder)."""
+    cfg = SAM_CONFIGS["vit_test"]
+    sd = init_sam_state_dict(cfg, 72, hq=True)
+    hf = H.build_hf_hq_model(cfg, sd)
+    x = torch.randn(1, 3, 256, 256, generator=torch.Generator().manual_seed(3))
+    emb, interm = H.hf_hq_embed(hf, x)
+    pts = torch.tensor([[[30.5, 40.2], [100.0, 200.0], [220.0, 15.0]]])
+    lab = torch.tensor([[1, 0, 1]])
+    low, iou = H.hf_hq_decode(hf, emb, interm, pts, lab)
+    box = torch.tensor([[10.0, 20.0, 200.0, 180.0]])
+    low2, iou2 = H.hf_hq_decode(hf, emb, interm, pts, lab, boxes=box, masks=low)
+    np.savez_compressed(os.path.join(OUT, "sam_hq_hf.npz"), emb=emb.numpy(), interm=interm[0].numpy()[:, ::4, ::4],
+                        pts=pts.numpy(), lab=lab.numpy(), low=low.numpy(), iou=iou.numpy(), box=box.numpy(),
+                        low2=low2.numpy(), iou2=iou2.numpy())
 
 
 def main():
@@ -157,6 +175,7 @@ def main():
     # x is NOT stored: tests regenerate it from the same generator seed (3)
     np.savez_compressed(os.path.join(OUT, "sam_hf.npz"), emb=emb.numpy(), pts=pts.numpy(), lab=lab.numpy(),
                         low=low.numpy(), iou=iou.numpy(), box=box.numpy(), low2=low2.numpy(), iou2=iou2.numpy())
+    make_hq_golden()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
 

@@ -111,21 +111,27 @@ def vit_block(sd: SD, cfg: SamConfig, i: int, x: torch.Tensor) -> torch.Tensor:
     return x + y
 
 
-def image_encoder(sd: SD, cfg: SamConfig, x: torch.Tensor, trace: Optional[dict] = None) -> torch.Tensor:
-    """x (B,3,S,S) normalised+padded -> (B,256,S/16,S/16)."""
+def image_encoder(sd: SD, cfg: SamConfig, x: torch.Tensor, trace: Optional[dict] = None, return_interm: bool = False):
+    """x (B,3,S,S) normalised+padded -> (B,256,S/16,S/16) [, interm = output (B,g,g,D) of the first global-attention
+    block, the only intermediate embedding HQ-SAM uses (App. A-5)]."""
     x = F.conv2d(x, sd["image_encoder.patch_embed.proj.weight"], sd["image_encoder.patch_embed.proj.bias"],
                  stride=cfg.patch_size).permute(0, 2, 3, 1)
     x = x + sd["image_encoder.pos_embed"]
     if trace is not None:
         trace["tokens0"] = x.clone()
+    interm = None
     for i in range(cfg.depth):
         x = vit_block(sd, cfg, i, x)
         if trace is not None:
             trace[f"block{i}"] = x.clone()
+        if i == cfg.global_attn_indexes[0]:
+            interm = x
+    tokens = x
     x = x.permute(0, 3, 1, 2)
     x = _ln2d(F.conv2d(x, sd["image_encoder.neck.0.weight"]), sd, "image_encoder.neck.1")
     x = _ln2d(F.conv2d(x, sd["image_encoder.neck.2.weight"], padding=1), sd, "image_encoder.neck.3")
-    return x
+    del tokens
+    return (x, interm) if return_interm else x
 
 
 def preprocess(cfg: SamConfig, x: torch.Tensor) -> torch.Tensor:
@@ -248,17 +254,41 @@ def _mlp3(sd: SD, p: str, x, n: int):
     return x
 
 
-def mask_decoder(sd: SD, cfg: SamConfig, image_embeddings, image_pe, sparse, dense, multimask_output: bool):
-    """-> (low_res masks (B,m,4g,4g), iou (B,m))."""
+def hq_features(sd: SD, image_embeddings, interm):
+    """HQ-SAM per-image features (1,32,4g,4g) = embedding_encoder(emb) + compress_vit_feat(interm[0]) (App. A-5)."""
+    M = "mask_decoder."
+
+    def up(x, p, eps=1e-6):
+        x = F.conv_transpose2d(x, sd[p + ".0.weight"], sd[p + ".0.bias"], stride=2)
+        x = F.gelu(_ln2d(x, sd, p + ".1", eps))
+        return F.conv_transpose2d(x, sd[p + ".3.weight"], sd[p + ".3.bias"], stride=2)
+
+    return up(image_embeddings, M + "embedding_encoder") + up(interm.permute(0, 3, 1, 2), M + "compress_vit_feat")
+
+
+def mask_decoder(sd: SD, cfg: SamConfig, image_embeddings, image_pe, sparse, dense, multimask_output: bool,
+                 hq_feat=None, hq_token_only: bool = False, _hf_samhq_quirk: bool = False):
+    """-> (low_res masks (B,m,4g,4g), iou (B,m)).  With ``hq_feat`` (HQ-SAM, MaskDecoderHQ): one extra output token whose
+    hyper-network output multiplies embedding_maskfeature(upscaled) + hq_feat; result = SAM mask + HQ mask.
+
+    ``_hf_samhq_quirk`` (pin test only): transformers' SamHQMaskDecoder (modeling_sam_hq.py:993-1003 in this image) drops
+    the transformer's updated image keys and upscales the *pre-transformer* embedding with H/W swapped, unlike upstream
+    sam-hq (and unlike transformers' own SamMaskDecoder).  The switch reproduces that so every other HQ step can be pinned
+    against HF; the keys->upscaling step itself is shared with plain SAM and pinned by sam_hf.npz."""
     nmt = cfg.num_multimask_outputs + 1
     out_tok = torch.cat([sd["mask_decoder.iou_token.weight"], sd["mask_decoder.mask_tokens.weight"]], dim=0)
+    if hq_feat is not None:
+        out_tok = torch.cat([out_tok, sd["mask_decoder.hf_token.weight"]], dim=0)
     tokens = torch.cat([out_tok.unsqueeze(0).expand(sparse.shape[0], -1, -1), sparse], dim=1)
     src = torch.repeat_interleave(image_embeddings, tokens.shape[0], dim=0) + dense
     pos = torch.repeat_interleave(image_pe, tokens.shape[0], dim=0)
     b, c, h, w = src.shape
     hs, keys = two_way_transformer(sd, cfg, src, pos, tokens)
     iou_tok, mask_toks = hs[:, 0, :], hs[:, 1:1 + nmt, :]
-    src = keys.transpose(1, 2).reshape(b, c, h, w)
+    if _hf_samhq_quirk:
+        src = src.transpose(2, 3).reshape(b, c, h, w)
+    else:
+        src = keys.transpose(1, 2).reshape(b, c, h, w)
     U = "mask_decoder.output_upscaling"
     up = F.conv_transpose2d(src, sd[U + ".0.weight"], sd[U + ".0.bias"], stride=2)
     up = F.gelu(_ln2d(up, sd, U + ".1"))
@@ -269,7 +299,17 @@ def mask_decoder(sd: SD, cfg: SamConfig, image_embeddings, image_pe, sparse, den
     masks = (hyper @ up.view(b, c, h * w)).view(b, -1, h, w)
     iou = _mlp3(sd, "mask_decoder.iou_prediction_head", iou_tok, cfg.iou_head_depth)
     sl = slice(1, None) if multimask_output else slice(0, 1)
-    return masks[:, sl], iou[:, sl]
+    if hq_feat is None:
+        return masks[:, sl], iou[:, sl]
+    assert not multimask_output, "SAM-PT only uses multimask_output=False"
+    E = "mask_decoder.embedding_maskfeature"
+    uh = F.conv2d(up, sd[E + ".0.weight"], sd[E + ".0.bias"], padding=1)
+    uh = F.gelu(_ln2d(uh, sd, E + ".1"))
+    uh = F.conv2d(uh, sd[E + ".3.weight"], sd[E + ".3.bias"], padding=1) + hq_feat
+    hyper_hq = _mlp3(sd, "mask_decoder.hf_mlp", hs[:, 1 + nmt, :], 3)
+    mask_hq = (hyper_hq.unsqueeze(1) @ uh.view(b, c, h * w)).view(b, 1, h, w)
+    out = mask_hq if hq_token_only else masks[:, sl] + mask_hq
+    return out, iou[:, sl]
 
 
 def postprocess_masks(cfg: SamConfig, masks, input_size, original_size):
@@ -308,8 +348,9 @@ class _Model:
 class SamPredictorRef:
     """fp32 CPU stand-in for ``segment_anything.SamPredictor`` over the functional oracle above."""
 
-    def __init__(self, sd: SD, cfg: SamConfig):
-        self.sd, self.cfg = sd, cfg
+    def __init__(self, sd: SD, cfg: SamConfig, hq: bool = False):
+        self.sd, self.cfg, self.hq = sd, cfg, hq
+        self.hq_feat = None
         self.model = _Model()
         self.transform = _Transform(cfg.img_size)
         self.features = None
@@ -325,7 +366,11 @@ class SamPredictorRef:
         assert get_preprocess_shape(H, W, self.cfg.img_size) == (H, W), "oracle supports identity resize only"
         x = torch.as_tensor(image).permute(2, 0, 1)[None].float()
         self.original_size, self.input_size = (H, W), (H, W)
-        self.features = image_encoder(self.sd, self.cfg, preprocess(self.cfg, x))
+        if self.hq:
+            self.features, interm = image_encoder(self.sd, self.cfg, preprocess(self.cfg, x), return_interm=True)
+            self.hq_feat = hq_features(self.sd, self.features, interm)
+        else:
+            self.features = image_encoder(self.sd, self.cfg, preprocess(self.cfg, x))
         self.n_set_image += 1
 
     @torch.no_grad()
@@ -336,7 +381,8 @@ class SamPredictorRef:
         pts = (point_coords, point_labels) if point_coords is not None else None
         sparse, dense = prompt_encoder(self.sd, self.cfg, pts, boxes.reshape(-1, 4) if boxes is not None else None,
                                        mask_input)
-        low, iou = mask_decoder(self.sd, self.cfg, self.features, self._pe, sparse, dense, multimask_output)
+        low, iou = mask_decoder(self.sd, self.cfg, self.features, self._pe, sparse, dense, multimask_output,
+                                hq_feat=self.hq_feat if self.hq else None)
         masks = postprocess_masks(self.cfg, low, self.input_size, self.original_size)
         if not return_logits:
             masks = masks > self.model.mask_threshold

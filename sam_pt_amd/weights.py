@@ -169,8 +169,9 @@ SAM_CONFIGS: Dict[str, SamConfig] = {
 }
 
 
-def init_sam_state_dict(cfg: SamConfig, seed: int = 72) -> "OrderedDict[str, torch.Tensor]":
-    """Random SAM weights with the upstream ``sam_vit_*.pth`` key layout."""
+def init_sam_state_dict(cfg: SamConfig, seed: int = 72, hq: bool = False) -> "OrderedDict[str, torch.Tensor]":
+    """Random SAM weights with the upstream ``sam_vit_*.pth`` key layout; ``hq=True`` adds the HQ-SAM decoder extras of
+    ``sam_hq_vit_*.pth`` (m43/sam-hq @ 75c73fa, MaskDecoderHQ: SURVEY.md App. A-5)."""
     w = _Init(seed)
     D, g, hd = cfg.embed_dim, cfg.grid, cfg.head_dim
     C = cfg.out_chans
@@ -246,4 +247,24 @@ def init_sam_state_dict(cfg: SamConfig, seed: int = 72) -> "OrderedDict[str, tor
     dims = [C] + [h] * (cfg.iou_head_depth - 1) + [nmt]
     for i in range(cfg.iou_head_depth):
         w.linear(f"{p}.{i}", dims[i + 1], dims[i])
+    if hq:
+        M = "mask_decoder."
+        w.normal(M + "hf_token.weight", (1, C), 1.0)
+        w.linear(M + "hf_mlp.layers.0", C, C)
+        w.linear(M + "hf_mlp.layers.1", C, C)
+        w.linear(M + "hf_mlp.layers.2", C // 8, C)
+
+        def convt(name, cin, cout):
+            w.uniform(name + ".weight", (cin, cout, 2, 2), 1.0 / math.sqrt(cin))
+            w.uniform(name + ".bias", (cout,), 1.0 / math.sqrt(cin))
+
+        convt(M + "compress_vit_feat.0", D, C)
+        w.norm(M + "compress_vit_feat.1", C)
+        convt(M + "compress_vit_feat.3", C, C // 8)
+        convt(M + "embedding_encoder.0", C, C // 4)
+        w.norm(M + "embedding_encoder.1", C // 4)
+        convt(M + "embedding_encoder.3", C // 4, C // 8)
+        w.conv(M + "embedding_maskfeature.0", C // 4, C // 8, 3, 3)
+        w.norm(M + "embedding_maskfeature.1", C // 4)
+        w.conv(M + "embedding_maskfeature.3", C // 8, C // 4, 3, 3)
     return w.sd
