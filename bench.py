@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--refine", type=int, default=12)
     ap.add_argument("--precision", default="f16", choices=["f16", "f32"])
     ap.add_argument("--encode-batch", type=int, default=8)
+    ap.add_argument("--hq", action="store_true", help="HQ-SAM decoder (reference default samhq_vit_huge; BASELINE config #5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -45,7 +46,7 @@ def build_model(args, dev):
     from sam_pt_amd.point_tracker import PipsPointTracker
     from sam_pt_amd.sam_predictor import SamHip, SamPredictor
     from sam_pt_amd.sam_pt import SamPt
-    sam = SamHip(args.model, precision=args.precision, seed=72, max_batch=args.encode_batch).to(dev)
+    sam = SamHip(args.model, precision=args.precision, seed=72, max_batch=args.encode_batch, hq=args.hq).to(dev)
     model = SamPt(PipsPointTracker(seed=72, fnet_chunk=8), SamPredictor(sam), sam_iou_threshold=-1e9,
                   positive_points_per_mask=args.points, negative_points_per_mask=0,
                   iterative_refinement_iterations=args.refine, point_tracker_mask_batch_size=5).eval()
@@ -117,12 +118,13 @@ def cpu_baseline(args, frames, qp):
     cores = min(os.cpu_count() or 1, 32)   # PyTorch-CPU collapses when oversubscribed on 256-thread hosts
     torch.set_num_threads(cores)
     cfg = SAM_CONFIGS[args.model]
-    sd, psd = init_sam_state_dict(cfg, 72), init_pips_state_dict(72)
+    sd, psd = init_sam_state_dict(cfg, 72, hq=args.hq), init_pips_state_dict(72)
     f = frames[:1].cpu()
     with torch.no_grad():
         t0 = time.time()
         x = R.preprocess(cfg, f.float())
-        emb = R.image_encoder(sd, cfg, x)
+        emb, interm = R.image_encoder(sd, cfg, x, return_interm=True)
+        hq_feat = R.hq_features(sd, emb, interm) if args.hq else None
         t_enc = time.time() - t0
         t0 = time.time()
         fm1 = PO.fnet(psd, PO.normalize_rgbs(f), 4)
@@ -131,7 +133,8 @@ def cpu_baseline(args, frames, qp):
         t0 = time.time()
         PO.pips_forward(psd, qp[0, :, 1:].cpu(), fm, None, iters=2)
         t_win = (time.time() - t0) * 3.0
-        pred = R.SamPredictorRef(sd, cfg)
+        pred = R.SamPredictorRef(sd, cfg, hq=args.hq)
+        pred.hq_feat = hq_feat
         pred.features, pred.original_size, pred.input_size = emb, tuple(f.shape[-2:]), tuple(f.shape[-2:])
         pts = qp[0, :, 1:].cpu()[None]
         lab = torch.ones(1, pts.shape[1], dtype=torch.int)
@@ -191,7 +194,7 @@ def main():
                "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None,
                "dtype": "f16" if args.precision == "f16" else "f32", "data": "synthetic",
-               "config": {"workload": f"SAM {args.model} + PIPS, {args.points} query points, {args.objects} object(s), "
+               "config": {"workload": f"{'HQ-SAM' if args.hq else 'SAM'} {args.model} + PIPS, {args.points} query points, {args.objects} object(s), "
                                       f"{args.frames}x 480p synthetic frames upscaled to {H}x{W}, "
                                       f"{args.refine} refinement iterations, random-init weights (seed 72)",
                           "frames_per_step": args.frames, "parallelism": f"sequence-sharded x{world}",

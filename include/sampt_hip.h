@@ -87,25 +87,37 @@ void sampt_vit_destroy(sampt_vit_t h);
 int sampt_vit_encode_workspace_bytes(sampt_vit_t h, int B, size_t* bytes);
 /* frames_dev: uint8, (B,3,H,W) if chw else (B,H,W,3), H,W <= img_size with the longest side == img_size already
  * (the reference pipelines resize before SamPt: configs/demo.yaml:20, configs/vos_eval_root.yaml:28).
- * features_dev: float32 [B][grid*grid][out_chans] — the (B,256,64,64) embedding in NHWC / token-major order. */
+ * features_dev: float32 [B][grid*grid][out_chans] — the (B,256,64,64) embedding in NHWC / token-major order.
+ * interm_out_dev: NULL, or float32 [B][grid*grid][embed_dim] receiving the token stream after the first
+ * global-attention block — HQ-SAM's interm_embeddings[0] (configs/model/sam/samhq_vit_*.yaml, MaskDecoderHQ). */
 int sampt_vit_encode(sampt_vit_t h, const uint8_t* frames_dev, int chw, int B, int H, int W, float* features_dev,
-                     void* workspace_dev, size_t workspace_bytes, sampt_stream_t stream);
+                     float* interm_out_dev, void* workspace_dev, size_t workspace_bytes, sampt_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * seam 2b — prompt encoder + mask decoder + postprocess = SamPredictor.predict_torch(multimask_output=False,
  * return_logits=True) as called at sam_pt.py:783-828.
  * --------------------------------------------------------------------------------------------------------- */
 /* max_frames: capacity of the frame batch of sampt_sam_track_decode (the packed pixel-shuffle row maps
- * "mask_decoder.__up0_map" / "__up1_map" must cover it, see sam_pt_amd/pack.py). */
+ * "mask_decoder.__up0_map" / "__up1_map" must cover it, see sam_pt_amd/pack.py).
+ * vit_dim: 0 = SAM MaskDecoder (configs/model/sam/mask_decoder/sam.yaml); > 0 = HQ-SAM MaskDecoderHQ
+ * (configs/model/sam/samhq_vit_huge.yaml:8-10, vit_dim = image encoder embed_dim), which needs the extra
+ * "mask_decoder.{hf_token,hf_mlp,compress_vit_feat,embedding_encoder,embedding_maskfeature}" weights. */
 int sampt_dec_create(const char* const* names, const void* const* ptrs, int n, int grid, int img_size, int max_frames,
-                     sampt_dec_t* out);
+                     int vit_dim, sampt_dec_t* out);
 void sampt_dec_destroy(sampt_dec_t h);
 int sampt_dec_workspace_bytes(sampt_dec_t h, int frames, int out_h, int out_w, size_t* bytes);
-/* One pass, one frame.  features_dev [grid*grid][256]; pts_dev [k][2] (input-frame pixels), labels_dev int32 [k];
+/* HQ-SAM only: hq_features_dev [frames][16*grid*grid][32] = embedding_encoder(features) +
+ * compress_vit_feat(interm) (MaskDecoderHQ.forward), computed once per frame from sampt_vit_encode's two outputs
+ * and passed to every decode pass of that frame. */
+int sampt_dec_hq_workspace_bytes(sampt_dec_t h, int frames, size_t* bytes);
+int sampt_dec_hq_features(sampt_dec_t h, int frames, const float* features_dev, const float* interm_dev,
+                          float* hq_features_dev, void* workspace_dev, size_t workspace_bytes, sampt_stream_t stream);
+/* One pass, one frame.  features_dev [grid*grid][256]; hq_features_dev: sampt_dec_hq_features output for the frame
+ * (HQ-SAM handles) or NULL (SAM handles); pts_dev [k][2] (input-frame pixels), labels_dev int32 [k];
  * box_dev 4 floats or NULL; mask_in_dev [4*grid][4*grid] low-res logits or NULL.  Outputs: logits_out_dev
  * [out_h][out_w], iou_out_dev [1], low_res_out_dev [4*grid][4*grid]. */
-int sampt_sam_decode(sampt_dec_t h, const float* features_dev, const float* pts_dev, const int32_t* labels_dev, int k,
-                     const float* box_dev, const float* mask_in_dev, int in_h, int in_w, int out_h, int out_w,
+int sampt_sam_decode(sampt_dec_t h, const float* features_dev, const float* hq_features_dev, const float* pts_dev,
+                     const int32_t* labels_dev, int k, const float* box_dev, const float* mask_in_dev, int in_h, int in_w, int out_h, int out_w,
                      float* logits_out_dev, float* iou_out_dev, float* low_res_out_dev, void* workspace_dev,
                      size_t workspace_bytes, sampt_stream_t stream);
 /* Whole SamPt.predict_mask chain (sam_pt.py:760-837) for `frames` independent (frame, object) items that share the
@@ -113,10 +125,11 @@ int sampt_sam_decode(sampt_dec_t h, const float* features_dev, const float* pts_
  * [positives-only pass over the first n_pos_first points when n_pos_first >= 0, i.e. negative_points_per_mask > 0;
  * pass -1 for the single-pass case] -> all-points pass -> `refine_iters` box+mask refinement passes
  * (bbox of logits>0 and the `sum < 2 -> stop` rule evaluated per item on device) -> logits = -inf if iou < iou_thr.
- * features_dev [frames][grid*grid][256]; pts_dev [frames][ld_pts][2]; labels_dev int32 [frames][ld_pts];
+ * features_dev [frames][grid*grid][256]; hq_features_dev [frames][16*grid*grid][32] (HQ-SAM) or NULL;
+ * pts_dev [frames][ld_pts][2]; labels_dev int32 [frames][ld_pts];
  * final_logits_dev [frames][out_h][out_w]; score_out_dev [frames] = predicted IoU. */
-int sampt_sam_track_decode(sampt_dec_t h, int frames, const float* features_dev, const float* pts_dev,
-                           const int32_t* labels_dev, int k, int ld_pts, int n_pos_first, int refine_iters, float iou_thr,
+int sampt_sam_track_decode(sampt_dec_t h, int frames, const float* features_dev, const float* hq_features_dev,
+                           const float* pts_dev, const int32_t* labels_dev, int k, int ld_pts, int n_pos_first, int refine_iters, float iou_thr,
                            int in_h, int in_w, int out_h, int out_w, float* final_logits_dev, float* score_out_dev,
                            void* workspace_dev, size_t workspace_bytes, sampt_stream_t stream);
 int sampt_postprocess_masks(const float* low_res_dev, int L, int img_size, int in_h, int in_w, float* out_dev, int out_h,

@@ -41,12 +41,15 @@ _SIGS = {
     "sampt_vit_create": (c_int, [C.POINTER(VitConfigC), C.POINTER(c_char_p), C.POINTER(_P), c_int, c_int, C.POINTER(_P)]),
     "sampt_vit_destroy": (None, [_P]),
     "sampt_vit_encode_workspace_bytes": (c_int, [_P, c_int, C.POINTER(c_size_t)]),
-    "sampt_vit_encode": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, c_size_t, _P]),
-    "sampt_dec_create": (c_int, [C.POINTER(c_char_p), C.POINTER(_P), c_int, c_int, c_int, c_int, C.POINTER(_P)]),
+    "sampt_vit_encode": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, c_size_t, _P]),
+    "sampt_dec_create": (c_int, [C.POINTER(c_char_p), C.POINTER(_P), c_int, c_int, c_int, c_int, c_int, C.POINTER(_P)]),
+    "sampt_dec_hq_workspace_bytes": (c_int, [_P, c_int, C.POINTER(c_size_t)]),
+    "sampt_dec_hq_features": (c_int, [_P, c_int, _P, _P, _P, _P, c_size_t, _P]),
     "sampt_dec_destroy": (None, [_P]),
     "sampt_dec_workspace_bytes": (c_int, [_P, c_int, c_int, c_int, C.POINTER(c_size_t)]),
-    "sampt_sam_decode": (c_int, [_P, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_size_t, _P]),
-    "sampt_sam_track_decode": (c_int, [_P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_int,
+    "sampt_sam_decode": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_size_t,
+                                 _P]),
+    "sampt_sam_track_decode": (c_int, [_P, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_int,
                                        c_int, _P, _P, _P, c_size_t, _P]),
     "sampt_postprocess_masks": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P]),
     "sampt_bbox_workspace_bytes": (c_size_t, [c_int, c_int]),

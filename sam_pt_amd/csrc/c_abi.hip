@@ -127,29 +127,29 @@ void sampt_vit_destroy(sampt_vit_t h) { delete h; }
 int sampt_vit_encode_workspace_bytes(sampt_vit_t h, int B, size_t* bytes) {
   if (!h || !bytes || B <= 0) return SAMPT_ERR_ARG;
   Arena a(nullptr, 0);
-  int rc = h->e.encode(nullptr, 1, B, h->e.c.img, h->e.c.img, nullptr, a, nullptr);
+  int rc = h->e.encode(nullptr, 1, B, h->e.c.img, h->e.c.img, nullptr, nullptr, a, nullptr);
   *bytes = a.peak + 256;
   return rc;
 }
 
-int sampt_vit_encode(sampt_vit_t h, const uint8_t* frames, int chw, int B, int H, int W, float* features, void* ws,
-                     size_t ws_bytes, sampt_stream_t stream) {
+int sampt_vit_encode(sampt_vit_t h, const uint8_t* frames, int chw, int B, int H, int W, float* features,
+                     float* interm_out, void* ws, size_t ws_bytes, sampt_stream_t stream) {
   if (!h || !frames || !features || !ws || B <= 0) return fail(SAMPT_ERR_ARG, "sampt_vit_encode: bad arguments");
   if (H > h->e.c.img || W > h->e.c.img || (H != h->e.c.img && W != h->e.c.img))
     return fail(SAMPT_ERR_UNSUPPORTED,
                 "sampt_vit_encode: the frame's longest side must equal img_size (resize before SamPt, as the reference "
                 "pipelines do)");
   Arena a(ws, ws_bytes);
-  return h->e.encode(frames, chw, B, H, W, features, a, (hipStream_t)stream);
+  return h->e.encode(frames, chw, B, H, W, features, interm_out, a, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------- decoder
 int sampt_dec_create(const char* const* names, const void* const* ptrs, int n, int grid, int img_size, int max_frames,
-                     sampt_dec_t* out) {
-  if (!names || !ptrs || !out || max_frames <= 0) return SAMPT_ERR_ARG;
+                     int vit_dim, sampt_dec_t* out) {
+  if (!names || !ptrs || !out || max_frames <= 0 || vit_dim < 0) return SAMPT_ERR_ARG;
   sampt_dec* h = new sampt_dec();
   DecConfig c;
-  c.grid = grid, c.img = img_size;
+  c.grid = grid, c.img = img_size, c.vit_dim = vit_dim;
   h->e.max_frames = max_frames;
   WeightMap w = make_map(names, ptrs, n);
   int rc = h->e.init(w, c);
@@ -167,31 +167,53 @@ int sampt_dec_workspace_bytes(sampt_dec_t h, int frames, int oh, int ow, size_t*
   if (!h || !bytes || frames <= 0 || frames > h->e.max_frames) return SAMPT_ERR_ARG;
   Arena a(nullptr, 0);
   float dummy = 0.f;
-  int rc = h->e.track_decode(frames, &dummy, &dummy, nullptr, 56, 56, 0, 1, 0.f, oh, ow, oh, ow, nullptr, nullptr, a,
-                             nullptr);
+  int rc = h->e.track_decode(frames, &dummy, h->e.is_hq() ? &dummy : nullptr, &dummy, nullptr, 56, 56, 0, 1, 0.f, oh, ow,
+                             oh, ow, nullptr, nullptr, a, nullptr);
   *bytes = a.peak + 256;
   return rc;
 }
 
-int sampt_sam_decode(sampt_dec_t h, const float* features, const float* pts, const int32_t* labels, int k,
-                     const float* box, const float* mask_in, int in_h, int in_w, int oh, int ow, float* logits_out,
+int sampt_dec_hq_workspace_bytes(sampt_dec_t h, int frames, size_t* bytes) {
+  if (!h || !bytes || frames <= 0 || frames > h->e.max_frames) return SAMPT_ERR_ARG;
+  if (!h->e.is_hq()) return fail(SAMPT_ERR_UNSUPPORTED, "sampt_dec_hq_workspace_bytes: not an HQ-SAM decoder handle");
+  Arena a(nullptr, 0);
+  int rc = h->e.hq_features(frames, nullptr, nullptr, nullptr, a, nullptr);
+  *bytes = a.peak + 256;
+  return rc;
+}
+
+int sampt_dec_hq_features(sampt_dec_t h, int frames, const float* features, const float* interm, float* hq_out, void* ws,
+                          size_t ws_bytes, sampt_stream_t stream) {
+  if (!h || !features || !interm || !hq_out || !ws || frames <= 0 || frames > h->e.max_frames)
+    return fail(SAMPT_ERR_ARG, "sampt_dec_hq_features: bad arguments");
+  if (!h->e.is_hq()) return fail(SAMPT_ERR_UNSUPPORTED, "sampt_dec_hq_features: not an HQ-SAM decoder handle");
+  Arena a(ws, ws_bytes);
+  return h->e.hq_features(frames, features, interm, hq_out, a, (hipStream_t)stream);
+}
+
+int sampt_sam_decode(sampt_dec_t h, const float* features, const float* hq_features, const float* pts,
+                     const int32_t* labels, int k, const float* box, const float* mask_in, int in_h, int in_w, int oh, int ow, float* logits_out,
                      float* iou_out, float* low_out, void* ws, size_t ws_bytes, sampt_stream_t stream) {
   if (!h || !features || !logits_out || !iou_out || !low_out || !ws || k < 0 || (k > 0 && (!pts || !labels)))
     return fail(SAMPT_ERR_ARG, "sampt_sam_decode: bad arguments");
+  if (h->e.is_hq() != (hq_features != nullptr))
+    return fail(SAMPT_ERR_ARG, "sampt_sam_decode: hq_features must be given for HQ-SAM handles and only for them");
   Arena a(ws, ws_bytes);
-  return h->e.decode(1, features, pts, labels, k, k > 0 ? k : 1, box, mask_in, in_h, in_w, oh, ow, logits_out, iou_out,
+  return h->e.decode(1, features, hq_features, pts, labels, k, k > 0 ? k : 1, box, mask_in, in_h, in_w, oh, ow, logits_out, iou_out,
                      low_out, nullptr, a, (hipStream_t)stream);
 }
 
-int sampt_sam_track_decode(sampt_dec_t h, int frames, const float* features, const float* pts, const int32_t* labels,
-                           int k, int ld_pts, int n_pos_first, int refine_iters, float iou_thr, int in_h, int in_w,
+int sampt_sam_track_decode(sampt_dec_t h, int frames, const float* features, const float* hq_features,
+                           const float* pts, const int32_t* labels, int k, int ld_pts, int n_pos_first, int refine_iters, float iou_thr, int in_h, int in_w,
                            int oh, int ow, float* final_logits, float* score_out, void* ws, size_t ws_bytes,
                            sampt_stream_t stream) {
   if (!h || !features || !pts || !labels || !final_logits || !score_out || !ws || k <= 0 || n_pos_first > k ||
       ld_pts < k || frames <= 0 || frames > h->e.max_frames)
     return fail(SAMPT_ERR_ARG, "sampt_sam_track_decode: bad arguments");
+  if (h->e.is_hq() != (hq_features != nullptr))
+    return fail(SAMPT_ERR_ARG, "sampt_sam_track_decode: hq_features must be given for HQ-SAM handles and only for them");
   Arena a(ws, ws_bytes);
-  return h->e.track_decode(frames, features, pts, labels, k, ld_pts, n_pos_first, refine_iters, iou_thr, in_h, in_w, oh,
+  return h->e.track_decode(frames, features, hq_features, pts, labels, k, ld_pts, n_pos_first, refine_iters, iou_thr, in_h, in_w, oh,
                            ow, final_logits, score_out, a, (hipStream_t)stream);
 }
 

@@ -96,13 +96,17 @@ struct VitEngine {
   std::string error;
 
   int init(const WeightMap& w, const VitConfig& cfg, int win_rows_batches);
-  // frames: uint8 (B,3,H,W) if chw else (B,H,W,3); features out: [B][grid*grid][out_chans] f32 (NHWC)
-  int encode(const uint8_t* frames, int chw, int B, int H, int W, float* features, Arena& ws, hipStream_t s);
+  // frames: uint8 (B,3,H,W) if chw else (B,H,W,3); features out: [B][grid*grid][out_chans] f32 (NHWC);
+  // interm_out (optional): [B][grid*grid][D] f32 = token stream after the first global-attention block (HQ-SAM's
+  // interm_embeddings[0])
+  int encode(const uint8_t* frames, int chw, int B, int H, int W, float* features, float* interm_out, Arena& ws,
+             hipStream_t s);
 };
 
 // -------------------------------------------------------------------------------------------------
 struct DecConfig {
   int grid = 64, C = 256, heads = 8, depth = 2, mlp = 2048, img = 1024;
+  int vit_dim = 0;  // > 0: HQ-SAM decoder (MaskDecoderHQ) fed by a ViT of that width
 };
 
 struct DecEngine {
@@ -124,20 +128,32 @@ struct DecEngine {
   const float *up0_w, *up0_b, *upln_w, *upln_b, *up1_w, *up1_b;  // ConvT weights packed [(dy,dx)][cout][cin]
   const int *up0_map, *up1_map;                  // pixel-shuffle row maps [4][max_frames*g*g], [4][max_frames*4*g*g]
   const float *hyp_w[3], *hyp_b[3], *iou_w[3], *iou_b[3];         // hypernetwork MLP 0 and IoU head
+  // HQ-SAM extras (c.vit_dim > 0): out_tokens has a 6th row (hf_token); ConvT weights packed like up0/up1
+  struct HqW {
+    const float *mlp_w[3], *mlp_b[3];                             // hf_mlp
+    const float *cv0_w, *cv0_b, *cvln_w, *cvln_b, *cv1_w, *cv1_b;  // compress_vit_feat  (vit_dim -> C -> C/8)
+    const float *ee0_w, *ee0_b, *eeln_w, *eeln_b, *ee1_w, *ee1_b;  // embedding_encoder  (C -> C/4 -> C/8)
+    const float *mf0_w, *mf0_b, *mfln_w, *mfln_b, *mf1_w, *mf1_b;  // embedding_maskfeature: conv3x3 [Cout][9*Cin]
+  } hq;
   std::string error;
 
+  bool is_hq() const { return c.vit_dim > 0; }
+  int n_out() const { return is_hq() ? 6 : 5; }
   int init(const WeightMap& w, const DecConfig& cfg);
+  // HQ-SAM per-frame features [F][16*g*g][C/8] = embedding_encoder(features) + compress_vit_feat(interm)
+  // (features [F][g*g][C], interm [F][g*g][vit_dim]); computed once per frame, shared by all decode passes.
+  int hq_features(int F, const float* features, const float* interm, float* out, Arena& ws, hipStream_t s);
   // One predict_torch pass (multimask_output=False, return_logits=True) for F frames with the same prompt shape.
   // features [F][g*g][256]; pts [F][ld_pts][2], labels [F][ld_pts] (first k used); box [F][4] or null;
   // mask_in [F][4g][4g] or null.  logits_out [F][oh][ow], iou_out [F], low_out [F][4g][4g];
-  // bbox_out: optional int [F][5] state of logits > 0.
-  int decode(int F, const float* features, const float* pts, const int* labels, int k, int ld_pts, const float* box,
+  // bbox_out: optional int [F][5] state of logits > 0.  hq_feat: hq_features() output (HQ-SAM) or null (SAM).
+  int decode(int F, const float* features, const float* hq_feat, const float* pts, const int* labels, int k, int ld_pts, const float* box,
              const float* mask_in, int in_h, int in_w, int oh, int ow, float* logits_out, float* iou_out, float* low_out,
              int* bbox_out, Arena& ws, hipStream_t s);
   // The whole per-(frame, object) chain of SamPt.predict_mask (sam_pt.py:760-837) for F frames, no host sync:
   // [positives-only pass when n_pos_first >= 0] -> all-points pass (+ mask) -> R box-refinement passes gated per frame
   // on device -> IoU-threshold rejection.  final_logits [F][oh][ow], score_out [F].
-  int track_decode(int F, const float* features, const float* pts, const int* labels, int k, int ld_pts, int n_pos_first,
+  int track_decode(int F, const float* features, const float* hq_feat, const float* pts, const int* labels, int k, int ld_pts, int n_pos_first,
                    int R, float iou_thr, int in_h, int in_w, int oh, int ow, float* final_logits, float* score_out,
                    Arena& ws, hipStream_t s);
 };

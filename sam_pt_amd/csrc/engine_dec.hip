@@ -60,6 +60,22 @@ int DecEngine::init(const WeightMap& w, const DecConfig& cfg) {
     iou_w[i] = w.f("mask_decoder.iou_prediction_head.layers." + std::to_string(i) + ".weight");
     iou_b[i] = w.f("mask_decoder.iou_prediction_head.layers." + std::to_string(i) + ".bias");
   }
+  if (is_hq()) {
+    const std::string M = "mask_decoder.";
+    for (int i = 0; i < 3; ++i) {
+      hq.mlp_w[i] = w.f(M + "hf_mlp.layers." + std::to_string(i) + ".weight");
+      hq.mlp_b[i] = w.f(M + "hf_mlp.layers." + std::to_string(i) + ".bias");
+    }
+    auto seq = [&](const std::string& p, const float*& w0, const float*& b0, const float*& lw, const float*& lb,
+                   const float*& w1, const float*& b1) {
+      w0 = w.f(M + p + ".0.weight_packed"), b0 = w.f(M + p + ".0.bias");
+      lw = w.f(M + p + ".1.weight"), lb = w.f(M + p + ".1.bias");
+      w1 = w.f(M + p + ".3.weight_packed"), b1 = w.f(M + p + ".3.bias");
+    };
+    seq("compress_vit_feat", hq.cv0_w, hq.cv0_b, hq.cvln_w, hq.cvln_b, hq.cv1_w, hq.cv1_b);
+    seq("embedding_encoder", hq.ee0_w, hq.ee0_b, hq.eeln_w, hq.eeln_b, hq.ee1_w, hq.ee1_b);
+    seq("embedding_maskfeature", hq.mf0_w, hq.mf0_b, hq.mfln_w, hq.mfln_b, hq.mf1_w, hq.mf1_b);
+  }
   if (!w.missing.empty()) {
     error = "DecEngine: missing weights: " + w.missing;
     return SAMPT_ERR_ARG;
@@ -101,12 +117,47 @@ static int attn_block(const L& l, const DecEngine::Attn& a, int heads, int C, in
   return layernorm_rows(out, lnw, lnb, out, (long)F * Nq, C, 1e-5f, nullptr, 0, ACT_NONE, s);
 }
 
-int DecEngine::decode(int F, const float* features, const float* pts, const int* labels, int k, int ld_pts,
-                      const float* box, const float* mask_in, int in_h, int in_w, int oh, int ow, float* logits_out,
-                      float* iou_out, float* low_out, int* bbox_out, Arena& ws, hipStream_t s) {
-  const int g = c.grid, P = g * g, C = c.C, H = c.heads;
-  const int nsparse = k + (box ? 2 : 1), Nt = 5 + nsparse;
+// two ConvT2x2s2 stages with LayerNorm2d + GELU in between (pixel shuffle through the row maps); the second stage
+// optionally applies `act` and adds `res` (same layout as out):  x [F*P][K0] -> mid [F*4P][N0] -> out [F*16P][N1]
+static int convt_pair(const DecEngine& e, int F, const float* x, int K0, const float* w0, const float* b0, int N0,
+                      const float* lnw, const float* lnb, const float* w1, const float* b1, int N1, int act,
+                      const float* res, float* mid, float* out, float* skws, size_t skn, hipStream_t s) {
+  const long FP = (long)F * e.c.grid * e.c.grid, P = (long)e.c.grid * e.c.grid;
+  GemmP p;
+  p.A = x, p.W = w0, p.bias = b0, p.C = mid, p.rowmap = e.up0_map;
+  p.M = (int)FP, p.N = N0, p.K = K0, p.lda = K0, p.ldw = K0, p.ldc = N0;
+  p.nb1 = 4, p.sW1 = (long)N0 * K0, p.sRowmap1 = (long)e.max_frames * P;
+  (void)skws, (void)skn;
+  SAMPT_TRY(gemm_f32(p, s));
+  SAMPT_TRY(layernorm_rows(mid, lnw, lnb, mid, 4L * FP, N0, 1e-6f, nullptr, 0, ACT_GELU, s));
+  GemmP q;
+  q.A = mid, q.W = w1, q.bias = b1, q.C = out, q.rowmap = e.up1_map, q.res = res;
+  q.M = (int)(4 * FP), q.N = N1, q.K = N0, q.lda = N0, q.ldw = N0, q.ldc = N1, q.ldr = N1, q.act = act;
+  q.nb1 = 4, q.sW1 = (long)N1 * N0, q.sRowmap1 = 4L * e.max_frames * P;
+  return gemm_f32(q, s);
+}
+
+int DecEngine::hq_features(int F, const float* features, const float* interm, float* out, Arena& ws, hipStream_t s) {
+  if (!is_hq() || F <= 0 || F > max_frames) return SAMPT_ERR_ARG;
+  const int C = c.C;
+  const size_t FP = (size_t)F * c.grid * c.grid;
+  float* mid = ws.f32(4 * FP * C);
+  if (!ws.ok()) return SAMPT_ERR_WORKSPACE;
+  if (ws.dry()) return SAMPT_OK;
+  // out = compress_vit_feat(interm) ; out += embedding_encoder(features)
+  SAMPT_TRY(convt_pair(*this, F, interm, c.vit_dim, hq.cv0_w, hq.cv0_b, C, hq.cvln_w, hq.cvln_b, hq.cv1_w, hq.cv1_b, C / 8,
+                       ACT_NONE, nullptr, mid, out, nullptr, 0, s));
+  return convt_pair(*this, F, features, C, hq.ee0_w, hq.ee0_b, C / 4, hq.eeln_w, hq.eeln_b, hq.ee1_w, hq.ee1_b, C / 8,
+                    ACT_NONE, out, mid, out, nullptr, 0, s);
+}
+
+int DecEngine::decode(int F, const float* features, const float* hq_feat, const float* pts, const int* labels, int k,
+                      int ld_pts, const float* box, const float* mask_in, int in_h, int in_w, int oh, int ow,
+                      float* logits_out, float* iou_out, float* low_out, int* bbox_out, Arena& ws, hipStream_t s) {
+  const int g = c.grid, P = g * g, C = c.C, H = c.heads, NO = n_out();
+  const int nsparse = k + (box ? 2 : 1), Nt = NO + nsparse;
   if (Nt > 64 || k < 0 || F <= 0 || F > max_frames) return SAMPT_ERR_UNSUPPORTED;
+  if (is_hq() != (hq_feat != nullptr)) return SAMPT_ERR_ARG;
   const size_t FP = (size_t)F * P, FT = (size_t)F * Nt;
   Bufs b;
   b.tokens = ws.f32(FT * C);
@@ -123,6 +174,8 @@ int DecEngine::decode(int F, const float* features, const float* pts, const int*
   b.up1 = ws.f32(16 * FP * (C / 8));
   b.t0 = ws.f32((size_t)F * C), b.t1 = ws.f32((size_t)F * C), b.t2 = ws.f32((size_t)F * C);
   b.me0 = ws.f32(4 * FP * 4), b.me1 = ws.f32(FP * 16);
+  float *uh0 = nullptr, *uh1 = nullptr, *t3 = nullptr;
+  if (is_hq()) uh0 = ws.f32(16 * FP * (C / 4)), uh1 = ws.f32(16 * FP * (C / 8)), t3 = ws.f32((size_t)F * C);
   int* bbox_partial = (int*)ws.get((size_t)F * bbox_partial_ints(oh, ow) * sizeof(int));
   const size_t skn = (size_t)16 * FT * C;
   float* skws = ws.f32(skn);
@@ -131,7 +184,8 @@ int DecEngine::decode(int F, const float* features, const float* pts, const int*
   L l{s, skws, skn};
 
   // ---- prompt encoder
-  SAMPT_TRY(sam_tokens(out_tokens, pts, labels, k, ld_pts, box, gauss, point_emb, not_a_point, (float)c.img, F, b.tokens, s));
+  SAMPT_TRY(sam_tokens(out_tokens, NO, pts, labels, k, ld_pts, box, gauss, point_emb, not_a_point, (float)c.img, F,
+                       b.tokens, s));
   if (mask_in) SAMPT_TRY(sam_mask_embed_src(mask_in, g, F, me, features, b.me0, b.me1, b.keys, s));
   else SAMPT_TRY(add_bcast(features, no_mask, b.keys, (long)FP * C, C, s));
 
@@ -165,26 +219,37 @@ int DecEngine::decode(int F, const float* features, const float* pts, const int*
 
   // ---- upscaling: ConvT2x2s2 (C -> C/4) + LN2d + GELU ; ConvT2x2s2 (C/4 -> C/8) + GELU   (pixel shuffle via row maps
   //      that cover max_frames frames: map[(dy,dx)][f*P + p] = f*4P + (2y+dy)*2g + 2x+dx)
-  {
-    GemmP p;
-    p.A = b.keys, p.W = up0_w, p.bias = up0_b, p.C = b.up0, p.rowmap = up0_map;
-    p.M = (int)FP, p.N = C / 4, p.K = C, p.lda = C, p.ldw = C, p.ldc = C / 4;
-    p.nb1 = 4, p.sW1 = (long)(C / 4) * C, p.sRowmap1 = (long)max_frames * P;
-    SAMPT_TRY(gemm_f32(p, s));
-    SAMPT_TRY(layernorm_rows(b.up0, upln_w, upln_b, b.up0, 4L * FP, C / 4, 1e-6f, nullptr, 0, ACT_GELU, s));
-    GemmP q;
-    q.A = b.up0, q.W = up1_w, q.bias = up1_b, q.C = b.up1, q.rowmap = up1_map;
-    q.M = (int)(4 * FP), q.N = C / 8, q.K = C / 4, q.lda = C / 4, q.ldw = C / 4, q.ldc = C / 8, q.act = ACT_GELU;
-    q.nb1 = 4, q.sW1 = (long)(C / 8) * (C / 4), q.sRowmap1 = 4L * max_frames * P;
-    SAMPT_TRY(gemm_f32(q, s));
-  }
+  SAMPT_TRY(convt_pair(*this, F, b.keys, C, up0_w, up0_b, C / 4, upln_w, upln_b, up1_w, up1_b, C / 8, ACT_GELU, nullptr,
+                       b.up0, b.up1, nullptr, 0, s));
   // ---- hypernetwork MLP of mask token 0 (multimask_output=False keeps slice 0 only) and the IoU head;
   //      A = row 1 (mask token 0) / row 0 (iou token) of every frame's token matrix: lda = Nt*C
   const float* mask_tok = queries + 1 * C;
   SAMPT_TRY(l.lin(mask_tok, F, C, hyp_w[0], hyp_b[0], b.t0, C, ACT_RELU, nullptr, Nt * C));
   SAMPT_TRY(l.lin(b.t0, F, C, hyp_w[1], hyp_b[1], b.t1, C, ACT_RELU));
   SAMPT_TRY(l.lin(b.t1, F, C, hyp_w[2], hyp_b[2], b.t2, C / 8, ACT_NONE));
-  SAMPT_TRY(sam_mask_dot(b.up1, b.t2, C / 8, low_out, F, 16 * P, C / 8, s));
+  if (!is_hq()) {
+    SAMPT_TRY(sam_mask_dot(b.up1, b.t2, C / 8, nullptr, nullptr, 0, low_out, F, 16 * P, C / 8, s));
+  } else {
+    // HQ-SAM: upscaled_hq = conv3x3(GELU(LN2d(conv3x3(upscaled)))) + hq_features ;  mask = <hyper0, upscaled> +
+    // <hf_mlp(hq token), upscaled_hq>   (MaskDecoderHQ.predict_masks, hq_token_only=False)
+    const int Lr = 4 * g;
+    GemmP p;
+    p.A = b.up1, p.W = hq.mf0_w, p.bias = hq.mf0_b, p.C = uh0;
+    p.M = (int)(16 * FP), p.N = C / 4, p.K = 9 * (C / 8), p.ldw = p.K, p.ldc = C / 4;
+    p.conv = 1, p.cH = Lr, p.cW = Lr, p.cC = C / 8, p.KH = 3, p.KW = 3, p.cstride = 1, p.cpad = 1, p.OH = Lr, p.OW = Lr;
+    SAMPT_TRY(gemm_f32(p, s));
+    SAMPT_TRY(layernorm_rows(uh0, hq.mfln_w, hq.mfln_b, uh0, 16L * FP, C / 4, 1e-6f, nullptr, 0, ACT_GELU, s));
+    GemmP q;
+    q.A = uh0, q.W = hq.mf1_w, q.bias = hq.mf1_b, q.C = uh1, q.res = hq_feat;
+    q.M = (int)(16 * FP), q.N = C / 8, q.K = 9 * (C / 4), q.ldw = q.K, q.ldc = C / 8, q.ldr = C / 8;
+    q.conv = 1, q.cH = Lr, q.cW = Lr, q.cC = C / 4, q.KH = 3, q.KW = 3, q.cstride = 1, q.cpad = 1, q.OH = Lr, q.OW = Lr;
+    SAMPT_TRY(gemm_f32(q, s));
+    const float* hq_tok = queries + 5 * C;
+    SAMPT_TRY(l.lin(hq_tok, F, C, hq.mlp_w[0], hq.mlp_b[0], b.t0, C, ACT_RELU, nullptr, Nt * C));
+    SAMPT_TRY(l.lin(b.t0, F, C, hq.mlp_w[1], hq.mlp_b[1], b.t1, C, ACT_RELU));
+    SAMPT_TRY(l.lin(b.t1, F, C, hq.mlp_w[2], hq.mlp_b[2], t3, C / 8, ACT_NONE));
+    SAMPT_TRY(sam_mask_dot(b.up1, b.t2, C / 8, uh1, t3, C / 8, low_out, F, 16 * P, C / 8, s));
+  }
   SAMPT_TRY(l.lin(queries, F, C, iou_w[0], iou_b[0], b.t0, C, ACT_RELU, nullptr, Nt * C));
   SAMPT_TRY(l.lin(b.t0, F, C, iou_w[1], iou_b[1], b.t1, C, ACT_RELU));
   SAMPT_TRY(l.lin(b.t1, F, C, iou_w[2], iou_b[2], iou_out, 1, ACT_NONE));  // N = 1: only IoU slot 0 is needed
@@ -193,8 +258,8 @@ int DecEngine::decode(int F, const float* features, const float* pts, const int*
   return SAMPT_OK;
 }
 
-int DecEngine::track_decode(int F, const float* features, const float* pts, const int* labels, int k, int ld_pts,
-                            int n_pos_first, int R, float iou_thr, int in_h, int in_w, int oh, int ow,
+int DecEngine::track_decode(int F, const float* features, const float* hq_feat, const float* pts, const int* labels,
+                            int k, int ld_pts, int n_pos_first, int R, float iou_thr, int in_h, int in_w, int oh, int ow,
                             float* final_logits, float* score_out, Arena& ws, hipStream_t s) {
   const int g = c.grid, Lr = 4 * g;
   const long nlog = (long)oh * ow, nlow = (long)Lr * Lr;
@@ -211,7 +276,7 @@ int DecEngine::track_decode(int F, const float* features, const float* pts, cons
   int* active = (int*)ws.get((size_t)F * sizeof(int));
   size_t mark = ws.off;
   if (ws.dry()) {  // measure the per-pass scratch once (all passes reuse it); box + mask = the largest variant
-    SAMPT_TRY(decode(F, features, pts, labels, k, ld_pts, pts, cur_low, in_h, in_w, oh, ow, cur_logits, cur_iou, cur_low,
+    SAMPT_TRY(decode(F, features, hq_feat, pts, labels, k, ld_pts, pts, cur_low, in_h, in_w, oh, ow, cur_logits, cur_iou, cur_low,
                      cur_bb, ws, s));
     return SAMPT_OK;
   }
@@ -219,19 +284,19 @@ int DecEngine::track_decode(int F, const float* features, const float* pts, cons
   const float* mask_in = nullptr;
   if (n_pos_first >= 0) {  // negative_points_per_mask > 0 (sam_pt.py:791-807): positives only, then all + low-res mask
     ws.off = mark;
-    SAMPT_TRY(decode(F, features, pts, labels, n_pos_first, ld_pts, nullptr, nullptr, in_h, in_w, oh, ow, cand_logits,
+    SAMPT_TRY(decode(F, features, hq_feat, pts, labels, n_pos_first, ld_pts, nullptr, nullptr, in_h, in_w, oh, ow, cand_logits,
                      cand_iou, low0, nullptr, ws, s));
     mask_in = low0;
   }
   ws.off = mark;
-  SAMPT_TRY(decode(F, features, pts, labels, k, ld_pts, nullptr, mask_in, in_h, in_w, oh, ow, cur_logits, cur_iou, cur_low,
+  SAMPT_TRY(decode(F, features, hq_feat, pts, labels, k, ld_pts, nullptr, mask_in, in_h, in_w, oh, ow, cur_logits, cur_iou, cur_low,
                    cur_bb, ws, s));
   if (R > 0) {
     if (hipMemsetAsync(active, 0xff, sizeof(int) * F, s) != hipSuccess) return SAMPT_ERR_HIP;
     for (int r = 0; r < R; ++r) {
       SAMPT_TRY(sam_refine_gate(active, cur_bb, boxf, F, s));
       ws.off = mark;
-      SAMPT_TRY(decode(F, features, pts, labels, k, ld_pts, boxf, cur_low, in_h, in_w, oh, ow, cand_logits, cand_iou,
+      SAMPT_TRY(decode(F, features, hq_feat, pts, labels, k, ld_pts, boxf, cur_low, in_h, in_w, oh, ow, cand_logits, cand_iou,
                        cand_low, cand_bb, ws, s));
       SAMPT_TRY(sam_commit(active, cand_logits, cur_logits, nlog, cand_low, cur_low, nlow, cand_iou, cur_iou, cand_bb,
                            cur_bb, F, s));

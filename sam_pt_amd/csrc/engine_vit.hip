@@ -56,7 +56,8 @@ struct G {
 };
 }  // namespace
 
-int VitEngine::encode(const uint8_t* frames, int chw, int B, int H, int W, float* features, Arena& ws, hipStream_t s) {
+int VitEngine::encode(const uint8_t* frames, int chw, int B, int H, int W, float* features, float* interm_out, Arena& ws,
+                      hipStream_t s) {
   const bool dry = ws.dry();
   const int g = c.grid, T = g * g, D = c.D, ws_ = c.window, hd = D / c.heads;
   const int gp = ((g + ws_ - 1) / ws_) * ws_, nw1 = gp / ws_, nwin = nw1 * nw1, wt = ws_ * ws_;
@@ -93,6 +94,7 @@ int VitEngine::encode(const uint8_t* frames, int chw, int B, int H, int W, float
   SAMPT_TRY(gm.run(xn, (int)Mg, Kp, patch_w, patch_b, x, D, ACT_NONE, false, pos, D, nullptr, T));
 
   const float scale = 1.0f / sqrtf((float)hd);
+  bool tapped = false;
   for (int i = 0; i < c.depth; ++i) {
     const Blk& b = blk[i];
     const bool glob = (c.global_mask >> i) & 1;
@@ -131,6 +133,11 @@ int VitEngine::encode(const uint8_t* frames, int chw, int B, int H, int W, float
     SAMPT_TRY(layernorm_rows(x, b.ln2w, b.ln2b, xn, Mg, D, 1e-6f, nullptr, c.f16, ACT_NONE, s));
     SAMPT_TRY(gm.run(xn, (int)Mg, D, b.w1, b.b1, hid, c.mlp_ratio * D, ACT_GELU, c.f16 != 0, nullptr, 0, nullptr, 0));
     SAMPT_TRY(gm.run(hid, (int)Mg, c.mlp_ratio * D, b.w2, b.b2, x, D, ACT_NONE, false, x, D, nullptr, 0));
+    if (interm_out && glob && !tapped) {  // HQ-SAM: the first global block's output feeds compress_vit_feat
+      if (hipMemcpyAsync(interm_out, x, (size_t)Mg * D * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
+        return SAMPT_ERR_HIP;
+      tapped = true;
+    }
   }
   // ---- neck: conv1x1 (no bias) -> LayerNorm2d -> conv3x3 (no bias) -> LayerNorm2d
   const void* xin = x;

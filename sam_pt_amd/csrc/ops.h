@@ -88,9 +88,9 @@ int pips_finalize(const float* ffeats, const float* vis_w, const float* vis_b, c
 // ---- sam_decoder.hip (every launcher takes the frame batch F; tensors are [F][...] contiguous) ---------------
 // decoder tokens [F][Nt][256] (Nt = 5 + k + (box ? 2 : 1)): out tokens, then the sparse prompt tokens (App. A-4).
 // pts [F][ld_pts][2] input-frame px, labels [F][ld_pts] i32, box [F][4] or null.
-int sam_tokens(const float* out_tokens, const float* pts, const int* labels, int k, int ld_pts, const float* box,
-               const float* gauss, const float* point_emb /*[4][256]*/, const float* not_a_point, float img_size, int F,
-               float* tokens, hipStream_t s);
+int sam_tokens(const float* out_tokens /*[n_out][256]*/, int n_out, const float* pts, const int* labels, int k, int ld_pts,
+               const float* box, const float* gauss, const float* point_emb /*[4][256]*/, const float* not_a_point,
+               float img_size, int F, float* tokens, hipStream_t s);
 // small f32 attention, one workgroup per (query, head, frame): q [F][Nq][H*hd], k,v [F][Nk][H*hd]
 int attn_rowblock(const float* q, const float* k, const float* v, float* out, int F, int Nq, int Nk, int heads, int hd,
                   hipStream_t s);
@@ -98,7 +98,8 @@ int attn_rowblock(const float* q, const float* k, const float* v, float* out, in
 int attn_fewkeys(const float* q, const float* k, const float* v, float* out, int F, int Nq, int Nk, int heads, int hd,
                  hipStream_t s);
 // low_res[f][p] = <hyper[f][0:C], up[f][p][0:C]>
-int sam_mask_dot(const float* up, const float* hyper, int ld_hyper, float* low_res, int F, int npix, int C, hipStream_t s);
+int sam_mask_dot(const float* up, const float* hyper, int ld_hyper, const float* up2 /*or null*/, const float* hyper2,
+                 int ld_hyper2, float* low_res, int F, int npix, int C, hipStream_t s);
 // fused Sam.postprocess_masks: low (L x L) -> bilinear to (img x img) -> crop (in_h,in_w) -> bilinear to (oh,ow)
 int sam_postprocess(const float* low, int L, int img, int in_h, int in_w, float* out, int oh, int ow, hipStream_t s);
 // bbox state per frame: int[5] = {xmin, ymin, xmax, ymax, count} of logits > 0 (refinement box of sam_pt.py:809-820);

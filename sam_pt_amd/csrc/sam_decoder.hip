@@ -7,7 +7,7 @@
 namespace sampt {
 
 // ---------------------------------------------------------------------------------------------
-// decoder token matrix [F][Nt][256]: rows 0..4 = iou token + 4 mask tokens, then the sparse prompt tokens:
+// decoder token matrix [F][Nt][256]: rows 0..n_out-1 = iou token + 4 mask tokens (+ HQ token), then the sparse tokens:
 // k points (random-Fourier PE + label embedding), then (no box) one "not a point" pad row | (box) two corner rows.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(128) void k_sam_tokens(const float* __restrict__ out_tokens, const float* __restrict__ pts,
@@ -15,15 +15,15 @@ __global__ __launch_bounds__(128) void k_sam_tokens(const float* __restrict__ ou
                                                     const float* __restrict__ box, const float* __restrict__ gauss,
                                                     const float* __restrict__ point_emb,
                                                     const float* __restrict__ not_a_point, float img_size, int Nt,
-                                                    float* __restrict__ tokens) {
+                                                    int n_out, float* __restrict__ tokens) {
   const int trow = blockIdx.x, f = blockIdx.y, j = threadIdx.x;
   float* out = tokens + ((long)f * Nt + trow) * 256;
-  if (trow < 5) {
+  if (trow < n_out) {
     out[j] = out_tokens[trow * 256 + j];
     out[128 + j] = out_tokens[trow * 256 + 128 + j];
     return;
   }
-  const int row = trow - 5;
+  const int row = trow - n_out;
   float x, y;
   int label;
   const float* emb;
@@ -53,12 +53,12 @@ __global__ __launch_bounds__(128) void k_sam_tokens(const float* __restrict__ ou
   out[128 + j] = c + emb[128 + j];
 }
 
-int sam_tokens(const float* out_tokens, const float* pts, const int* labels, int k, int ld_pts, const float* box,
-               const float* gauss, const float* point_emb, const float* not_a_point, float img_size, int F,
-               float* tokens, hipStream_t s) {
-  int Nt = 5 + k + (box ? 2 : 1);
+int sam_tokens(const float* out_tokens, int n_out, const float* pts, const int* labels, int k, int ld_pts,
+               const float* box, const float* gauss, const float* point_emb, const float* not_a_point, float img_size,
+               int F, float* tokens, hipStream_t s) {
+  int Nt = n_out + k + (box ? 2 : 1);
   hipLaunchKernelGGL(k_sam_tokens, dim3(Nt, F), dim3(128), 0, s, out_tokens, pts, labels, k, ld_pts, box, gauss,
-                     point_emb, not_a_point, img_size, Nt, tokens);
+                     point_emb, not_a_point, img_size, Nt, n_out, tokens);
   SAMPT_CHECK_LAUNCH("sam_tokens");
   return SAMPT_OK;
 }
@@ -222,7 +222,9 @@ int attn_fewkeys(const float* q, const float* k, const float* v, float* out, int
 // ---------------------------------------------------------------------------------------------
 // low_res[f][p] = <hyper[f], upscaled[f][p]>   (masks = hyper_in @ upscaled, App. A-4)
 // ---------------------------------------------------------------------------------------------
+// HQ-SAM adds a second term  <hyper2[f], up2[f][p]>  (mask_sam + mask_hq), summed after each dot is complete.
 __global__ void k_sam_mask_dot(const float* __restrict__ up, const float* __restrict__ hyper, int ld_hyper,
+                               const float* __restrict__ up2, const float* __restrict__ hyper2, int ld_hyper2,
                                float* __restrict__ low, int npix, int C) {
   int p = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
   if (p >= npix) return;
@@ -233,13 +235,24 @@ __global__ void k_sam_mask_dot(const float* __restrict__ up, const float* __rest
     float4 t = u[c];
     a += hy[4 * c] * t.x + hy[4 * c + 1] * t.y + hy[4 * c + 2] * t.z + hy[4 * c + 3] * t.w;
   }
+  if (up2) {
+    const float4* u2 = (const float4*)(up2 + ((long)f * npix + p) * C);
+    const float* h2 = hyper2 + (long)f * ld_hyper2;
+    float b = 0.f;
+    for (int c = 0; c < C / 4; ++c) {
+      float4 t = u2[c];
+      b += h2[4 * c] * t.x + h2[4 * c + 1] * t.y + h2[4 * c + 2] * t.z + h2[4 * c + 3] * t.w;
+    }
+    a += b;
+  }
   low[(long)f * npix + p] = a;
 }
 
-int sam_mask_dot(const float* up, const float* hyper, int ld_hyper, float* low_res, int F, int npix, int C,
-                 hipStream_t s) {
+int sam_mask_dot(const float* up, const float* hyper, int ld_hyper, const float* up2, const float* hyper2, int ld_hyper2,
+                 float* low_res, int F, int npix, int C, hipStream_t s) {
   if (C % 4) return SAMPT_ERR_ARG;
-  hipLaunchKernelGGL(k_sam_mask_dot, dim3(cdiv(npix, 256), F), dim3(256), 0, s, up, hyper, ld_hyper, low_res, npix, C);
+  hipLaunchKernelGGL(k_sam_mask_dot, dim3(cdiv(npix, 256), F), dim3(256), 0, s, up, hyper, ld_hyper, up2, hyper2,
+                     ld_hyper2, low_res, npix, C);
   SAMPT_CHECK_LAUNCH("sam_mask_dot");
   return SAMPT_OK;
 }

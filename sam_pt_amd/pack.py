@@ -112,13 +112,23 @@ def _shuffle_map(side: int, frames: int = 1) -> torch.Tensor:
     return torch.stack(maps).to(torch.int32).contiguous()
 
 
-def pack_decoder(sd: Dict[str, torch.Tensor], cfg: SamConfig, device, max_frames: int = 1) -> Dict[str, torch.Tensor]:
+def pack_decoder(sd: Dict[str, torch.Tensor], cfg: SamConfig, device, max_frames: int = 1,
+                 hq: bool = False) -> Dict[str, torch.Tensor]:
     out: Dict[str, torch.Tensor] = {}
     for k, v in sd.items():
         if k.startswith("mask_decoder.") or k.startswith("prompt_encoder."):
             out[k] = v.detach().float().contiguous()
-    out["mask_decoder.__out_tokens"] = torch.cat([sd["mask_decoder.iou_token.weight"],
-                                                   sd["mask_decoder.mask_tokens.weight"]], dim=0).float().contiguous()
+    toks = [sd["mask_decoder.iou_token.weight"], sd["mask_decoder.mask_tokens.weight"]]
+    if hq:
+        toks.append(sd["mask_decoder.hf_token.weight"])                       # 6th output token (MaskDecoderHQ)
+        for p in ("compress_vit_feat", "embedding_encoder"):
+            for i in (0, 3):
+                out[f"mask_decoder.{p}.{i}.weight_packed"] = _convt_pack(sd[f"mask_decoder.{p}.{i}.weight"].float())
+        for i in (0, 3):                                                       # conv3x3 OIHW -> [O][(ky,kx,ci)]
+            w = sd[f"mask_decoder.embedding_maskfeature.{i}.weight"].float()
+            out[f"mask_decoder.embedding_maskfeature.{i}.weight_packed"] = \
+                w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
+    out["mask_decoder.__out_tokens"] = torch.cat(toks, dim=0).float().contiguous()
     out["prompt_encoder.__point_embeddings"] = torch.cat(
         [sd[f"prompt_encoder.point_embeddings.{i}.weight"] for i in range(4)], dim=0).float().contiguous()
     g = sd["prompt_encoder.pe_layer.positional_encoding_gaussian_matrix"].float()

@@ -55,6 +55,30 @@ class ResizeLongestSide:
         return self.apply_coords(boxes.reshape(-1, 2, 2), original_size).reshape(-1, 4)
 
 
+class ClipFeatures:
+    """Per-frame SAM embeddings of a clip plus (HQ-SAM) the per-frame HQ features; indexes/flips along the frame axis like
+    the plain embedding tensor it replaces in ``SamPt``."""
+
+    def __init__(self, emb: torch.Tensor, hq: torch.Tensor):
+        self.emb, self.hq = emb, hq
+
+    def __len__(self):
+        return self.emb.shape[0]
+
+    @property
+    def shape(self):
+        return self.emb.shape
+
+    def __getitem__(self, i):
+        return ClipFeatures(self.emb[i], self.hq[i])
+
+    def flip(self, *dims):
+        return ClipFeatures(self.emb.flip(*dims), self.hq.flip(*dims))
+
+    def index_select(self, dim, idx):
+        return ClipFeatures(self.emb.index_select(dim, idx), self.hq.index_select(dim, idx))
+
+
 class SamHip(nn.Module):
     """The ``Sam``-like object a predictor exposes as ``.model`` (sam_pt.py:96, 118-120, 334).  Holds the upstream-layout
     state dict; the constructor keywords mirror ``BaseHydra`` (sam_pt/modeling/sam.py:18-31)."""
@@ -64,13 +88,21 @@ class SamHip(nn.Module):
 
     def __init__(self, variant: str = "vit_h", checkpoint: Optional[str] = None, state_dict=None, seed: int = 72,
                  precision: str = "f16", config: Optional[SamConfig] = None, max_batch: int = 8,
-                 max_decode_batch: int = 32, **hydra_kwargs):
+                 max_decode_batch: int = 32, hq: Optional[bool] = None, **hydra_kwargs):
+        """``hq``: build the HQ-SAM decoder (sam_pt/modeling/sam.py SamHQHydra, configs/model/sam/samhq_vit_*.yaml);
+        default: inferred from the checkpoint (presence of ``mask_decoder.hf_token.weight``)."""
         super().__init__()
         self.cfg = config if config is not None else SAM_CONFIGS[variant]
         if state_dict is None and checkpoint is not None:
             with open(checkpoint, "rb") as f:
                 state_dict = torch.load(f, map_location="cpu")
-        self.sd = state_dict if state_dict is not None else init_sam_state_dict(self.cfg, seed)
+        if state_dict is None:
+            state_dict = init_sam_state_dict(self.cfg, seed, hq=bool(hq))
+        self.sd = state_dict
+        has_hq = "mask_decoder.hf_token.weight" in self.sd
+        self.hq = has_hq if hq is None else bool(hq)
+        if self.hq and not has_hq:
+            raise ValueError("hq=True but the checkpoint has no MaskDecoderHQ weights (mask_decoder.hf_token.weight ...)")
         assert precision in ("f16", "f32")
         self.precision = precision
         self.max_batch = max_batch
@@ -92,13 +124,14 @@ class SamPredictor:
         self._dev = None
         self._ws_vit: Dict[int, torch.Tensor] = {}
         self._ws_dec: Dict[Tuple[int, int], torch.Tensor] = {}
+        self._ws_hq = None
         self.reset_image()
         self.stats = {"set_image": 0, "predict": 0, "encoded_frames": 0}
 
     def reset_image(self):
         self.is_image_set = False
         self.features = None
-        self._feat_tokens = None
+        self._feat_tokens = self._hq_tokens = None
         self.original_size = self.input_size = None
 
     # -- engines -------------------------------------------------------------------------------------
@@ -123,11 +156,11 @@ class SamPredictor:
         h = C.c_void_p()
         _lib.check(lib.sampt_vit_create(C.byref(c), names, ptrs, n, m.max_batch, C.byref(h)), "sampt_vit_create")
         self._vit = h
-        self._wd = pack_decoder(m.sd, cfg, dev, m.max_decode_batch)
+        self._wd = pack_decoder(m.sd, cfg, dev, m.max_decode_batch, hq=m.hq)
         names, ptrs, n = _lib.name_table(self._wd)
         h2 = C.c_void_p()
-        _lib.check(lib.sampt_dec_create(names, ptrs, n, cfg.grid, cfg.img_size, m.max_decode_batch, C.byref(h2)),
-                   "sampt_dec_create")
+        _lib.check(lib.sampt_dec_create(names, ptrs, n, cfg.grid, cfg.img_size, m.max_decode_batch,
+                                        cfg.embed_dim if m.hq else 0, C.byref(h2)), "sampt_dec_create")
         self._dec, self._dev, self._lib = h2, dev, lib
 
     def __del__(self):
@@ -157,27 +190,45 @@ class SamPredictor:
 
     # -- image encoder -------------------------------------------------------------------------------
     @torch.no_grad()
-    def encode_frames(self, frames: torch.Tensor, chw: bool = True) -> torch.Tensor:
-        """frames uint8 (T,3,H,W) [chw] or (T,H,W,3) on device -> token-major embeddings (T, grid*grid, 256) f32."""
+    def encode_frames(self, frames: torch.Tensor, chw: bool = True):
+        """frames uint8 (T,3,H,W) [chw] or (T,H,W,3) on device -> token-major embeddings (T, grid*grid, 256) f32; for an
+        HQ-SAM model a ``ClipFeatures`` that also carries the per-frame HQ features (T, 16*grid*grid, 32)."""
         self._ensure()
         frames = frames.to(self._dev).contiguous()
         T = frames.shape[0]
         H, W = (frames.shape[2], frames.shape[3]) if chw else (frames.shape[1], frames.shape[2])
         g, Cc = self.model.cfg.grid, self.model.cfg.out_chans
         out = torch.empty((T, g * g, Cc), dtype=torch.float32, device=self._dev)
-        Bm = self.model.max_batch
+        Bm = min(self.model.max_batch, self.model.max_decode_batch)
+        hq = interm = None
+        if self.model.hq:
+            hq = torch.empty((T, 16 * g * g, Cc // 8), dtype=torch.float32, device=self._dev)
+            interm = torch.empty((min(Bm, T), g * g, self.model.cfg.embed_dim), dtype=torch.float32, device=self._dev)
         for t0 in range(0, T, Bm):
             B = min(Bm, T - t0)
             ws = self._vit_ws(B)
             _lib.check(self._lib.sampt_vit_encode(self._vit, _lib.ptr(frames[t0:t0 + B]), 1 if chw else 0, B, H, W,
-                                                  _lib.ptr(out[t0:t0 + B]), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()),
-                       "sampt_vit_encode")
+                                                  _lib.ptr(out[t0:t0 + B]), _lib.ptr(interm), _lib.ptr(ws), ws.numel(),
+                                                  _lib.stream_ptr()), "sampt_vit_encode")
+            if hq is not None:      # the ViT tap is consumed batch by batch: only the 32-channel HQ features stay resident
+                if self._ws_hq is None or self._ws_hq[0] < B:
+                    n = C.c_size_t()
+                    _lib.check(self._lib.sampt_dec_hq_workspace_bytes(self._dec, B, C.byref(n)), "hq_workspace")
+                    self._ws_hq = (B, torch.empty(n.value, dtype=torch.uint8, device=self._dev))
+                wsh = self._ws_hq[1]
+                _lib.check(self._lib.sampt_dec_hq_features(self._dec, B, _lib.ptr(out[t0:t0 + B]), _lib.ptr(interm),
+                                                           _lib.ptr(hq[t0:t0 + B]), _lib.ptr(wsh), wsh.numel(),
+                                                           _lib.stream_ptr()), "sampt_dec_hq_features")
         self.stats["encoded_frames"] += T
-        return out
+        return ClipFeatures(out, hq) if hq is not None else out
 
-    def set_features(self, feat_tokens: torch.Tensor, original_size, input_size=None):
+    def set_features(self, feat_tokens, original_size, input_size=None):
         """Install a pre-computed embedding (one frame of ``encode_frames``) as the current image."""
         g, Cc = self.model.cfg.grid, self.model.cfg.out_chans
+        if isinstance(feat_tokens, ClipFeatures):
+            feat_tokens, self._hq_tokens = feat_tokens.emb, feat_tokens.hq.contiguous()
+        elif self.model.hq:
+            raise ValueError("HQ-SAM: set_features needs the ClipFeatures item returned by encode_frames")
         self._feat_tokens = feat_tokens.contiguous()
         self.features = self._feat_tokens.view(g, g, Cc).permute(2, 0, 1).unsqueeze(0)  # (1,256,g,g) view, as upstream
         self.original_size = tuple(original_size)
@@ -196,7 +247,7 @@ class SamPredictor:
         self._ensure()
         t = torch.as_tensor(np.ascontiguousarray(image), device=self._dev)
         feats = self.encode_frames(t[None], chw=False)
-        self.set_features(feats[0], (H, W), (H, W))
+        self.set_features(feats[0], (H, W), (H, W))     # (ClipFeatures[0] for HQ-SAM)
         self.stats["set_image"] += 1
 
     # -- prompt encoder + mask decoder ---------------------------------------------------------------
@@ -222,7 +273,8 @@ class SamPredictor:
         iou = torch.empty((1, 1), dtype=torch.float32, device=dev)
         low = torch.empty((1, 1, L, L), dtype=torch.float32, device=dev)
         ws = self._dec_ws(oh, ow)
-        _lib.check(self._lib.sampt_sam_decode(self._dec, _lib.ptr(self._feat_tokens), _lib.ptr(pts), _lib.ptr(lab),
+        _lib.check(self._lib.sampt_sam_decode(self._dec, _lib.ptr(self._feat_tokens), _lib.ptr(self._hq_tokens),
+                                              _lib.ptr(pts), _lib.ptr(lab),
                                               pts.shape[0], _lib.ptr(box), _lib.ptr(mi), ih, iw, oh, ow, _lib.ptr(logits),
                                               _lib.ptr(iou), _lib.ptr(low), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()),
                    "sampt_sam_decode")
@@ -253,10 +305,14 @@ class SamPredictor:
         Results are written into out_logits (F,H,W) and out_score (F,)."""
         self._ensure()
         oh, ow = size_hw
+        hq_tokens = None
+        if isinstance(feat_tokens, ClipFeatures):
+            feat_tokens, hq_tokens = feat_tokens.emb, feat_tokens.hq
         F = feat_tokens.shape[0]
         assert F <= self.model.max_decode_batch
         ws = self._dec_ws(oh, ow, F)
-        _lib.check(self._lib.sampt_sam_track_decode(self._dec, F, _lib.ptr(feat_tokens), _lib.ptr(pts), _lib.ptr(labels),
+        _lib.check(self._lib.sampt_sam_track_decode(self._dec, F, _lib.ptr(feat_tokens), _lib.ptr(hq_tokens),
+                                                    _lib.ptr(pts), _lib.ptr(labels),
                                                     k, pts.shape[1], n_pos_first, refine_iters, float(iou_thr), oh, ow,
                                                     oh, ow, _lib.ptr(out_logits), _lib.ptr(out_score), _lib.ptr(ws),
                                                     ws.numel(), _lib.stream_ptr()), "sampt_sam_track_decode")

@@ -318,3 +318,118 @@ def test_reinit_and_query_masks_device_path_vs_reference_golden(dev, pips_sd, cl
     assert np.where(union > 0, inter / np.maximum(union, 1), 1.0).min() >= 1 - 1e-3
     assert np.allclose(np.array(out["scores_per_frame"], dtype=np.float32), g[f"{name}_scores_per_frame"], atol=1e-3,
                        equal_nan=True)
+
+
+# ------------------------------------------------------------------------------------------ HQ-SAM (MaskDecoderHQ)
+def test_hq_sam_vit_test_vs_oracle(dev):
+    """HQ-SAM on the reduced geometry, exact fp32: ViT tap + HQ features, predict_torch (points; points+box+mask) against
+    the oracle (itself pinned on HuggingFace SamHQModel, tests/test_oracle_pins.py)."""
+    from oracle import sam_ref as R
+    from sam_pt_amd.sam_predictor import ClipFeatures, SamHip, SamPredictor
+    from sam_pt_amd.weights import SAM_CONFIGS, init_sam_state_dict
+    cfg = SAM_CONFIGS["vit_test"]
+    sd = init_sam_state_dict(cfg, 72, hq=True)
+    frames, centres = synthetic_clip(T=3, H=144, W=256, seed=5)
+    pred = SamPredictor(SamHip(config=cfg, state_dict=sd, precision="f32", max_batch=2).to(dev))   # 2 encode batches
+    assert pred.model.hq
+    feats = pred.encode_frames(frames.to(dev))
+    assert isinstance(feats, ClipFeatures) and feats.hq.shape == (3, 64 * 64, 32)
+    x = R.preprocess(cfg, frames.float())
+    emb, interm = R.image_encoder(sd, cfg, x, return_interm=True)
+    hq_ref = torch.cat([R.hq_features(sd, emb[i:i + 1], interm[i:i + 1]) for i in range(3)])          # (3,32,64,64)
+    assert rel_err(feats.emb.view(3, 16, 16, 256).permute(0, 3, 1, 2), emb) < 3e-5
+    assert rel_err(feats.hq.view(3, 64, 64, 32).permute(0, 3, 1, 2), hq_ref) < 3e-5
+    ref = R.SamPredictorRef(sd, cfg, hq=True)
+    img = frames[1].permute(1, 2, 0).numpy()
+    ref.set_image(img)
+    pred.set_features(feats[1], (144, 256))
+    q = disc_queries(centres, n_pos=4, r=9.0)[:, 1:]
+    pts = torch.as_tensor(pred.transform.apply_coords(q.numpy(), (144, 256)), dtype=torch.float)[None]
+    lab = torch.tensor([[1, 1, 1, 0]], dtype=torch.int)
+    m0, i0, l0 = ref.predict_torch(pts, lab, None, None, False, True)
+    m1, i1, l1 = pred.predict_torch(pts.to(dev), lab.to(dev), None, None, False, True)
+    assert max_abs(l1, l0) < 3e-4 and max_abs(i1, i0) < 1e-4 and max_abs(m1, m0) < 3e-4
+    box = torch.tensor([[[20.0, 10.0, 200.0, 120.0]]])
+    m2, i2, l2 = ref.predict_torch(pts, lab, box, l0, False, True)
+    m3, i3, l3 = pred.predict_torch(pts.to(dev), lab.to(dev), box.to(dev), l0.to(dev), False, True)
+    assert max_abs(l3, l2) < 3e-4 and max_abs(i3, i2) < 1e-4
+    assert iou(m3 > 0, m2 > 0) >= 1 - 1e-3
+    # and the HQ term is really there: the plain-SAM decoder on the same weights gives a different mask
+    plain = R.SamPredictorRef(sd, cfg)
+    plain.set_image(img)
+    _, _, lp = plain.predict_torch(pts, lab, None, None, False, True)
+    assert max_abs(lp, l0) > 1e-2
+    # set_image path (encode + hq features for one HWC frame)
+    pred.set_image(img)
+    _, _, l4 = pred.predict_torch(pts.to(dev), lab.to(dev), None, None, False, True)
+    assert max_abs(l4, l0) < 3e-4
+
+
+def test_hq_sam_decoder_full_geometry_vs_oracle(dev):
+    """HQ decoder at the production geometry (grid 64, 1024 px, vit_dim 768) from random embeddings, exact fp32."""
+    from oracle import sam_ref as R
+    from sam_pt_amd.sam_predictor import ClipFeatures, SamHip, SamPredictor
+    from sam_pt_amd.weights import SAM_CONFIGS, init_sam_state_dict
+    import ctypes as C
+    from sam_pt_amd import _lib
+    cfg = SAM_CONFIGS["vit_b"]
+    sd = init_sam_state_dict(cfg, 72, hq=True)
+    g = torch.Generator().manual_seed(11)
+    emb = torch.randn(1, 256, 64, 64, generator=g) * 0.5
+    interm = torch.randn(1, 64, 64, 768, generator=g)
+    hq_ref = R.hq_features(sd, emb, interm)
+    pred = SamPredictor(SamHip(config=cfg, state_dict=sd, precision="f32", max_batch=1, max_decode_batch=2).to(dev))
+    pred._ensure()
+    emb_d = emb[0].permute(1, 2, 0).reshape(1, 4096, 256).contiguous().to(dev)
+    int_d = interm.reshape(1, 4096, 768).contiguous().to(dev)
+    hq_d = torch.empty((1, 65536, 32), device=dev)
+    n = C.c_size_t()
+    _lib.check(pred._lib.sampt_dec_hq_workspace_bytes(pred._dec, 1, C.byref(n)), "ws")
+    ws = torch.empty(n.value, dtype=torch.uint8, device=dev)
+    _lib.check(pred._lib.sampt_dec_hq_features(pred._dec, 1, _lib.ptr(emb_d), _lib.ptr(int_d), _lib.ptr(hq_d), _lib.ptr(ws),
+                                               ws.numel(), _lib.stream_ptr()), "hq")
+    assert rel_err(hq_d.view(1, 256, 256, 32).permute(0, 3, 1, 2), hq_ref) < 3e-5
+    ref = R.SamPredictorRef(sd, cfg, hq=True)
+    ref.features, ref.hq_feat = emb, hq_ref
+    ref.original_size = ref.input_size = (576, 1024)
+    ref.is_image_set = True
+    pred.set_features(ClipFeatures(emb_d, hq_d)[0], (576, 1024))
+    pts = torch.tensor([[[300.0, 200.0], [420.0, 260.0], [800.0, 100.0]]])
+    lab = torch.tensor([[1, 1, 0]], dtype=torch.int)
+    m0, i0, l0 = ref.predict_torch(pts, lab, None, None, False, True)
+    m1, i1, l1 = pred.predict_torch(pts.to(dev), lab.to(dev), None, None, False, True)
+    assert max_abs(l1, l0) < 5e-4 and max_abs(i1, i0) < 1e-4
+    assert iou(m1 > 0, m0 > 0) >= 1 - 1e-3
+
+
+@pytest.mark.parametrize("neg", [0, 1])
+def test_hq_sampt_fused_vs_oracle_stepwise(dev, pips_sd, neg):
+    """End to end with the HQ-SAM decoder: fused device path vs the oracle predictor driven call by call."""
+    from oracle import sam_ref as R
+    from sam_pt_amd.point_tracker import PipsPointTracker
+    from sam_pt_amd.sam_predictor import SamHip, SamPredictor
+    from sam_pt_amd.sam_pt import SamPt
+    from sam_pt_amd.weights import SAM_CONFIGS, init_sam_state_dict
+    cfg = SAM_CONFIGS["vit_test"]
+    sd = init_sam_state_dict(cfg, 72, hq=True)
+    frames, centres = synthetic_clip(T=6, H=128, W=256, seed=3)
+    q = disc_queries(centres, n_pos=3 + neg, r=9.0)
+    if neg:
+        q[3:, 1:] += torch.tensor([40.0, 30.0])
+    video = {"image": [f for f in frames], "target_hw": (128, 256), "query_points": q[None]}
+    kw = dict(sam_iou_threshold=-1e9, positive_points_per_mask=3, negative_points_per_mask=neg,
+              iterative_refinement_iterations=2)
+    trk = PipsPointTracker(state_dict=pips_sd)
+    pred = SamPredictor(SamHip(config=cfg, state_dict=sd, precision="f32").to(dev))
+    out = SamPt(trk, pred, **kw).eval()(video)
+    ref_pred = R.SamPredictorRef(sd, cfg, hq=True)
+    ref_pred.model = torch.nn.Module()
+    ref_pred.model.device, ref_pred.model.mask_threshold = torch.device("cpu"), 0.0
+
+    ref = SamPt(trk, ref_pred, **kw).eval()           # same trajectories on both sides: isolates the SAM stage
+    _, l_ref, spf = ref._apply_sam_to_trajectories(frames, out["trajectories"].cpu(), out["visibilities"].cpu(), None)
+    l_got = torch.stack([l for l in out["logits"]]).cpu()
+    for t in range(6):
+        assert iou(l_got[0, t] > 0, l_ref[0, t] > 0) >= 1 - 1e-3
+    assert max_abs(l_got, l_ref) < 3e-3
+    assert np.allclose(np.array(out["scores_per_frame"], dtype=np.float32).reshape(-1), spf.numpy().reshape(-1), atol=1e-4)
