@@ -114,7 +114,8 @@ int sampt_dec_hq_features(sampt_dec_t h, int frames, const float* features_dev, 
                           float* hq_features_dev, void* workspace_dev, size_t workspace_bytes, sampt_stream_t stream);
 /* One pass, one frame.  features_dev [grid*grid][256]; hq_features_dev: sampt_dec_hq_features output for the frame
  * (HQ-SAM handles) or NULL (SAM handles); pts_dev [k][2] (input-frame pixels), labels_dev int32 [k];
- * box_dev 4 floats or NULL; mask_in_dev [4*grid][4*grid] low-res logits or NULL.  Outputs: logits_out_dev
+ * box_dev 4 floats or NULL; mask_in_dev [4*grid][4*grid] low-res logits or NULL.  Limit: 5 (6 for HQ-SAM) output
+ * tokens + k + 2 <= 128 decoder tokens, i.e. k <= 120 prompt points (SAMPT_ERR_UNSUPPORTED beyond).  Outputs: logits_out_dev
  * [out_h][out_w], iou_out_dev [1], low_res_out_dev [4*grid][4*grid]. */
 int sampt_sam_decode(sampt_dec_t h, const float* features_dev, const float* hq_features_dev, const float* pts_dev,
                      const int32_t* labels_dev, int k, const float* box_dev, const float* mask_in_dev, int in_h, int in_w, int out_h, int out_w,

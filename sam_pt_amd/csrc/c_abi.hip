@@ -167,7 +167,7 @@ int sampt_dec_workspace_bytes(sampt_dec_t h, int frames, int oh, int ow, size_t*
   if (!h || !bytes || frames <= 0 || frames > h->e.max_frames) return SAMPT_ERR_ARG;
   Arena a(nullptr, 0);
   float dummy = 0.f;
-  int rc = h->e.track_decode(frames, &dummy, h->e.is_hq() ? &dummy : nullptr, &dummy, nullptr, 56, 56, 0, 1, 0.f, oh, ow,
+  int rc = h->e.track_decode(frames, &dummy, h->e.is_hq() ? &dummy : nullptr, &dummy, nullptr, 120, 120, 0, 1, 0.f, oh, ow,
                              oh, ow, nullptr, nullptr, a, nullptr);
   *bytes = a.peak + 256;
   return rc;

@@ -211,8 +211,17 @@ __global__ __launch_bounds__(256) void k_attn_fewkeys(const float* __restrict__ 
 
 int attn_fewkeys(const float* q, const float* k, const float* v, float* out, int F, int Nq, int Nk, int heads, int hd,
                  hipStream_t s) {
-  if (Nk <= 0 || Nk > 64 || hd != 16 || F <= 0) return SAMPT_ERR_UNSUPPORTED;
+  if (Nk <= 0 || Nk > 128 || hd != 16 || F <= 0) return SAMPT_ERR_UNSUPPORTED;
   size_t sh = (size_t)2 * Nk * heads * hd * sizeof(float);
+  if (sh > 64 * 1024) {  // above the default dynamic-LDS limit (gfx950 has 160 KiB per workgroup)
+    static bool raised = false;
+    if (!raised) {
+      if (hipFuncSetAttribute((const void*)k_attn_fewkeys<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) !=
+          hipSuccess)
+        return SAMPT_ERR_HIP;
+      raised = true;
+    }
+  }
   hipLaunchKernelGGL(k_attn_fewkeys<16>, dim3(cdiv((long)Nq * heads, 256), F), dim3(256), sh, s, q, k, v, out, Nq, Nk,
                      heads);
   SAMPT_CHECK_LAUNCH("attn_fewkeys");

@@ -433,3 +433,38 @@ def test_hq_sampt_fused_vs_oracle_stepwise(dev, pips_sd, neg):
         assert iou(l_got[0, t] > 0, l_ref[0, t] > 0) >= 1 - 1e-3
     assert max_abs(l_got, l_ref) < 3e-3
     assert np.allclose(np.array(out["scores_per_frame"], dtype=np.float32).reshape(-1), spf.numpy().reshape(-1), atol=1e-4)
+
+
+def test_many_objects_long_prompts(dev):
+    """BASELINE config #5 prompt shape: 5 objects x 16 positive points; every other object's positives are appended as
+    negatives (sam_pt.py:737-756) -> k = 80 prompt points, 88 decoder tokens in the HQ decoder.  Fused batched chain vs the
+    call-by-call protocol on the same HIP predictor, plus one frame against the CPU oracle."""
+    from oracle import sam_ref as R
+    from sam_pt_amd.point_tracker import PipsPointTracker
+    from sam_pt_amd.sam_predictor import SamHip, SamPredictor
+    from sam_pt_amd.sam_pt import SamPt
+    from sam_pt_amd.weights import SAM_CONFIGS, init_sam_state_dict
+    cfg = SAM_CONFIGS["vit_test"]
+    sd = init_sam_state_dict(cfg, 72, hq=True)
+    T, M, P = 3, 5, 16
+    frames, _ = synthetic_clip(T=T, H=128, W=256, seed=3)
+    g = torch.Generator().manual_seed(17)
+    traj = torch.rand(T, M, P, 2, generator=g) * torch.tensor([250.0, 120.0]) + 3.0
+    vis = torch.ones(T, M, P)
+    pred = SamPredictor(SamHip(config=cfg, state_dict=sd, precision="f32", max_decode_batch=8).to(dev))
+    model = SamPt(PipsPointTracker(seed=72), pred, sam_iou_threshold=-1e9, positive_points_per_mask=P,
+                  negative_points_per_mask=0, iterative_refinement_iterations=1).eval()
+    images = frames.to(dev)
+    feats = pred.encode_frames(images)
+    _, l_f, spf_f = model._apply_sam_to_trajectories(images, traj, vis, feats)
+    _, l_s, spf_s = model._apply_sam_to_trajectories(images, traj, vis, None)
+    assert max_abs(l_f.cpu(), l_s) < 2e-3 and np.allclose(spf_f.numpy(), spf_s.numpy(), atol=1e-4)
+    ref_pred = R.SamPredictorRef(sd, cfg, hq=True)
+    ref_pred.model = torch.nn.Module()
+    ref_pred.model.device, ref_pred.model.mask_threshold = torch.device("cpu"), 0.0
+    ref = SamPt(PipsPointTracker(seed=72), ref_pred, sam_iou_threshold=-1e9, positive_points_per_mask=P,
+                negative_points_per_mask=0, iterative_refinement_iterations=1).eval()
+    _, l_r, _ = ref._apply_sam_to_trajectories(frames[:1], traj[:1], vis[:1], None)
+    assert max_abs(l_f[:, :1].cpu(), l_r) < 3e-3
+    for m in range(M):
+        assert iou(l_f[m, 0].cpu() > 0, l_r[m, 0] > 0) >= 1 - 1e-3
