@@ -14,6 +14,8 @@
 // columns the epilogue never stores); K must be a multiple of 64 (true for every ViT GEMM: 768..5120).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace sampt {
@@ -21,19 +23,24 @@ namespace sampt {
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
-template <int BM, int BN, int NBUF>
-__global__ __launch_bounds__(BM * 2, NBUF == 1 ? 4 : 2) void gemm_f16_glds(GemmP p) {
+// MF = 16: v_mfma_f32_16x16x32_f16 fragments; MF = 32: v_mfma_f32_32x32x16_f16 (each operand element feeds 32 instead of
+// 16 products: half the operand-register reads per FLOP, which matters on a power-limited part).  The source-side
+// swizzle differs with the fragment read pattern: chunk ^= row & 7 (MF 16) or chunk ^= (row >> 1) & 7 (MF 32), both
+// conflict-free for their ds_read_b128 lane groups.
+template <int BM, int BN, int NBUF, int WTM, int WTN, int MF, int OCC = (NBUF == 1 ? 4 : 2)>
+__global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64, OCC) void gemm_f16_glds(GemmP p) {
   constexpr int BK = 64;
-  constexpr int NWM = BM / 64, NWAVES = NWM * 2;          // waves: NWM x 2, each owning a 64 x (BN/2) sub-tile
+  constexpr int NWM = BM / WTM, NWN = BN / WTN, NWAVES = NWM * NWN;   // waves: NWM x NWN, each a WTM x WTN sub-tile
   constexpr int A_IT = BM / (8 * NWAVES), B_IT = BN / (8 * NWAVES);   // 8-row DMA pieces per wave
-  constexpr int WTM = 64, WTN = BN / 2, FM = WTM / 16, FN = WTN / 16;
+  constexpr int FM = WTM / MF, FN = WTN / MF;
+  typedef typename std::conditional<MF == 16, f32x4, f32x16>::type acc_t;
   __shared__ __attribute__((aligned(1024))) half_t lds[NBUF * (BM + BN) * BK];  // ONE object: [buf][A rows | B rows][64]
   half_t* As0 = lds;
   half_t* Bs0 = lds + BM * BK;
   constexpr int BUF = (BM + BN) * BK;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / NWN, wn = wave % NWN;
   int tile_m, tile_n;
   if (p.xcd_swizzle) {
     // XCD-aware tile order (blocks are dispatched round-robin over the 8 XCDs, each with a private 4 MiB L2): XCD x
@@ -59,18 +66,22 @@ __global__ __launch_bounds__(BM * 2, NBUF == 1 ? 4 : 2) void gemm_f16_glds(GemmP
   const half_t* __restrict__ W = (const half_t*)p.W;
 
   // per-lane DMA source pointers (row clamped, chunk XOR-swizzled); piece i of this wave = tile rows (wave*IT+i)*8..+8
-  const int sub = lane >> 3, chunk = (lane & 7) ^ sub;
+  const int sub = lane >> 3;
   const half_t* a_src[A_IT];
   const half_t* b_src[B_IT];
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
-    int row = m0 + (wave * A_IT + i) * 8 + sub;
+    const int trow = (wave * A_IT + i) * 8 + sub;               // row inside the tile
+    const int chunk = (lane & 7) ^ (MF == 16 ? (trow & 7) : ((trow >> 1) & 7));
+    int row = m0 + trow;
     if (row > p.M - 1) row = p.M - 1;
     a_src[i] = A + (long)row * p.lda + chunk * 8;
   }
 #pragma unroll
   for (int i = 0; i < B_IT; ++i) {
-    int row = n0 + (wave * B_IT + i) * 8 + sub;
+    const int trow = (wave * B_IT + i) * 8 + sub;
+    const int chunk = (lane & 7) ^ (MF == 16 ? (trow & 7) : ((trow >> 1) & 7));
+    int row = n0 + trow;
     if (row > p.N - 1) row = p.N - 1;
     b_src[i] = W + (long)row * p.ldw + chunk * 8;
   }
@@ -85,21 +96,26 @@ __global__ __launch_bounds__(BM * 2, NBUF == 1 ? 4 : 2) void gemm_f16_glds(GemmP
       __builtin_amdgcn_global_load_lds((glb_void*)(b_src[i] + kt * BK), (lds_void*)(bb + i * 8 * BK), 16, 0, 0);
   };
 
-  f32x4 acc[FM][FN];
+  acc_t acc[FM][FN];
 #pragma unroll
   for (int i = 0; i < FM; ++i)
 #pragma unroll
-    for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < (MF == 16 ? 4 : 16); ++r) acc[i][j][r] = 0.f;
 
   const int nk = p.K / BK;
-  const int lr = lane & 15, lq = lane >> 4;
-  // fragment read offsets (halfs) inside a buffer: row*64 + ((kk*4+lq) ^ (row&7))*8 ; row&7 == lr&7 for every fragment
+  // fragment reads: lane (lr, lq) takes row lr of the fragment and the 16-byte K-chunk kk*KQ + lq of that row
+  // (MF 16: lr = lane & 15, 4 chunks per 32-wide K step; MF 32: lr = lane & 31, 2 chunks per 16-wide K step);
+  // offsets in halfs inside a buffer: row*64 + ((kk*KQ + lq) ^ swz(row))*8 ; swz(row) is the same for every fragment
+  constexpr int KQ = MF == 16 ? 4 : 2;
+  const int lr = lane & (MF - 1), lq = lane / MF;
   int a_off[FM], b_off[FN];
 #pragma unroll
-  for (int i = 0; i < FM; ++i) a_off[i] = (wm * WTM + i * 16 + lr) * BK;
+  for (int i = 0; i < FM; ++i) a_off[i] = (wm * WTM + i * MF + lr) * BK;
 #pragma unroll
-  for (int j = 0; j < FN; ++j) b_off[j] = BM * BK + (wn * WTN + j * 16 + lr) * BK;
-  const int sw = lr & 7;
+  for (int j = 0; j < FN; ++j) b_off[j] = BM * BK + (wn * WTN + j * MF + lr) * BK;
+  const int sw = MF == 16 ? (lr & 7) : ((lr >> 1) & 7);
 
   if (NBUF == 2) issue(0, 0);
   for (int kt = 0; kt < nk; ++kt) {
@@ -114,8 +130,8 @@ __global__ __launch_bounds__(BM * 2, NBUF == 1 ? 4 : 2) void gemm_f16_glds(GemmP
     if (NBUF == 2 && kt + 1 < nk) issue(kt + 1, buf ^ 1);
     const half_t* base = lds + buf * BUF;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int pos = ((kk * 4 + lq) ^ sw) * 8;
+    for (int kk = 0; kk < 8 / KQ; ++kk) {
+      const int pos = ((kk * KQ + lq) ^ sw) * 8;
       h8 a[FM], b[FN];
 #pragma unroll
       for (int i = 0; i < FM; ++i) a[i] = *(const h8*)(base + a_off[i] + pos);
@@ -124,8 +140,10 @@ __global__ __launch_bounds__(BM * 2, NBUF == 1 ? 4 : 2) void gemm_f16_glds(GemmP
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < FN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[j], a[i], acc[i][j], 0, 0, 0);  // D^T: see epilogue
+        for (int j = 0; j < FN; ++j) {  // swapped operands -> D^T: see epilogue
+          if constexpr (MF == 16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[j], a[i], acc[i][j], 0, 0, 0);
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[j], a[i], acc[i][j], 0, 0, 0);
+        }
     }
   }
 
@@ -133,49 +151,39 @@ __global__ __launch_bounds__(BM * 2, NBUF == 1 ? 4 : 2) void gemm_f16_glds(GemmP
   // fragment holds C^T: lane (lr, lq) owns row m = lr and the 4 CONSECUTIVE columns lq*4..+3 -> one 16-byte (f32) or
   // 8-byte (f16) store per fragment instead of four scattered scalar stores.  Same contract as gemm_kernel: bias,
   // activation, residual at the (row-mapped) destination row.
-  const bool vec_ok = (p.N % 4 == 0) && (p.ldc % 4 == 0) && (!p.res || p.ldr % 4 == 0);
+  // (MF 32: the 16 accumulator registers are 4 such groups, columns 8*g + 4*lq .. +3 of the fragment.)
+  // The launcher guarantees N, ldc, ldr multiples of 4 (16-byte rows), so every store below is one vector.
+  constexpr int NG = MF == 16 ? 1 : 4;
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
-    int row = m0 + wm * WTM + i * 16 + lr;
+    int row = m0 + wm * WTM + i * MF + lr;
     if (row >= p.M) continue;
     int drow = p.rowmap ? p.rowmap[row] : row;
     if (drow < 0) continue;
     int rrow = p.res_mod > 0 ? drow % p.res_mod : drow;
 #pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      int col = n0 + wn * WTN + j * 16 + lq * 4;
+    for (int jg = 0; jg < FN * NG; ++jg) {
+      const int j = jg / NG, g = jg % NG;
+      int col = n0 + wn * WTN + j * MF + (MF == 16 ? lq * 4 : 8 * g + 4 * lq);
       if (col >= p.N) continue;
       float v[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * p.alpha;
-      if (vec_ok) {
-        if (p.bias) {
-          float4 bv = *(const float4*)(p.bias + col);
-          v[0] += bv.x, v[1] += bv.y, v[2] += bv.z, v[3] += bv.w;
-        }
+      for (int r = 0; r < 4; ++r) v[r] = acc[i][j][4 * g + r] * p.alpha;
+      if (p.bias) {
+        float4 bv = *(const float4*)(p.bias + col);
+        v[0] += bv.x, v[1] += bv.y, v[2] += bv.z, v[3] += bv.w;
+      }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act);
-        if (p.res) {
-          float4 rv = *(const float4*)(p.res + (long)rrow * p.ldr + col);
-          v[0] += rv.x, v[1] += rv.y, v[2] += rv.z, v[3] += rv.w;
-        }
-        if (p.out_f16) {
-          h4 o = (h4){(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-          *(h4*)((half_t*)p.C + (long)drow * p.ldc + col) = o;
-        } else {
-          *(float4*)((float*)p.C + (long)drow * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
-        }
+      for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act);
+      if (p.res) {
+        float4 rv = *(const float4*)(p.res + (long)rrow * p.ldr + col);
+        v[0] += rv.x, v[1] += rv.y, v[2] += rv.z, v[3] += rv.w;
+      }
+      if (p.out_f16) {
+        h4 o = (h4){(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+        *(h4*)((half_t*)p.C + (long)drow * p.ldc + col) = o;
       } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (col + r >= p.N) continue;
-          float x = v[r];
-          if (p.bias) x += p.bias[col + r];
-          x = apply_act(x, p.act);
-          if (p.res) x += p.res[(long)rrow * p.ldr + col + r];
-          if (p.out_f16) ((half_t*)p.C)[(long)drow * p.ldc + col + r] = (half_t)x;
-          else ((float*)p.C)[(long)drow * p.ldc + col + r] = x;
-        }
+        *(float4*)((float*)p.C + (long)drow * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
       }
     }
   }
@@ -185,6 +193,7 @@ __global__ __launch_bounds__(BM * 2, NBUF == 1 ? 4 : 2) void gemm_f16_glds(GemmP
 int gemm_f16_glds_launch(const GemmP& p, hipStream_t s) {
   if (p.conv || p.w_kn || p.nb1 * p.nb2 != 1 || p.K % 64 || p.M < 128 || p.N < 128) return SAMPT_ERR_UNSUPPORTED;
   if ((p.lda % 8) || (p.ldw % 8) || (((uintptr_t)p.A | (uintptr_t)p.W) & 15)) return SAMPT_ERR_UNSUPPORTED;
+  if ((p.N % 4) || (p.ldc % 4) || (p.res && (p.ldr % 4))) return SAMPT_ERR_UNSUPPORTED;   // vector epilogue only
   GemmP q = p;
   static const int swz = getenv("SAMPT_GEMM_SWZ") ? atoi(getenv("SAMPT_GEMM_SWZ")) : 1;
   q.xcd_swizzle = swz;
@@ -198,15 +207,28 @@ int gemm_f16_glds_launch(const GemmP& p, hipStream_t s) {
     grid = dim3(8 * per_xcd * R * nt_n, 1, 1);
   }
   static const int variant = getenv("SAMPT_GEMM_VARIANT") ? atoi(getenv("SAMPT_GEMM_VARIANT")) : 1;
-  if (variant == 3 && swz && p.M >= 256) {
+  if ((variant == 4 || variant == 5 || variant == 7) && swz && p.M >= 256 && p.N >= 256) {
+    // 256 x 256 tile, 8 waves of 128 x 64, two 64 KiB LDS stages (1 workgroup per CU): a K-slab is 64 MFMAs per wave, so
+    // the DMA of the next slab has ~2000 cycles to land and LDS traffic per FLOP halves against the 128 x 128 tile
+    const int nt_m = cdiv(p.M, 256), nt_n = cdiv(p.N, 256);
+    int R = 4;
+    while (R > 1 && cdiv(nt_m, R) < 16) R /= 2;
+    q.xcd_swizzle = R;
+    grid = dim3(8 * cdiv(cdiv(nt_m, R), 8) * R * nt_n, 1, 1);
+    if (variant == 7) hipLaunchKernelGGL((gemm_f16_glds<256, 256, 2, 128, 128, 16, 1>), grid, dim3(256), 0, s, q);
+    else if (variant == 4) hipLaunchKernelGGL((gemm_f16_glds<256, 256, 2, 128, 64, 16>), grid, dim3(512), 0, s, q);
+    else hipLaunchKernelGGL((gemm_f16_glds<256, 256, 2, 128, 64, 32>), grid, dim3(512), 0, s, q);
+  } else if (variant == 6) {
+    hipLaunchKernelGGL((gemm_f16_glds<128, 128, 1, 64, 64, 32>), grid, block, 0, s, q);
+  } else if (variant == 3 && swz && p.M >= 256) {
     const int nt_m = cdiv(p.M, 256), nt_n = cdiv(p.N, 128);
     int R = 4;
     while (R > 1 && cdiv(nt_m, R) < 16) R /= 2;
     q.xcd_swizzle = R;
     grid = dim3(8 * cdiv(cdiv(nt_m, R), 8) * R * nt_n, 1, 1);
-    hipLaunchKernelGGL((gemm_f16_glds<256, 128, 1>), grid, dim3(512), 0, s, q);
-  } else if (variant == 1 || variant == 3) hipLaunchKernelGGL((gemm_f16_glds<128, 128, 1>), grid, block, 0, s, q);
-  else hipLaunchKernelGGL((gemm_f16_glds<128, 128, 2>), grid, block, 0, s, q);
+    hipLaunchKernelGGL((gemm_f16_glds<256, 128, 1, 64, 64, 16>), grid, dim3(512), 0, s, q);
+  } else if (variant == 1 || variant == 3) hipLaunchKernelGGL((gemm_f16_glds<128, 128, 1, 64, 64, 16>), grid, block, 0, s, q);
+  else hipLaunchKernelGGL((gemm_f16_glds<128, 128, 2, 64, 64, 16>), grid, block, 0, s, q);
   SAMPT_CHECK_LAUNCH("gemm_f16_glds");
   return SAMPT_OK;
 }

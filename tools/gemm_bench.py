@@ -11,6 +11,7 @@ from sam_pt_amd import _lib  # noqa: E402
 lib = _lib.load()
 dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+ZERO = len(sys.argv) > 2 and sys.argv[2] == "zeros"     # zero-filled operands: separates power (DVFS) limits from stalls
 D = 1280
 shapes = [(B * 4900, 3 * D, D, 2), (B * 4096, 3 * D, D, 2), (B * 4900, D, D, 1), (B * 4096, 4 * D, D, 2),
           (B * 4096, D, 4 * D, 1), (B * 4096, D, 768, 1), (B * 4096, 256, D, 1), (4096, 4096, 4096, 1), (8192, 8192, 8192, 1)]
@@ -18,6 +19,8 @@ g = torch.Generator().manual_seed(0)
 for (M, N, K, dt) in shapes:
     A = (torch.randn(M, K, generator=g) * 0.5).half().to(dev)
     W = (torch.randn(N, K, generator=g) / K ** 0.5).half().to(dev)
+    if ZERO:
+        A.zero_(), W.zero_()
     bias = torch.zeros(N, device=dev)
     Cc = torch.empty(M, N, device=dev, dtype=torch.float16 if dt == 2 else torch.float32)
     for _ in range(3):
