@@ -9,6 +9,8 @@
 
 namespace sampt {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 // ---------------------------------------------------------------------------------------------
 // rel tables: relhT[bh][kh][q] = <q_vec, rel_pos_h[qh - kh + S-1]>,  relwT[bh][kw][q] likewise with qw
 // One workgroup per (grid row qh, head, batch): its S query vectors are staged in LDS as fp32.
@@ -108,7 +110,7 @@ int softmax_rel_rows(float* scores, const float* relh, const float* relw, long B
 template <int HD, int NW, int SG>
 __global__ __launch_bounds__(NW * 64, 2) void k_flash_f16(const half_t* __restrict__ qkv, const float* __restrict__ rel_h,
                                                        const float* __restrict__ rel_w, half_t* __restrict__ out, int N,
-                                                       int heads, float scale) {
+                                                       int heads, float scale, int dbg) {
   constexpr int KS = HD / 16;            // k-steps of QK^T
   constexpr int DT = (HD + 31) / 32;     // 32-row tiles of O^T
   constexpr int QT = NW * 32;
@@ -190,22 +192,30 @@ __global__ __launch_bounds__(NW * 64, 2) void k_flash_f16(const half_t* __restri
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  // ---- register-staged K/V pipeline: the global loads of tile t+1 are issued before tile t is multiplied and written
-  //      to LDS (K row-major, V transposed) only after the barrier that retires tile t
+  // ---- key tiles.  A tile has 64 slots holding KTV = RPT*SG keys = RPT whole rows of the SG x SG token grid (global
+  //      blocks: 1 row of 64; 14x14 windows: 4 rows = 56 keys + 8 pad slots), so that the rel_w bias of a lane's 32
+  //      score slots is the same for every tile (registers) and rel_h is RPT values per tile.  Pad slots and rows
+  //      beyond the grid get a -inf bias (their K/V rows are clamped copies of valid keys: finite, weight 0).
+  //      Everything is kept in the log2 domain: s2 = s*scale*log2e + bias*log2e, p = exp2(s2 - m2) (one v_exp_f32).
+  constexpr int RPT = SG >= 64 ? 1 : 64 / SG, KTV = SG >= 64 ? 64 : RPT * SG;
+  constexpr float LOG2E = 1.4426950408889634f;
+  const float c2 = scale * LOG2E;
   constexpr int TV = 64 * (HD / 8);                 // 16-byte vectors per K (or V) tile
   constexpr int LI = (TV + NT - 1) / NT;            // vectors per thread
   h8 kreg[LI], vreg[LI];
+  // register-staged K/V pipeline: the global loads of tile t+1 are issued before tile t is multiplied and written
+  // to LDS (K row-major, V transposed) only after the barrier that retires tile t
   auto load_tile = [&](int kt0) {
 #pragma unroll
     for (int i = 0; i < LI; ++i) {
       const int v = tid + i * NT;
-      kreg[i] = (h8){0, 0, 0, 0, 0, 0, 0, 0};
-      vreg[i] = (h8){0, 0, 0, 0, 0, 0, 0, 0};
       if (v < TV) {
         const int kr = v / (HD / 8), kv = v - kr * (HD / 8);
-        if (kt0 + kr < N) kreg[i] = *(const h8*)(qkv + (tok0 + kt0 + kr) * 3 * D + D + h * HD + kv * 8);
+        const int krow = min(kt0 + min(kr, KTV - 1), N - 1);
+        kreg[i] = *(const h8*)(qkv + (tok0 + krow) * 3 * D + D + h * HD + kv * 8);
         const int vr = v & 63, dv = v >> 6;
-        if (kt0 + vr < N) vreg[i] = *(const h8*)(qkv + (tok0 + kt0 + vr) * 3 * D + 2 * D + h * HD + dv * 8);
+        const int vrow = min(kt0 + min(vr, KTV - 1), N - 1);
+        vreg[i] = *(const h8*)(qkv + (tok0 + vrow) * 3 * D + 2 * D + h * HD + dv * 8);
       }
     }
   };
@@ -222,25 +232,26 @@ __global__ __launch_bounds__(NW * 64, 2) void k_flash_f16(const half_t* __restri
       }
     }
   };
-  // global blocks (SG == 64): one key tile == one grid row, so the rel_w bias of a lane's 32 score slots is the same
-  // for every tile (kept in registers) and rel_h is one value per tile
-  float relw_r[SG == 64 ? 32 : 1];
-  if constexpr (SG == 64) {
-    __syncthreads();
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) relw_r[kt * 16 + r] = (float)relw_s[kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi][ql];
-  }
-
   load_tile(0);
-  for (int kt0 = 0; kt0 < N; kt0 += 64) {
-    __syncthreads();  // previous tile fully consumed (also orders the prologue LDS writes)
+  __syncthreads();                                   // rel tables of all waves are in LDS
+  float relw2[32];                                   // log2e * rel_w bias of this lane's 32 slots (tile-invariant)
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;      // slot
+      const int kw = SG >= 64 ? j : j % SG;
+      relw2[kt * 16 + r] = j < KTV ? LOG2E * (float)relw_s[kw][ql] : -INFINITY;
+    }
+  (void)dbg;
+
+  for (int kt0 = 0, kh0 = 0; kt0 < N; kt0 += KTV, kh0 += RPT) {
+    __syncthreads();  // previous tile fully consumed
     store_tile();
     __syncthreads();
-    if (kt0 + 64 < N) load_tile(kt0 + 64);
+    if (kt0 + KTV < N) load_tile(kt0 + KTV);
 
-    // ---- S^T = K . Q^T  (two 32-key tiles)
+    // ---- S^T = K . Q^T  (two 32-slot tiles)
     f32x16 st[2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
@@ -252,49 +263,53 @@ __global__ __launch_bounds__(NW * 64, 2) void k_flash_f16(const half_t* __restri
         st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], st[kt], 0, 0, 0);
       }
     }
-    // ---- scale + decomposed rel-pos bias + key mask, running max
+    // ---- log2-domain scores: fma(s, scale*log2e, rel_w2[slot]) + rel_h2[row of the slot], running max
+    float rh[RPT];
+#pragma unroll
+    for (int jr = 0; jr < RPT; ++jr) rh[jr] = kh0 + jr < SG ? LOG2E * (float)relh_s[kh0 + jr][ql] : -INFINITY;
     float mloc = -INFINITY;
-    const float relh_t = SG == 64 ? (float)relh_s[(kt0 >> 6) & (SG - 1)][ql] : 0.f;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        int key = kt0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        float sv;
-        if constexpr (SG == 64) {
-          sv = key < N ? st[kt][r] * scale + relh_t + relw_r[kt * 16 + r] : -INFINITY;
-        } else if (key < N) {
-          int kh = key / SG, kw = key - kh * SG;
-          sv = st[kt][r] * scale + (float)relh_s[kh][ql] + (float)relw_s[kw][ql];
-        } else {
-          sv = -INFINITY;
-        }
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int j0 = kt * 32 + (r & 3) + 8 * (r >> 2);            // slot of the hi = 0 half; hi = 1 is j0 + 4
+        const int ja = SG >= 64 ? 0 : min(j0 / SG, RPT - 1), jb = SG >= 64 ? 0 : min((j0 + 4) / SG, RPT - 1);
+        const float b = ja == jb ? rh[ja] : (hi ? rh[jb] : rh[ja]);
+        const float sv = __builtin_fmaf(st[kt][r], c2, relw2[kt * 16 + r]) + b;
         st[kt][r] = sv;
         mloc = fmaxf(mloc, sv);
       }
     }
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-    const float m_new = fmaxf(m_run, mloc);          // finite: every tile holds >= 1 valid key
-    const float alpha = expf(m_run - m_new);          // exp(-inf) = 0 on the first tile
+    const float m_new = fmaxf(m_run, mloc);           // finite: slot 0 of every tile is a valid key
     float lsum = 0.f;
     h8 pb[4];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float p = expf(st[kt][r] - m_new);
-        lsum += p;
-        pb[kt * 2 + (r >> 3)][r & 7] = (half_t)p;
+      for (int r = 0; r < 16; r += 2) {
+        const float p0 = __builtin_amdgcn_exp2f(st[kt][r] - m_new), p1 = __builtin_amdgcn_exp2f(st[kt][r + 1] - m_new);
+        lsum += p0 + p1;
+        f32x2 pp = (f32x2){p0, p1};
+        h2 ph = __builtin_convertvector(pp, h2);
+        pb[kt * 2 + (r >> 3)][r & 7] = ph[0];
+        pb[kt * 2 + (r >> 3)][(r & 7) + 1] = ph[1];
       }
     }
     lsum += __shfl_xor(lsum, 32, 64);
-    l_run = l_run * alpha + lsum;
-    m_run = m_new;
+    if (__any(m_new > m_run)) {                       // wave-uniform: the running max settles after a few tiles
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // exp2(-inf) = 0 on the first tile
+      l_run *= alpha;
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
+      for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-    // ---- O^T += V^T . P^T : k-slot (hi, j) of step t is key 16t + 4hi + (j&3) + 8(j>>2) on BOTH operands
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+      m_run = m_new;
+    }
+    l_run += lsum;
+    // ---- O^T += V^T . P^T : k-slot (hi, j) of step t is key slot 16t + 4hi + (j&3) + 8(j>>2) on BOTH operands
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
 #pragma unroll
@@ -331,9 +346,10 @@ int vit_flash_attention_f16(const half_t* qkv, const float* relh, const float* r
                             int heads, int hd, hipStream_t s) {
   const int N = S * S;
   const float scale = 1.0f / sqrtf((float)hd);
+  static const int dbg = getenv("SAMPT_FLASH_DBG") ? atoi(getenv("SAMPT_FLASH_DBG")) : 0;
 #define FL(HDv, NWv, SGv)                                                                                        \
   hipLaunchKernelGGL((k_flash_f16<HDv, NWv, SGv>), dim3(cdiv(N, NWv * 32), heads, B), dim3(NWv * 64), 0, s, qkv, \
-                     relh, relw, out, N, heads, scale)
+                     relh, relw, out, N, heads, scale, dbg)
   if (S == 64 && hd == 80) FL(80, 4, 64);
   else if (S == 64 && hd == 64) FL(64, 4, 64);
   else if (S == 14 && hd == 80) FL(80, 4, 14);

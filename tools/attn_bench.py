@@ -1,0 +1,34 @@
+#!/usr/bin/env python
+"""Micro-benchmark of the fused ViT attention kernel through the C ABI (ViT-H geometry, 8 frames)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sam_pt_amd import _lib  # noqa: E402
+
+lib = _lib.load()
+dev = torch.device("cuda:0")
+heads, hd = 16, 80
+D = heads * hd
+g = torch.Generator().manual_seed(0)
+for name, B, S_ in (("window", 200, 14), ("global", 8, 64)):
+    N = S_ * S_
+    qkv = (torch.randn(B * N, 3 * D, generator=g) * 0.5).half().to(dev)
+    rh = (torch.randn(2 * S_ - 1, hd, generator=g) * 0.1).to(dev)
+    rw = (torch.randn(2 * S_ - 1, hd, generator=g) * 0.1).to(dev)
+    out = torch.empty(B * N, D, dtype=torch.float16, device=dev)
+    for _ in range(3):
+        _lib.check(lib.sampt_vit_attention_f16(_lib.ptr(qkv), _lib.ptr(rh), _lib.ptr(rw), _lib.ptr(out), B, S_, heads, hd,
+                                               None, 0, _lib.stream_ptr()), "attn")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        lib.sampt_vit_attention_f16(_lib.ptr(qkv), _lib.ptr(rh), _lib.ptr(rw), _lib.ptr(out), B, S_, heads, hd, None, 0,
+                                    _lib.stream_ptr())
+    e1.record()
+    torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) / 10 * 1e-3
+    fl = 4.0 * B * heads * N * N * hd
+    print(f"{name:7s} B={B:4d} N={N:5d}  {t * 1e6:9.1f} us  {fl / t / 1e12:7.1f} TFLOP/s  {(4 * B * N * D * 2) / t / 1e12:6.2f} TB/s")
