@@ -132,8 +132,11 @@ __global__ __launch_bounds__(NW * 64, 2) void k_flash_f16(const half_t* __restri
   // ---- prologue: zero the unused V^T rows, Q fragments, then the decomposed rel-pos tables of THIS wave's 32 queries
   //      computed with MFMA straight into LDS (fp16): G[rho][q] = <rel_pos[rho], q_vec> for all 2*SG-1 table rows, and
   //      rel_h[q][kh] = G_h[qh - kh + SG-1][q], rel_w[q][kw] = G_w[qw - kw + SG-1][q]   (App. A-3) — no HBM round trip.
-  if (DT * 32 > HD) {
-    for (int i = tid; i < (DT * 32 - HD) * VLD; i += NT) Vt[HD + i / VLD][i % VLD] = (half_t)0.f;
+  // With HD % 32 != 0 the padded V^T rows are free MFMA work: row HD is all ones, so O^T[HD][q] accumulates the
+  // softmax denominator sum_k P[k][q] (of the SAME fp16-rounded P the numerator uses) with no VALU adds.
+  constexpr bool LROW = DT * 32 > HD;
+  if (LROW) {
+    for (int i = tid; i < (DT * 32 - HD) * VLD; i += NT) Vt[HD + i / VLD][i % VLD] = (half_t)(i < VLD ? 1.f : 0.f);
   }
   for (int i = tid; i < SG * RLD; i += NT) {
     (&relh_s[0][0])[i] = (half_t)0.f;
@@ -291,14 +294,14 @@ __global__ __launch_bounds__(NW * 64, 2) void k_flash_f16(const half_t* __restri
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
         const float p0 = __builtin_amdgcn_exp2f(st[kt][r] - m_new), p1 = __builtin_amdgcn_exp2f(st[kt][r + 1] - m_new);
-        lsum += p0 + p1;
+        if (!LROW) lsum += p0 + p1;
         f32x2 pp = (f32x2){p0, p1};
         h2 ph = __builtin_convertvector(pp, h2);
         pb[kt * 2 + (r >> 3)][r & 7] = ph[0];
         pb[kt * 2 + (r >> 3)][(r & 7) + 1] = ph[1];
       }
     }
-    lsum += __shfl_xor(lsum, 32, 64);
+    if (!LROW) lsum += __shfl_xor(lsum, 32, 64);
     if (__any(m_new > m_run)) {                       // wave-uniform: the running max settles after a few tiles
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // exp2(-inf) = 0 on the first tile
       l_run *= alpha;
@@ -323,6 +326,10 @@ __global__ __launch_bounds__(NW * 64, 2) void k_flash_f16(const half_t* __restri
   }
 
   // ---- epilogue: out[q][h*HD + d] = O^T[d][q] / l
+  if (LROW) {
+    constexpr int LR = HD % 32, RL = (LR % 4) + 4 * (LR / 8), HL = (LR / 4) % 2;   // C-layout slot of O^T row HD
+    l_run = __shfl(o[DT - 1][RL], li | (HL << 5), 64);
+  }
   if (q < N) {
     const float inv = 1.0f / l_run;
     half_t* op = out + (tok0 + q) * D + h * HD;
