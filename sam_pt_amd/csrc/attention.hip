@@ -270,30 +270,45 @@ __global__ __launch_bounds__(NW * 64, 2) void k_flash_f16(const half_t* __restri
     float rh[RPT];
 #pragma unroll
     for (int jr = 0; jr < RPT; ++jr) rh[jr] = kh0 + jr < SG ? LOG2E * (float)relh_s[kh0 + jr][ql] : -INFINITY;
+    // (pairs of slots as 2-vectors: v_pk_fma_f32 / v_pk_add_f32 halve the VALU issue count of this VALU-bound part;
+    //  with one grid row per tile (RPT == 1) the rel_h term is constant over the tile and moves into the max instead)
     float mloc = -INFINITY;
+    f32x2 sv2[2][8];
+    const f32x2 c2v = (f32x2){c2, c2};
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        constexpr int dummy = 0;
-        (void)dummy;
-        const int j0 = kt * 32 + (r & 3) + 8 * (r >> 2);            // slot of the hi = 0 half; hi = 1 is j0 + 4
-        const int ja = SG >= 64 ? 0 : min(j0 / SG, RPT - 1), jb = SG >= 64 ? 0 : min((j0 + 4) / SG, RPT - 1);
-        const float b = ja == jb ? rh[ja] : (hi ? rh[jb] : rh[ja]);
-        const float sv = __builtin_fmaf(st[kt][r], c2, relw2[kt * 16 + r]) + b;
-        st[kt][r] = sv;
-        mloc = fmaxf(mloc, sv);
+      for (int rp = 0; rp < 8; ++rp) {
+        f32x2 x = (f32x2){st[kt][2 * rp], st[kt][2 * rp + 1]};
+        x = x * c2v + (f32x2){relw2[kt * 16 + 2 * rp], relw2[kt * 16 + 2 * rp + 1]};
+        if (RPT > 1) {
+          f32x2 bb;
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int r = 2 * rp + e;
+            const int j0 = kt * 32 + (r & 3) + 8 * (r >> 2);        // slot of the hi = 0 half; hi = 1 is j0 + 4
+            const int ja = min(j0 / SG, RPT - 1), jb = min((j0 + 4) / SG, RPT - 1);
+            bb[e] = ja == jb ? rh[ja] : (hi ? rh[jb] : rh[ja]);
+          }
+          x = x + bb;
+        }
+        sv2[kt][rp] = x;
+        mloc = fmaxf(mloc, fmaxf(x[0], x[1]));
       }
     }
+    if (RPT == 1) mloc += rh[0];
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
     const float m_new = fmaxf(m_run, mloc);           // finite: slot 0 of every tile is a valid key
+    const float msub = RPT == 1 ? m_new - rh[0] : m_new;
+    const f32x2 mv = (f32x2){msub, msub};
     float lsum = 0.f;
     h8 pb[4];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
-        const float p0 = __builtin_amdgcn_exp2f(st[kt][r] - m_new), p1 = __builtin_amdgcn_exp2f(st[kt][r + 1] - m_new);
+        const f32x2 e2 = sv2[kt][r >> 1] - mv;
+        const float p0 = __builtin_amdgcn_exp2f(e2[0]), p1 = __builtin_amdgcn_exp2f(e2[1]);
         if (!LROW) lsum += p0 + p1;
         f32x2 pp = (f32x2){p0, p1};
         h2 ph = __builtin_convertvector(pp, h2);
