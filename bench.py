@@ -79,6 +79,13 @@ def gemm_roofline(args, dev):
         (Mg, 4 * D, D, 2, cfg.depth), (Mg, D, 4 * D, 1, cfg.depth), (Mg, D, 768, 1, 1), (Mg, 256, D, 1, 1)]
     tot_flop = tot_t = 0.0
     launches = 0
+    # L2-miss (HBM + Infinity Cache) bytes per launch from the committed --pmc passes (tools/gemm_traffic.py); bench.py
+    # cannot run rocprofv3 on itself, so the figure is looked up per shape and is null for shapes that were not profiled
+    traffic_tab, tot_traffic, tot_alg_bytes = {}, 0.0, 0.0
+    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_gemm_hbm_traffic.json")
+    if os.path.exists(tpath):
+        with open(tpath) as fh:
+            traffic_tab = json.load(fh)["per_launch"]
     g = torch.Generator(device="cpu").manual_seed(0)
     for (M, N, K, dt, cnt) in shapes:
         A = (torch.randn(M, K, generator=g) * 0.5).half().to(dev)
@@ -99,11 +106,20 @@ def gemm_roofline(args, dev):
         tot_flop += 2.0 * M * N * K * cnt
         tot_t += t * cnt
         launches += cnt
+        tr = traffic_tab.get(f"{M},{N},{K},{dt}")
+        if tr is None or tot_traffic is None:
+            tot_traffic = None
+        else:
+            tot_traffic += (tr["read_bytes"] + tr["write_bytes"]) * cnt
+            tot_alg_bytes += (tr["algorithmic_read_bytes"] + tr["algorithmic_write_bytes"]) * cnt
         del A, W, Cc
     ach = tot_flop / tot_t / 1e12
     return {"bound": "mfma", "kernel": "gemm_f16_glds<128,128,1> (ViT qkv/proj/MLP/patch/neck GEMMs, LDS-DMA fp16 MFMA)",
             "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
-            "traffic": None, "launches_per_encode_call": launches,
+            "traffic": None if tot_traffic is None else round(tot_traffic / launches),
+            "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE; counts Infinity-Cache hits)",
+            "algorithmic_bytes_per_launch": None if tot_traffic is None else round(tot_alg_bytes / launches),
+            "launches_per_encode_call": launches,
             "avg_launch_us": round(tot_t / launches * 1e6, 1), "encode_batch": B}
 
 

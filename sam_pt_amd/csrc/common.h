@@ -92,6 +92,7 @@ struct GemmP {
   // implicit-GEMM convolution over an NHWC input: A is [Nimg][H][W][Cin], W is [Cout][KH*KW*Cin]
   // split-K (set by the dispatcher; callers only provide the workspace): partial tiles [splitk][M][N] f32
   int xcd_swizzle = 0;           // set by the LDS-DMA fp16 launcher
+  int persist = 0;               // set by the LDS-DMA fp16 launcher: tiles per XCD when workgroups are persistent
   int force_generic = 0;         // tests: bypass the specialised LDS-DMA fp16 kernel
   int splitk = 1;
   float* splitk_ws = nullptr;

@@ -41,6 +41,12 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64, OCC) void gemm_f16_gl
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / NWN, wn = wave % NWN;
+  // Persistent mode (p.persist): the grid is one generation of workgroups (4 per CU) and each walks its XCD's tile
+  // sequence with a stride of one generation, so the ~128 tiles co-resident on an XCD start together and stay within a
+  // few K-slabs of each other: their working set (8 A panels + 16 W tiles, one slab deep) then fits the 4 MiB L2, which
+  // the free-running order does not (measured: 7.8x -> see profiles/r1_gemm_hbm_traffic.json).
+  const int idx_step = p.persist ? (int)(gridDim.x >> 3) : 0x40000000;
+  for (int idx = blockIdx.x >> 3, first = 1; idx < (p.persist ? p.persist : 0x40000000); idx += idx_step, first = 0) {
   int tile_m, tile_n;
   if (p.xcd_swizzle) {
     // XCD-aware tile order (blocks are dispatched round-robin over the 8 XCDs, each with a private 4 MiB L2): XCD x
@@ -50,17 +56,21 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64, OCC) void gemm_f16_gl
     const int nt_m = (p.M + BM - 1) / BM, nt_n = (p.N + BN - 1) / BN;
     const int R = p.xcd_swizzle;                    // strip height in row panels (8, or less for small M)
     const int nstrips = (nt_m + R - 1) / R, per_strip = R * nt_n;
-    const int id = blockIdx.x, xcd = id & 7, idx = id >> 3;
+    const int xcd = blockIdx.x & 7;
     const int j = idx / per_strip, t = idx - j * per_strip;
     const int strip = xcd + 8 * j;
-    if (strip >= nstrips) return;
+    if (strip >= nstrips) break;
     const int rows = min(R, nt_m - R * strip);
     tile_n = t / rows;
-    if (tile_n >= nt_n) return;
+    if (tile_n >= nt_n) {
+      if (p.persist) continue;
+      break;
+    }
     tile_m = strip * R + (t - tile_n * rows);
   } else {
     tile_m = blockIdx.y, tile_n = blockIdx.x;
   }
+  if (!first) __syncthreads();  // every wave is done with the previous tile's LDS slab
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const half_t* __restrict__ A = (const half_t*)p.A;
   const half_t* __restrict__ W = (const half_t*)p.W;
@@ -183,10 +193,15 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64, OCC) void gemm_f16_gl
         h4 o = (h4){(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
         *(h4*)((half_t*)p.C + (long)drow * p.ldc + col) = o;
       } else {
-        *(float4*)((float*)p.C + (long)drow * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+        // fp32 C (64-byte row segments per store group) is streamed out non-temporally: +3..8 % on the proj / fc2 shapes;
+        // the 32-byte segments of fp16 C need the L2's write combining and lose with it (measured both ways)
+        f32x4 o = (f32x4){v[0], v[1], v[2], v[3]};
+        __builtin_nontemporal_store(o, (f32x4*)((float*)p.C + (long)drow * p.ldc + col));
       }
     }
   }
+  if (!p.xcd_swizzle) break;
+  }  // tile loop
 }
 
 // returns SAMPT_ERR_UNSUPPORTED when the shape does not fit this kernel (caller falls back to gemm_kernel)
@@ -227,6 +242,13 @@ int gemm_f16_glds_launch(const GemmP& p, hipStream_t s) {
     q.xcd_swizzle = R;
     grid = dim3(8 * cdiv(cdiv(nt_m, R), 8) * R * nt_n, 1, 1);
     hipLaunchKernelGGL((gemm_f16_glds<256, 128, 1, 64, 64, 16>), grid, dim3(512), 0, s, q);
+  } else if (variant == 8 && swz) {
+    // persistent: one generation = 4 workgroups per CU x 256 CUs = 128 per XCD
+    const int nt_m = cdiv(p.M, 128), nt_n = cdiv(p.N, 128);
+    const int R = q.xcd_swizzle, per_xcd = cdiv(cdiv(nt_m, R), 8) * R * nt_n;
+    q.persist = per_xcd;
+    const int gen = per_xcd < 128 ? per_xcd : 128;
+    hipLaunchKernelGGL((gemm_f16_glds<128, 128, 1, 64, 64, 16>), dim3(8 * gen), block, 0, s, q);
   } else if (variant == 1 || variant == 3) hipLaunchKernelGGL((gemm_f16_glds<128, 128, 1, 64, 64, 16>), grid, block, 0, s, q);
   else hipLaunchKernelGGL((gemm_f16_glds<128, 128, 2, 64, 64, 16>), grid, block, 0, s, q);
   SAMPT_CHECK_LAUNCH("gemm_f16_glds");

@@ -13,7 +13,7 @@ dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 ZERO = len(sys.argv) > 2 and sys.argv[2] == "zeros"     # zero-filled operands: separates power (DVFS) limits from stalls
 D = 1280
-shapes = [(B * 4900, 3 * D, D, 2), (B * 4096, 3 * D, D, 2), (B * 4900, D, D, 1), (B * 4096, 4 * D, D, 2),
+shapes = [(B * 4900, 3 * D, D, 2), (B * 4096, 3 * D, D, 2), (B * 4900, D, D, 1), (B * 4096, D, D, 1), (B * 4096, 4 * D, D, 2),
           (B * 4096, D, 4 * D, 1), (B * 4096, D, 768, 1), (B * 4096, 256, D, 1), (4096, 4096, 4096, 1), (8192, 8192, 8192, 1)]
 g = torch.Generator().manual_seed(0)
 for (M, N, K, dt) in shapes:
