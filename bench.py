@@ -37,6 +37,10 @@ def parse():
     ap.add_argument("--precision", default="f16", choices=["f16", "f32"])
     ap.add_argument("--encode-batch", type=int, default=8)
     ap.add_argument("--hq", action="store_true", help="HQ-SAM decoder (reference default samhq_vit_huge; BASELINE config #5)")
+    ap.add_argument("--pips-vis-bias", type=float, default=2.0,
+                    help="bias of the random PIPS visibility head (weights.py default 2.0 -> sigmoid 0.88, just under the 0.9 "
+                         "link threshold: short hops, ~23 tracker rounds per clip; 4.0 behaves like a trained model on "
+                         "trackable points: 7-frame hops).  Sensitivity knob only; the headline number uses the default.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -47,7 +51,9 @@ def build_model(args, dev):
     from sam_pt_amd.sam_predictor import SamHip, SamPredictor
     from sam_pt_amd.sam_pt import SamPt
     sam = SamHip(args.model, precision=args.precision, seed=72, max_batch=args.encode_batch, hq=args.hq).to(dev)
-    model = SamPt(PipsPointTracker(seed=72, fnet_chunk=8), SamPredictor(sam), sam_iou_threshold=-1e9,
+    from sam_pt_amd.weights import init_pips_state_dict
+    tracker = PipsPointTracker(state_dict=init_pips_state_dict(72, vis_bias=args.pips_vis_bias), fnet_chunk=8)
+    model = SamPt(tracker, SamPredictor(sam), sam_iou_threshold=-1e9,
                   positive_points_per_mask=args.points, negative_points_per_mask=0,
                   iterative_refinement_iterations=args.refine, point_tracker_mask_batch_size=5).eval()
     return model

@@ -71,6 +71,8 @@ class SamPt(nn.Module):
         self.reinit_point_tracker_horizon, self.reinit_horizon = reinit_point_tracker_horizon, reinit_horizon
         self.reinit_variant = reinit_variant
         self.profile = {}
+        self.overlap_tracker_and_encoder = True        # fused path only: tracker on a second HIP stream (see forward)
+        self._side_stream = None
 
     @property
     def device(self):
@@ -87,20 +89,38 @@ class SamPt(nn.Module):
         feats = None
         if fused:
             images = images.to(self.device)
-            feats = self.sam_predictor.encode_frames(images, chw=True)   # every frame exactly once, embeddings in HBM
+        if video.get("query_masks") is None and video.get("query_points") is None:
+            raise ValueError("No query points or masks provided")
+        query_masks = None
         if video.get("query_masks") is not None:                         # VOS task (sam_pt.py:171-177)
             assert video.get("query_points") is None
             query_masks = video["query_masks"].float()
             query_points = self.extract_query_points(images, query_masks, video["query_point_timestep"])
-        elif video.get("query_points") is not None:                      # demo (sam_pt.py:178-182)
+        else:                                                            # demo (sam_pt.py:178-182)
             query_points = video["query_points"]
+        tracked = None
+        if fused:
+            # The image encoder (compute-bound, no host syncs) and the point tracker (many small launches, one host sync
+            # per round) only share the input frames: the whole clip's encoder work is enqueued on the current stream and
+            # the tracker then runs on a second, high-priority stream, filling the GPU around the big GEMMs.
+            overlap = (not self.use_point_reinit) and images.is_cuda and self.overlap_tracker_and_encoder
+            if overlap:
+                ready = torch.cuda.Event()
+                ready.record()
+            feats = self.sam_predictor.encode_frames(images, chw=True)   # every frame exactly once, embeddings in HBM
+            if overlap:
+                if self._side_stream is None:
+                    self._side_stream = torch.cuda.Stream(device=images.device, priority=-1)
+                self._side_stream.wait_event(ready)
+                with torch.cuda.stream(self._side_stream):
+                    tracked = self._track_points(images, query_points)
+                torch.cuda.current_stream().wait_stream(self._side_stream)
+        if query_masks is None:
             query_masks = self.extract_query_masks(images, query_points, feats)
-        else:
-            raise ValueError("No query points or masks provided")
         n_masks, n_points_per_mask, _ = query_points.shape
         assert query_masks.shape == (n_masks, height, width)
         if not self.use_point_reinit:
-            trajectories, visibilities = self._track_points(images, query_points)
+            trajectories, visibilities = tracked if tracked is not None else self._track_points(images, query_points)
             _, logits, scores_per_frame = self._apply_sam_to_trajectories(images, trajectories, visibilities, feats)
             scores = scores_per_frame.mean(dim=0)
         else:
