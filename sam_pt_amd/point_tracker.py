@@ -132,6 +132,12 @@ class PipsPointTracker(PointTracker):
         return pyr
 
     # -- chained windows for a set of independent point chains (pips/tracker.py:42-153) --------------------------
+    def prepare(self, frames: torch.Tensor):
+        """Optional: build the feature pyramid of ``frames`` (T,3,H,W) now, on the current stream; the next ``forward``
+        on the same frames tensor reuses it.  Lets a caller keep the compute-bound fnet on its main stream and run only
+        the latency-bound window rounds on a second stream (sam_pt_amd.SamPt)."""
+        self._prepared = ((frames.data_ptr(), tuple(frames.shape)), self.compute_pyramid(frames))
+
     def _run_chains(self, pyr, T: int, query_points: torch.Tensor, flipped: torch.Tensor, ws):
         """query_points (N,3) CPU float = (t, x, y) in each chain's OWN time axis; ``flipped[i]`` marks chains that run on
         the time-reversed clip (direction frame d = original frame T-1-d).  Returns CPU (T,N,2), (T,N) bool in each
@@ -220,7 +226,11 @@ class PipsPointTracker(PointTracker):
         T = frames.shape[0]
         q = query_points[0].detach().float().cpu()
         N = q.shape[0]
-        pyr = self.compute_pyramid(frames)
+        prepared = getattr(self, "_prepared", None)
+        if prepared is not None and prepared[0] == (frames.data_ptr(), tuple(frames.shape)):
+            pyr = prepared[1]
+        else:
+            pyr = self.compute_pyramid(frames)
         nbytes = C.c_size_t()
         _lib.check(self._lib.sampt_pips_update_workspace_bytes(self._h, 2 * N, C.byref(nbytes)), "update_workspace")
         ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)

@@ -105,6 +105,8 @@ class SamPt(nn.Module):
             # the tracker then runs on a second, high-priority stream, filling the GPU around the big GEMMs.
             overlap = (not self.use_point_reinit) and images.is_cuda and self.overlap_tracker_and_encoder
             if overlap:
+                if hasattr(self.point_tracker, "prepare"):                 # compute-bound fnet stays on this stream
+                    self.point_tracker.to(self.device).prepare(images)
                 ready = torch.cuda.Event()
                 ready.record()
             feats = self.sam_predictor.encode_frames(images, chw=True)   # every frame exactly once, embeddings in HBM
@@ -115,6 +117,8 @@ class SamPt(nn.Module):
                 with torch.cuda.stream(self._side_stream):
                     tracked = self._track_points(images, query_points)
                 torch.cuda.current_stream().wait_stream(self._side_stream)
+                if hasattr(self.point_tracker, "_prepared"):
+                    self.point_tracker._prepared = None
         if query_masks is None:
             query_masks = self.extract_query_masks(images, query_points, feats)
         n_masks, n_points_per_mask, _ = query_points.shape
