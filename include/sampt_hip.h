@@ -126,11 +126,15 @@ int sampt_sam_decode(sampt_dec_t h, const float* features_dev, const float* hq_f
  * [positives-only pass over the first n_pos_first points when n_pos_first >= 0, i.e. negative_points_per_mask > 0;
  * pass -1 for the single-pass case] -> all-points pass -> `refine_iters` box+mask refinement passes
  * (bbox of logits>0 and the `sum < 2 -> stop` rule evaluated per item on device) -> logits = -inf if iou < iou_thr.
+ * Ragged batches: k_item_dev / npos_item_dev (int32 [frames], or NULL for uniform) give each item's own point count
+ * (<= k) and leading-positive count (<= n_pos_first); an item's prompt tokens are packed in front of its token matrix
+ * and the padding rows are masked out of every attention, so each item's result equals its un-batched one.
  * features_dev [frames][grid*grid][256]; hq_features_dev [frames][16*grid*grid][32] (HQ-SAM) or NULL;
  * pts_dev [frames][ld_pts][2]; labels_dev int32 [frames][ld_pts];
  * final_logits_dev [frames][out_h][out_w]; score_out_dev [frames] = predicted IoU. */
 int sampt_sam_track_decode(sampt_dec_t h, int frames, const float* features_dev, const float* hq_features_dev,
-                           const float* pts_dev, const int32_t* labels_dev, int k, int ld_pts, int n_pos_first, int refine_iters, float iou_thr,
+                           const float* pts_dev, const int32_t* labels_dev, int k, const int32_t* k_item_dev,
+                           const int32_t* npos_item_dev, int ld_pts, int n_pos_first, int refine_iters, float iou_thr,
                            int in_h, int in_w, int out_h, int out_w, float* final_logits_dev, float* score_out_dev,
                            void* workspace_dev, size_t workspace_bytes, sampt_stream_t stream);
 int sampt_postprocess_masks(const float* low_res_dev, int L, int img_size, int in_h, int in_w, float* out_dev, int out_h,

@@ -49,7 +49,7 @@ _SIGS = {
     "sampt_dec_workspace_bytes": (c_int, [_P, c_int, c_int, c_int, C.POINTER(c_size_t)]),
     "sampt_sam_decode": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_size_t,
                                  _P]),
-    "sampt_sam_track_decode": (c_int, [_P, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_int,
+    "sampt_sam_track_decode": (c_int, [_P, c_int, _P, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_float, c_int, c_int, c_int,
                                        c_int, _P, _P, _P, c_size_t, _P]),
     "sampt_postprocess_masks": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P]),
     "sampt_bbox_workspace_bytes": (c_size_t, [c_int, c_int]),

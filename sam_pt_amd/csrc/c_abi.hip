@@ -167,7 +167,7 @@ int sampt_dec_workspace_bytes(sampt_dec_t h, int frames, int oh, int ow, size_t*
   if (!h || !bytes || frames <= 0 || frames > h->e.max_frames) return SAMPT_ERR_ARG;
   Arena a(nullptr, 0);
   float dummy = 0.f;
-  int rc = h->e.track_decode(frames, &dummy, h->e.is_hq() ? &dummy : nullptr, &dummy, nullptr, 120, 120, 0, 1, 0.f, oh, ow,
+  int rc = h->e.track_decode(frames, &dummy, h->e.is_hq() ? &dummy : nullptr, &dummy, nullptr, 120, nullptr, nullptr, 120, 0, 1, 0.f, oh, ow,
                              oh, ow, nullptr, nullptr, a, nullptr);
   *bytes = a.peak + 256;
   return rc;
@@ -199,22 +199,25 @@ int sampt_sam_decode(sampt_dec_t h, const float* features, const float* hq_featu
   if (h->e.is_hq() != (hq_features != nullptr))
     return fail(SAMPT_ERR_ARG, "sampt_sam_decode: hq_features must be given for HQ-SAM handles and only for them");
   Arena a(ws, ws_bytes);
-  return h->e.decode(1, features, hq_features, pts, labels, k, k > 0 ? k : 1, box, mask_in, in_h, in_w, oh, ow, logits_out, iou_out,
+  return h->e.decode(1, features, hq_features, pts, labels, k, nullptr, k > 0 ? k : 1, box, mask_in, in_h, in_w, oh, ow, logits_out, iou_out,
                      low_out, nullptr, a, (hipStream_t)stream);
 }
 
 int sampt_sam_track_decode(sampt_dec_t h, int frames, const float* features, const float* hq_features,
-                           const float* pts, const int32_t* labels, int k, int ld_pts, int n_pos_first, int refine_iters, float iou_thr, int in_h, int in_w,
-                           int oh, int ow, float* final_logits, float* score_out, void* ws, size_t ws_bytes,
-                           sampt_stream_t stream) {
+                           const float* pts, const int32_t* labels, int k, const int32_t* k_item,
+                           const int32_t* npos_item, int ld_pts, int n_pos_first, int refine_iters, float iou_thr,
+                           int in_h, int in_w, int oh, int ow, float* final_logits, float* score_out, void* ws,
+                           size_t ws_bytes, sampt_stream_t stream) {
   if (!h || !features || !pts || !labels || !final_logits || !score_out || !ws || k <= 0 || n_pos_first > k ||
       ld_pts < k || frames <= 0 || frames > h->e.max_frames)
     return fail(SAMPT_ERR_ARG, "sampt_sam_track_decode: bad arguments");
   if (h->e.is_hq() != (hq_features != nullptr))
     return fail(SAMPT_ERR_ARG, "sampt_sam_track_decode: hq_features must be given for HQ-SAM handles and only for them");
   Arena a(ws, ws_bytes);
-  return h->e.track_decode(frames, features, hq_features, pts, labels, k, ld_pts, n_pos_first, refine_iters, iou_thr, in_h, in_w, oh,
-                           ow, final_logits, score_out, a, (hipStream_t)stream);
+  if (npos_item && n_pos_first < 0)
+    return fail(SAMPT_ERR_ARG, "sampt_sam_track_decode: npos_item needs the two-pass mode (n_pos_first >= 0)");
+  return h->e.track_decode(frames, features, hq_features, pts, labels, k, k_item, npos_item, ld_pts, n_pos_first,
+                           refine_iters, iou_thr, in_h, in_w, oh, ow, final_logits, score_out, a, (hipStream_t)stream);
 }
 
 int sampt_postprocess_masks(const float* low, int L, int img, int in_h, int in_w, float* out, int oh, int ow,

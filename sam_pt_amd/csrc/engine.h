@@ -147,14 +147,17 @@ struct DecEngine {
   // features [F][g*g][256]; pts [F][ld_pts][2], labels [F][ld_pts] (first k used); box [F][4] or null;
   // mask_in [F][4g][4g] or null.  logits_out [F][oh][ow], iou_out [F], low_out [F][4g][4g];
   // bbox_out: optional int [F][5] state of logits > 0.  hq_feat: hq_features() output (HQ-SAM) or null (SAM).
-  int decode(int F, const float* features, const float* hq_feat, const float* pts, const int* labels, int k, int ld_pts, const float* box,
-             const float* mask_in, int in_h, int in_w, int oh, int ow, float* logits_out, float* iou_out, float* low_out,
+  // k_item: optional device int [F]: item f only uses its first min(k, k_item[f]) points (ragged batch: its tokens are
+  // packed in front, padding rows are masked out of every attention).
+  int decode(int F, const float* features, const float* hq_feat, const float* pts, const int* labels, int k,
+             const int* k_item, int ld_pts, const float* box, const float* mask_in, int in_h, int in_w, int oh, int ow, float* logits_out, float* iou_out, float* low_out,
              int* bbox_out, Arena& ws, hipStream_t s);
   // The whole per-(frame, object) chain of SamPt.predict_mask (sam_pt.py:760-837) for F frames, no host sync:
   // [positives-only pass when n_pos_first >= 0] -> all-points pass (+ mask) -> R box-refinement passes gated per frame
   // on device -> IoU-threshold rejection.  final_logits [F][oh][ow], score_out [F].
-  int track_decode(int F, const float* features, const float* hq_feat, const float* pts, const int* labels, int k, int ld_pts, int n_pos_first,
-                   int R, float iou_thr, int in_h, int in_w, int oh, int ow, float* final_logits, float* score_out,
+  // k_item / npos_item: optional per-item point counts (all points / leading positives) of a ragged batch.
+  int track_decode(int F, const float* features, const float* hq_feat, const float* pts, const int* labels, int k,
+                   const int* k_item, const int* npos_item, int ld_pts, int n_pos_first, int R, float iou_thr, int in_h, int in_w, int oh, int ow, float* final_logits, float* score_out,
                    Arena& ws, hipStream_t s);
 };
 

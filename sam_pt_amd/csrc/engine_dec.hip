@@ -105,14 +105,14 @@ struct Bufs {
 
 // attention block over F frames: out = LN(resid + out_proj(attn(q_in Wq, k_in Wk, v_in Wv)))  (resid null: replace)
 static int attn_block(const L& l, const DecEngine::Attn& a, int heads, int C, int F, const float* q_in, int Nq,
-                      const float* k_in, const float* v_in, int Nk, bool few_keys, Bufs& b, const float* resid,
-                      float* out, const float* lnw, const float* lnb, hipStream_t s) {
+                      const float* k_in, const float* v_in, int Nk, bool few_keys, const int* nk_item, Bufs& b,
+                      const float* resid, float* out, const float* lnw, const float* lnb, hipStream_t s) {
   SAMPT_TRY(l.lin(q_in, F * Nq, C, a.qw, a.qb, b.Q, a.inner));
   SAMPT_TRY(l.lin(k_in, F * Nk, C, a.kw, a.kb, b.K, a.inner));
   SAMPT_TRY(l.lin(v_in, F * Nk, C, a.vw, a.vb, b.V, a.inner));
   const int hd = a.inner / heads;
-  if (few_keys) SAMPT_TRY(attn_fewkeys(b.Q, b.K, b.V, b.att, F, Nq, Nk, heads, hd, s));
-  else SAMPT_TRY(attn_rowblock(b.Q, b.K, b.V, b.att, F, Nq, Nk, heads, hd, s));
+  if (few_keys) SAMPT_TRY(attn_fewkeys(b.Q, b.K, b.V, b.att, F, Nq, Nk, heads, hd, nk_item, s));
+  else SAMPT_TRY(attn_rowblock(b.Q, b.K, b.V, b.att, F, Nq, Nk, heads, hd, nk_item, s));
   SAMPT_TRY(l.lin(b.att, F * Nq, a.inner, a.ow, a.ob, out, C, ACT_NONE, resid));
   return layernorm_rows(out, lnw, lnb, out, (long)F * Nq, C, 1e-5f, nullptr, 0, ACT_NONE, s);
 }
@@ -152,7 +152,7 @@ int DecEngine::hq_features(int F, const float* features, const float* interm, fl
 }
 
 int DecEngine::decode(int F, const float* features, const float* hq_feat, const float* pts, const int* labels, int k,
-                      int ld_pts, const float* box, const float* mask_in, int in_h, int in_w, int oh, int ow,
+                      const int* k_item, int ld_pts, const float* box, const float* mask_in, int in_h, int in_w, int oh, int ow,
                       float* logits_out, float* iou_out, float* low_out, int* bbox_out, Arena& ws, hipStream_t s) {
   const int g = c.grid, P = g * g, C = c.C, H = c.heads, NO = n_out();
   const int nsparse = k + (box ? 2 : 1), Nt = NO + nsparse;
@@ -177,6 +177,7 @@ int DecEngine::decode(int F, const float* features, const float* hq_feat, const 
   float *uh0 = nullptr, *uh1 = nullptr, *t3 = nullptr;
   if (is_hq()) uh0 = ws.f32(16 * FP * (C / 4)), uh1 = ws.f32(16 * FP * (C / 8)), t3 = ws.f32((size_t)F * C);
   int* bbox_partial = (int*)ws.get((size_t)F * bbox_partial_ints(oh, ow) * sizeof(int));
+  int* ntok = (int*)ws.get((size_t)F * sizeof(int));           // valid tokens per item (ragged batch)
   const size_t skn = (size_t)16 * FT * C;
   float* skws = ws.f32(skn);
   if (!ws.ok()) return SAMPT_ERR_WORKSPACE;
@@ -185,7 +186,8 @@ int DecEngine::decode(int F, const float* features, const float* hq_feat, const 
 
   // ---- prompt encoder
   SAMPT_TRY(sam_tokens(out_tokens, NO, pts, labels, k, ld_pts, box, gauss, point_emb, not_a_point, (float)c.img, F,
-                       b.tokens, s));
+                       k_item, ntok, b.tokens, s));
+  const int* nkt = k_item ? ntok : nullptr;                    // tokens-as-keys mask; null = all Nt rows are valid
   if (mask_in) SAMPT_TRY(sam_mask_embed_src(mask_in, g, F, me, features, b.me0, b.me1, b.keys, s));
   else SAMPT_TRY(add_bcast(features, no_mask, b.keys, (long)FP * C, C, s));
 
@@ -195,27 +197,30 @@ int DecEngine::decode(int F, const float* features, const float* hq_feat, const 
   for (int i = 0; i < c.depth; ++i) {
     const Layer& Ly = layer[i];
     if (i == 0) {
-      SAMPT_TRY(attn_block(l, Ly.self, H, C, F, b.tokens, Nt, b.tokens, b.tokens, Nt, false, b, nullptr, queries, Ly.n1w,
-                           Ly.n1b, s));
+      SAMPT_TRY(attn_block(l, Ly.self, H, C, F, b.tokens, Nt, b.tokens, b.tokens, Nt, false, nkt, b, nullptr, queries,
+                           Ly.n1w, Ly.n1b, s));
     } else {
       SAMPT_TRY(add_bcast(queries, qpe, b.qin, nT, nT, s));
-      SAMPT_TRY(attn_block(l, Ly.self, H, C, F, b.qin, Nt, b.qin, queries, Nt, false, b, queries, queries, Ly.n1w, Ly.n1b, s));
+      SAMPT_TRY(attn_block(l, Ly.self, H, C, F, b.qin, Nt, b.qin, queries, Nt, false, nkt, b, queries, queries, Ly.n1w,
+                           Ly.n1b, s));
     }
     // tokens -> image
     SAMPT_TRY(add_bcast(queries, qpe, b.qin, nT, nT, s));
     SAMPT_TRY(add_bcast(b.keys, dense_pe, b.kin, nP, pe_mod, s));
-    SAMPT_TRY(attn_block(l, Ly.t2i, H, C, F, b.qin, Nt, b.kin, b.keys, P, false, b, queries, queries, Ly.n2w, Ly.n2b, s));
+    SAMPT_TRY(attn_block(l, Ly.t2i, H, C, F, b.qin, Nt, b.kin, b.keys, P, false, nullptr, b, queries, queries, Ly.n2w,
+                         Ly.n2b, s));
     // MLP (ReLU)
     SAMPT_TRY(l.lin(queries, (int)FT, C, Ly.m1w, Ly.m1b, b.hid, c.mlp, ACT_RELU));
     SAMPT_TRY(l.lin(b.hid, (int)FT, c.mlp, Ly.m2w, Ly.m2b, queries, C, ACT_NONE, queries));
     SAMPT_TRY(layernorm_rows(queries, Ly.n3w, Ly.n3b, queries, (long)FT, C, 1e-5f, nullptr, 0, ACT_NONE, s));
     // image -> tokens
     SAMPT_TRY(add_bcast(queries, qpe, b.qin, nT, nT, s));
-    SAMPT_TRY(attn_block(l, Ly.i2t, H, C, F, b.kin, P, b.qin, queries, Nt, true, b, b.keys, b.keys, Ly.n4w, Ly.n4b, s));
+    SAMPT_TRY(attn_block(l, Ly.i2t, H, C, F, b.kin, P, b.qin, queries, Nt, true, nkt, b, b.keys, b.keys, Ly.n4w, Ly.n4b,
+                         s));
   }
   SAMPT_TRY(add_bcast(queries, qpe, b.qin, nT, nT, s));
   SAMPT_TRY(add_bcast(b.keys, dense_pe, b.kin, nP, pe_mod, s));
-  SAMPT_TRY(attn_block(l, fin, H, C, F, b.qin, Nt, b.kin, b.keys, P, false, b, queries, queries, nfw, nfb, s));
+  SAMPT_TRY(attn_block(l, fin, H, C, F, b.qin, Nt, b.kin, b.keys, P, false, nullptr, b, queries, queries, nfw, nfb, s));
 
   // ---- upscaling: ConvT2x2s2 (C -> C/4) + LN2d + GELU ; ConvT2x2s2 (C/4 -> C/8) + GELU   (pixel shuffle via row maps
   //      that cover max_frames frames: map[(dy,dx)][f*P + p] = f*4P + (2y+dy)*2g + 2x+dx)
@@ -259,7 +264,7 @@ int DecEngine::decode(int F, const float* features, const float* hq_feat, const 
 }
 
 int DecEngine::track_decode(int F, const float* features, const float* hq_feat, const float* pts, const int* labels,
-                            int k, int ld_pts, int n_pos_first, int R, float iou_thr, int in_h, int in_w, int oh, int ow,
+                            int k, const int* k_item, const int* npos_item, int ld_pts, int n_pos_first, int R, float iou_thr, int in_h, int in_w, int oh, int ow,
                             float* final_logits, float* score_out, Arena& ws, hipStream_t s) {
   const int g = c.grid, Lr = 4 * g;
   const long nlog = (long)oh * ow, nlow = (long)Lr * Lr;
@@ -276,28 +281,28 @@ int DecEngine::track_decode(int F, const float* features, const float* hq_feat, 
   int* active = (int*)ws.get((size_t)F * sizeof(int));
   size_t mark = ws.off;
   if (ws.dry()) {  // measure the per-pass scratch once (all passes reuse it); box + mask = the largest variant
-    SAMPT_TRY(decode(F, features, hq_feat, pts, labels, k, ld_pts, pts, cur_low, in_h, in_w, oh, ow, cur_logits, cur_iou, cur_low,
-                     cur_bb, ws, s));
+    SAMPT_TRY(decode(F, features, hq_feat, pts, labels, k, nullptr, ld_pts, pts, cur_low, in_h, in_w, oh, ow, cur_logits,
+                     cur_iou, cur_low, cur_bb, ws, s));
     return SAMPT_OK;
   }
   if (!ws.ok()) return SAMPT_ERR_WORKSPACE;
   const float* mask_in = nullptr;
   if (n_pos_first >= 0) {  // negative_points_per_mask > 0 (sam_pt.py:791-807): positives only, then all + low-res mask
     ws.off = mark;
-    SAMPT_TRY(decode(F, features, hq_feat, pts, labels, n_pos_first, ld_pts, nullptr, nullptr, in_h, in_w, oh, ow, cand_logits,
-                     cand_iou, low0, nullptr, ws, s));
+    SAMPT_TRY(decode(F, features, hq_feat, pts, labels, n_pos_first, npos_item, ld_pts, nullptr, nullptr, in_h, in_w, oh, ow,
+                     cand_logits, cand_iou, low0, nullptr, ws, s));
     mask_in = low0;
   }
   ws.off = mark;
-  SAMPT_TRY(decode(F, features, hq_feat, pts, labels, k, ld_pts, nullptr, mask_in, in_h, in_w, oh, ow, cur_logits, cur_iou, cur_low,
-                   cur_bb, ws, s));
+  SAMPT_TRY(decode(F, features, hq_feat, pts, labels, k, k_item, ld_pts, nullptr, mask_in, in_h, in_w, oh, ow, cur_logits,
+                   cur_iou, cur_low, cur_bb, ws, s));
   if (R > 0) {
     if (hipMemsetAsync(active, 0xff, sizeof(int) * F, s) != hipSuccess) return SAMPT_ERR_HIP;
     for (int r = 0; r < R; ++r) {
       SAMPT_TRY(sam_refine_gate(active, cur_bb, boxf, F, s));
       ws.off = mark;
-      SAMPT_TRY(decode(F, features, hq_feat, pts, labels, k, ld_pts, boxf, cur_low, in_h, in_w, oh, ow, cand_logits, cand_iou,
-                       cand_low, cand_bb, ws, s));
+      SAMPT_TRY(decode(F, features, hq_feat, pts, labels, k, k_item, ld_pts, boxf, cur_low, in_h, in_w, oh, ow, cand_logits,
+                       cand_iou, cand_low, cand_bb, ws, s));
       SAMPT_TRY(sam_commit(active, cand_logits, cur_logits, nlog, cand_low, cur_low, nlow, cand_iou, cur_iou, cand_bb,
                            cur_bb, F, s));
     }

@@ -90,13 +90,15 @@ int pips_finalize(const float* ffeats, const float* vis_w, const float* vis_b, c
 // pts [F][ld_pts][2] input-frame px, labels [F][ld_pts] i32, box [F][4] or null.
 int sam_tokens(const float* out_tokens /*[n_out][256]*/, int n_out, const float* pts, const int* labels, int k, int ld_pts,
                const float* box, const float* gauss, const float* point_emb /*[4][256]*/, const float* not_a_point,
-               float img_size, int F, float* tokens, hipStream_t s);
+               float img_size, int F, const int* k_item /*[F] or null*/, int* ntok /*[F] out or null*/, float* tokens,
+               hipStream_t s);
 // small f32 attention, one workgroup per (query, head, frame): q [F][Nq][H*hd], k,v [F][Nk][H*hd]
+// nk_item: optional per-frame key count (<= Nk) of a ragged batch
 int attn_rowblock(const float* q, const float* k, const float* v, float* out, int F, int Nq, int Nk, int heads, int hd,
-                  hipStream_t s);
+                  const int* nk_item, hipStream_t s);
 // small f32 attention with few keys (Nk <= 64): one thread per (query, head)
 int attn_fewkeys(const float* q, const float* k, const float* v, float* out, int F, int Nq, int Nk, int heads, int hd,
-                 hipStream_t s);
+                 const int* nk_item, hipStream_t s);
 // low_res[f][p] = <hyper[f][0:C], up[f][p][0:C]>
 int sam_mask_dot(const float* up, const float* hyper, int ld_hyper, const float* up2 /*or null*/, const float* hyper2,
                  int ld_hyper2, float* low_res, int F, int npix, int C, hipStream_t s);

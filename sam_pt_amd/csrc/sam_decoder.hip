@@ -15,9 +15,19 @@ __global__ __launch_bounds__(128) void k_sam_tokens(const float* __restrict__ ou
                                                     const float* __restrict__ box, const float* __restrict__ gauss,
                                                     const float* __restrict__ point_emb,
                                                     const float* __restrict__ not_a_point, float img_size, int Nt,
-                                                    int n_out, float* __restrict__ tokens) {
+                                                    int n_out, const int* __restrict__ k_item,
+                                                    int* __restrict__ ntok, float* __restrict__ tokens) {
   const int trow = blockIdx.x, f = blockIdx.y, j = threadIdx.x;
   float* out = tokens + ((long)f * Nt + trow) * 256;
+  // ragged batch: item f uses its first k_item[f] points; its tokens are packed at the front, the rest of its rows are
+  // zero padding that the attention kernels mask out as keys (ntok[f] = valid token count)
+  if (k_item) k = min(k, k_item[f]);
+  const int nvalid = n_out + k + (box ? 2 : 1);
+  if (ntok && trow == 0 && j == 0) ntok[f] = nvalid;
+  if (trow >= nvalid) {
+    out[j] = 0.f, out[128 + j] = 0.f;
+    return;
+  }
   if (trow < n_out) {
     out[j] = out_tokens[trow * 256 + j];
     out[128 + j] = out_tokens[trow * 256 + 128 + j];
@@ -55,10 +65,10 @@ __global__ __launch_bounds__(128) void k_sam_tokens(const float* __restrict__ ou
 
 int sam_tokens(const float* out_tokens, int n_out, const float* pts, const int* labels, int k, int ld_pts,
                const float* box, const float* gauss, const float* point_emb, const float* not_a_point, float img_size,
-               int F, float* tokens, hipStream_t s) {
+               int F, const int* k_item, int* ntok, float* tokens, hipStream_t s) {
   int Nt = n_out + k + (box ? 2 : 1);
   hipLaunchKernelGGL(k_sam_tokens, dim3(Nt, F), dim3(128), 0, s, out_tokens, pts, labels, k, ld_pts, box, gauss,
-                     point_emb, not_a_point, img_size, Nt, n_out, tokens);
+                     point_emb, not_a_point, img_size, Nt, n_out, k_item, ntok, tokens);
   SAMPT_CHECK_LAUNCH("sam_tokens");
   return SAMPT_OK;
 }
@@ -69,13 +79,14 @@ int sam_tokens(const float* out_tokens, int n_out, const float* pts, const int* 
 template <int HD>
 __global__ __launch_bounds__(256) void k_attn_rowblock(const float* __restrict__ q, const float* __restrict__ k,
                                                        const float* __restrict__ v, float* __restrict__ out, int Nq,
-                                                       int Nk, int ld) {
+                                                       int Nk, int ld, const int* __restrict__ nk_item) {
   constexpr int KPT = 16;  // keys per thread (Nk <= 4096)
   __shared__ float red[8];
   __shared__ float accs[4][HD];
   const int qi = blockIdx.x, h = blockIdx.y, f = blockIdx.z;
   q += (long)f * Nq * ld, out += (long)f * Nq * ld;
   k += (long)f * Nk * ld, v += (long)f * Nk * ld;
+  if (nk_item) Nk = nk_item[f];   // ragged batch: only the item's valid tokens are keys (strides keep the padded Nk)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float qv[HD];
 #pragma unroll
@@ -140,12 +151,12 @@ __global__ __launch_bounds__(256) void k_attn_rowblock(const float* __restrict__
 }
 
 int attn_rowblock(const float* q, const float* k, const float* v, float* out, int F, int Nq, int Nk, int heads, int hd,
-                  hipStream_t s) {
+                  const int* nk_item, hipStream_t s) {
   if (Nk > 4096 || Nk <= 0 || Nq <= 0 || F <= 0) return SAMPT_ERR_ARG;
   int ld = heads * hd;
   dim3 grid(Nq, heads, F);
-  if (hd == 16) hipLaunchKernelGGL(k_attn_rowblock<16>, grid, dim3(256), 0, s, q, k, v, out, Nq, Nk, ld);
-  else if (hd == 32) hipLaunchKernelGGL(k_attn_rowblock<32>, grid, dim3(256), 0, s, q, k, v, out, Nq, Nk, ld);
+  if (hd == 16) hipLaunchKernelGGL(k_attn_rowblock<16>, grid, dim3(256), 0, s, q, k, v, out, Nq, Nk, ld, nk_item);
+  else if (hd == 32) hipLaunchKernelGGL(k_attn_rowblock<32>, grid, dim3(256), 0, s, q, k, v, out, Nq, Nk, ld, nk_item);
   else return SAMPT_ERR_UNSUPPORTED;
   SAMPT_CHECK_LAUNCH("attn_rowblock");
   return SAMPT_OK;
@@ -157,7 +168,7 @@ int attn_rowblock(const float* q, const float* k, const float* v, float* out, in
 template <int HD>
 __global__ __launch_bounds__(256) void k_attn_fewkeys(const float* __restrict__ q, const float* __restrict__ k,
                                                       const float* __restrict__ v, float* __restrict__ out, int Nq,
-                                                      int Nk, int heads) {
+                                                      int Nk, int heads, const int* __restrict__ nk_item) {
   extern __shared__ float kv[];  // [2][Nk][ld]
   const int ld = heads * HD, f = blockIdx.y;
   q += (long)f * Nq * ld, out += (long)f * Nq * ld;
@@ -169,6 +180,7 @@ __global__ __launch_bounds__(256) void k_attn_fewkeys(const float* __restrict__ 
     vs[i] = v[i];
   }
   __syncthreads();
+  if (nk_item) Nk = nk_item[f];   // ragged batch: mask the item's padding tokens
   long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (long)Nq * heads) return;
   int qi = (int)(idx / heads), h = (int)(idx % heads);
@@ -210,7 +222,7 @@ __global__ __launch_bounds__(256) void k_attn_fewkeys(const float* __restrict__ 
 }
 
 int attn_fewkeys(const float* q, const float* k, const float* v, float* out, int F, int Nq, int Nk, int heads, int hd,
-                 hipStream_t s) {
+                 const int* nk_item, hipStream_t s) {
   if (Nk <= 0 || Nk > 128 || hd != 16 || F <= 0) return SAMPT_ERR_UNSUPPORTED;
   size_t sh = (size_t)2 * Nk * heads * hd * sizeof(float);
   if (sh > 64 * 1024) {  // above the default dynamic-LDS limit (gfx950 has 160 KiB per workgroup)
@@ -223,7 +235,7 @@ int attn_fewkeys(const float* q, const float* k, const float* v, float* out, int
     }
   }
   hipLaunchKernelGGL(k_attn_fewkeys<16>, dim3(cdiv((long)Nq * heads, 256), F), dim3(256), sh, s, q, k, v, out, Nq, Nk,
-                     heads);
+                     heads, nk_item);
   SAMPT_CHECK_LAUNCH("attn_fewkeys");
   return SAMPT_OK;
 }

@@ -297,11 +297,14 @@ class SamPredictor:
 
     @torch.no_grad()
     def track_decode(self, feat_tokens: torch.Tensor, pts: torch.Tensor, labels: torch.Tensor, k: int, n_pos_first: int,
-                     refine_iters: int, iou_thr: float, size_hw, out_logits: torch.Tensor, out_score: torch.Tensor):
+                     refine_iters: int, iou_thr: float, size_hw, out_logits: torch.Tensor, out_score: torch.Tensor,
+                     k_item: Optional[torch.Tensor] = None, npos_item: Optional[torch.Tensor] = None):
         """SamPt.predict_mask (sam_pt.py:760-837) for F independent (frame, object) items that share the visible-point
         count k, as ONE batched device-side chain without host syncs.  feat_tokens (F,g*g,256); pts (F,ld,2) f32 in
         input-frame px and labels (F,ld) i32 with the first k entries valid (positives first); n_pos_first = -1 for
         the single-pass case, else the number of leading positives used by the positives-only first pass.
+        Ragged batches: ``k_item`` / ``npos_item`` (F,) int32 device tensors give every item its own point / leading
+        positive count (<= k / n_pos_first); padding tokens are masked on the device, results equal the un-batched ones.
         Results are written into out_logits (F,H,W) and out_score (F,)."""
         self._ensure()
         oh, ow = size_hw
@@ -313,6 +316,7 @@ class SamPredictor:
         ws = self._dec_ws(oh, ow, F)
         _lib.check(self._lib.sampt_sam_track_decode(self._dec, F, _lib.ptr(feat_tokens), _lib.ptr(hq_tokens),
                                                     _lib.ptr(pts), _lib.ptr(labels),
-                                                    k, pts.shape[1], n_pos_first, refine_iters, float(iou_thr), oh, ow,
+                                                    k, _lib.ptr(k_item), _lib.ptr(npos_item), pts.shape[1], n_pos_first,
+                                                    refine_iters, float(iou_thr), oh, ow,
                                                     oh, ow, _lib.ptr(out_logits), _lib.ptr(out_score), _lib.ptr(ws),
                                                     ws.numel(), _lib.stream_ptr()), "sampt_sam_track_decode")

@@ -373,27 +373,30 @@ class SamPt(nn.Module):
         logits = torch.full((n_masks, n_frames, height, width), -float("inf"), dtype=torch.float32, device=dev)
         scores = torch.full((n_frames * n_masks,), -float("inf"), dtype=torch.float32, device=dev)
         two_pass = self.negative_points_per_mask > 0
-        # group the (frame, object) items by prompt shape: items of one group run as ONE batched device-side chain
-        groups = {}
-        for i, (c, l) in enumerate(prompts):
-            if len(c) == 0:
-                continue                                                         # sam_pt.py:766-767
-            key = (len(c), int((l == 1).sum()) if two_pass else -1)
-            groups.setdefault(key, []).append(i)
+        # All (frame, object) items with a non-empty prompt run as ONE batched device-side chain per chunk of Fmax items,
+        # whatever their number of visible points: the batch is ragged (per-item point counts, padding tokens masked in
+        # the decoder's attention), so an item's result equals its un-batched one.
+        items = [i for i, (c, l) in enumerate(prompts) if len(c) > 0]            # empty prompt: sam_pt.py:766-767
+        k_all = np.array([len(c) for c, _ in prompts], dtype=np.int32)
+        npos_all = np.array([int((l == 1).sum()) for _, l in prompts], dtype=np.int32)
+        k_d, npos_d = torch.from_numpy(k_all).to(dev), torch.from_numpy(npos_all).to(dev)
         Fmax = getattr(pred.model, "max_decode_batch", 1)
-        for (k, n_pos_first), items in groups.items():
-            for s0 in range(0, len(items), Fmax):
-                idx = torch.tensor(items[s0:s0 + Fmax], dtype=torch.long, device=dev)
-                t_idx, m_idx = idx // n_masks, idx % n_masks
-                F_ = idx.numel()
-                out_l = torch.empty((F_, height, width), dtype=torch.float32, device=dev)
-                out_s = torch.empty((F_,), dtype=torch.float32, device=dev)
-                pred.track_decode(feats.index_select(0, t_idx), xy_d.index_select(0, idx).contiguous(),
-                                  lab_d.index_select(0, idx).contiguous(), k, n_pos_first,
-                                  int(self.iterative_refinement_iterations), float(self.sam_iou_threshold), size,
-                                  out_l, out_s)
-                logits[m_idx, t_idx] = out_l
-                scores[idx] = out_s
+        for s0 in range(0, len(items), Fmax):
+            chunk = items[s0:s0 + Fmax]
+            idx = torch.tensor(chunk, dtype=torch.long, device=dev)
+            t_idx, m_idx = idx // n_masks, idx % n_masks
+            F_ = idx.numel()
+            ks, ps = k_all[chunk], npos_all[chunk]
+            ragged = bool((ks != ks[0]).any() or (two_pass and (ps != ps[0]).any()))
+            out_l = torch.empty((F_, height, width), dtype=torch.float32, device=dev)
+            out_s = torch.empty((F_,), dtype=torch.float32, device=dev)
+            pred.track_decode(feats.index_select(0, t_idx), xy_d.index_select(0, idx).contiguous(),
+                              lab_d.index_select(0, idx).contiguous(), int(ks.max()), int(ps.max()) if two_pass else -1,
+                              int(self.iterative_refinement_iterations), float(self.sam_iou_threshold), size,
+                              out_l, out_s, k_item=k_d.index_select(0, idx).contiguous() if ragged else None,
+                              npos_item=npos_d.index_select(0, idx).contiguous() if (ragged and two_pass) else None)
+            logits[m_idx, t_idx] = out_l
+            scores[idx] = out_s
         scores_cpu = scores.cpu().view(n_frames, n_masks)                        # the only sync of the SAM stage
         pred_scores = self._mean_scores(scores_cpu)
         return pred_scores, logits, scores_cpu
