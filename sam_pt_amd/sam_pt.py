@@ -71,6 +71,7 @@ class SamPt(nn.Module):
         self.reinit_point_tracker_horizon, self.reinit_horizon = reinit_point_tracker_horizon, reinit_horizon
         self.reinit_variant = reinit_variant
         self.profile = {}
+        self.compute_unused_query_masks = False        # fused path: see forward()
         self.overlap_tracker_and_encoder = True        # fused path only: tracker on a second HIP stream (see forward)
         self._side_stream = None
 
@@ -119,10 +120,14 @@ class SamPt(nn.Module):
                 torch.cuda.current_stream().wait_stream(self._side_stream)
                 if hasattr(self.point_tracker, "_prepared"):
                     self.point_tracker._prepared = None
-        if query_masks is None:
-            query_masks = self.extract_query_masks(images, query_points, feats)
         n_masks, n_points_per_mask, _ = query_points.shape
-        assert query_masks.shape == (n_masks, height, width)
+        if query_masks is None:
+            # In query_points mode the reference computes the query masks (sam_pt.py:181) but only asserts their shape
+            # (:186) and hands them to SuperGlue-style trackers (:189-191); with any other tracker they are dead work
+            # (M extra encoder + decoder chains), so the device path skips them unless asked to (or a tracker wants them).
+            if not fused or self.compute_unused_query_masks or hasattr(self.point_tracker, "set_masks"):
+                query_masks = self.extract_query_masks(images, query_points, feats)
+        assert query_masks is None or query_masks.shape == (n_masks, height, width)
         if not self.use_point_reinit:
             trajectories, visibilities = tracked if tracked is not None else self._track_points(images, query_points)
             _, logits, scores_per_frame = self._apply_sam_to_trajectories(images, trajectories, visibilities, feats)
