@@ -173,7 +173,8 @@ int sampt_avgpool2x2_nhwc(const float* src_dev, int n, int h, int w, int C, floa
 int sampt_corr_sample_f32(const float* const pyr_dev[4], int H0, int W0, const int32_t* frame_idx_dev, int S, int n,
                           const float* ffeats_dev, const float* coords_dev, float* out_dev, sampt_stream_t stream);
 /* ViT attention on a packed qkv matrix [B*S*S][3*heads*hd] (f16), decomposed rel-pos tables (2S-1, hd) f32.
- * out_dev f16 [B*S*S][heads*hd]; workspace: 2 * B*heads*S*S*S floats. */
+ * out_dev f16 [B*S*S][heads*hd].  The bias tables are built inside the kernel; the workspace arguments are kept for
+ * ABI stability and ignored (may be NULL / 0). */
 int sampt_vit_attention_f16(const void* qkv_dev, const float* rel_h_dev, const float* rel_w_dev, void* out_dev, int B,
                             int S, int heads, int hd, void* workspace_dev, size_t workspace_bytes, sampt_stream_t stream);
 

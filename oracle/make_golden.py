@@ -9,6 +9,7 @@ reference's own code run in place from /root/reference (never copied):
   sampt_ref.npz     sam_pt.modeling.sam_pt.SamPt.forward                  (reference orchestration; predictor = the
                                                                            SAM oracle, tracker = reference PIPS)
   sam_hf.npz        HuggingFace transformers SamModel                     (secondary pin of the absent third-party SAM)
+  pips2.npz         sam_pt.point_tracker.pips_plus_plus.{PipsPlusPlus, PipsPlusPlusPointTracker}   (row f4)
   sam_hq_hf.npz     HuggingFace transformers SamHQModel                   (secondary pin of the absent HQ-SAM decoder)
 
 Weights are NOT stored: they are regenerated from the seed (sam_pt_amd/weights.py), inputs from
@@ -95,6 +96,35 @@ def make_hq_golden():
                         low2=low2.numpy(), iou2=iou2.numpy())
 
 
+def make_pips2_golden():
+    """Reference PipsPlusPlus / PipsPlusPlusPointTracker (run in place) on the synthetic clip."""
+    from sam_pt_amd.weights import init_pips2_state_dict
+    Pips2, Tracker2 = RL.load_pips2()
+    sd = init_pips2_state_dict(72)
+    frames, centres = synthetic_clip(T=12, H=128, W=256, seed=72)
+    m = Pips2(stride=8).eval()
+    m.load_state_dict(sd, strict=True)
+    q = disc_queries(centres, n_pos=5, r=9.0)
+    out = {}
+    with torch.no_grad():
+        preds, _, feats, _ = m(q[None, :, 1:].repeat(12, 1, 1)[None], frames[None].float(), iters=6)
+        fm = m.fnet(2 * (frames.float() / 255.0) - 1.0)
+    out["model_xys"] = q[:, 1:].numpy()
+    out["model_traj_iter0"], out["model_traj"] = preds[0][0].numpy(), preds[-1][0].numpy()
+    out["model_feats2"] = feats[1][0].numpy()
+    out["fmap_patch"] = fm[:, :, 4:8, 12:16].numpy()
+    out["fmap_abs_mean"] = fm.abs().mean(dim=(1, 2, 3)).numpy()
+    d = tempfile.mkdtemp()
+    torch.save({"model_state_dict": sd}, os.path.join(d, "model-000000001.pth"))
+    for name, t, maxlen, iters in (("t0", 0, 128, 16), ("t5", 5, 128, 8), ("t5_chunked", 5, 5, 3)):
+        trk = Tracker2(checkpoint_path=d, stride=8, max_sequence_length=maxlen, iters=iters, image_size=None).eval()
+        qq = disc_queries(centres, n_pos=4, r=9.0, t=t)[None]
+        with torch.no_grad():
+            tr, vi = trk(frames[None].float(), qq.clone())
+        out[f"trk_{name}_q"], out[f"trk_{name}_traj"], out[f"trk_{name}_vis"] = qq.numpy(), tr.numpy(), vi.numpy()
+    np.savez_compressed(os.path.join(OUT, "pips2.npz"), **out)
+
+
 def main():
     assert RL.available(), "the reference tree is required to (re)generate goldens"
     os.makedirs(OUT, exist_ok=True)
@@ -176,6 +206,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, "sam_hf.npz"), emb=emb.numpy(), pts=pts.numpy(), lab=lab.numpy(),
                         low=low.numpy(), iou=iou.numpy(), box=box.numpy(), low2=low2.numpy(), iou2=iou2.numpy())
     make_hq_golden()
+    make_pips2_golden()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
 

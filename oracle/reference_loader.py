@@ -57,6 +57,26 @@ def load_pips():
     return P.Pips, PT.PipsPointTracker, T.PointTracker
 
 
+def load_pips2():
+    """Returns (PipsPlusPlus class, PipsPlusPlusPointTracker class) of the reference.  The model hard-codes a
+    ``.cuda()`` (pips_plus_plus.py:438) and the tracker several more; on a CPU-only box ``Tensor.cuda`` is shimmed to
+    the identity for the lifetime of the process (test infrastructure only)."""
+    import torch
+    load_pips()
+    _ns("sam_pt.point_tracker.pips_plus_plus", "/sam_pt/point_tracker/pips_plus_plus")
+    if not torch.cuda.is_available():
+        torch.Tensor.cuda = lambda self, *a, **k: self
+    import sam_pt.point_tracker.utils.basic  # noqa: F401
+    import sam_pt.point_tracker.utils.misc  # noqa: F401
+    import sam_pt.point_tracker.utils.samp  # noqa: F401
+    import sam_pt.point_tracker.pips_plus_plus.pips_plus_plus as P2
+    sys.modules["sam_pt.point_tracker.pips_plus_plus"].PipsPlusPlus = P2.PipsPlusPlus
+    _link_children()
+    import sam_pt.point_tracker.pips_plus_plus.tracker as PT2
+    _link_children()
+    return P2.PipsPlusPlus, PT2.PipsPlusPlusPointTracker
+
+
 def load_sam_pt():
     """Returns the reference ``SamPt`` class (sam_pt/modeling/sam_pt.py) with absent third-party imports
     stubbed (segment_anything, skimage, cv2, wandb, sklearn_extra)."""

@@ -123,6 +123,46 @@ def init_pips_state_dict(seed: int = 72, S: int = PIPS_S, delta_scale: float = 0
     return w.sd
 
 
+PIPS2_KITCHEN = 3 * PIPS_CORR_LEVELS * (2 * PIPS_CORR_RADIUS + 1) ** 2 + PIPS_LATENT + 2      # 718
+PIPS2_BLOCKS = [(128, 128), (128, 128), (128, 256), (256, 256), (256, 512), (512, 512), (512, 1024), (1024, 1024)]
+
+
+def init_pips2_state_dict(seed: int = 72, delta_scale: float = 0.05) -> "OrderedDict[str, torch.Tensor]":
+    """Random PIPS++ weights, keys as in the reference module tree (pips_plus_plus.py:420-434: ``fnet`` BasicEncoder
+    (:180-260, instance norm -> no norm parameters), ``delta_block`` 1-D ResNet (:263-342) and the unused ``norm``).
+    ``delta_scale`` shrinks the final dense layer so that the 16-iteration update is contractive (see
+    ``init_pips_state_dict``).  Unused-but-present modules of the reference (``first_block_norm``, ``final_norm``,
+    InstanceNorm without affine) have no parameters; ``norm`` (GroupNorm) has and is kept so the dict strict-loads."""
+    w = _Init(seed)
+    w.conv("fnet.conv1", 64, 3, 7, 7, kaiming_fan_out=True)
+    in_planes = 64
+    for li, (dim, stride) in enumerate([(64, 1), (96, 2), (128, 2), (128, 2)], start=1):
+        for bi in range(2):
+            cin = in_planes if bi == 0 else dim
+            p = f"fnet.layer{li}.{bi}"
+            w.conv(p + ".conv1", dim, cin, 3, 3, kaiming_fan_out=True)
+            w.conv(p + ".conv2", dim, dim, 3, 3, kaiming_fan_out=True)
+            if bi == 0 and stride != 1:
+                w.conv(p + ".downsample.0", dim, cin, 1, 1, kaiming_fan_out=True)
+        in_planes = dim
+    w.conv("fnet.conv2", 2 * PIPS_LATENT, 128 + 128 + 96 + 64, 3, 3, kaiming_fan_out=True)
+    w.conv("fnet.conv3", PIPS_LATENT, 2 * PIPS_LATENT, 1, 1, kaiming_fan_out=True)
+
+    def conv1d(name, cout, cin):
+        w.conv(name, cout, cin, 3, 1)
+        w.sd[name + ".weight"] = w.sd[name + ".weight"].squeeze(-1)          # (cout, cin, 3)
+
+    conv1d("delta_block.first_block_conv.conv", 128, PIPS2_KITCHEN)
+    for i, (cin, cout) in enumerate(PIPS2_BLOCKS):
+        conv1d(f"delta_block.basicblock_list.{i}.conv1.conv", cout, cin)
+        conv1d(f"delta_block.basicblock_list.{i}.conv2.conv", cout, cout)
+    w.linear("delta_block.dense", 2, 1024)
+    w.sd["delta_block.dense.weight"] *= delta_scale
+    w.sd["delta_block.dense.bias"] *= delta_scale
+    w.norm("norm", PIPS_LATENT)
+    return w.sd
+
+
 # --------------------------------------------------------------------------------------
 # SAM
 # --------------------------------------------------------------------------------------
