@@ -30,6 +30,7 @@ extern "C" {
 
 typedef void* sampt_stream_t; /* hipStream_t */
 typedef struct sampt_pips* sampt_pips_t;
+typedef struct sampt_pips2* sampt_pips2_t;
 typedef struct sampt_vit* sampt_vit_t;
 typedef struct sampt_dec* sampt_dec_t;
 
@@ -68,6 +69,28 @@ int sampt_pips_update_workspace_bytes(sampt_pips_t h, int n, size_t* bytes);
 int sampt_pips_update_f32(sampt_pips_t h, const float* const pyr_dev[4], int H0, int W0, const int32_t* frame_idx_dev,
                           int n, const float* xys_dev, const float* feat_init_dev, int iters, float* traj_out_dev,
                           float* vis_out_dev, void* workspace_dev, size_t workspace_bytes, sampt_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * seam 1b — PIPS++ point tracker (sam_pt/point_tracker/pips_plus_plus/{pips_plus_plus.py:420-546, tracker.py:25-134}).
+ * Weights keyed by the checkpoint names after sam_pt_amd.pack.pack_pips2 (fnet convs as for PIPS; Conv1d weights
+ * (Cout, Cin, 3) -> [Cout][3][Cin] with the first conv's 718 input channels zero-padded to 720; "__omega" [32]).
+ * fnet_f32 = PipsPlusPlus.fnet on every frame + the 4-level average-pool pyramid of CorrBlock.__init__ (:366-379),
+ * stride 8.  update_f32 = one PipsPlusPlus.forward after the encoder for n points over a chunk of S frames
+ * (frame_idx_dev int32 [n][S] selects each point's pyramid frames, so sub-clips and time-reversed clips are index
+ * maps): trajs0_dev [S][n][2] px is `trajs_e0`, feats_dev[3] = (feats1, feats2, feats4) [n][S][128] are read as
+ * `feat_init` when have_feat_init != 0 and always written back (tracker.py:49-54), trajs_out_dev [S][n][2] px =
+ * coord_predictions1[-1].
+ * --------------------------------------------------------------------------------------------------------- */
+int sampt_pips2_create(const char* const* names, const void* const* ptrs, int n, int stride, sampt_pips2_t* out);
+void sampt_pips2_destroy(sampt_pips2_t h);
+int sampt_pips2_fnet_workspace_bytes(sampt_pips2_t h, int nf, int H, int W, size_t* bytes);
+int sampt_pips2_fnet_f32(sampt_pips2_t h, const uint8_t* frames_dev, int nf, int H, int W, float* const pyr_dev[4],
+                         void* workspace_dev, size_t workspace_bytes, sampt_stream_t stream);
+int sampt_pips2_update_workspace_bytes(sampt_pips2_t h, int n, int S, size_t* bytes);
+int sampt_pips2_update_f32(sampt_pips2_t h, const float* const pyr_dev[4], int H0, int W0, const int32_t* frame_idx_dev,
+                           int n, int S, const float* trajs0_dev, int have_feat_init, float* const feats_dev[3],
+                           int iters, float* trajs_out_dev, void* workspace_dev, size_t workspace_bytes,
+                           sampt_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * seam 2a — SAM image encoder = SamPredictor.set_image (Sam.preprocess + ImageEncoderViT, Appendix A-1..A-3).

@@ -26,6 +26,7 @@ static WeightMap make_map(const char* const* names, const void* const* ptrs, int
 using namespace sampt;
 
 struct sampt_pips { PipsEngine e; };
+struct sampt_pips2 { Pips2Engine e; };
 struct sampt_vit { VitEngine e; };
 struct sampt_dec { DecEngine e; };
 
@@ -141,6 +142,62 @@ int sampt_vit_encode(sampt_vit_t h, const uint8_t* frames, int chw, int B, int H
                 "pipelines do)");
   Arena a(ws, ws_bytes);
   return h->e.encode(frames, chw, B, H, W, features, interm_out, a, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------- PIPS++
+int sampt_pips2_create(const char* const* names, const void* const* ptrs, int n, int stride, sampt_pips2_t* out) {
+  if (!names || !ptrs || !out || stride <= 0) return fail(SAMPT_ERR_ARG, "sampt_pips2_create: bad arguments");
+  sampt_pips2* h = new sampt_pips2();
+  WeightMap w = make_map(names, ptrs, n);
+  int rc = h->e.init(w, stride);
+  if (rc != SAMPT_OK) {
+    std::string m = h->e.error;
+    delete h;
+    return fail(rc, m);
+  }
+  *out = h;
+  return SAMPT_OK;
+}
+void sampt_pips2_destroy(sampt_pips2_t h) { delete h; }
+
+int sampt_pips2_fnet_workspace_bytes(sampt_pips2_t h, int nf, int H, int W, size_t* bytes) {
+  if (!h || !bytes) return SAMPT_ERR_ARG;
+  Arena a(nullptr, 0);
+  float* out[4] = {nullptr, nullptr, nullptr, nullptr};
+  int rc = h->e.enc.fnet(nullptr, nf, H, W, out, a, nullptr);
+  *bytes = a.peak + 256;
+  return rc;
+}
+
+int sampt_pips2_fnet_f32(sampt_pips2_t h, const uint8_t* frames, int nf, int H, int W, float* const pyr[4], void* ws,
+                         size_t ws_bytes, sampt_stream_t stream) {
+  if (!h || !frames || !pyr || !ws || H % (8 * h->e.stride) || W % (8 * h->e.stride))
+    return fail(SAMPT_ERR_ARG, "sampt_pips2_fnet_f32: bad arguments (H, W must be multiples of 8*stride)");
+  Arena a(ws, ws_bytes);
+  return h->e.enc.fnet(frames, nf, H, W, pyr, a, (hipStream_t)stream);
+}
+
+int sampt_pips2_update_workspace_bytes(sampt_pips2_t h, int n, int S, size_t* bytes) {
+  if (!h || !bytes || n <= 0 || S <= 0) return SAMPT_ERR_ARG;
+  Arena a(nullptr, 0);
+  PyramidLevels p = {};
+  float* feats[3] = {nullptr, nullptr, nullptr};
+  int rc = h->e.update(p, nullptr, n, S, nullptr, 0, feats, 1, nullptr, a, nullptr);
+  *bytes = a.peak + 256;
+  return rc;
+}
+
+static PyramidLevels make_pyr(const float* const pyr[4], int H0, int W0);
+
+int sampt_pips2_update_f32(sampt_pips2_t h, const float* const pyr[4], int H0, int W0, const int32_t* frame_idx, int n,
+                           int S, const float* trajs0, int have_feat_init, float* const feats[3], int iters,
+                           float* trajs_out, void* ws, size_t ws_bytes, sampt_stream_t stream) {
+  if (!h || !pyr || !frame_idx || !trajs0 || !feats || !feats[0] || !feats[1] || !feats[2] || !trajs_out || !ws ||
+      n <= 0 || S <= 0 || iters <= 0)
+    return fail(SAMPT_ERR_ARG, "sampt_pips2_update_f32: bad arguments");
+  Arena a(ws, ws_bytes);
+  return h->e.update(make_pyr(pyr, H0, W0), (const int*)frame_idx, n, S, trajs0, have_feat_init, feats, iters, trajs_out,
+                     a, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------- decoder

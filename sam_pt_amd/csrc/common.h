@@ -99,6 +99,7 @@ struct GemmP {
   size_t splitk_ws_floats = 0;
   int conv = 0;
   int cH = 0, cW = 0, cC = 0, KH = 0, KW = 0, cstride = 1, cpad = 0, OH = 0, OW = 0;
+  int cpadw = -1;                // >= 0: padding along W differs from cpad (1-D convolutions over time: KW = 1, cpadw = 0)
 };
 
 int gemm_f32(const GemmP& p, hipStream_t s);

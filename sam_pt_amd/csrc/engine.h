@@ -65,12 +65,34 @@ struct PipsEngine {
   std::string error;
 
   int init(const WeightMap& w);
+  int init_fnet(const WeightMap& w);   // encoder only (shared with PIPS++: same BasicEncoder, other stride)
   // frames: uint8 (nf,3,H,W).  out[l]: level-l feature maps [nf][H_l][W_l][128] f32 (H_0 = H/stride).
   int fnet(const uint8_t* frames, int nf, int H, int W, float* const out[4], Arena& ws, hipStream_t s);
   // one PIPS window per point: frame_idx (device, [n][S] ints into the pyramid), xys (device [n][2], px at frame 0),
   // feat_init (device [n][128]).  traj_out [S][n][2] px, vis_out [S][n] = sigmoid(logit).
   int update(const PyramidLevels& pyr, const int* frame_idx, int n, const float* xys, const float* feat_init, int iters,
              float* traj_out, float* vis_out, Arena& ws, hipStream_t s);
+};
+
+// PIPS++ (pips_plus_plus.py): the PIPS encoder at stride 8 + a 1-D ResNet over time instead of the MLP-Mixer; one call
+// refines a whole chunk of S <= max_sequence_length frames for n points.
+struct Pips2Engine {
+  PipsEngine enc;                      // fnet only
+  int stride = 8;
+  struct Conv1 {
+    const float *w, *b;                // [Cout][3*Cin] (tap-major, ci fastest), [Cout]
+    int cin, cout;
+  };
+  Conv1 first, blk[8][2];
+  const float *dense_w, *dense_b, *omega;
+  std::string error;
+
+  int init(const WeightMap& w, int stride);
+  // frame_idx (device int [n][S]): pyramid frame of chunk frame s for point pt; trajs0 (device [S][n][2] px): initial
+  // trajectory (zero velocity or the previous chunk's); feats[3] (device [n][S][128] each): templates, read as the
+  // feat_init of the previous chunk when have_init != 0, always written back.  trajs_out [S][n][2] px.
+  int update(const PyramidLevels& pyr, const int* frame_idx, int n, int S, const float* trajs0, int have_init,
+             float* const feats[3], int iters, float* trajs_out, Arena& ws, hipStream_t s);
 };
 
 // -------------------------------------------------------------------------------------------------

@@ -11,7 +11,7 @@ static int load_conv(const WeightMap& w, const std::string& name, int cin, int c
   return (c.w && c.b) ? SAMPT_OK : SAMPT_ERR_ARG;
 }
 
-int PipsEngine::init(const WeightMap& w) {
+int PipsEngine::init_fnet(const WeightMap& w) {
   int rc = SAMPT_OK;
   // conv weights arrive repacked [Cout][KH*KW*Cin] (ci fastest); the stem's Cin is zero-padded 3 -> 4
   rc |= load_conv(w, "fnet.conv1", 4, 64, 7, 2, 3, stem);
@@ -31,6 +31,16 @@ int PipsEngine::init(const WeightMap& w) {
   }
   rc |= load_conv(w, "fnet.conv2", 416, 256, 3, 1, 1, conv2);
   rc |= load_conv(w, "fnet.conv3", 256, 128, 1, 1, 0, conv3);
+  if (rc != SAMPT_OK || !w.missing.empty()) {
+    error = "PipsEngine: missing fnet weights: " + w.missing;
+    return SAMPT_ERR_ARG;
+  }
+  return SAMPT_OK;
+}
+
+int PipsEngine::init(const WeightMap& w) {
+  int rc = init_fnet(w);
+  if (rc != SAMPT_OK) return rc;
   const std::string d = "delta_block.to_delta.";
   in_w = w.f(d + "0.weight"), in_b = w.f(d + "0.bias");
   for (int i = 0; i < 12; ++i) {

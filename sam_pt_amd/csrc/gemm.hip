@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
       int oy = rem / p.OW, ox = rem - oy * p.OW;
       a_off[i] = (long)img * p.cH * p.cW * p.cC;
       a_iy0[i] = oy * p.cstride - p.cpad;
-      a_ix0[i] = ox * p.cstride - p.cpad;
+      a_ix0[i] = ox * p.cstride - (p.cpadw >= 0 ? p.cpadw : p.cpad);
     } else {
       a_off[i] = (long)m * p.lda;
       a_iy0[i] = a_ix0[i] = 0;

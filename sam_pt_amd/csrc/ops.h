@@ -68,6 +68,16 @@ int pips_corr_sample(const PyramidLevels& pyr, const int* frame_idx, int S, int 
 // times: device [S] = torch.linspace(0, S, S) (pips.py:527)
 int pips_build_input(const float* ffeats, const float* coords, const float* times, int S, int n, float* x, int ldx,
                      hipStream_t s);
+// ---- PIPS++ (pips2.hip; pips_plus_plus.py:263-342, 436-546) — rows are (point, frame): row = pt*S + s
+int pips2_init(const float* trajs0, const float* fmap, int H, int W, const int* frame_idx, float stride, int S, int n,
+               int have_init, float* coords, float* bak, float* f1, float* f2, float* f4, hipStream_t s);
+int pips2_templates(const float* fmap, int H, int W, const int* frame_idx, const float* coords, int S, int n, float* f2,
+                    float* f4, hipStream_t s);
+int pips2_build_input(const float* coords, const float* omega, int S, int n, float* x, int ldx, hipStream_t s);
+int instnorm1d_relu(const float* x, float* y, int n, int S, int C, hipStream_t s);
+int add_chanpad(float* out, const float* identity, long rows, int cin, int cout, int relu, hipStream_t s);
+int pips2_apply_delta(const float* delta, const float* bak, float stride, int S, int n, int last, float* coords,
+                      float* trajs, hipStream_t s);
 // coords[s][pt] = coords0[pt] = xys[pt]/stride ; ffeats[pt][s] = feat_init[pt]     (pips.py:458-476)
 int pips_init_state(const float* xys, const float* feat_init, float stride, int S, int n, float* coords,
                     float* coords0, float* ffeats, hipStream_t s);

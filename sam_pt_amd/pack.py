@@ -43,6 +43,27 @@ def pack_pips(sd: Dict[str, torch.Tensor], device, S: int = 8) -> Dict[str, torc
     return {k: v.to(device) for k, v in out.items()}
 
 
+def pack_pips2(sd: Dict[str, torch.Tensor], device) -> Dict[str, torch.Tensor]:
+    """PIPS++ (pips_plus_plus.py:420-434): fnet convs as for PIPS; DeltaBlock Conv1d weights (Cout, Cin, 3) ->
+    [Cout][3][Cin] (tap-major, channel fastest = the implicit-GEMM K order over an [n][S][1][C] image), the first conv's
+    718 input channels zero-padded to 720; ``__omega`` = the 32 frequencies of posemb_sincos_2d_xy (misc.py:18-19)."""
+    out: Dict[str, torch.Tensor] = {}
+    for k, v in sd.items():
+        v = v.detach().float()
+        if k.startswith("fnet.") and k.endswith(".weight"):
+            out[k] = _khwc(v, pad_cin_to=4 if k == "fnet.conv1.weight" else 0)
+        elif k.startswith("delta_block.") and k.endswith(".conv.weight"):
+            w = v.permute(0, 2, 1).contiguous()                                   # (Cout, 3, Cin)
+            if k == "delta_block.first_block_conv.conv.weight":
+                w = torch.nn.functional.pad(w, (0, 720 - w.shape[-1]))
+            out[k] = w.reshape(w.shape[0], -1).contiguous()
+        else:
+            out[k] = v.contiguous()
+    omega = torch.arange(32) / 31
+    out["__omega"] = (1.0 / (10000 ** omega)).float()
+    return {k: v.to(device) for k, v in out.items()}
+
+
 def window_row_map(grid: int, window: int, batches: int) -> torch.Tensor:
     """Row map of SAM's window_partition (App. A-3): entry ((b*nwin + w)*window^2 + i) = source token row
     b*grid^2 + y*grid + x, or -1 where the window hangs over the zero padding."""

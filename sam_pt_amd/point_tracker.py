@@ -19,7 +19,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 from abc import ABC, abstractmethod
-from typing import Dict, Optional, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import torch
 from torch import nn
@@ -248,3 +248,143 @@ class PipsPointTracker(PointTracker):
             vis[:s, n] = vi_l[:s, n]
             assert torch.allclose(traj[s, n], q[n, 1:]) and bool(vis[s, n])
         return traj.unsqueeze(0).to(dev), vis.unsqueeze(0).to(dev)
+
+
+class PipsPlusPlusPointTracker(PointTracker):
+    """PIPS++ behind the reference constructor of
+    ``sam_pt.point_tracker.pips_plus_plus.PipsPlusPlusPointTracker`` (tracker.py:11-24; configs/model/point_tracker/
+    pips_plus_plus.yaml).  Differences from the reference, on purpose:
+
+    * the encoder runs ONCE per clip; the reference re-runs it for every (query frame, direction, chunk) although its
+      per-frame InstanceNorm makes the maps identical, and sub-clips / time-reversed clips become frame-index maps;
+    * queries on several frames and on the last frame work (the reference raises IndexError at tracker.py:121 for the
+      former and returns T-1 frames for the latter — see oracle/pips2_ref.py);
+    * ``image_size`` (bilinear pre-resize to a float video, off in the shipped config) is not built.
+    """
+
+    def __init__(self, checkpoint_path=None, stride=8, max_sequence_length=128, iters=16, image_size=None,
+                 state_dict: Optional[Dict[str, torch.Tensor]] = None, seed: int = 72, fnet_chunk: int = 8):
+        super().__init__()
+        if image_size is not None:
+            raise NotImplementedError("PipsPlusPlusPointTracker(image_size=...) is not built; the shipped config uses null")
+        from .weights import init_pips2_state_dict
+        self.checkpoint_path, self.stride = checkpoint_path, stride
+        self.max_sequence_length, self.iters, self.image_size = max_sequence_length, iters, None
+        sd = state_dict if state_dict is not None else load_pips_checkpoint(checkpoint_path)
+        self._sd = sd if sd is not None else init_pips2_state_dict(seed)
+        self.fnet_chunk = fnet_chunk
+        self._h = None
+        self._device = None
+        self.stats = {"chunks": 0, "fnet_frames": 0}
+
+    def _ensure(self, device: torch.device):
+        if self._h is not None and self._device == device:
+            return
+        if device.type != "cuda":
+            raise _lib.SamptError("PipsPlusPlusPointTracker runs on the HIP device only (no CPU fallback); got " + str(device))
+        from .pack import pack_pips2
+        lib = _lib.load()
+        self._w = pack_pips2(self._sd, device)
+        names, ptrs, n = _lib.name_table(self._w)
+        h = C.c_void_p()
+        _lib.check(lib.sampt_pips2_create(names, ptrs, n, self.stride, C.byref(h)), "sampt_pips2_create")
+        self._h, self._device, self._lib = h, device, lib
+
+    def __del__(self):
+        if getattr(self, "_h", None) is not None:
+            try:
+                self._lib.sampt_pips2_destroy(self._h)
+            except Exception:
+                pass
+
+    def compute_pyramid(self, frames: torch.Tensor):
+        """frames (T,3,H,W) uint8 on device -> 4 NHWC f32 levels [T][H/8 >> l][W/8 >> l][128]."""
+        self._ensure(frames.device)
+        T, _, H, W = frames.shape
+        H0, W0 = H // self.stride, W // self.stride
+        pyr = [torch.empty((T, H0 >> l, W0 >> l, 128), dtype=torch.float32, device=frames.device) for l in range(4)]
+        chunk = min(self.fnet_chunk, T)
+        nbytes = C.c_size_t()
+        _lib.check(self._lib.sampt_pips2_fnet_workspace_bytes(self._h, chunk, H, W, C.byref(nbytes)), "fnet_workspace")
+        ws = torch.empty(nbytes.value, dtype=torch.uint8, device=frames.device)
+        frames = frames.contiguous()
+        for t0 in range(0, T, chunk):
+            nf = min(chunk, T - t0)
+            outs = _lib.ptr_array([p[t0:t0 + nf] for p in pyr])
+            _lib.check(self._lib.sampt_pips2_fnet_f32(self._h, _lib.ptr(frames[t0:t0 + nf]), nf, H, W, outs, _lib.ptr(ws),
+                                                      ws.numel(), _lib.stream_ptr()), "sampt_pips2_fnet_f32")
+        self.stats["fnet_frames"] += T
+        return pyr
+
+    def prepare(self, frames: torch.Tensor):
+        self._prepared = ((frames.data_ptr(), tuple(frames.shape)), self.compute_pyramid(frames))
+
+    def _track(self, pyr, frame_ids: List[int], query_xy: torch.Tensor) -> torch.Tensor:
+        """One direction (tracker.py:26-62): the clip is ``frame_ids`` (pyramid frame of every time step); chunks of
+        ``max_sequence_length`` frames overlapping by one, templates carried from chunk to chunk.  -> (S,N,2) on device."""
+        dev = pyr[0].device
+        S_all, N = len(frame_ids), query_xy.shape[0]
+        H0, W0 = pyr[0].shape[1:3]
+        trajs = query_xy.to(dev)[None].repeat(S_all, 1, 1).contiguous()          # zero-velocity init
+        pyr_ptrs = _lib.ptr_array(pyr)
+        cur, done, have_init = 0, False, 0
+        feats = None
+        while not done:
+            end = cur + self.max_sequence_length
+            if end > S_all:
+                diff = end - S_all
+                end -= diff
+                cur = max(cur - diff, 0)
+            S = end - cur
+            fidx = torch.tensor(frame_ids[cur:end], dtype=torch.int32)[None].repeat(N, 1).contiguous().to(dev)
+            if feats is None:
+                feats = [torch.empty((N, S, 128), dtype=torch.float32, device=dev) for _ in range(3)]
+            else:                                                                # feat_init[:, :S_local] (tracker.py:52-54)
+                feats = [f[:, :S].contiguous() for f in feats]
+            nbytes = C.c_size_t()
+            _lib.check(self._lib.sampt_pips2_update_workspace_bytes(self._h, N, S, C.byref(nbytes)), "update_workspace")
+            ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+            t0 = trajs[cur:end].contiguous()
+            out = torch.empty_like(t0)
+            _lib.check(self._lib.sampt_pips2_update_f32(self._h, pyr_ptrs, H0, W0, _lib.ptr(fidx), N, S, _lib.ptr(t0),
+                                                        have_init, _lib.ptr_array(feats), self.iters, _lib.ptr(out),
+                                                        _lib.ptr(ws), ws.numel(), _lib.stream_ptr()),
+                       "sampt_pips2_update_f32")
+            trajs[cur:end] = out
+            trajs[end:] = trajs[end - 1:end]                                     # zero-velocity for the future
+            have_init = 1
+            self.stats["chunks"] += 1
+            if end >= S_all:
+                done = True
+            else:
+                cur = cur + self.max_sequence_length - 1
+        return trajs
+
+    def forward(self, rgbs, query_points):
+        if rgbs.shape[0] != 1:
+            raise NotImplementedError("Only batch size 1 is supported.")          # tracker.py:83
+        assert rgbs.dtype == torch.uint8, "rgbs must be uint8 (PointTracker.forward contract)"
+        dev = rgbs.device
+        self._ensure(dev)
+        frames = rgbs[0]
+        T = frames.shape[0]
+        prepared = getattr(self, "_prepared", None)
+        if prepared is not None and prepared[0] == (frames.data_ptr(), tuple(frames.shape)):
+            pyr = prepared[1]
+        else:
+            pyr = self.compute_pyramid(frames)
+        q = query_points[0].detach().float().cpu()
+        N = q.shape[0]
+        groups: Dict[int, List[int]] = {}
+        for i in range(N):
+            groups.setdefault(int(q[i, 0].item()), []).append(i)
+        traj = torch.zeros((T, N, 2), dtype=torch.float32, device=dev)
+        for t, idxs in groups.items():                                           # tracker.py:84-122
+            xy = q[idxs, 1:].contiguous()
+            if t != T - 1:
+                traj[t:, idxs] = self._track(pyr, list(range(t, T)), xy)
+            if t != 0:
+                right = self._track(pyr, list(range(t, -1, -1)), xy).flip(0)     # frames 0..t
+                traj[:t + 1 if t == T - 1 else t, idxs] = right if t == T - 1 else right[:-1]
+        vis = torch.ones((1, T, N), dtype=torch.float32, device=dev)             # PIPS++ predicts no visibility (:64)
+        return traj.unsqueeze(0), vis

@@ -468,3 +468,77 @@ def test_many_objects_long_prompts(dev):
     assert max_abs(l_f[:, :1].cpu(), l_r) < 3e-3
     for m in range(M):
         assert iou(l_f[m, 0].cpu() > 0, l_r[m, 0] > 0) >= 1 - 1e-3
+
+
+# ------------------------------------------------------------------------------------------ PIPS++ (row f4)
+def test_pips2_chunk_vs_oracle(dev, clip):
+    """Stride-8 encoder + one PIPS++ chunk (16 iterations of: 3-template local correlation, sincos flow embedding, 1-D
+    ResNet over time) through the C ABI against the CPU oracle (bit-identical to the reference model, test_oracle_pins)."""
+    from oracle import pips2_ref as O2
+    from oracle import pips_ref as O1
+    from sam_pt_amd.point_tracker import PipsPlusPlusPointTracker
+    from sam_pt_amd.weights import init_pips2_state_dict
+    frames, centres = clip
+    sd = init_pips2_state_dict(72)
+    trk = PipsPlusPlusPointTracker(state_dict=sd, iters=16)
+    pyr = trk.compute_pyramid(frames.to(dev))
+    fm = O2.fnet(sd, O1.normalize_rgbs(frames), 8)                                # (12,128,16,32)
+    assert rel_err(pyr[0].permute(0, 3, 1, 2), fm) < 2e-5
+    q = disc_queries(centres, n_pos=5, r=9.0)[:, 1:]
+    preds, _ = O2.pips2_forward(sd, q[None].repeat(12, 1, 1), fm, iters=16)
+    got = trk._track(pyr, list(range(12)), q)
+    assert max_abs(got, preds[-1]) < 5e-3
+    assert torch.equal(got.cpu().round(), preds[-1].round())
+
+
+def test_pips2_tracker_vs_reference_golden(dev, clip):
+    """HIP PipsPlusPlusPointTracker against the committed outputs of the REFERENCE's tracker (single query frame, with and
+    without chunking) and, for what the reference cannot run (several query frames, a query on the last frame), against
+    the oracle."""
+    import os
+    from oracle import pips2_ref as O2
+    from sam_pt_amd.point_tracker import PipsPlusPlusPointTracker
+    from sam_pt_amd.weights import init_pips2_state_dict
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pips2.npz"))
+    frames, centres = clip
+    sd = init_pips2_state_dict(72)
+    for name, maxlen, iters in (("t0", 128, 16), ("t5", 128, 8), ("t5_chunked", 5, 3)):
+        trk = PipsPlusPlusPointTracker(state_dict=sd, max_sequence_length=maxlen, iters=iters)
+        q = torch.from_numpy(g[f"trk_{name}_q"])
+        tr, vi = trk(frames[None].to(dev), q.to(dev))
+        assert np.abs(tr.cpu().numpy() - g[f"trk_{name}_traj"]).max() < 5e-3, name
+        assert np.array_equal(np.round(tr.cpu().numpy()), np.round(g[f"trk_{name}_traj"])), name
+        assert np.array_equal(vi.cpu().numpy(), g[f"trk_{name}_vis"])
+    q = torch.cat([disc_queries(centres, n_pos=3, r=9.0, t=0), disc_queries(centres, n_pos=2, r=6.0, t=5),
+                   disc_queries(centres, n_pos=1, r=3.0, t=11)])[None]
+    trk = PipsPlusPlusPointTracker(state_dict=sd, iters=8)
+    tr, vi = trk(frames[None].to(dev), q.to(dev))
+    tr_ref, vi_ref = O2.Pips2TrackerRef(sd, 8, 128, 8).forward(frames[None], q)
+    assert max_abs(tr, tr_ref) < 5e-3 and torch.equal(vi.cpu(), vi_ref)
+    for i in range(q.shape[1]):                                                   # query frame holds the query point
+        t = int(q[0, i, 0])
+        assert torch.allclose(tr[0, t, i].cpu(), q[0, i, 1:], atol=1e-4)
+
+
+def test_sampt_with_pips2_tracker(dev, clip):
+    """SamPt on the device path with the PIPS++ tracker (second-stream overlap, prepare()): trajectories are the
+    tracker's, masks equal the call-by-call protocol on the same trajectories."""
+    from sam_pt_amd.point_tracker import PipsPlusPlusPointTracker
+    from sam_pt_amd.sam_predictor import SamHip, SamPredictor
+    from sam_pt_amd.sam_pt import SamPt
+    from sam_pt_amd.weights import SAM_CONFIGS
+    frames, centres = clip
+    cfg = SAM_CONFIGS["vit_test"]
+    q = disc_queries(centres, n_pos=4, r=9.0)
+    video = {"image": [f for f in frames[:8]], "target_hw": (128, 256), "query_points": q[None]}
+    trk = PipsPlusPlusPointTracker(seed=72, iters=4)
+    pred = SamPredictor(SamHip(config=cfg, seed=72, precision="f32").to(dev))
+    model = SamPt(trk, pred, sam_iou_threshold=-1e9, positive_points_per_mask=4, negative_points_per_mask=0,
+                  iterative_refinement_iterations=2).eval()
+    out = model(video)
+    tr, _ = trk(frames[None, :8].to(dev), q[None].to(dev))
+    assert max_abs(out["trajectories"][:, 0], tr[0]) < 1e-4
+    images = frames[:8].to(dev)
+    _, l_s, _ = model._apply_sam_to_trajectories(images, out["trajectories"].cpu(), out["visibilities"].cpu(), None)
+    l_f = torch.stack(out["logits"]).cpu()
+    assert max_abs(l_f, l_s) < 2e-3
