@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--refine", type=int, default=12)
     ap.add_argument("--precision", default="f16", choices=["f16", "f32"])
     ap.add_argument("--encode-batch", type=int, default=8)
+    ap.add_argument("--tracker", default="pips", choices=["pips", "pips_plus_plus"],
+                    help="point tracker (the metric is quoted on PIPS; PIPS++ = SURVEY.md §8 row f4)")
     ap.add_argument("--hq", action="store_true", help="HQ-SAM decoder (reference default samhq_vit_huge; BASELINE config #5)")
     ap.add_argument("--pips-vis-bias", type=float, default=2.0,
                     help="bias of the random PIPS visibility head (weights.py default 2.0 -> sigmoid 0.88, just under the 0.9 "
@@ -52,7 +54,11 @@ def build_model(args, dev):
     from sam_pt_amd.sam_pt import SamPt
     sam = SamHip(args.model, precision=args.precision, seed=72, max_batch=args.encode_batch, hq=args.hq).to(dev)
     from sam_pt_amd.weights import init_pips_state_dict
-    tracker = PipsPointTracker(state_dict=init_pips_state_dict(72, vis_bias=args.pips_vis_bias), fnet_chunk=8)
+    if args.tracker == "pips":
+        tracker = PipsPointTracker(state_dict=init_pips_state_dict(72, vis_bias=args.pips_vis_bias), fnet_chunk=8)
+    else:
+        from sam_pt_amd.point_tracker import PipsPlusPlusPointTracker
+        tracker = PipsPlusPlusPointTracker(seed=72, fnet_chunk=8)
     model = SamPt(tracker, SamPredictor(sam), sam_iou_threshold=-1e9,
                   positive_points_per_mask=args.points, negative_points_per_mask=0,
                   iterative_refinement_iterations=args.refine, point_tracker_mask_batch_size=5).eval()
@@ -216,7 +222,7 @@ def main():
                "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None,
                "dtype": "f16" if args.precision == "f16" else "f32", "data": "synthetic",
-               "config": {"workload": f"{'HQ-SAM' if args.hq else 'SAM'} {args.model} + PIPS, {args.points} query points, {args.objects} object(s), "
+               "config": {"workload": f"{'HQ-SAM' if args.hq else 'SAM'} {args.model} + {'PIPS' if args.tracker == 'pips' else 'PIPS++'}, {args.points} query points, {args.objects} object(s), "
                                       f"{args.frames}x 480p synthetic frames upscaled to {H}x{W}, "
                                       f"{args.refine} refinement iterations, random-init weights (seed 72)",
                           "frames_per_step": args.frames, "parallelism": f"sequence-sharded x{world}",
