@@ -10,7 +10,9 @@ Needed by ``SamPt`` in ``query_masks`` mode (every VOS run, sam_pt.py:171-177) a
   euclidean metric, ``method='alternate'``, ``init='heuristic'``, ``max_iter=300``).  scikit-learn-extra is a
   third-party dependency that is absent here, so ``kmedoids_alternate`` restates its published algorithm; **parity
   unpinned** for this function.
-* Shi-Tomasi corners / "mixed" selection need ``cv2.goodFeaturesToTrack`` (absent): ``NotImplementedError``.
+* ``extract_mixed_points`` — the reference's n/4 k-medoid + n/3 Shi-Tomasi + rest random split; with the shipped default
+  of one negative point it is a single random point.  Shi-Tomasi corners themselves (``cv2.goodFeaturesToTrack`` on an
+  eroded mask) need cv2, which is absent: ``NotImplementedError`` once a Shi-Tomasi share is requested (n >= 3).
 """
 from __future__ import annotations
 
@@ -70,12 +72,40 @@ def extract_kmedoid_points(mask: torch.Tensor, n_points_to_select: int, subsampl
     return sel.flip(1)
 
 
+def extract_corner_points(image, mask, n_points_to_select):
+    """Shi-Tomasi corners inside the (eroded) mask (query_points.py:102-162) — needs cv2.goodFeaturesToTrack / cv2.erode,
+    which are absent here and have nothing to be pinned against."""
+    raise NotImplementedError("point selection method 'shi-tomasi' needs cv2.goodFeaturesToTrack (absent in this build)")
+
+
+def extract_mixed_points(query_masks, query_points_timestep, images, n_points: int) -> List[torch.Tensor]:
+    """n/4 k-medoid + n/3 Shi-Tomasi + the rest random points per mask, in that order (query_points.py:197-237).  The
+    shipped default (configs/model/sam_pt.yaml: 1 negative point, method "mixed") degenerates to ONE RANDOM point; the
+    Shi-Tomasi share only exists from n = 3 on and then needs cv2 (see ``extract_corner_points``)."""
+    n_kmedoid, n_shi_tomasi = n_points // 4, n_points // 3
+    n_random = n_points - n_kmedoid - n_shi_tomasi
+    parts = []
+    if n_kmedoid > 0:
+        parts.append([extract_kmedoid_points(qm, n_kmedoid) for qm in query_masks])
+    if n_shi_tomasi > 0:
+        parts.append([extract_corner_points(images[int(t.item())], qm, n_shi_tomasi)
+                      for qm, t in zip(query_masks, query_points_timestep)])
+    if n_random > 0:
+        parts.append([extract_random_mask_points(qm, n_random) for qm in query_masks])
+    if len(parts) == 1:
+        return parts[0]
+    return [torch.cat(x, dim=0) for x in zip(*parts)]
+
+
 def extract_query_points_xy(images, query_masks, query_points_timestep, method: str, points_per_mask: int) -> List[torch.Tensor]:
     """Dispatch of SamPt._extract_query_points_xy (sam_pt.py:290-306)."""
     if method == "kmedoids":
         return [extract_kmedoid_points(qm, points_per_mask) for qm in query_masks]
     if method == "random":
         return [extract_random_mask_points(qm, points_per_mask) for qm in query_masks]
-    if method in ("shi-tomasi", "mixed"):
-        raise NotImplementedError(f"point selection method '{method}' needs cv2.goodFeaturesToTrack (absent in this build)")
+    if method == "shi-tomasi":
+        return [extract_corner_points(images[int(t.item())], qm, points_per_mask)
+                for qm, t in zip(query_masks, query_points_timestep)]
+    if method == "mixed":
+        return extract_mixed_points(query_masks, query_points_timestep, images, points_per_mask)
     raise NotImplementedError(f"Point selection method {method} not implemented")
