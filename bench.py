@@ -83,11 +83,9 @@ def gemm_roofline(args, dev):
     lib = _lib.load()
     cfg = SAM_CONFIGS[args.model]
     B, D = args.encode_batch, cfg.embed_dim
-    Mg, Mw = B * 4096, B * 25 * 196
-    nglob = len(cfg.global_attn_indexes)
-    nwin = cfg.depth - nglob
+    Mg = B * 4096        # windowed blocks also run their GEMMs on the real tokens only (padding rows are never multiplied)
     shapes = [  # (M, N, K, dtype(2 = f16 out, 1 = f32 out), count per encode call)
-        (Mw, 3 * D, D, 2, nwin), (Mg, 3 * D, D, 2, nglob), (Mw, D, D, 1, nwin), (Mg, D, D, 1, nglob),
+        (Mg, 3 * D, D, 2, cfg.depth), (Mg, D, D, 1, cfg.depth),
         (Mg, 4 * D, D, 2, cfg.depth), (Mg, D, 4 * D, 1, cfg.depth), (Mg, D, 768, 1, 1), (Mg, 256, D, 1, 1)]
     tot_flop = tot_t = 0.0
     launches = 0

@@ -78,6 +78,7 @@ struct GemmP {
   const float* res = nullptr;    // residual, f32, row stride ldr, or null
   void* C = nullptr;
   const int* rowmap = nullptr;   // optional: destination row of C/res for GEMM row m (-1 = drop the row)
+  const int* a_rowmap = nullptr; // optional: GEMM row m reads row a_rowmap[m] of A (gather; plain GEMMs only)
   int M = 0, N = 0, K = 0;
   int lda = 0, ldw = 0, ldc = 0, ldr = 0;
   // batching: blockIdx.z = z1 * nb2 + z2, element strides

@@ -482,4 +482,20 @@ int index_masks(const float* logits, int M, long npix, uint8_t* out, hipStream_t
   return SAMPT_OK;
 }
 
+// rows[i] of a [*][N] matrix := bias (the qkv of SAM's zero-padded window tokens is the bias alone, App. A-3)
+template <typename T>
+__global__ void k_fill_rows_bias(T* __restrict__ out, const int* __restrict__ rows, const float* __restrict__ bias, int N) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < N) out[(long)rows[blockIdx.y] * N + c] = (T)bias[c];
+}
+
+int fill_rows_bias(void* out, int f16, const int* rows, int nrows, const float* bias, int N, hipStream_t s) {
+  if (nrows <= 0) return SAMPT_OK;
+  dim3 grid(cdiv(N, 256), nrows);
+  if (f16) hipLaunchKernelGGL(k_fill_rows_bias<half_t>, grid, dim3(256), 0, s, (half_t*)out, rows, bias, N);
+  else hipLaunchKernelGGL(k_fill_rows_bias<float>, grid, dim3(256), 0, s, (float*)out, rows, bias, N);
+  SAMPT_CHECK_LAUNCH("fill_rows_bias");
+  return SAMPT_OK;
+}
+
 }  // namespace sampt

@@ -114,6 +114,8 @@ struct VitEngine {
   const void *patch_w, *neck0_w, *neck2_w;
   const float *patch_b, *pos, *neck1w, *neck1b, *neck3w, *neck3b;
   const int* win_rows;  // [Bmax * nwin * window^2] -> token row or -1
+  const int* win_inv;   // [Bmax * grid^2] token row -> window-order row
+  const int* win_pad;   // [Bmax * npad] window-order rows that are zero padding
   int win_rows_batches = 0;
   std::string error;
 

@@ -33,6 +33,7 @@ int VitEngine::init(const WeightMap& w, const VitConfig& cfg, int wrb) {
   neck2_w = w.get(e + "neck.2.weight_khwc" + sfx);  // repacked [Cout][ky][kx][Cin]
   neck3w = w.f(e + "neck.3.weight"), neck3b = w.f(e + "neck.3.bias");
   win_rows = w.i("__win_rows");
+  win_inv = w.i("__win_inv"), win_pad = w.i("__win_pad");
   if (!w.missing.empty()) {
     error = "VitEngine: missing weights: " + w.missing;
     return SAMPT_ERR_ARG;
@@ -46,9 +47,9 @@ struct G {
   hipStream_t s;
   // C = act(A.W^T + bias) (+ residual at the (row-mapped) destination row)
   int run(const void* A, int M, int K, const void* W, const float* bias, void* C, int N, int act, bool out_f16,
-          const float* res, int ldr, const int* rowmap, int res_mod) const {
+          const float* res, int ldr, const int* rowmap, int res_mod, const int* a_rowmap = nullptr) const {
     GemmP p;
-    p.A = A, p.W = W, p.bias = bias, p.C = C, p.res = res, p.rowmap = rowmap;
+    p.A = A, p.W = W, p.bias = bias, p.C = C, p.res = res, p.rowmap = rowmap, p.a_rowmap = a_rowmap;
     p.M = M, p.N = N, p.K = K, p.lda = K, p.ldw = K, p.ldc = N, p.ldr = ldr, p.act = act, p.res_mod = res_mod;
     p.out_f16 = out_f16 ? 1 : 0;
     return f16 ? gemm_f16(p, s) : gemm_f32(p, s);
@@ -101,10 +102,12 @@ int VitEngine::encode(const uint8_t* frames, int chw, int B, int H, int W, float
     const int S = glob ? g : ws_, N = S * S;
     const int Bw = glob ? B : B * nwin;
     const long M = (long)Bw * N;
-    const int* map = glob ? nullptr : win_rows;
-    // norm1 (+ window partition with zero padding AFTER the norm)
-    SAMPT_TRY(layernorm_rows(x, b.ln1w, b.ln1b, xn, M, D, 1e-6f, map, c.f16, ACT_NONE, s));
-    SAMPT_TRY(gm.run(xn, (int)M, D, b.qkv_w, b.qkv_b, qkv, 3 * D, ACT_NONE, c.f16 != 0, nullptr, 0, nullptr, 0));
+    const int* inv = glob ? nullptr : win_inv;
+    // norm1; the window partition (zero padding AFTER the norm, App. A-3) is a row scatter of the qkv GEMM: only the
+    // real tokens go through the GEMM, the padded rows' qkv is the bias alone
+    SAMPT_TRY(layernorm_rows(x, b.ln1w, b.ln1b, xn, Mg, D, 1e-6f, nullptr, c.f16, ACT_NONE, s));
+    SAMPT_TRY(gm.run(xn, (int)Mg, D, b.qkv_w, b.qkv_b, qkv, 3 * D, ACT_NONE, c.f16 != 0, nullptr, 0, inv, 0));
+    if (!glob) SAMPT_TRY(fill_rows_bias(qkv, c.f16, win_pad, (int)(M - Mg), b.qkv_b, 3 * D, s));
     if (c.f16) {
       SAMPT_TRY(vit_flash_attention_f16((const half_t*)qkv, b.rel_h, b.rel_w, (half_t*)att, Bw, S, c.heads, hd, s));
     } else {
@@ -127,8 +130,8 @@ int VitEngine::encode(const uint8_t* frames, int chw, int B, int H, int W, float
       v.sC1 = (long)N * D, v.sC2 = hd;
       SAMPT_TRY(gemm_f32(v, s));
     }
-    // proj + bias + residual, un-partitioning windows through the row map (padded rows are dropped)
-    SAMPT_TRY(gm.run(att, (int)M, D, b.proj_w, b.proj_b, x, D, ACT_NONE, false, x, D, map, 0));
+    // proj + bias + residual on the real tokens: A rows are gathered from the window-ordered attention output
+    SAMPT_TRY(gm.run(att, (int)Mg, D, b.proj_w, b.proj_b, x, D, ACT_NONE, false, x, D, nullptr, 0, inv));
     // MLP
     SAMPT_TRY(layernorm_rows(x, b.ln2w, b.ln2b, xn, Mg, D, 1e-6f, nullptr, c.f16, ACT_NONE, s));
     SAMPT_TRY(gm.run(xn, (int)Mg, D, b.w1, b.b1, hid, c.mlp_ratio * D, ACT_GELU, c.f16 != 0, nullptr, 0, nullptr, 0));

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
       a_iy0[i] = oy * p.cstride - p.cpad;
       a_ix0[i] = ox * p.cstride - (p.cpadw >= 0 ? p.cpadw : p.cpad);
     } else {
-      a_off[i] = (long)m * p.lda;
+      a_off[i] = (long)(p.a_rowmap && a_ok[i] ? p.a_rowmap[m] : m) * p.lda;
       a_iy0[i] = a_ix0[i] = 0;
     }
   }
@@ -321,7 +321,7 @@ static int gemm_dispatch(const GemmP& p_in, hipStream_t s) {
   if (((uintptr_t)p.A | (uintptr_t)p.W) & 15) return SAMPT_ERR_ARG;
   if ((p.sA1 | p.sA2 | p.sW1 | p.sW2) % VEC) return SAMPT_ERR_ARG;
   const int batch = p.nb1 * p.nb2;
-  const bool plain = !p.conv && !p.w_kn && batch == 1 && !p.rowmap;
+  const bool plain = !p.conv && !p.w_kn && batch == 1 && !p.rowmap && !p.a_rowmap;
 
   // ---- skinny path
   if constexpr (sizeof(T) == 4) {

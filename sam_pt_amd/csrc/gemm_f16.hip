@@ -85,6 +85,7 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64, OCC) void gemm_f16_gl
     const int chunk = (lane & 7) ^ (MF == 16 ? (trow & 7) : ((trow >> 1) & 7));
     int row = m0 + trow;
     if (row > p.M - 1) row = p.M - 1;
+    if (p.a_rowmap) row = p.a_rowmap[row];
     a_src[i] = A + (long)row * p.lda + chunk * 8;
   }
 #pragma unroll

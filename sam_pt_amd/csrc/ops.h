@@ -68,6 +68,7 @@ int pips_corr_sample(const PyramidLevels& pyr, const int* frame_idx, int S, int 
 // times: device [S] = torch.linspace(0, S, S) (pips.py:527)
 int pips_build_input(const float* ffeats, const float* coords, const float* times, int S, int n, float* x, int ldx,
                      hipStream_t s);
+int fill_rows_bias(void* out, int f16, const int* rows, int nrows, const float* bias, int N, hipStream_t s);
 // ---- PIPS++ (pips2.hip; pips_plus_plus.py:263-342, 436-546) — rows are (point, frame): row = pt*S + s
 int pips2_init(const float* trajs0, const float* fmap, int H, int W, const int* frame_idx, float stride, int S, int n,
                int have_init, float* coords, float* bak, float* f1, float* f2, float* f4, hipStream_t s);

@@ -103,7 +103,15 @@ def pack_vit(sd: Dict[str, torch.Tensor], cfg: SamConfig, device, f16: bool, win
             out[k + (".f16" if f16 else "")] = w.half() if f16 else w
         else:
             out[k] = v.contiguous()
-    out["__win_rows"] = window_row_map(cfg.grid, cfg.window_size, win_batches)
+    rows = window_row_map(cfg.grid, cfg.window_size, win_batches)
+    out["__win_rows"] = rows
+    # token row -> row in window order (a permutation into the padded layout), and the padded rows themselves: the
+    # qkv / proj GEMMs of windowed blocks then run on the REAL tokens only (padding adds 20 % rows at grid 64, window 14)
+    valid = (rows >= 0).nonzero().flatten()
+    inv = torch.empty(win_batches * cfg.grid * cfg.grid, dtype=torch.int32)
+    inv[rows[valid].long()] = valid.to(torch.int32)
+    out["__win_inv"] = inv
+    out["__win_pad"] = (rows < 0).nonzero().flatten().to(torch.int32)
     return {k: v.to(device) for k, v in out.items()}
 
 
