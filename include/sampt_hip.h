@@ -172,6 +172,11 @@ int sampt_bbox_from_logits(const float* logits_dev, int h, int w, int32_t* bbox_
  * {background logit 0, logits_dev[M][npix]}, i.e. the bg-stack + softmax + argmax of vos_eval/eval.py:304, 326, 355. */
 int sampt_resize_logits(const float* src_dev, int n, int sh, int sw, float* dst_dev, int dh, int dw, sampt_stream_t stream);
 int sampt_index_masks(const float* logits_dev, int M, long npix, uint8_t* out_dev, sampt_stream_t stream);
+/* The same for logits_dev [M][T][hw] with the evaluator's overrides (vos_eval/eval.py:318-326): object m is -1e8 on
+ * frames before query_t_dev[m] (int32 [M]) and, when gt_masks_dev (uint8 [M][hw], already at this resolution) is given,
+ * +-1e8 from its ground-truth mask on the query frame.  out_dev uint8 [T][hw]. */
+int sampt_vos_index_masks(const float* logits_dev, int M, int T, long hw, const int32_t* query_t_dev,
+                          const uint8_t* gt_masks_dev, uint8_t* out_dev, sampt_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Kernel-level entry points (used by the parity tests and the roofline bench; same kernels the engines launch).

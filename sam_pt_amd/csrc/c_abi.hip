@@ -343,6 +343,12 @@ int sampt_resize_logits(const float* src, int n, int sh, int sw, float* dst, int
   return resize_logits(src, n, sh, sw, dst, dh, dw, (hipStream_t)stream);
 }
 
+int sampt_vos_index_masks(const float* logits, int M, int T, long hw, const int32_t* query_t, const uint8_t* gt_masks,
+                          uint8_t* out, sampt_stream_t stream) {
+  if (!logits || !out || !query_t || T <= 0 || hw <= 0) return SAMPT_ERR_ARG;
+  return vos_index_masks(logits, M, T, hw, (const int*)query_t, gt_masks, out, (hipStream_t)stream);
+}
+
 int sampt_index_masks(const float* logits, int M, long npix, uint8_t* out, sampt_stream_t stream) {
   if (!logits || !out || npix <= 0) return SAMPT_ERR_ARG;
   return index_masks(logits, M, npix, out, (hipStream_t)stream);

@@ -482,6 +482,36 @@ int index_masks(const float* logits, int M, long npix, uint8_t* out, hipStream_t
   return SAMPT_OK;
 }
 
+// VOS variant (vos_eval/eval.py:318-326): object m's logits are -1e8 on the frames before its query frame qt[m], and on
+// the query frame itself they are replaced by the ground-truth mask (+1e8 inside, -1e8 outside) before the argmax
+__global__ void k_vos_index_masks(const float* __restrict__ logits, int M, int T, long hw, const int* __restrict__ qt,
+                                  const uint8_t* __restrict__ gt, uint8_t* __restrict__ out) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)T * hw) return;
+  const int t = (int)(i / hw);
+  const long p = i - (long)t * hw;
+  float best = 0.f;
+  int arg = 0;
+  for (int m = 0; m < M; ++m) {
+    float v = logits[((long)m * T + t) * hw + p];
+    if (t < qt[m]) v = -1e8f;
+    else if (t == qt[m] && gt) v = gt[(long)m * hw + p] ? 1e8f : -1e8f;
+    if (v > best) {
+      best = v;
+      arg = m + 1;
+    }
+  }
+  out[i] = (uint8_t)arg;
+}
+
+int vos_index_masks(const float* logits, int M, int T, long hw, const int* qt, const uint8_t* gt, uint8_t* out,
+                    hipStream_t s) {
+  if (M <= 0 || M > 254 || !qt) return SAMPT_ERR_ARG;
+  hipLaunchKernelGGL(k_vos_index_masks, dim3(cdiv((long)T * hw, 256)), dim3(256), 0, s, logits, M, T, hw, qt, gt, out);
+  SAMPT_CHECK_LAUNCH("vos_index_masks");
+  return SAMPT_OK;
+}
+
 // rows[i] of a [*][N] matrix := bias (the qkv of SAM's zero-padded window tokens is the bias alone, App. A-3)
 template <typename T>
 __global__ void k_fill_rows_bias(T* __restrict__ out, const int* __restrict__ rows, const float* __restrict__ bias, int N) {

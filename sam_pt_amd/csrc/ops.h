@@ -68,6 +68,8 @@ int pips_corr_sample(const PyramidLevels& pyr, const int* frame_idx, int S, int 
 // times: device [S] = torch.linspace(0, S, S) (pips.py:527)
 int pips_build_input(const float* ffeats, const float* coords, const float* times, int S, int n, float* x, int ldx,
                      hipStream_t s);
+int vos_index_masks(const float* logits, int M, int T, long hw, const int* qt, const uint8_t* gt, uint8_t* out,
+                    hipStream_t s);
 int fill_rows_bias(void* out, int f16, const int* rows, int nrows, const float* bias, int N, hipStream_t s);
 // ---- PIPS++ (pips2.hip; pips_plus_plus.py:263-342, 436-546) — rows are (point, frame): row = pt*S + s
 int pips2_init(const float* trajs0, const float* fmap, int H, int W, const int* frame_idx, float stride, int S, int n,

@@ -49,18 +49,34 @@ def frame_batches(n_frames: int, world: int, rank: int, batch: int = 8) -> List[
     return [range(s, min(s + batch, n_frames)) for i, s in enumerate(starts) if i % world == rank]
 
 
-def index_masks(logits: torch.Tensor) -> torch.Tensor:
+def index_masks(logits: torch.Tensor, query_timestep=None, query_masks=None) -> torch.Tensor:
     """(M,T,H,W) per-object logits -> uint8 (T,H,W) object index map with background 0 (bg logit 0 stacked in front,
-    softmax/argmax over objects: sam_pt/vos_eval/eval.py:304, 326, 355)."""
+    softmax/argmax over objects: sam_pt/vos_eval/eval.py:304, 326, 355).  With ``query_timestep`` (M,) the evaluator's
+    overrides are applied first (eval.py:318-323): object m is -1e8 before its query frame, and on the query frame its
+    logits are +-1e8 from ``query_masks`` (M,H,W) {0,1} when given (resized with ``nearest`` to (H,W) by the caller)."""
     M, T, H, W = logits.shape
     if logits.is_cuda:
         from . import _lib
         lib = _lib.load()
         logits = logits.contiguous()
         out = torch.empty((T, H, W), dtype=torch.uint8, device=logits.device)
-        _lib.check(lib.sampt_index_masks(_lib.ptr(logits), M, T * H * W, _lib.ptr(out), _lib.stream_ptr()), "sampt_index_masks")
+        if query_timestep is None:
+            _lib.check(lib.sampt_index_masks(_lib.ptr(logits), M, T * H * W, _lib.ptr(out), _lib.stream_ptr()),
+                       "sampt_index_masks")
+        else:
+            qt = torch.as_tensor(query_timestep).to(logits.device, torch.int32).contiguous()
+            gt = None if query_masks is None else (query_masks.to(logits.device) > 0).to(torch.uint8).contiguous()
+            _lib.check(lib.sampt_vos_index_masks(_lib.ptr(logits), M, T, H * W, _lib.ptr(qt), _lib.ptr(gt), _lib.ptr(out),
+                                                 _lib.stream_ptr()), "sampt_vos_index_masks")
         return out
-    bg = torch.zeros((1, T, H, W), dtype=logits.dtype, device=logits.device)      # host-side helper for CPU tests
+    logits = logits.clone()                                                       # host-side helper for CPU tests
+    if query_timestep is not None:
+        for m in range(M):
+            t = int(query_timestep[m])
+            logits[m, :t] = -1e8
+            if query_masks is not None:
+                logits[m, t] = torch.where(query_masks[m] > 0, 1e8, -1e8)
+    bg = torch.zeros((1, T, H, W), dtype=logits.dtype, device=logits.device)
     prob = torch.softmax(torch.cat([bg, logits], dim=0), dim=0)
     return prob.argmax(dim=0).to(torch.uint8)
 

@@ -140,3 +140,20 @@ dist.barrier(); dist.destroy_process_group()
         os.unlink(path)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "GATHER_OK" in r.stdout
+
+
+def test_vos_index_masks_formula_matches_the_evaluator():
+    """dist.index_masks with query-frame overrides == the reference evaluator's sequence (vos_eval/eval.py:304-326)."""
+    from sam_pt_amd.dist import index_masks
+    g = torch.Generator().manual_seed(5)
+    M, T, H, W = 3, 5, 24, 40
+    logits = torch.randn(M, T, H, W, generator=g) * 3
+    qt = torch.tensor([0, 2, 4])
+    gt = (torch.rand(M, H, W, generator=g) > 0.6).float()
+    lg = torch.stack([torch.zeros(T, H, W)] + [l for l in logits], dim=1)        # (T, M+1, H, W), bg first
+    for i, t in enumerate(qt):
+        lg[:t, i + 1] = -1e8
+    for i, t in enumerate(qt):
+        lg[t, i + 1] = torch.where(gt[i].bool(), 1e8, -1e8)
+    ref = torch.softmax(lg, dim=1).argmax(dim=1).to(torch.uint8)
+    assert torch.equal(ref, index_masks(logits, qt, gt))

@@ -234,3 +234,22 @@ def test_resize_logits_and_index_masks(lib, dev):
     idx = torch.empty(4, 36, 64, dtype=torch.uint8, device=dev)
     ok(lib.sampt_index_masks(P(ld), 3, 4 * 36 * 64, P(idx), S()), "index_masks")
     assert torch.equal(idx.cpu(), exp)
+
+
+def test_vos_index_masks_overrides(lib, dev):
+    """Evaluator overrides fused into the index-mask kernel (vos_eval/eval.py:318-326) vs the torch formula."""
+    from sam_pt_amd.dist import index_masks
+    g = torch.Generator().manual_seed(5)
+    M, T, H, W = 3, 5, 24, 40
+    logits = torch.randn(M, T, H, W, generator=g) * 3
+    logits[1, 2] = -float("inf")
+    qt = torch.tensor([0, 2, 4])
+    gt = (torch.rand(M, H, W, generator=g) > 0.6).float()
+    gt[2] = gt[0]                                                                  # overlapping GT: the first object wins
+    ref = index_masks(logits, qt, gt)
+    got = index_masks(logits.to(dev), qt, gt.to(dev))
+    assert torch.equal(got.cpu(), ref)
+    ref2 = index_masks(logits, qt, None)
+    got2 = index_masks(logits.to(dev), qt, None)
+    assert torch.equal(got2.cpu(), ref2) and not torch.equal(ref, ref2)
+    assert (ref[:2] != 2).all() and (ref[:4] != 3).all()                           # nothing before the query frame
