@@ -27,8 +27,8 @@ import torch.distributed as dist  # noqa: E402
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--model", default="vit_h", choices=["vit_h", "vit_l", "vit_b"])
     ap.add_argument("--frames", type=int, default=24)
     ap.add_argument("--points", type=int, default=8)
