@@ -542,3 +542,46 @@ def test_sampt_with_pips2_tracker(dev, clip):
     _, l_s, _ = model._apply_sam_to_trajectories(images, out["trajectories"].cpu(), out["visibilities"].cpu(), None)
     l_f = torch.stack(out["logits"]).cpu()
     assert max_abs(l_f, l_s) < 2e-3
+
+
+# ------------------------------------------------------------------------------------------ limits
+def test_prompt_size_limits(dev):
+    """Largest supported prompt (120 points -> 127/128 decoder tokens) against the oracle; one more is refused loudly."""
+    from oracle import sam_ref as R
+    from sam_pt_amd import _lib
+    from sam_pt_amd.sam_predictor import SamHip, SamPredictor
+    from sam_pt_amd.weights import SAM_CONFIGS, init_sam_state_dict
+    cfg = SAM_CONFIGS["vit_test"]
+    sd = init_sam_state_dict(cfg, 72)
+    frames, _ = synthetic_clip(T=1, H=144, W=256, seed=5)
+    img = frames[0].permute(1, 2, 0).numpy()
+    pred = SamPredictor(SamHip(config=cfg, state_dict=sd, precision="f32").to(dev))
+    ref = R.SamPredictorRef(sd, cfg)
+    pred.set_image(img), ref.set_image(img)
+    g = torch.Generator().manual_seed(3)
+    pts = (torch.rand(1, 120, 2, generator=g) * torch.tensor([250.0, 140.0])).float()
+    lab = (torch.rand(1, 120, generator=g) > 0.3).int()
+    box = torch.tensor([[[20.0, 10.0, 200.0, 120.0]]])
+    m0, i0, l0 = ref.predict_torch(pts, lab, box, None, False, True)
+    m1, i1, l1 = pred.predict_torch(pts.to(dev), lab.to(dev), box.to(dev), None, False, True)
+    assert max_abs(l1, l0) < 5e-4 and max_abs(i1, i0) < 1e-4
+    pts2, lab2 = torch.cat([pts, pts[:, :1]], 1), torch.cat([lab, lab[:, :1]], 1)
+    with pytest.raises(_lib.SamptError):
+        pred.predict_torch(pts2.to(dev), lab2.to(dev), box.to(dev), None, False, True)
+
+
+def test_single_frame_and_single_point_video(dev, pips_sd):
+    """Degenerate clips: T = 1 (no tracker window ever runs: the trajectory is the query) and one point."""
+    from sam_pt_amd.point_tracker import PipsPointTracker
+    from sam_pt_amd.sam_predictor import SamHip, SamPredictor
+    from sam_pt_amd.sam_pt import SamPt
+    from sam_pt_amd.weights import SAM_CONFIGS
+    cfg = SAM_CONFIGS["vit_test"]
+    frames, centres = synthetic_clip(T=1, H=128, W=256, seed=3)
+    q = disc_queries(centres, n_pos=1, r=0.0)
+    pred = SamPredictor(SamHip(config=cfg, seed=72, precision="f32").to(dev))
+    model = SamPt(PipsPointTracker(state_dict=pips_sd), pred, sam_iou_threshold=-1e9, positive_points_per_mask=1,
+                  negative_points_per_mask=0, iterative_refinement_iterations=1).eval()
+    out = model({"image": [frames[0]], "target_hw": (128, 256), "query_points": q[None]})
+    assert out["trajectories"].shape == (1, 1, 1, 2) and torch.allclose(out["trajectories"][0, 0, 0].cpu(), q[0, 1:])
+    assert out["logits"][0].shape == (1, 128, 256) and torch.isfinite(out["logits"][0]).all()
