@@ -11,8 +11,10 @@ Needed by ``SamPt`` in ``query_masks`` mode (every VOS run, sam_pt.py:171-177) a
   third-party dependency that is absent here, so ``kmedoids_alternate`` restates its published algorithm; **parity
   unpinned** for this function.
 * ``extract_mixed_points`` — the reference's n/4 k-medoid + n/3 Shi-Tomasi + rest random split; with the shipped default
-  of one negative point it is a single random point.  Shi-Tomasi corners themselves (``cv2.goodFeaturesToTrack`` on an
-  eroded mask) need cv2, which is absent: ``NotImplementedError`` once a Shi-Tomasi share is requested (n >= 3).
+  of one negative point it is a single random point.
+* ``extract_corner_points`` — Shi-Tomasi corners on an eroded mask.  The reference uses ``cv2.cvtColor``, ``cv2.erode``
+  and ``cv2.goodFeaturesToTrack``; OpenCV is absent, so its published algorithms are restated in numpy — **parity
+  unpinned**.
 """
 from __future__ import annotations
 
@@ -72,16 +74,146 @@ def extract_kmedoid_points(mask: torch.Tensor, n_points_to_select: int, subsampl
     return sel.flip(1)
 
 
-def extract_corner_points(image, mask, n_points_to_select):
-    """Shi-Tomasi corners inside the (eroded) mask (query_points.py:102-162) — needs cv2.goodFeaturesToTrack / cv2.erode,
-    which are absent here and have nothing to be pinned against."""
-    raise NotImplementedError("point selection method 'shi-tomasi' needs cv2.goodFeaturesToTrack (absent in this build)")
+# ---- Shi-Tomasi corners without OpenCV -------------------------------------------------------------------------------
+# The reference calls cv2.cvtColor / cv2.erode / cv2.goodFeaturesToTrack (query_points.py:102-194).  OpenCV is a
+# third-party dependency that is absent here, so the functions below restate its published algorithms (imgproc:
+# color_rgb RGB2Gray, morph erode, corner.cpp cornerMinEigenVal, featureselect.cpp goodFeaturesToTrack).  PARITY UNPINNED:
+# there is no OpenCV in this image to compare against; the property tests in tests/test_cpu_host.py only check the
+# algorithm's invariants.
+def _rgb_to_gray_u8(img: np.ndarray) -> np.ndarray:
+    """(H,W,3) uint8 RGB -> uint8 gray with OpenCV's 15-bit fixed-point weights (0.299, 0.587, 0.114)."""
+    r, g, b = (img[..., i].astype(np.int64) for i in range(3))
+    return ((r * 9798 + g * 19235 + b * 3735 + (1 << 14)) >> 15).astype(np.uint8)
+
+
+def _erode(mask: np.ndarray, k: int) -> np.ndarray:
+    """cv2.erode(mask, np.ones((k, k))): anchor at (k//2, k//2), pixels outside the image never erode.  An empty kernel
+    (k = 0) is OpenCV's default 3x3; k = 1 is the identity."""
+    if k == 0:
+        k = 3
+    if k == 1:
+        return mask.copy()
+    H, W = mask.shape
+    a = k // 2
+    pad = np.ones((H + k - 1, W + k - 1), dtype=mask.dtype)
+    pad[a:a + H, a:a + W] = mask
+    out = np.ones_like(mask)
+    for i in range(k):
+        for j in range(k):
+            out &= pad[i:i + H, j:j + W]
+    return out
+
+
+def erode_mask_proportional_to_its_furthest_points_distance(mask: torch.Tensor, erosion_percentage: float) -> torch.Tensor:
+    """query_points.py:165-194: square erosion by a percentage of the mask's bounding-box diagonal."""
+    px = mask.nonzero().float()
+    diameter = torch.norm(px.max(0)[0] - px.min(0)[0]).item()
+    k = int(diameter * erosion_percentage)
+    return torch.from_numpy(_erode(mask.cpu().numpy().astype(np.uint8), k)).type(mask.dtype).to(mask.device)
+
+
+def _reflect101(a: np.ndarray, p: int) -> np.ndarray:
+    return np.pad(a, p, mode="reflect")
+
+
+def corner_min_eigen_val(gray: np.ndarray, block_size: int = 3, ksize: int = 3) -> np.ndarray:
+    """cv::cornerMinEigenVal on a uint8 image: Sobel derivatives scaled by 1/(2^(ksize-1) * block_size * 255), unnormalised
+    box filter of (dx^2, dx dy, dy^2) over block_size, smaller eigenvalue; BORDER_REFLECT_101 throughout."""
+    assert ksize == 3 and block_size == 3
+    g = _reflect101(gray.astype(np.float32), 1)
+    scale = np.float32(1.0 / (4.0 * block_size * 255.0))
+    dx = ((g[:-2, 2:] - g[:-2, :-2]) + 2 * (g[1:-1, 2:] - g[1:-1, :-2]) + (g[2:, 2:] - g[2:, :-2])) * scale
+    dy = ((g[2:, :-2] - g[:-2, :-2]) + 2 * (g[2:, 1:-1] - g[:-2, 1:-1]) + (g[2:, 2:] - g[:-2, 2:])) * scale
+
+    def box(a):
+        p = _reflect101(a.astype(np.float32), 1)
+        H, W = a.shape
+        return sum(p[i:i + H, j:j + W] for i in range(3) for j in range(3))
+
+    a, b, c = box(dx * dx) * np.float32(0.5), box(dx * dy), box(dy * dy) * np.float32(0.5)
+    return ((a + c) - np.sqrt((a - c) * (a - c) + b * b)).astype(np.float32)
+
+
+def good_features_to_track(gray: np.ndarray, max_corners: int, quality_level: float, min_distance: float,
+                           mask: np.ndarray) -> np.ndarray:
+    """cv::goodFeaturesToTrack (Shi-Tomasi, blockSize 3, gradientSize 3): local maxima of the min-eigenvalue map above
+    quality_level * max, strongest first, greedily thinned to a minimum mutual distance.  -> (n, 2) float32 (x, y)."""
+    eig = corner_min_eigen_val(gray)
+    H, W = eig.shape
+    m = mask.astype(bool)
+    if not m.any():
+        return np.empty((0, 2), np.float32)
+    max_val = eig[m].max()
+    eig = np.where(eig > max_val * quality_level, eig, 0).astype(np.float32)         # THRESH_TOZERO
+    p = np.pad(eig, 1, mode="constant", constant_values=-np.inf)
+    dil = np.max([p[i:i + H, j:j + W] for i in range(3) for j in range(3)], axis=0)  # 3x3 dilation
+    cand = (eig != 0) & (eig == dil) & m
+    cand[0, :] = cand[-1, :] = False                                                # OpenCV scans 1 .. size-2 only
+    cand[:, 0] = cand[:, -1] = False
+    ys, xs = np.nonzero(cand)
+    if len(ys) == 0:
+        return np.empty((0, 2), np.float32)
+    order = np.lexsort((-(ys * W + xs), -eig[ys, xs]))       # value descending, ties: higher address first
+    ys, xs = ys[order], xs[order]
+    if min_distance < 1:
+        sel = list(range(min(len(ys), max_corners) if max_corners > 0 else len(ys)))
+        return np.stack([xs[sel], ys[sel]], axis=1).astype(np.float32)
+    cell = int(round(min_distance))
+    gw, gh = (W + cell - 1) // cell, (H + cell - 1) // cell
+    grid = [[] for _ in range(gw * gh)]
+    md2 = min_distance * min_distance
+    out = []
+    for y, x in zip(ys.tolist(), xs.tolist()):
+        cx, cy = x // cell, y // cell
+        good = True
+        for yy in range(max(0, cy - 1), min(gh - 1, cy + 1) + 1):
+            for xx in range(max(0, cx - 1), min(gw - 1, cx + 1) + 1):
+                for (px, py) in grid[yy * gw + xx]:
+                    if (x - px) * (x - px) + (y - py) * (y - py) < md2:
+                        good = False
+                        break
+                if not good:
+                    break
+            if not good:
+                break
+        if good:
+            grid[cy * gw + cx].append((x, y))
+            out.append((x, y))
+            if 0 < max_corners <= len(out):
+                break
+    return np.asarray(out, dtype=np.float32).reshape(-1, 2)
+
+
+def extract_corner_points(image: torch.Tensor, mask: torch.Tensor, n_points_to_select: int,
+                          kmedoid_subsample_size: int = 2000) -> torch.Tensor:
+    """Shi-Tomasi corners inside the eroded mask, topped up with k-medoid points (query_points.py:102-162).
+    image (3,H,W) uint8, mask (H,W) {0,1} -> (n,2) float32 (x, y).  PARITY UNPINNED (see the note above)."""
+    if mask.sum() == 0:
+        print("Warning: mask.sum() == 0 in extract_corner_points")
+        return torch.zeros((n_points_to_select, 2))
+    img = image.permute(1, 2, 0).cpu().numpy()
+    eroded = erode_mask_proportional_to_its_furthest_points_distance(mask, 0.06)
+    for pct in (0.02, 0.01):
+        if eroded.sum() < 10:
+            eroded = erode_mask_proportional_to_its_furthest_points_distance(mask, pct)
+    if eroded.sum() < 10:
+        eroded = mask
+    px = eroded.nonzero().float()
+    diameter = torch.norm(px.max(0)[0] - px.min(0)[0]).item()
+    corners = good_features_to_track(_rgb_to_gray_u8(img), n_points_to_select, 0.001, diameter / n_points_to_select,
+                                     eroded.cpu().numpy().astype(np.uint8))
+    corners = torch.from_numpy(corners).type(torch.float32)
+    if len(corners) < n_points_to_select:
+        corners = torch.cat((corners, extract_kmedoid_points(mask, n_points_to_select - corners.shape[0],
+                                                             subsample_size=kmedoid_subsample_size)), dim=0)
+    assert corners.shape == (n_points_to_select, 2)
+    return corners
 
 
 def extract_mixed_points(query_masks, query_points_timestep, images, n_points: int) -> List[torch.Tensor]:
     """n/4 k-medoid + n/3 Shi-Tomasi + the rest random points per mask, in that order (query_points.py:197-237).  The
     shipped default (configs/model/sam_pt.yaml: 1 negative point, method "mixed") degenerates to ONE RANDOM point; the
-    Shi-Tomasi share only exists from n = 3 on and then needs cv2 (see ``extract_corner_points``)."""
+    Shi-Tomasi share only exists from n = 3 on (see ``extract_corner_points`` for its parity status)."""
     n_kmedoid, n_shi_tomasi = n_points // 4, n_points // 3
     n_random = n_points - n_kmedoid - n_shi_tomasi
     parts = []

@@ -18,8 +18,8 @@ With a predictor that lacks ``encode_frames``/``track_decode`` (e.g. the CPU ora
 Also built: ``query_masks`` mode with host-side query-point selection
 (``sam_pt_amd/query_points.py``: random and k-medoids) and point re-initialisation with all four ``reinit_variant``s
 (sam_pt.py:355-543), re-using the cached image embeddings across re-initialisation segments.
-Not implemented (raise ``NotImplementedError``): Shi-Tomasi / "mixed" point selection (needs cv2) and patch-similarity
-filtering (default off).
+Shi-Tomasi / "mixed" point selection restate OpenCV's algorithms on the host (parity unpinned, query_points.py).
+Not implemented (raise ``NotImplementedError``): patch-similarity filtering (default off).
 """
 from __future__ import annotations
 

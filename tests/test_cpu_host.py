@@ -157,3 +157,39 @@ def test_vos_index_masks_formula_matches_the_evaluator():
         lg[t, i + 1] = torch.where(gt[i].bool(), 1e8, -1e8)
     ref = torch.softmax(lg, dim=1).argmax(dim=1).to(torch.uint8)
     assert torch.equal(ref, index_masks(logits, qt, gt))
+
+
+def test_shi_tomasi_restatement_properties():
+    """Shi-Tomasi point selection without OpenCV (parity unpinned: cv2 is absent): invariants of the restated algorithms —
+    the min-eigenvalue map peaks on a corner and vanishes on flat areas and straight edges, erosion matches the square
+    structuring element incl. OpenCV's empty-kernel default, selected corners lie inside the mask, are distinct, respect
+    the minimum distance, and missing corners are topped up with k-medoid points."""
+    import numpy as np
+    from sam_pt_amd import query_points as Q
+    from sam_pt_amd.synth import synthetic_clip
+    img = np.zeros((40, 40), np.uint8)
+    img[10:30, 10:30] = 200
+    eig = Q.corner_min_eigen_val(img)
+    assert eig[20, 20] == 0 and eig[5, 5] == 0                       # flat inside / outside
+    assert eig[20, 10] < 1e-6 and eig[10, 20] < 1e-6                  # straight edges: one zero eigenvalue
+    y, x = np.unravel_index(eig.argmax(), eig.shape)
+    assert min(abs(y - 10), abs(y - 29)) <= 1 and min(abs(x - 10), abs(x - 29)) <= 1
+    m = np.zeros((9, 9), np.uint8)
+    m[2:7, 2:7] = 1
+    assert [int(Q._erode(m, k).sum()) for k in (3, 2, 0, 1, 5)] == [9, 16, 9, 25, 1]
+    assert Q._erode(np.ones((6, 6), np.uint8), 3).sum() == 36         # the image border never erodes
+    frames, centres = synthetic_clip(T=1, H=128, W=256, seed=3)
+    yy, xx = torch.meshgrid(torch.arange(128), torch.arange(256), indexing="ij")
+    mask = (((xx - centres[0, 0]) ** 2 + (yy - centres[0, 1]) ** 2) <= 30 ** 2).float()
+    torch.manual_seed(0)
+    pts = Q.extract_corner_points(frames[0], mask, 8)
+    assert pts.shape == (8, 2) and all(mask[int(py), int(px)] == 1 for px, py in pts)
+    d = torch.cdist(pts, pts) + torch.eye(8) * 1e9
+    eroded = Q.erode_mask_proportional_to_its_furthest_points_distance(mask, 0.06)
+    px_ = eroded.nonzero().float()
+    assert d.min() >= torch.norm(px_.max(0)[0] - px_.min(0)[0]).item() / 8 - 1e-4
+    flat = torch.zeros(3, 128, 256, dtype=torch.uint8)                 # no texture -> no corners -> all k-medoid points
+    torch.manual_seed(0)
+    assert Q.extract_corner_points(flat, mask, 5).shape == (5, 2)
+    mixed = Q.extract_mixed_points([mask, 1 - mask], torch.tensor([0.0, 0.0]), frames, 7)   # 1 + 2 + 4
+    assert [tuple(p.shape) for p in mixed] == [(7, 2), (7, 2)]
