@@ -19,7 +19,8 @@ Also built: ``query_masks`` mode with host-side query
 (``sam_pt_amd/query_points.py``: random and k-medoids) and point re-initialisation with all four ``reinit_variant``s
 (sam_pt.py:355-543), re-using the cached image embeddings across re-initialisation segments.
 Shi-Tomasi / "mixed" point selection restate OpenCV's algorithms on the host (parity unpinned, query_points.py).
-Not implemented (raise ``NotImplementedError``): patch-similarity filtering (default off).
+The optional patch-similarity filter (sam_pt.py:597-682, off in every shipped config) is built on the host with a
+restated ``rgb2lab`` (skimage absent: that one function is parity unpinned).
 """
 from __future__ import annotations
 
@@ -30,6 +31,20 @@ import numpy as np
 import torch
 from torch import nn
 from torch.nn import functional as F
+
+
+def rgb2lab(rgb_u8: torch.Tensor) -> torch.Tensor:
+    """(...,3) uint8 sRGB -> CIELAB (D65, 2 degree observer), float64: the published algorithm of skimage.color.rgb2lab
+    (sRGB companding, the sRGB->XYZ matrix, white (0.95047, 1, 1.08883), cube-root / linear f).  skimage is absent here:
+    parity unpinned."""
+    rgb = rgb_u8.double() / 255.0
+    rgb = torch.where(rgb > 0.04045, ((rgb + 0.055) / 1.055) ** 2.4, rgb / 12.92)
+    M = torch.tensor([[0.412453, 0.357580, 0.180423], [0.212671, 0.715160, 0.072169], [0.019334, 0.119193, 0.950227]],
+                     dtype=torch.float64)
+    xyz = rgb @ M.T / torch.tensor([0.95047, 1.0, 1.08883], dtype=torch.float64)
+    f = torch.where(xyz > 0.008856, xyz.clamp(min=0) ** (1.0 / 3.0), 7.787 * xyz + 16.0 / 116.0)
+    x, y, z = f[..., 0], f[..., 1], f[..., 2]
+    return torch.stack([116.0 * y - 16.0, 500.0 * (x - y), 200.0 * (y - z)], dim=-1)
 
 
 class PointVisibilityType(IntEnum):
@@ -297,8 +312,6 @@ class SamPt(nn.Module):
 
     def _track_points(self, rgbs, query_points):
         """Chunks of ``point_tracker_mask_batch_size`` objects per tracker call (sam_pt.py:545-576, 578-692)."""
-        if self.use_patch_matching_filtering:
-            raise NotImplementedError("patch-similarity filtering (sam_pt.py:597-682) is off by default and not built")
         trajs, viss = [], []
         n_masks = query_points.shape[0]
         rgbs_dev = rgbs.to(self.device).unsqueeze(0)
@@ -310,6 +323,8 @@ class SamPt(nn.Module):
                 out = self.point_tracker.to(self.device).evaluate_batch(rgbs_dev, q.reshape(1, m * p, 3).to(self.device))
             t = out["trajectories_pred"].squeeze(0)
             v = out["visibilities_pred"].squeeze(0).float()
+            if self.use_patch_matching_filtering:
+                v = self._patch_similarity_filter(rgbs, q.reshape(m * p, 3).cpu(), t, v, m, p)
             h, w = rgbs.shape[-2:]
             v[t[:, :, 0] / w < 0.01] = PointVisibilityType.OUTSIDE_FRAME.value   # sam_pt.py:684-690
             v[t[:, :, 1] / h < 0.01] = PointVisibilityType.OUTSIDE_FRAME.value
@@ -320,6 +335,43 @@ class SamPt(nn.Module):
         return torch.cat(trajs, dim=1), torch.cat(viss, dim=1)
 
     # ------------------------------------------------------------------------------------------------
+    def _patch_similarity_filter(self, rgbs, query_points, traj, vis, n_masks, n_pts):
+        """Optional patch-similarity filter (sam_pt.py:597-682; off in every shipped config): a point whose CIELAB patch
+        differs too much from its query patch is marked PATCH_NON_SIMILAR and everything beyond it (away from the query
+        frame) REJECTED_AFTER_PATCH_WAS_NON_SIMILAR.  Host-side like the reference; ``rgb2lab`` restates
+        ``skimage.color.rgb2lab`` (absent here, parity unpinned) — the rest is pinned against the reference with that
+        function substituted.  rgbs (T,3,H,W) uint8, query_points (N,3), traj (T,N,2), vis (T,N) float."""
+        rgbs = rgbs.cpu()
+        lab = rgb2lab(rgbs[:, [2, 1, 0], :, :].permute(0, 2, 3, 1)).permute(0, 3, 1, 2).float()   # (channel swap: :645)
+        ps = self.patch_size
+
+        def patches(lab_frames, xy):                                                # (F,3,h,w), (F,K,2) -> (F,K,ps*ps,3)
+            _, _, h, w = lab_frames.shape
+            tmpl = torch.arange(-(ps // 2), ps // 2 + 1)
+            tmpl = torch.stack(torch.meshgrid(tmpl, tmpl, indexing="ij"), dim=-1).reshape(-1, 2)
+            grid = ((xy[:, :, None, :] + tmpl[None, None] + 0.5) / torch.tensor([w, h])[None, None, None]) * 2 - 1
+            return F.grid_sample(lab_frames, grid.float(), align_corners=False, mode="bilinear").permute(0, 2, 3, 1)
+
+        qt = query_points[:, 0].long()
+        qp = patches(lab[qt], query_points[:, None, 1:].float()).squeeze(1)         # (N,ps*ps,3)
+        tp = patches(lab, traj.cpu().float())                                       # (T,N,ps*ps,3)
+        diff = tp.flatten(2, 3) - qp[None].flatten(2, 3)
+        similar = torch.exp(-torch.norm(diff, dim=-1) / (2 * ps ** 2)) > self.patch_similarity_threshold
+        vis = vis.clone()
+        vis[(vis == 1) & ~similar] = PointVisibilityType.PATCH_NON_SIMILAR.value
+        T = vis.shape[0]
+        for i in range(n_masks * n_pts):
+            t0 = int(query_points[i, 0].item())
+            for t in range(t0 + 1, T):
+                if vis[t, i] == PointVisibilityType.PATCH_NON_SIMILAR.value:
+                    vis[t + 1:, i] = PointVisibilityType.REJECTED_AFTER_PATCH_WAS_NON_SIMILAR.value
+                    break
+            for t in range(t0 - 1, -1, -1):
+                if vis[t, i] == PointVisibilityType.PATCH_NON_SIMILAR.value:
+                    vis[:t, i] = PointVisibilityType.REJECTED_AFTER_PATCH_WAS_NON_SIMILAR.value
+                    break
+        return vis
+
     def _prepare_points(self, trajectories, visibilities, frame_idx, mask_idx, n_masks):
         """Prompt assembly of sam_pt.py:726-758: visible points (== 1), tail points negative, the other objects'
         visible positives appended as negatives."""
