@@ -84,8 +84,10 @@ int sampt_pips_update_f32(sampt_pips_t h, const float* const pyr_dev[4], int H0,
 int sampt_pips2_create(const char* const* names, const void* const* ptrs, int n, int stride, sampt_pips2_t* out);
 void sampt_pips2_destroy(sampt_pips2_t h);
 int sampt_pips2_fnet_workspace_bytes(sampt_pips2_t h, int nf, int H, int W, size_t* bytes);
-int sampt_pips2_fnet_f32(sampt_pips2_t h, const uint8_t* frames_dev, int nf, int H, int W, float* const pyr_dev[4],
-                         void* workspace_dev, size_t workspace_bytes, sampt_stream_t stream);
+/* frames_dev: (nf,3,H,W) uint8, or float32 in [0, 255] when frames_are_f32 != 0 (the bilinearly pre-resized video of
+ * PipsPlusPlusPointTracker(image_size=...), tracker.py:69-76). */
+int sampt_pips2_fnet_f32(sampt_pips2_t h, const void* frames_dev, int frames_are_f32, int nf, int H, int W,
+                         float* const pyr_dev[4], void* workspace_dev, size_t workspace_bytes, sampt_stream_t stream);
 int sampt_pips2_update_workspace_bytes(sampt_pips2_t h, int n, int S, size_t* bytes);
 int sampt_pips2_update_f32(sampt_pips2_t h, const float* const pyr_dev[4], int H0, int W0, const int32_t* frame_idx_dev,
                            int n, int S, const float* trajs0_dev, int have_feat_init, float* const feats_dev[3],

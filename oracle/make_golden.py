@@ -161,6 +161,11 @@ def make_pips2_golden():
         with torch.no_grad():
             tr, vi = trk(frames[None].float(), qq.clone())
         out[f"trk_{name}_q"], out[f"trk_{name}_traj"], out[f"trk_{name}_vis"] = qq.numpy(), tr.numpy(), vi.numpy()
+    trk = Tracker2(checkpoint_path=d, stride=8, max_sequence_length=128, iters=4, image_size=(128, 192)).eval()
+    qq = disc_queries(centres, n_pos=4, r=9.0, t=3)[None]
+    with torch.no_grad():
+        tr, _ = trk(frames[None].float(), qq.clone())
+    out["trk_resized_q"], out["trk_resized_traj"] = qq.numpy(), tr.numpy()
     np.savez_compressed(os.path.join(OUT, "pips2.npz"), **out)
 
 

@@ -120,8 +120,9 @@ class Pips2TrackerRef:
     """PipsPlusPlusPointTracker (tracker.py:11-134) on the CPU oracle; ``image_size=None`` (configs/model/point_tracker/
     pips_plus_plus.yaml:6).  The encoder is run once per clip (per-frame InstanceNorm -> identical per-frame maps)."""
 
-    def __init__(self, sd: SD, stride: int = 8, max_sequence_length: int = 128, iters: int = 16):
+    def __init__(self, sd: SD, stride: int = 8, max_sequence_length: int = 128, iters: int = 16, image_size=None):
         self.sd, self.stride, self.max_len, self.iters = sd, stride, max_sequence_length, iters
+        self.image_size = tuple(image_size) if image_size is not None else None
 
     def _forward(self, fmaps: torch.Tensor, query_xy: torch.Tensor):
         S = fmaps.shape[0]
@@ -147,8 +148,14 @@ class Pips2TrackerRef:
 
     def forward(self, rgbs: torch.Tensor, query_points: torch.Tensor):
         """rgbs (1,T,3,H,W) uint8, query_points (1,N,3)=(t,x,y) -> trajectories (1,T,N,2), visibilities (1,T,N) = 1."""
-        T = rgbs.shape[1]
-        fmaps = fnet(self.sd, P1.normalize_rgbs(rgbs[0]), self.stride)
+        T, _, H, W = rgbs.shape[1:]
+        frames = rgbs[0]
+        query_points = query_points.clone()
+        if self.image_size is not None:                                   # tracker.py:69-78 (x <-> H, y <-> W as there)
+            frames = F.interpolate(frames.float() / 255.0, size=self.image_size, mode="bilinear") * 255.0
+            query_points[:, :, 1] *= self.image_size[0] / H
+            query_points[:, :, 2] *= self.image_size[1] / W
+        fmaps = fnet(self.sd, P1.normalize_rgbs(frames), self.stride)
         groups = defaultdict(list)
         for idx, pt in enumerate(query_points[0]):
             groups[int(pt[0].item())].append(idx)
@@ -166,4 +173,7 @@ class Pips2TrackerRef:
                 out[:, idxs] = right
             else:
                 out[:, idxs] = torch.cat([right[:-1], left], dim=0) if len(right) else left
+        if self.image_size is not None:                                   # tracker.py:126-128
+            out[:, :, 0] *= H / self.image_size[0]
+            out[:, :, 1] *= W / self.image_size[1]
         return out[None], torch.ones(1, T, N)

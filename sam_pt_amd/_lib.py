@@ -39,7 +39,7 @@ _SIGS = {
     "sampt_pips2_create": (c_int, [C.POINTER(c_char_p), C.POINTER(_P), c_int, c_int, C.POINTER(_P)]),
     "sampt_pips2_destroy": (None, [_P]),
     "sampt_pips2_fnet_workspace_bytes": (c_int, [_P, c_int, c_int, c_int, C.POINTER(c_size_t)]),
-    "sampt_pips2_fnet_f32": (c_int, [_P, _P, c_int, c_int, c_int, C.POINTER(_P), _P, c_size_t, _P]),
+    "sampt_pips2_fnet_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, C.POINTER(_P), _P, c_size_t, _P]),
     "sampt_pips2_update_workspace_bytes": (c_int, [_P, c_int, c_int, C.POINTER(c_size_t)]),
     "sampt_pips2_update_f32": (c_int, [_P, C.POINTER(_P), c_int, c_int, _P, c_int, c_int, _P, c_int, C.POINTER(_P), c_int, _P,
                                        _P, c_size_t, _P]),

@@ -169,12 +169,13 @@ int sampt_pips2_fnet_workspace_bytes(sampt_pips2_t h, int nf, int H, int W, size
   return rc;
 }
 
-int sampt_pips2_fnet_f32(sampt_pips2_t h, const uint8_t* frames, int nf, int H, int W, float* const pyr[4], void* ws,
-                         size_t ws_bytes, sampt_stream_t stream) {
+int sampt_pips2_fnet_f32(sampt_pips2_t h, const void* frames, int frames_are_f32, int nf, int H, int W,
+                         float* const pyr[4], void* ws, size_t ws_bytes, sampt_stream_t stream) {
   if (!h || !frames || !pyr || !ws || H % (8 * h->e.stride) || W % (8 * h->e.stride))
     return fail(SAMPT_ERR_ARG, "sampt_pips2_fnet_f32: bad arguments (H, W must be multiples of 8*stride)");
   Arena a(ws, ws_bytes);
-  return h->e.enc.fnet(frames, nf, H, W, pyr, a, (hipStream_t)stream);
+  h->e.enc.frames_f32 = frames_are_f32 ? 1 : 0;
+  return h->e.enc.fnet((const uint8_t*)frames, nf, H, W, pyr, a, (hipStream_t)stream);
 }
 
 int sampt_pips2_update_workspace_bytes(sampt_pips2_t h, int n, int S, size_t* bytes) {

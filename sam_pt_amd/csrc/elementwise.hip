@@ -8,21 +8,27 @@ namespace sampt {
 // ---------------------------------------------------------------------------------------------
 // uint8 CHW -> normalised f32 NHWC4
 // ---------------------------------------------------------------------------------------------
-__global__ void k_rgb_u8chw_to_nhwc4(const uint8_t* __restrict__ src, float4* __restrict__ dst, long npix_total,
-                                     long hw) {
+template <typename T>
+__global__ void k_rgb_u8chw_to_nhwc4(const T* __restrict__ src, float4* __restrict__ dst, long npix_total, long hw) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npix_total) return;
   long t = i / hw, p = i - t * hw;
-  const uint8_t* b = src + t * 3 * hw + p;
+  const T* b = src + t * 3 * hw + p;
   float r = 2.0f * ((float)b[0] / 255.0f) - 1.0f;
   float g = 2.0f * ((float)b[hw] / 255.0f) - 1.0f;
   float bl = 2.0f * ((float)b[2 * hw] / 255.0f) - 1.0f;
   dst[i] = make_float4(r, g, bl, 0.f);
 }
 
-int rgb_u8chw_to_nhwc4(const uint8_t* src, float* dst, int T, int H, int W, hipStream_t s) {
+// src: uint8 frames, or (src_f32 != 0) float frames with values in [0, 255] (a resized video, PIPS++ image_size)
+int rgb_u8chw_to_nhwc4(const void* src, int src_f32, float* dst, int T, int H, int W, hipStream_t s) {
   long hw = (long)H * W, n = hw * T;
-  hipLaunchKernelGGL(k_rgb_u8chw_to_nhwc4, dim3(cdiv(n, 256)), dim3(256), 0, s, src, (float4*)dst, n, hw);
+  if (src_f32)
+    hipLaunchKernelGGL(k_rgb_u8chw_to_nhwc4<float>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const float*)src, (float4*)dst, n,
+                       hw);
+  else
+    hipLaunchKernelGGL(k_rgb_u8chw_to_nhwc4<uint8_t>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const uint8_t*)src,
+                       (float4*)dst, n, hw);
   SAMPT_CHECK_LAUNCH("rgb_u8chw_to_nhwc4");
   return SAMPT_OK;
 }

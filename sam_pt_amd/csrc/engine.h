@@ -53,6 +53,7 @@ struct ConvW {
 
 struct PipsEngine {
   int S = 8, stride = 4;
+  int frames_f32 = 0;   // fnet input: 0 = uint8 frames, 1 = float frames in [0, 255] (PIPS++ with image_size)
   ConvW stem, conv2, conv3;
   ConvW blk[4][2][3];  // [layer][block][conv1, conv2, downsample]
   bool has_down[4][2] = {};

@@ -101,7 +101,7 @@ int PipsEngine::fnet(const uint8_t* frames, int nf, int H, int W, float* const o
   nc.partials = (double*)ws.get(instnorm_partial_doubles(nf, (long)H2 * W2, 256) * sizeof(double));
   nc.mean_rstd = ws.f32((size_t)nf * 256 * 2);
   float* x0 = ws.f32((size_t)nf * H * W * 4);
-  if (!dry) SAMPT_TRY(rgb_u8chw_to_nhwc4(frames, x0, nf, H, W, s));
+  if (!dry) SAMPT_TRY(rgb_u8chw_to_nhwc4(frames, frames_f32, x0, nf, H, W, s));
   int h, w;
   float* cur = ws.f32((size_t)nf * H2 * W2 * 64);
   SAMPT_TRY(run_conv(stem, x0, nf, H, W, cur, h, w, dry, s));

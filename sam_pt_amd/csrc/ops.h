@@ -8,7 +8,7 @@ namespace sampt {
 
 // ---- elementwise.hip ------------------------------------------------------------------------
 // uint8 CHW frames (T,3,H,W) -> f32 NHWC4 (T,H,W,4) = 2*(x/255)-1, 4th channel 0      (pips.py:446)
-int rgb_u8chw_to_nhwc4(const uint8_t* src, float* dst, int T, int H, int W, hipStream_t s);
+int rgb_u8chw_to_nhwc4(const void* src, int src_f32, float* dst, int T, int H, int W, hipStream_t s);
 // per-(image, channel) mean / rstd over H*W of an NHWC f32 tensor (InstanceNorm2d, eps, biased variance)
 // partials: workspace of at least instnorm_partial_floats(nimg, hw, C) doubles
 size_t instnorm_partial_doubles(int nimg, long hw, int C);

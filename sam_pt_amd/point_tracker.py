@@ -259,17 +259,18 @@ class PipsPlusPlusPointTracker(PointTracker):
       per-frame InstanceNorm makes the maps identical, and sub-clips / time-reversed clips become frame-index maps;
     * queries on several frames and on the last frame work (the reference raises IndexError at tracker.py:121 for the
       former and returns T-1 frames for the latter — see oracle/pips2_ref.py);
-    * ``image_size`` (bilinear pre-resize to a float video, off in the shipped config) is not built.
+    * ``image_size`` (off in the shipped config): the bilinear pre-resize runs on the device with torch (plumbing) and
+      the float video feeds the encoder directly; the reference's coordinate scaling is kept verbatim, including its
+      x <-> height / y <-> width mix-up (tracker.py:77-78, 126-128), which cancels on the way back.
     """
 
     def __init__(self, checkpoint_path=None, stride=8, max_sequence_length=128, iters=16, image_size=None,
                  state_dict: Optional[Dict[str, torch.Tensor]] = None, seed: int = 72, fnet_chunk: int = 8):
         super().__init__()
-        if image_size is not None:
-            raise NotImplementedError("PipsPlusPlusPointTracker(image_size=...) is not built; the shipped config uses null")
         from .weights import init_pips2_state_dict
         self.checkpoint_path, self.stride = checkpoint_path, stride
-        self.max_sequence_length, self.iters, self.image_size = max_sequence_length, iters, None
+        self.max_sequence_length, self.iters = max_sequence_length, iters
+        self.image_size = tuple(image_size) if image_size is not None else None
         sd = state_dict if state_dict is not None else load_pips_checkpoint(checkpoint_path)
         self._sd = sd if sd is not None else init_pips2_state_dict(seed)
         self.fnet_chunk = fnet_chunk
@@ -298,8 +299,9 @@ class PipsPlusPlusPointTracker(PointTracker):
                 pass
 
     def compute_pyramid(self, frames: torch.Tensor):
-        """frames (T,3,H,W) uint8 on device -> 4 NHWC f32 levels [T][H/8 >> l][W/8 >> l][128]."""
+        """frames (T,3,H,W) uint8 (or float32 in [0,255]) on device -> 4 NHWC f32 levels [T][H/8 >> l][W/8 >> l][128]."""
         self._ensure(frames.device)
+        is_f32 = 1 if frames.dtype == torch.float32 else 0
         T, _, H, W = frames.shape
         H0, W0 = H // self.stride, W // self.stride
         pyr = [torch.empty((T, H0 >> l, W0 >> l, 128), dtype=torch.float32, device=frames.device) for l in range(4)]
@@ -311,7 +313,7 @@ class PipsPlusPlusPointTracker(PointTracker):
         for t0 in range(0, T, chunk):
             nf = min(chunk, T - t0)
             outs = _lib.ptr_array([p[t0:t0 + nf] for p in pyr])
-            _lib.check(self._lib.sampt_pips2_fnet_f32(self._h, _lib.ptr(frames[t0:t0 + nf]), nf, H, W, outs, _lib.ptr(ws),
+            _lib.check(self._lib.sampt_pips2_fnet_f32(self._h, _lib.ptr(frames[t0:t0 + nf]), is_f32, nf, H, W, outs, _lib.ptr(ws),
                                                       ws.numel(), _lib.stream_ptr()), "sampt_pips2_fnet_f32")
         self.stats["fnet_frames"] += T
         return pyr
@@ -367,13 +369,18 @@ class PipsPlusPlusPointTracker(PointTracker):
         dev = rgbs.device
         self._ensure(dev)
         frames = rgbs[0]
-        T = frames.shape[0]
+        T, _, H, W = frames.shape
+        q = query_points[0].detach().float().cpu()
         prepared = getattr(self, "_prepared", None)
-        if prepared is not None and prepared[0] == (frames.data_ptr(), tuple(frames.shape)):
+        if self.image_size is not None:                                          # tracker.py:69-78
+            fr = torch.nn.functional.interpolate(frames.float() / 255.0, size=self.image_size, mode="bilinear") * 255.0
+            pyr = self.compute_pyramid(fr.contiguous())
+            q[:, 1] *= self.image_size[0] / H
+            q[:, 2] *= self.image_size[1] / W
+        elif prepared is not None and prepared[0] == (frames.data_ptr(), tuple(frames.shape)):
             pyr = prepared[1]
         else:
             pyr = self.compute_pyramid(frames)
-        q = query_points[0].detach().float().cpu()
         N = q.shape[0]
         groups: Dict[int, List[int]] = {}
         for i in range(N):
@@ -386,5 +393,8 @@ class PipsPlusPlusPointTracker(PointTracker):
             if t != 0:
                 right = self._track(pyr, list(range(t, -1, -1)), xy).flip(0)     # frames 0..t
                 traj[:t + 1 if t == T - 1 else t, idxs] = right if t == T - 1 else right[:-1]
+        if self.image_size is not None:                                          # tracker.py:126-128
+            traj[:, :, 0] *= H / self.image_size[0]
+            traj[:, :, 1] *= W / self.image_size[1]
         vis = torch.ones((1, T, N), dtype=torch.float32, device=dev)             # PIPS++ predicts no visibility (:64)
         return traj.unsqueeze(0), vis

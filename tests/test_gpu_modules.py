@@ -509,6 +509,9 @@ def test_pips2_tracker_vs_reference_golden(dev, clip):
         assert np.abs(tr.cpu().numpy() - g[f"trk_{name}_traj"]).max() < 5e-3, name
         assert np.array_equal(np.round(tr.cpu().numpy()), np.round(g[f"trk_{name}_traj"])), name
         assert np.array_equal(vi.cpu().numpy(), g[f"trk_{name}_vis"])
+    trk = PipsPlusPlusPointTracker(state_dict=sd, iters=4, image_size=(128, 192))     # float video after the pre-resize
+    tr, _ = trk(frames[None].to(dev), torch.from_numpy(g["trk_resized_q"]).to(dev))
+    assert np.abs(tr.cpu().numpy() - g["trk_resized_traj"]).max() < 5e-3
     q = torch.cat([disc_queries(centres, n_pos=3, r=9.0, t=0), disc_queries(centres, n_pos=2, r=6.0, t=5),
                    disc_queries(centres, n_pos=1, r=3.0, t=11)])[None]
     trk = PipsPlusPlusPointTracker(state_dict=sd, iters=8)
