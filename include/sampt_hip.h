@@ -110,6 +110,11 @@ int sampt_vit_create(const sampt_vit_config* cfg, const char* const* names, cons
                      int win_batches, sampt_vit_t* out);
 void sampt_vit_destroy(sampt_vit_t h);
 int sampt_vit_encode_workspace_bytes(sampt_vit_t h, int B, size_t* bytes);
+/* Measurement hook: between begin and end every fp16 GEMM launch of sampt_vit_encode is bracketed by HIP events on the
+ * launching stream; end waits for them and returns the summed algorithmic FLOP (2*M*N*K), the summed kernel time and the
+ * number of launches — the in-situ figures behind bench.py's `roofline`. */
+int sampt_vit_profile_begin(sampt_vit_t h);
+int sampt_vit_profile_end(sampt_vit_t h, double* flop, double* ms, int* launches);
 /* frames_dev: uint8, (B,3,H,W) if chw else (B,H,W,3), H,W <= img_size with the longest side == img_size already
  * (the reference pipelines resize before SamPt: configs/demo.yaml:20, configs/vos_eval_root.yaml:28).
  * features_dev: float32 [B][grid*grid][out_chans] — the (B,256,64,64) embedding in NHWC / token-major order.

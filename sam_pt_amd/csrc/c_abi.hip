@@ -125,6 +125,16 @@ int sampt_vit_create(const sampt_vit_config* cfg, const char* const* names, cons
 }
 void sampt_vit_destroy(sampt_vit_t h) { delete h; }
 
+int sampt_vit_profile_begin(sampt_vit_t h) {
+  if (!h) return SAMPT_ERR_ARG;
+  h->e.profiling = true;
+  return SAMPT_OK;
+}
+int sampt_vit_profile_end(sampt_vit_t h, double* flop, double* ms, int* launches) {
+  if (!h || !flop || !ms || !launches) return SAMPT_ERR_ARG;
+  return h->e.profile_end(flop, ms, launches);
+}
+
 int sampt_vit_encode_workspace_bytes(sampt_vit_t h, int B, size_t* bytes) {
   if (!h || !bytes || B <= 0) return SAMPT_ERR_ARG;
   Arena a(nullptr, 0);

@@ -119,6 +119,15 @@ struct VitEngine {
   const int* win_pad;   // [Bmax * npad] window-order rows that are zero padding
   int win_rows_batches = 0;
   std::string error;
+  // Optional in-situ timing of the fp16 GEMM launches (bench.py's roofline): HIP events on the launching stream around
+  // every gemm_f16 call of encode() while `profiling` is set; collected (and destroyed) by profile_end().
+  struct GemmEv {
+    hipEvent_t a, b;
+    double flop;
+  };
+  mutable std::vector<GemmEv> prof;
+  bool profiling = false;
+  int profile_end(double* flop, double* ms, int* launches);
 
   int init(const WeightMap& w, const VitConfig& cfg, int win_rows_batches);
   // frames: uint8 (B,3,H,W) if chw else (B,H,W,3); features out: [B][grid*grid][out_chans] f32 (NHWC);

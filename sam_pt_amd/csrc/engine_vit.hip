@@ -41,10 +41,26 @@ int VitEngine::init(const WeightMap& w, const VitConfig& cfg, int wrb) {
   return SAMPT_OK;
 }
 
+int VitEngine::profile_end(double* flop, double* ms, int* launches) {
+  double f = 0.0, t = 0.0;
+  for (auto& e : prof) {
+    float dt = 0.f;
+    if (hipEventSynchronize(e.b) != hipSuccess || hipEventElapsedTime(&dt, e.a, e.b) != hipSuccess) return SAMPT_ERR_HIP;
+    f += e.flop, t += dt;
+    (void)hipEventDestroy(e.a);
+    (void)hipEventDestroy(e.b);
+  }
+  *flop = f, *ms = t, *launches = (int)prof.size();
+  prof.clear();
+  profiling = false;
+  return SAMPT_OK;
+}
+
 namespace {
 struct G {
   bool f16;
   hipStream_t s;
+  const VitEngine* eng = nullptr;
   // C = act(A.W^T + bias) (+ residual at the (row-mapped) destination row)
   int run(const void* A, int M, int K, const void* W, const float* bias, void* C, int N, int act, bool out_f16,
           const float* res, int ldr, const int* rowmap, int res_mod, const int* a_rowmap = nullptr) const {
@@ -52,7 +68,16 @@ struct G {
     p.A = A, p.W = W, p.bias = bias, p.C = C, p.res = res, p.rowmap = rowmap, p.a_rowmap = a_rowmap;
     p.M = M, p.N = N, p.K = K, p.lda = K, p.ldw = K, p.ldc = N, p.ldr = ldr, p.act = act, p.res_mod = res_mod;
     p.out_f16 = out_f16 ? 1 : 0;
-    return f16 ? gemm_f16(p, s) : gemm_f32(p, s);
+    if (!f16) return gemm_f32(p, s);
+    if (!eng || !eng->profiling) return gemm_f16(p, s);
+    VitEngine::GemmEv ev;
+    ev.flop = 2.0 * M * N * K;
+    if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) return SAMPT_ERR_HIP;
+    if (hipEventRecord(ev.a, s) != hipSuccess) return SAMPT_ERR_HIP;
+    int rc = gemm_f16(p, s);
+    if (hipEventRecord(ev.b, s) != hipSuccess) return SAMPT_ERR_HIP;
+    eng->prof.push_back(ev);
+    return rc;
   }
 };
 }  // namespace
@@ -89,7 +114,7 @@ int VitEngine::encode(const uint8_t* frames, int chw, int B, int H, int W, float
   if (dry) return SAMPT_OK;
   (void)Smax;
 
-  G gm{c.f16 != 0, s};
+  G gm{c.f16 != 0, s, this};
   // ---- patch embedding: preprocess + im2col, GEMM + bias + positional embedding (broadcast over the batch)
   SAMPT_TRY(sam_patchify(frames, chw, B, H, W, c.img, c.patch, c.mean, c.stdv, xn, c.f16, s));
   SAMPT_TRY(gm.run(xn, (int)Mg, Kp, patch_w, patch_b, x, D, ACT_NONE, false, pos, D, nullptr, T));

@@ -172,6 +172,17 @@ class SamPredictor:
         except Exception:
             pass
 
+    def gemm_profile_begin(self):
+        """Start timing every fp16 GEMM launch of the image encoder with HIP events (see sampt_vit_profile_begin)."""
+        self._ensure()
+        _lib.check(self._lib.sampt_vit_profile_begin(self._vit), "sampt_vit_profile_begin")
+
+    def gemm_profile_end(self):
+        """-> (algorithmic FLOP, kernel milliseconds, launches) since gemm_profile_begin."""
+        fl, ms, n = C.c_double(), C.c_double(), C.c_int()
+        _lib.check(self._lib.sampt_vit_profile_end(self._vit, C.byref(fl), C.byref(ms), C.byref(n)), "sampt_vit_profile_end")
+        return fl.value, ms.value, n.value
+
     def _vit_ws(self, B: int) -> torch.Tensor:
         if B not in self._ws_vit:
             n = C.c_size_t()
