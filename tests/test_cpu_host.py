@@ -193,3 +193,79 @@ def test_shi_tomasi_restatement_properties():
     assert Q.extract_corner_points(flat, mask, 5).shape == (5, 2)
     mixed = Q.extract_mixed_points([mask, 1 - mask], torch.tensor([0.0, 0.0]), frames, 7)   # 1 + 2 + 4
     assert [tuple(p.shape) for p in mixed] == [(7, 2), (7, 2)]
+
+
+def test_fused_host_logic_on_cpu_with_a_fake_device_predictor():
+    """The device path of SamPt (clip-level encode, ONE ragged batched decode chain, skipped query-mask pass) is host
+    logic too: drive it on the CPU with a predictor that implements ``encode_frames`` / ``track_decode`` on top of the
+    oracle and compare with the reference call-by-call protocol — ragged prompts (different visible-point counts, an
+    empty prompt, two-pass mode with negatives) included."""
+    from oracle import sam_ref as R
+    from sam_pt_amd.point_tracker import PointTracker
+    from sam_pt_amd.sam_pt import SamPt
+    from sam_pt_amd.synth import synthetic_clip
+    from sam_pt_amd.weights import SAM_CONFIGS, init_sam_state_dict
+    cfg = SAM_CONFIGS["vit_test"]
+    sd = init_sam_state_dict(cfg, 72)
+
+    class FakeDevicePredictor(R.SamPredictorRef):
+        """encode_frames / track_decode with the semantics of sam_pt_amd.SamPredictor, computed by the oracle."""
+
+        def __init__(self):
+            super().__init__(sd, cfg)
+            self.model.max_decode_batch = 3                      # forces several chunks
+            self.calls = []
+
+        def encode_frames(self, frames, chw=True):
+            x = R.preprocess(cfg, frames.float())
+            return torch.cat([R.image_encoder(sd, cfg, x[i:i + 1]) for i in range(len(x))])    # (T,256,g,g)
+
+        def track_decode(self, feats, pts, labels, k, n_pos_first, refine_iters, iou_thr, size_hw, out_logits, out_score,
+                         k_item=None, npos_item=None):
+            self.calls.append((feats.shape[0], k, n_pos_first, k_item is not None))
+            for i in range(feats.shape[0]):
+                ki = int(k_item[i]) if k_item is not None else k
+                pi = int(npos_item[i]) if npos_item is not None else n_pos_first
+                self.features, self.original_size, self.input_size = feats[i:i + 1], tuple(size_hw), tuple(size_hw)
+                pc, pl = pts[i:i + 1, :ki], labels[i:i + 1, :ki]
+                kw = dict(multimask_output=False, return_logits=True)
+                low = None
+                if n_pos_first >= 0:
+                    _, _, low = self.predict_torch(pc[:, :pi], pl[:, :pi], None, None, **kw)
+                ml, iou, low = self.predict_torch(pc, pl, None, low, **kw)
+                for _ in range(refine_iters):
+                    msk = ml[0, 0] > 0
+                    if msk.sum() < 2:
+                        break
+                    yx = msk.nonzero()
+                    box = torch.tensor([[yx[:, 1].min(), yx[:, 0].min(), yx[:, 1].max(), yx[:, 0].max()]], dtype=torch.float)
+                    ml, iou, low = self.predict_torch(pc, pl, box, low, **kw)
+                out_score[i] = iou[0, 0]
+                out_logits[i] = ml[0, 0] if float(iou[0, 0]) >= iou_thr else -float("inf")
+
+    class NoTracker(PointTracker):
+        def forward(self, rgbs, query_points):
+            raise AssertionError("not used")
+
+    T, M = 4, 2
+    frames, _ = synthetic_clip(T=T, H=128, W=256, seed=3)
+    g = torch.Generator().manual_seed(7)
+    for neg in (0, 1):
+        P = 3 + neg
+        traj = torch.rand(T, M, P, 2, generator=g) * torch.tensor([250.0, 120.0]) + 3.0
+        vis = torch.ones(T, M, P)
+        vis[1, 0, :] = 0                      # object 0 invisible in frame 1 (still gets object 1's positives as negatives)
+        vis[2, 1, 1:] = 0                     # a single visible point
+        vis[3, :, 0] = 0
+        fake = FakeDevicePredictor()
+        fused = SamPt(NoTracker(), fake, sam_iou_threshold=0.0, positive_points_per_mask=3, negative_points_per_mask=neg,
+                      iterative_refinement_iterations=2).eval()
+        feats = fake.encode_frames(frames)
+        _, l_f, s_f = fused._apply_sam_to_trajectories(frames, traj, vis, feats)
+        ref = SamPt(NoTracker(), R.SamPredictorRef(sd, cfg), sam_iou_threshold=0.0, positive_points_per_mask=3,
+                    negative_points_per_mask=neg, iterative_refinement_iterations=2).eval()
+        _, l_s, s_s = ref._apply_sam_to_trajectories(frames, traj, vis, None)
+        assert torch.equal(torch.isfinite(l_f), torch.isfinite(l_s))
+        fin = torch.isfinite(l_s)
+        assert (l_f[fin] - l_s[fin]).abs().max() < 1e-4 and torch.allclose(s_f, s_s, atol=1e-5)
+        assert len(fake.calls) == 3 and any(c[3] for c in fake.calls)          # 8 items in chunks of 3, ragged batches
