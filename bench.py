@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--encode-batch", type=int, default=8)
     ap.add_argument("--tracker", default="pips", choices=["pips", "pips_plus_plus"],
                     help="point tracker (the metric is quoted on PIPS; PIPS++ = SURVEY.md §8 row f4)")
+    ap.add_argument("--shard", default="sequences", choices=["sequences", "frames"],
+                    help="N > 1: 'sequences' = one clip per rank (weak scaling, the default the metric uses); 'frames' = ONE "
+                         "clip, its frame batches dealt over the ranks (strong scaling, BASELINE config #5)")
     ap.add_argument("--hq", action="store_true", help="HQ-SAM decoder (reference default samhq_vit_huge; BASELINE config #5)")
     ap.add_argument("--pips-vis-bias", type=float, default=2.0,
                     help="bias of the random PIPS visibility head (weights.py default 2.0 -> sigmoid 0.88, just under the 0.9 "
@@ -65,8 +68,11 @@ def build_model(args, dev):
     return model
 
 
-def one_step(model, video, max_frames):
-    from sam_pt_amd.dist import gather_masks, index_masks
+def one_step(model, video, max_frames, shard="sequences"):
+    from sam_pt_amd.dist import gather_masks, index_masks, sharded_forward
+    if shard == "frames":
+        full, out = sharded_forward(model, video, batch=8)
+        return index_masks(torch.stack(out["logits"], dim=0)), full
     out = model(video)
     logits = torch.stack(out["logits"], dim=0)          # (M,T,H,W) on device
     masks = index_masks(logits)                          # bg stack + softmax + argmax (eval.py:304-326)
@@ -197,7 +203,9 @@ def main():
     torch.cuda.set_device(dev)
     # host-side weight generation / packing: keep N ranks from oversubscribing the host cores
     torch.set_num_threads(max(1, min(32, (os.cpu_count() or 8) // max(world, 1))))
-    frames, qp = bench_clip(T=args.frames, seed=72 + rank, n_pos=args.points, n_objects=args.objects)
+    frames_sharded = args.shard == "frames" and world > 1
+    frames, qp = bench_clip(T=args.frames, seed=72 + (0 if frames_sharded else rank), n_pos=args.points,
+                            n_objects=args.objects)
     H, W = frames.shape[-2:]
     model = build_model(args, dev)
     frames_dev = frames.to(dev)
@@ -208,19 +216,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    shard = "frames" if frames_sharded else "sequences"
     for _ in range(args.warmup):
-        one_step(model, video, args.frames)
+        one_step(model, video, args.frames, shard)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        masks, _ = one_step(model, video, args.frames)
+        masks, _ = one_step(model, video, args.frames, shard)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    total_frames = world * args.frames * args.steps
+    total_frames = (1 if frames_sharded else world) * args.frames * args.steps
     fps = total_frames / dt
     insitu = None
     if rank == 0 and not args.no_roofline and args.precision == "f16":   # one more step, GEMM launches event-timed
@@ -231,13 +240,13 @@ def main():
     if rank == 0:
         res = {"metric": "frames/sec end-to-end (SAM-PT: ViT + PIPS, 480p, 8 pts, 1 obj)", "value": round(fps, 3),
                "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+               "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "strong" if frames_sharded else "weak",
                "vs_baseline": None,
                "dtype": "f16" if args.precision == "f16" else "f32", "data": "synthetic",
                "config": {"workload": f"{'HQ-SAM' if args.hq else 'SAM'} {args.model} + {'PIPS' if args.tracker == 'pips' else 'PIPS++'}, {args.points} query points, {args.objects} object(s), "
                                       f"{args.frames}x 480p synthetic frames upscaled to {H}x{W}, "
                                       f"{args.refine} refinement iterations, random-init weights (seed 72)",
-                          "frames_per_step": args.frames, "parallelism": f"sequence-sharded x{world}",
+                          "frames_per_step": args.frames, "parallelism": f"{'frame-batch' if frames_sharded else 'sequence'}-sharded x{world}",
                           "vit_precision": args.precision + " MFMA inputs, fp32 accumulate/LN/softmax/residual",
                           "tracker_precision": "fp32 (exact f32 MFMA)", "decoder_precision": "fp32"},
                "mask_foreground_fraction": round(float((masks > 0).float().mean()), 4),

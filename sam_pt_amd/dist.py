@@ -92,3 +92,27 @@ def gather_masks(masks: torch.Tensor, max_frames: int) -> Optional[torch.Tensor]
     outs = [torch.empty_like(pad) for _ in range(dist.get_world_size())]
     dist.all_gather(outs, pad)
     return torch.stack(outs) if dist.get_rank() == 0 else None
+
+
+def sharded_forward(model, video, batch: int = 8):
+    """One clip over all ranks (BASELINE config #5 / SURVEY.md §8e): frame batches of ``batch`` frames are dealt round
+    robin (``frame_batches``); every rank tracks the whole clip (the tracker is cheap and needs every frame), runs the
+    image encoder and the mask decoder on ITS frames only and contributes their uint8 index masks to one fixed-shape
+    all_gather.  Returns (index masks (T,H,W) uint8 on rank 0 / None elsewhere, the rank's own SamPt output dict).
+    No activation ever crosses ranks."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    T = len(video["image"])
+    mine = [t for r in frame_batches(T, world, rank, batch) for t in r]
+    out = model({**video, "frame_ids": mine})
+    logits = torch.stack(out["logits"], dim=0)                                   # (M, len(mine), H, W)
+    masks = index_masks(logits)
+    per_rank = max(len([t for r in frame_batches(T, world, k, batch) for t in r]) for k in range(world))
+    gathered = gather_masks(masks, per_rank)
+    if rank != 0:
+        return None, out
+    full = torch.zeros((T,) + tuple(masks.shape[1:]), dtype=torch.uint8, device=masks.device)
+    for k in range(world):
+        ids = [t for r in frame_batches(T, world, k, batch) for t in r]
+        full[torch.as_tensor(ids, dtype=torch.long, device=masks.device)] = gathered[k, :len(ids)]
+    return full, out

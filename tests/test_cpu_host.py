@@ -205,43 +205,9 @@ def test_fused_host_logic_on_cpu_with_a_fake_device_predictor():
     from sam_pt_amd.sam_pt import SamPt
     from sam_pt_amd.synth import synthetic_clip
     from sam_pt_amd.weights import SAM_CONFIGS, init_sam_state_dict
+    from tests.util import make_fake_device_predictor
     cfg = SAM_CONFIGS["vit_test"]
     sd = init_sam_state_dict(cfg, 72)
-
-    class FakeDevicePredictor(R.SamPredictorRef):
-        """encode_frames / track_decode with the semantics of sam_pt_amd.SamPredictor, computed by the oracle."""
-
-        def __init__(self):
-            super().__init__(sd, cfg)
-            self.model.max_decode_batch = 3                      # forces several chunks
-            self.calls = []
-
-        def encode_frames(self, frames, chw=True):
-            x = R.preprocess(cfg, frames.float())
-            return torch.cat([R.image_encoder(sd, cfg, x[i:i + 1]) for i in range(len(x))])    # (T,256,g,g)
-
-        def track_decode(self, feats, pts, labels, k, n_pos_first, refine_iters, iou_thr, size_hw, out_logits, out_score,
-                         k_item=None, npos_item=None):
-            self.calls.append((feats.shape[0], k, n_pos_first, k_item is not None))
-            for i in range(feats.shape[0]):
-                ki = int(k_item[i]) if k_item is not None else k
-                pi = int(npos_item[i]) if npos_item is not None else n_pos_first
-                self.features, self.original_size, self.input_size = feats[i:i + 1], tuple(size_hw), tuple(size_hw)
-                pc, pl = pts[i:i + 1, :ki], labels[i:i + 1, :ki]
-                kw = dict(multimask_output=False, return_logits=True)
-                low = None
-                if n_pos_first >= 0:
-                    _, _, low = self.predict_torch(pc[:, :pi], pl[:, :pi], None, None, **kw)
-                ml, iou, low = self.predict_torch(pc, pl, None, low, **kw)
-                for _ in range(refine_iters):
-                    msk = ml[0, 0] > 0
-                    if msk.sum() < 2:
-                        break
-                    yx = msk.nonzero()
-                    box = torch.tensor([[yx[:, 1].min(), yx[:, 0].min(), yx[:, 1].max(), yx[:, 0].max()]], dtype=torch.float)
-                    ml, iou, low = self.predict_torch(pc, pl, box, low, **kw)
-                out_score[i] = iou[0, 0]
-                out_logits[i] = ml[0, 0] if float(iou[0, 0]) >= iou_thr else -float("inf")
 
     class NoTracker(PointTracker):
         def forward(self, rgbs, query_points):
@@ -257,7 +223,7 @@ def test_fused_host_logic_on_cpu_with_a_fake_device_predictor():
         vis[1, 0, :] = 0                      # object 0 invisible in frame 1 (still gets object 1's positives as negatives)
         vis[2, 1, 1:] = 0                     # a single visible point
         vis[3, :, 0] = 0
-        fake = FakeDevicePredictor()
+        fake = make_fake_device_predictor(sd, cfg)
         fused = SamPt(NoTracker(), fake, sam_iou_threshold=0.0, positive_points_per_mask=3, negative_points_per_mask=neg,
                       iterative_refinement_iterations=2).eval()
         feats = fake.encode_frames(frames)
@@ -269,3 +235,57 @@ def test_fused_host_logic_on_cpu_with_a_fake_device_predictor():
         fin = torch.isfinite(l_s)
         assert (l_f[fin] - l_s[fin]).abs().max() < 1e-4 and torch.allclose(s_f, s_s, atol=1e-5)
         assert len(fake.calls) == 3 and any(c[3] for c in fake.calls)          # 8 items in chunks of 3, ragged batches
+
+
+def test_frame_sharded_forward_two_ranks_gloo():
+    """dist.sharded_forward (one clip, frame batches dealt over the ranks: BASELINE config #5) with 2 gloo processes on
+    the CPU: rank 0's assembled index masks equal the single-process result; nothing but uint8 masks crosses ranks."""
+    code = r"""
+import os, sys, torch
+sys.path.insert(0, %r)
+import torch.distributed as dist
+from oracle import pips_ref as PO
+from sam_pt_amd.dist import init_from_env, sharded_forward, index_masks
+from sam_pt_amd.point_tracker import PointTracker
+from sam_pt_amd.sam_pt import SamPt
+from sam_pt_amd.synth import disc_queries, synthetic_clip
+from sam_pt_amd.weights import SAM_CONFIGS, init_pips_state_dict, init_sam_state_dict
+from tests.util import make_fake_device_predictor
+rank, world, local = init_from_env("gloo")
+assert world == 2
+torch.set_num_threads(4)
+cfg = SAM_CONFIGS["vit_test"]
+sd, psd = init_sam_state_dict(cfg, 72), init_pips_state_dict(72)
+class OracleTracker(PointTracker):
+    def forward(self, rgbs, query_points):
+        return PO.PipsTrackerRef(psd).forward(rgbs.cpu(), query_points.cpu())
+frames, centres = synthetic_clip(T=6, H=128, W=256, seed=72)
+q = disc_queries(centres, n_pos=3, r=9.0)
+video = {"image": [f for f in frames], "target_hw": (128, 256), "query_points": q[None]}
+def model():
+    return SamPt(OracleTracker(), make_fake_device_predictor(sd, cfg, 4), sam_iou_threshold=-1e9, positive_points_per_mask=3,
+                 negative_points_per_mask=0, iterative_refinement_iterations=1).eval()
+full, own = sharded_forward(model(), video, batch=2)          # batches {0,1},{4,5} -> rank 0 ; {2,3} -> rank 1
+assert len(own["logits"][0]) == (4 if rank == 0 else 2) and own["trajectories"].shape[0] == 6
+if rank == 0:
+    ref = model()(video)
+    want = index_masks(torch.stack(ref["logits"], dim=0))
+    assert full.shape == want.shape and torch.equal(full, want) and int(want.sum()) > 0
+    print("SHARDED_OK")
+else:
+    assert full is None
+dist.barrier(); dist.destroy_process_group()
+""" % ROOT
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:
+        f.write(code)
+        path = f.name
+    try:
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                            "--master-addr", "127.0.0.1", "--master-port", "29547", path], env=env, capture_output=True,
+                           text=True, timeout=600)
+    finally:
+        os.unlink(path)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "SHARDED_OK" in r.stdout
