@@ -205,6 +205,114 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64, OCC) void gemm_f16_gl
   }  // tile loop
 }
 
+// ---------------------------------------------------------------------------------------------
+// Experimental (SAMPT_GEMM_VARIANT=9): BK = 32 slabs, double-buffered, still 32 KiB of LDS -> 4 workgroups per CU AND a
+// slab of prefetch per workgroup.  128 x 128 tile, 4 waves x (64 x 64), one v_mfma_f32_16x16x32_f16 K-step per slab.
+// LDS rows are 64 B (4 chunks of 16 B); a DMA piece covers 16 rows; chunk swizzle pos = chunk ^ F[(row >> 2) & 3],
+// F = {0, 3, 2, 1}: every ds_read_b128 lane group then touches 16 distinct 16-byte slots of the 256-B bank row.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 4) void gemm_f16_glds_bk32(GemmP p) {
+  constexpr int BM = 128, BN = 128, BK = 32, FM = 4, FN = 4, BUF = (BM + BN) * BK;
+  __shared__ __attribute__((aligned(1024))) half_t lds[2 * BUF];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nt_m = (p.M + BM - 1) / BM, nt_n = (p.N + BN - 1) / BN;
+  const int R = p.xcd_swizzle, nstrips = (nt_m + R - 1) / R, per_strip = R * nt_n;
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int j = idx / per_strip, t = idx - j * per_strip, strip = xcd + 8 * j;
+  if (strip >= nstrips) return;
+  const int rows = min(R, nt_m - R * strip);
+  const int tile_n = t / rows;
+  if (tile_n >= nt_n) return;
+  const int tile_m = strip * R + (t - tile_n * rows);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const half_t* __restrict__ A = (const half_t*)p.A;
+  const half_t* __restrict__ W = (const half_t*)p.W;
+  const int prow = lane >> 2, ppos = lane & 3;
+  const half_t* a_src[2];
+  const half_t* b_src[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int trow = (wave * 2 + i) * 16 + prow;
+    const int f = (trow >> 2) & 3, chunk = ppos ^ ((4 - f) & 3);          // F = {0, 3, 2, 1}
+    int row = min(m0 + trow, p.M - 1);
+    if (p.a_rowmap) row = p.a_rowmap[row];
+    a_src[i] = A + (long)row * p.lda + chunk * 8;
+    b_src[i] = W + (long)min(n0 + trow, p.N - 1) * p.ldw + chunk * 8;
+  }
+  auto issue = [&](int kt, int buf) {
+    half_t* ab = lds + buf * BUF + wave * 2 * 16 * BK;
+    half_t* bb = lds + buf * BUF + BM * BK + wave * 2 * 16 * BK;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      __builtin_amdgcn_global_load_lds((glb_void*)(a_src[i] + kt * BK), (lds_void*)(ab + i * 16 * BK), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void*)(b_src[i] + kt * BK), (lds_void*)(bb + i * 16 * BK), 16, 0, 0);
+    }
+  };
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int jj = 0; jj < FN; ++jj) acc[i][jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int nk = p.K / BK;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int fsw = (lr >> 2) & 3, pos = (lq ^ ((4 - fsw) & 3)) * 8;
+  int a_off[FM], b_off[FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) a_off[i] = (wm * 64 + i * 16 + lr) * BK + pos;
+#pragma unroll
+  for (int jj = 0; jj < FN; ++jj) b_off[jj] = BM * BK + (wn * 64 + jj * 16 + lr) * BK + pos;
+  issue(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                      // slab kt landed everywhere; everyone is done reading slab kt-1
+    if (kt + 1 < nk) issue(kt + 1, buf ^ 1);
+    const half_t* base = lds + buf * BUF;
+    h8 a[FM], b[FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) a[i] = *(const h8*)(base + a_off[i]);
+#pragma unroll
+    for (int jj = 0; jj < FN; ++jj) b[jj] = *(const h8*)(base + b_off[jj]);
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int jj = 0; jj < FN; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[jj], a[i], acc[i][jj], 0, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    int row = m0 + wm * 64 + i * 16 + lr;
+    if (row >= p.M) continue;
+    int drow = p.rowmap ? p.rowmap[row] : row;
+    if (drow < 0) continue;
+    int rrow = p.res_mod > 0 ? drow % p.res_mod : drow;
+#pragma unroll
+    for (int jj = 0; jj < FN; ++jj) {
+      int col = n0 + wn * 64 + jj * 16 + lq * 4;
+      if (col >= p.N) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[i][jj][r] * p.alpha;
+      if (p.bias) {
+        float4 bv = *(const float4*)(p.bias + col);
+        v[0] += bv.x, v[1] += bv.y, v[2] += bv.z, v[3] += bv.w;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act);
+      if (p.res) {
+        float4 rv = *(const float4*)(p.res + (long)rrow * p.ldr + col);
+        v[0] += rv.x, v[1] += rv.y, v[2] += rv.z, v[3] += rv.w;
+      }
+      if (p.out_f16) {
+        *(h4*)((half_t*)p.C + (long)drow * p.ldc + col) = (h4){(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+      } else {
+        f32x4 o = (f32x4){v[0], v[1], v[2], v[3]};
+        __builtin_nontemporal_store(o, (f32x4*)((float*)p.C + (long)drow * p.ldc + col));
+      }
+    }
+  }
+}
+
 // returns SAMPT_ERR_UNSUPPORTED when the shape does not fit this kernel (caller falls back to gemm_kernel)
 int gemm_f16_glds_launch(const GemmP& p, hipStream_t s) {
   if (p.conv || p.w_kn || p.nb1 * p.nb2 != 1 || p.K % 64 || p.M < 128 || p.N < 128) return SAMPT_ERR_UNSUPPORTED;
@@ -243,6 +351,8 @@ int gemm_f16_glds_launch(const GemmP& p, hipStream_t s) {
     q.xcd_swizzle = R;
     grid = dim3(8 * cdiv(cdiv(nt_m, R), 8) * R * nt_n, 1, 1);
     hipLaunchKernelGGL((gemm_f16_glds<256, 128, 1, 64, 64, 16>), grid, dim3(512), 0, s, q);
+  } else if (variant == 9 && swz) {
+    hipLaunchKernelGGL(gemm_f16_glds_bk32, grid, block, 0, s, q);
   } else if (variant == 8 && swz) {
     // persistent: one generation = 4 workgroups per CU x 256 CUs = 128 per XCD
     const int nt_m = cdiv(p.M, 128), nt_n = cdiv(p.N, 128);
