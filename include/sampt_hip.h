@@ -151,6 +151,14 @@ int sampt_sam_decode(sampt_dec_t h, const float* features_dev, const float* hq_f
                      const int32_t* labels_dev, int k, const float* box_dev, const float* mask_in_dev, int in_h, int in_w, int out_h, int out_w,
                      float* logits_out_dev, float* iou_out_dev, float* low_res_out_dev, void* workspace_dev,
                      size_t workspace_bytes, sampt_stream_t stream);
+/* The same pass with multimask_output=True (SAM decoder only): the 3 masks / IoU predictions of mask tokens 1..3, in
+ * that order (MaskDecoder.forward mask_slice = slice(1, None)).  logits_out_dev [3][out_h][out_w], iou_out_dev [3],
+ * low_res_out_dev [3][4*grid][4*grid].  Not on the SAM-PT path (sam_pt.py always passes False); part of the
+ * SamPredictor.predict_torch surface. */
+int sampt_sam_decode_multimask(sampt_dec_t h, const float* features_dev, const float* pts_dev, const int32_t* labels_dev,
+                               int k, const float* box_dev, const float* mask_in_dev, int in_h, int in_w, int out_h,
+                               int out_w, float* logits_out_dev, float* iou_out_dev, float* low_res_out_dev,
+                               void* workspace_dev, size_t workspace_bytes, sampt_stream_t stream);
 /* Whole SamPt.predict_mask chain (sam_pt.py:760-837) for `frames` independent (frame, object) items that share the
  * visible-point count k, batched into one launch sequence and without host synchronisation:
  * [positives-only pass over the first n_pos_first points when n_pos_first >= 0, i.e. negative_points_per_mask > 0;

@@ -58,6 +58,7 @@ _SIGS = {
     "sampt_dec_workspace_bytes": (c_int, [_P, c_int, c_int, c_int, C.POINTER(c_size_t)]),
     "sampt_sam_decode": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_size_t,
                                  _P]),
+    "sampt_sam_decode_multimask": (c_int, [_P, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_size_t, _P]),
     "sampt_sam_track_decode": (c_int, [_P, c_int, _P, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_float, c_int, c_int, c_int,
                                        c_int, _P, _P, _P, c_size_t, _P]),
     "sampt_postprocess_masks": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P]),

@@ -271,6 +271,21 @@ int sampt_sam_decode(sampt_dec_t h, const float* features, const float* hq_featu
                      low_out, nullptr, a, (hipStream_t)stream);
 }
 
+int sampt_sam_decode_multimask(sampt_dec_t h, const float* features, const float* pts, const int32_t* labels, int k,
+                               const float* box, const float* mask_in, int in_h, int in_w, int oh, int ow,
+                               float* logits_out, float* iou_out, float* low_out, void* ws, size_t ws_bytes,
+                               sampt_stream_t stream) {
+  if (!h || !features || !logits_out || !iou_out || !low_out || !ws || k < 0 || (k > 0 && (!pts || !labels)))
+    return fail(SAMPT_ERR_ARG, "sampt_sam_decode_multimask: bad arguments");
+  if (h->e.is_hq()) return fail(SAMPT_ERR_UNSUPPORTED, "sampt_sam_decode_multimask: SAM decoder handles only");
+  Arena a(ws, ws_bytes);
+  h->e.multimask = true;
+  int rc = h->e.decode(1, features, nullptr, pts, labels, k, nullptr, k > 0 ? k : 1, box, mask_in, in_h, in_w, oh, ow,
+                       logits_out, iou_out, low_out, nullptr, a, (hipStream_t)stream);
+  h->e.multimask = false;
+  return rc;
+}
+
 int sampt_sam_track_decode(sampt_dec_t h, int frames, const float* features, const float* hq_features,
                            const float* pts, const int32_t* labels, int k, const int32_t* k_item,
                            const int32_t* npos_item, int ld_pts, int n_pos_first, int refine_iters, float iou_thr,

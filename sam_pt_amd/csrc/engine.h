@@ -162,6 +162,8 @@ struct DecEngine {
   const float *up0_w, *up0_b, *upln_w, *upln_b, *up1_w, *up1_b;  // ConvT weights packed [(dy,dx)][cout][cin]
   const int *up0_map, *up1_map;                  // pixel-shuffle row maps [4][max_frames*g*g], [4][max_frames*4*g*g]
   const float *hyp_w[3], *hyp_b[3], *iou_w[3], *iou_b[3];         // hypernetwork MLP 0 and IoU head
+  const float *hypx_w[3][3], *hypx_b[3][3];                       // hypernetwork MLPs 1..3 (multimask_output=True)
+  bool multimask = false;  // next decode(): SAM's multimask_output=True — 3 masks / IoUs of mask tokens 1..3 (F == 1, SAM only)
   // HQ-SAM extras (c.vit_dim > 0): out_tokens has a 6th row (hf_token); ConvT weights packed like up0/up1
   struct HqW {
     const float *mlp_w[3], *mlp_b[3];                             // hf_mlp

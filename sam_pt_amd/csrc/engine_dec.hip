@@ -57,6 +57,10 @@ int DecEngine::init(const WeightMap& w, const DecConfig& cfg) {
   for (int i = 0; i < 3; ++i) {
     hyp_w[i] = w.f("mask_decoder.output_hypernetworks_mlps.0.layers." + std::to_string(i) + ".weight");
     hyp_b[i] = w.f("mask_decoder.output_hypernetworks_mlps.0.layers." + std::to_string(i) + ".bias");
+    for (int m = 0; m < 3; ++m) {
+      const std::string hp = "mask_decoder.output_hypernetworks_mlps." + std::to_string(m + 1) + ".layers." + std::to_string(i);
+      hypx_w[m][i] = w.f(hp + ".weight"), hypx_b[m][i] = w.f(hp + ".bias");
+    }
     iou_w[i] = w.f("mask_decoder.iou_prediction_head.layers." + std::to_string(i) + ".weight");
     iou_b[i] = w.f("mask_decoder.iou_prediction_head.layers." + std::to_string(i) + ".bias");
   }
@@ -178,6 +182,8 @@ int DecEngine::decode(int F, const float* features, const float* hq_feat, const 
   if (is_hq()) uh0 = ws.f32(16 * FP * (C / 4)), uh1 = ws.f32(16 * FP * (C / 8)), t3 = ws.f32((size_t)F * C);
   int* bbox_partial = (int*)ws.get((size_t)F * bbox_partial_ints(oh, ow) * sizeof(int));
   int* ntok = (int*)ws.get((size_t)F * sizeof(int));           // valid tokens per item (ragged batch)
+  float* iou4 = ws.f32((size_t)F * 4);
+  if (multimask && (is_hq() || F != 1)) return SAMPT_ERR_UNSUPPORTED;
   const size_t skn = (size_t)16 * FT * C;
   float* skws = ws.f32(skn);
   if (!ws.ok()) return SAMPT_ERR_WORKSPACE;
@@ -226,6 +232,21 @@ int DecEngine::decode(int F, const float* features, const float* hq_feat, const 
   //      that cover max_frames frames: map[(dy,dx)][f*P + p] = f*4P + (2y+dy)*2g + 2x+dx)
   SAMPT_TRY(convt_pair(*this, F, b.keys, C, up0_w, up0_b, C / 4, upln_w, upln_b, up1_w, up1_b, C / 8, ACT_GELU, nullptr,
                        b.up0, b.up1, nullptr, 0, s));
+  if (multimask) {
+    // multimask_output=True (MaskDecoder.forward: mask_slice = slice(1, None)): masks and IoUs of mask tokens 1..3;
+    // low_out [3][4g][4g], logits_out [3][oh][ow], iou_out [3]
+    for (int m = 0; m < 3; ++m) {
+      SAMPT_TRY(l.lin(queries + (2 + m) * C, 1, C, hypx_w[m][0], hypx_b[m][0], b.t0, C, ACT_RELU, nullptr, Nt * C));
+      SAMPT_TRY(l.lin(b.t0, 1, C, hypx_w[m][1], hypx_b[m][1], b.t1, C, ACT_RELU));
+      SAMPT_TRY(l.lin(b.t1, 1, C, hypx_w[m][2], hypx_b[m][2], b.t2, C / 8, ACT_NONE));
+      SAMPT_TRY(sam_mask_dot(b.up1, b.t2, C / 8, nullptr, nullptr, 0, low_out + (size_t)m * 16 * P, 1, 16 * P, C / 8, s));
+    }
+    SAMPT_TRY(l.lin(queries, 1, C, iou_w[0], iou_b[0], b.t0, C, ACT_RELU, nullptr, Nt * C));
+    SAMPT_TRY(l.lin(b.t0, 1, C, iou_w[1], iou_b[1], b.t1, C, ACT_RELU));
+    SAMPT_TRY(l.lin(b.t1, 1, C, iou_w[2], iou_b[2], iou4, 4, ACT_NONE));
+    if (hipMemcpyAsync(iou_out, iou4 + 1, 3 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return SAMPT_ERR_HIP;
+    return sam_postprocess_bbox(low_out, 4 * g, c.img, in_h, in_w, logits_out, oh, ow, 3, nullptr, nullptr, s);
+  }
   // ---- hypernetwork MLP of mask token 0 (multimask_output=False keeps slice 0 only) and the IoU head;
   //      A = row 1 (mask token 0) / row 0 (iou token) of every frame's token matrix: lda = Nt*C
   const float* mask_tok = queries + 1 * C;

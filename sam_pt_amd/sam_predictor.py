@@ -267,8 +267,9 @@ class SamPredictor:
                       return_logits: bool = False):
         if not self.is_image_set:
             raise RuntimeError("An image must be set with .set_image(...) before mask prediction.")
-        if multimask_output:
-            raise NotImplementedError("multimask_output=True is not on the SAM-PT path (sam_pt.py:787, 796, 805, 826)")
+        if multimask_output and self.model.hq:
+            raise NotImplementedError("multimask_output=True with the HQ-SAM decoder is not built (SAM-PT never asks for "
+                                      "it: sam_pt.py:787, 796, 805, 826)")
         if point_coords is None or point_coords.shape[0] != 1:
             raise NotImplementedError("predict_torch: exactly one prompt batch with points is supported")
         self._ensure()
@@ -280,10 +281,18 @@ class SamPredictor:
         box = boxes.reshape(-1)[:4].to(dev, torch.float32).contiguous() if boxes is not None else None
         L = 4 * self.model.cfg.grid
         mi = mask_input.reshape(L, L).to(dev, torch.float32).contiguous() if mask_input is not None else None
-        logits = torch.empty((1, 1, oh, ow), dtype=torch.float32, device=dev)
-        iou = torch.empty((1, 1), dtype=torch.float32, device=dev)
-        low = torch.empty((1, 1, L, L), dtype=torch.float32, device=dev)
+        nm = 3 if multimask_output else 1
+        logits = torch.empty((1, nm, oh, ow), dtype=torch.float32, device=dev)
+        iou = torch.empty((1, nm), dtype=torch.float32, device=dev)
+        low = torch.empty((1, nm, L, L), dtype=torch.float32, device=dev)
         ws = self._dec_ws(oh, ow)
+        if multimask_output:
+            _lib.check(self._lib.sampt_sam_decode_multimask(self._dec, _lib.ptr(self._feat_tokens), _lib.ptr(pts), _lib.ptr(lab),
+                                                            pts.shape[0], _lib.ptr(box), _lib.ptr(mi), ih, iw, oh, ow,
+                                                            _lib.ptr(logits), _lib.ptr(iou), _lib.ptr(low), _lib.ptr(ws),
+                                                            ws.numel(), _lib.stream_ptr()), "sampt_sam_decode_multimask")
+            self.stats["predict"] += 1
+            return (logits if return_logits else logits > self.model.mask_threshold), iou, low
         _lib.check(self._lib.sampt_sam_decode(self._dec, _lib.ptr(self._feat_tokens), _lib.ptr(self._hq_tokens),
                                               _lib.ptr(pts), _lib.ptr(lab),
                                               pts.shape[0], _lib.ptr(box), _lib.ptr(mi), ih, iw, oh, ow, _lib.ptr(logits),

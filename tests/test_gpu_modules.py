@@ -588,3 +588,34 @@ def test_single_frame_and_single_point_video(dev, pips_sd):
     out = model({"image": [frames[0]], "target_hw": (128, 256), "query_points": q[None]})
     assert out["trajectories"].shape == (1, 1, 1, 2) and torch.allclose(out["trajectories"][0, 0, 0].cpu(), q[0, 1:])
     assert out["logits"][0].shape == (1, 128, 256) and torch.isfinite(out["logits"][0]).all()
+
+
+def test_predict_torch_multimask_vs_oracle(dev):
+    """multimask_output=True (not on the SAM-PT path, part of the SamPredictor surface): the three masks / IoUs of mask
+    tokens 1..3 against the oracle (whose multimask branch agrees with HuggingFace SamModel to 3e-5)."""
+    from oracle import sam_ref as R
+    from sam_pt_amd.sam_predictor import SamHip, SamPredictor
+    from sam_pt_amd.weights import SAM_CONFIGS, init_sam_state_dict
+    cfg = SAM_CONFIGS["vit_test"]
+    sd = init_sam_state_dict(cfg, 72)
+    frames, centres = synthetic_clip(T=1, H=144, W=256, seed=5)
+    img = frames[0].permute(1, 2, 0).numpy()
+    pred = SamPredictor(SamHip(config=cfg, state_dict=sd, precision="f32").to(dev))
+    ref = R.SamPredictorRef(sd, cfg)
+    pred.set_image(img), ref.set_image(img)
+    q = disc_queries(centres, n_pos=3, r=9.0)[:, 1:]
+    pts = torch.as_tensor(pred.transform.apply_coords(q.numpy(), (144, 256)), dtype=torch.float)[None]
+    lab = torch.tensor([[1, 1, 0]], dtype=torch.int)
+    m0, i0, l0 = ref.predict_torch(pts, lab, None, None, True, True)
+    m1, i1, l1 = pred.predict_torch(pts.to(dev), lab.to(dev), None, None, True, True)
+    assert m1.shape == (1, 3, 144, 256) and i1.shape == (1, 3) and l1.shape == (1, 3, 64, 64)
+    assert max_abs(l1, l0) < 3e-4 and max_abs(i1, i0) < 1e-4 and max_abs(m1, m0) < 3e-4
+    box = torch.tensor([[[20.0, 10.0, 200.0, 120.0]]])
+    m2, i2, l2 = ref.predict_torch(pts, lab, box, l0[:, :1], True, False)
+    m3, i3, l3 = pred.predict_torch(pts.to(dev), lab.to(dev), box.to(dev), l0[:, :1].to(dev), True, False)
+    assert m3.dtype == torch.bool and max_abs(l3, l2) < 3e-4 and max_abs(i3, i2) < 1e-4
+    assert all(iou(m3[0, j].cpu(), m2[0, j]) >= 1 - 1e-3 for j in range(3))
+    # the single-mask call afterwards is unaffected by the multimask one
+    m4, i4, l4 = pred.predict_torch(pts.to(dev), lab.to(dev), None, None, False, True)
+    m5, i5, l5 = ref.predict_torch(pts, lab, None, None, False, True)
+    assert max_abs(l4, l5) < 3e-4 and m4.shape == (1, 1, 144, 256)
