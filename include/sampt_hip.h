@@ -182,6 +182,14 @@ size_t sampt_bbox_workspace_bytes(int h, int w);
 int sampt_bbox_from_logits(const float* logits_dev, int h, int w, int32_t* bbox_state_dev, void* workspace_dev,
                            size_t workspace_bytes, sampt_stream_t stream);
 
+/* One axis of PIL's 8-bit separable resampler (Image.resize, the arithmetic behind ResizeLongestSide.apply_image =
+ * torchvision resize(to_pil_image(.)) in SamPredictor.set_image, App. A-1): src_dev [outer][in_len][inner] uint8 ->
+ * dst_dev [outer][out_len][inner], dst = clip8((2^21 + sum_x src[xmin+x]*coef[xx][x]) >> 22).  coef_dev int32
+ * [out_len][ksize] / bounds_dev int32 [out_len][2] = PIL's precompute_coeffs + normalize_coeffs_8bpc tables, built by the
+ * host (sam_pt_amd/sam_predictor.py); horizontal pass first, then vertical, each rounded to uint8 as PIL does. */
+int sampt_pil_resample_u8(const uint8_t* src_dev, uint8_t* dst_dev, long outer, int in_len, int out_len, int inner,
+                          const int32_t* coef_dev, const int32_t* bounds_dev, int ksize, sampt_stream_t stream);
+
 /* VOS post-processing.  sampt_resize_logits: F.interpolate(logits, target_hw, bilinear, align_corners=False) of
  * sam_pt.py:205-206 for n single-channel maps.  sampt_index_masks: uint8 object index per pixel = argmax over
  * {background logit 0, logits_dev[M][npix]}, i.e. the bg-stack + softmax + argmax of vos_eval/eval.py:304, 326, 355. */

@@ -360,12 +360,16 @@ class SamPredictorRef:
 
     @torch.no_grad()
     def set_image(self, image: np.ndarray):
-        """image: HxWx3 uint8 RGB.  Only the identity-resize case (longest side == img_size) is supported,
-        which is what the reference pipelines feed (configs/demo.yaml:20, vos_eval_root.yaml:28)."""
+        """image: HxWx3 uint8 RGB.  ResizeLongestSide.apply_image = torchvision resize(to_pil_image(image), target) =
+        PIL bilinear (App. A-1); the identity when the longest side is already img_size, which is what the reference
+        pipelines feed (configs/demo.yaml:20, vos_eval_root.yaml:28)."""
         H, W = image.shape[:2]
-        assert get_preprocess_shape(H, W, self.cfg.img_size) == (H, W), "oracle supports identity resize only"
-        x = torch.as_tensor(image).permute(2, 0, 1)[None].float()
-        self.original_size, self.input_size = (H, W), (H, W)
+        nh, nw = get_preprocess_shape(H, W, self.cfg.img_size)
+        if (nh, nw) != (H, W):
+            from PIL import Image
+            image = np.array(Image.fromarray(np.ascontiguousarray(image)).resize((nw, nh), Image.BILINEAR))
+        x = torch.as_tensor(np.ascontiguousarray(image)).permute(2, 0, 1)[None].float()
+        self.original_size, self.input_size = (H, W), (nh, nw)
         if self.hq:
             self.features, interm = image_encoder(self.sd, self.cfg, preprocess(self.cfg, x), return_interm=True)
             self.hq_feat = hq_features(self.sd, self.features, interm)

@@ -65,6 +65,7 @@ _SIGS = {
     "sampt_bbox_workspace_bytes": (c_size_t, [c_int, c_int]),
     "sampt_bbox_from_logits": (c_int, [_P, c_int, c_int, _P, _P, c_size_t, _P]),
     "sampt_resize_logits": (c_int, [_P, c_int, c_int, c_int, _P, c_int, c_int, _P]),
+    "sampt_pil_resample_u8": (c_int, [_P, _P, C.c_long, c_int, c_int, c_int, _P, _P, c_int, _P]),
     "sampt_index_masks": (c_int, [_P, c_int, C.c_long, _P, _P]),
     "sampt_vos_index_masks": (c_int, [_P, c_int, c_int, C.c_long, _P, _P, _P, _P]),
     "sampt_gemm": (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),

@@ -375,6 +375,14 @@ int sampt_vos_index_masks(const float* logits, int M, int T, long hw, const int3
   return vos_index_masks(logits, M, T, hw, (const int*)query_t, gt_masks, out, (hipStream_t)stream);
 }
 
+int sampt_pil_resample_u8(const uint8_t* src, uint8_t* dst, long outer, int in_len, int out_len, int inner,
+                          const int32_t* coef, const int32_t* bounds, int ksize, sampt_stream_t stream) {
+  if (!src || !dst || !coef || !bounds || outer <= 0 || in_len <= 0 || out_len <= 0 || inner <= 0)
+    return fail(SAMPT_ERR_ARG, "sampt_pil_resample_u8: bad arguments");
+  return pil_resample_u8(src, dst, outer, in_len, out_len, inner, (const int*)coef, (const int*)bounds, ksize,
+                         (hipStream_t)stream);
+}
+
 int sampt_index_masks(const float* logits, int M, long npix, uint8_t* out, sampt_stream_t stream) {
   if (!logits || !out || npix <= 0) return SAMPT_ERR_ARG;
   return index_masks(logits, M, npix, out, (hipStream_t)stream);

@@ -518,6 +518,37 @@ int vos_index_masks(const float* logits, int M, int T, long hw, const int* qt, c
   return SAMPT_OK;
 }
 
+// One pass of PIL's 8-bit separable resampler (ImagingResampleHorizontal/Vertical_8bpc): out = clip8((2^21 + sum_x
+// in[xmin + x] * k[x]) >> 22) along one axis, intermediate image rounded to uint8 between the passes exactly as PIL does.
+// The fixed-point coefficient tables (precompute_coeffs + normalize_coeffs_8bpc) come from the host.
+// src viewed as [outer][in_len][inner] bytes, dst [outer][out_len][inner].
+__global__ void k_pil_resample_u8(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, long outer, int in_len,
+                                  int out_len, int inner, const int* __restrict__ coef, const int* __restrict__ bounds,
+                                  int ksize) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= outer * out_len * inner) return;
+  const int c = (int)(i % inner);
+  const int xx = (int)((i / inner) % out_len);
+  const long o = i / ((long)inner * out_len);
+  const int xmin = bounds[2 * xx], n = bounds[2 * xx + 1];
+  const int* k = coef + (long)xx * ksize;
+  const uint8_t* p = src + (o * in_len + xmin) * inner + c;
+  int ss = 1 << 21;
+  for (int x = 0; x < n; ++x) ss += (int)p[(long)x * inner] * k[x];
+  ss >>= 22;
+  dst[i] = (uint8_t)min(max(ss, 0), 255);
+}
+
+int pil_resample_u8(const uint8_t* src, uint8_t* dst, long outer, int in_len, int out_len, int inner, const int* coef,
+                    const int* bounds, int ksize, hipStream_t s) {
+  const long n = outer * out_len * inner;
+  if (n <= 0 || ksize <= 0) return SAMPT_ERR_ARG;
+  hipLaunchKernelGGL(k_pil_resample_u8, dim3(cdiv(n, 256)), dim3(256), 0, s, src, dst, outer, in_len, out_len, inner, coef,
+                     bounds, ksize);
+  SAMPT_CHECK_LAUNCH("pil_resample_u8");
+  return SAMPT_OK;
+}
+
 // rows[i] of a [*][N] matrix := bias (the qkv of SAM's zero-padded window tokens is the bias alone, App. A-3)
 template <typename T>
 __global__ void k_fill_rows_bias(T* __restrict__ out, const int* __restrict__ rows, const float* __restrict__ bias, int N) {

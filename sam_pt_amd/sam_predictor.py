@@ -24,11 +24,66 @@ from .pack import pack_decoder, pack_vit
 from .weights import SAM_CONFIGS, SamConfig, init_sam_state_dict
 
 
+def pil_bilinear_tables(in_size: int, out_size: int):
+    """PIL's fixed-point bilinear resampling tables for one axis (src/libImaging/Resample.c: precompute_coeffs with the
+    bilinear filter, support 1 scaled by max(1, in/out), then normalize_coeffs_8bpc with 22 fractional bits).
+    -> (coef int32 [out][ksize], bounds int32 [out][2] = (first input index, tap count)).  Bit-exact against PIL 12.2
+    (tests/test_cpu_host.py)."""
+    import math
+    scale = in_size / out_size
+    fs = max(scale, 1.0)
+    support = 1.0 * fs
+    ksize = int(math.ceil(support)) * 2 + 1
+    kk = np.zeros((out_size, ksize), np.float64)
+    bounds = np.zeros((out_size, 2), np.int32)
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        x = np.arange(xmax)
+        a = np.abs((x + xmin - center + 0.5) * (1.0 / fs))
+        w = np.where(a < 1.0, 1.0 - a, 0.0)
+        ww = w.sum()
+        kk[xx, :xmax] = w / ww if ww != 0 else w
+        bounds[xx] = (xmin, xmax)
+    coef = np.trunc(np.where(kk < 0, -0.5 + kk * (1 << 22), 0.5 + kk * (1 << 22))).astype(np.int32)
+    return coef, bounds
+
+
 class ResizeLongestSide:
-    """Coordinate part of segment_anything.utils.transforms.ResizeLongestSide (App. A-1)."""
+    """segment_anything.utils.transforms.ResizeLongestSide (App. A-1): coordinates on the host, ``apply_image`` =
+    torchvision ``resize(to_pil_image(image), target)`` = PIL bilinear, done on the device with PIL's own fixed-point
+    arithmetic (bit-identical to ``PIL.Image.resize``)."""
 
     def __init__(self, target_length: int):
         self.target_length = target_length
+        self._tables = {}
+
+    def apply_image_torch(self, image: torch.Tensor) -> torch.Tensor:
+        """(H,W,3) uint8 on the HIP device -> (new_h,new_w,3) uint8, longest side = target_length."""
+        H, W, Cc = image.shape
+        nh, nw = self.get_preprocess_shape(H, W, self.target_length)
+        if (nh, nw) == (H, W):
+            return image
+        lib, dev = _lib.load(), image.device
+        cur = image.contiguous()
+        for axis, (n_in, n_out) in ((1, (W, nw)), (0, (H, nh))):          # PIL: horizontal pass first, then vertical
+            if n_in == n_out:
+                continue
+            key = (n_in, n_out, str(dev))
+            if key not in self._tables:
+                coef, bounds = pil_bilinear_tables(n_in, n_out)
+                self._tables[key] = (torch.from_numpy(coef).to(dev), torch.from_numpy(bounds).to(dev), coef.shape[1])
+            coef_d, bounds_d, ks = self._tables[key]
+            if axis == 1:
+                outer, inner, shape = cur.shape[0], Cc, (cur.shape[0], n_out, Cc)
+            else:
+                outer, inner, shape = 1, cur.shape[1] * Cc, (n_out, cur.shape[1], Cc)
+            dst = torch.empty(shape, dtype=torch.uint8, device=dev)
+            _lib.check(lib.sampt_pil_resample_u8(_lib.ptr(cur), _lib.ptr(dst), outer, n_in, n_out, inner, _lib.ptr(coef_d),
+                                                 _lib.ptr(bounds_d), ks, _lib.stream_ptr()), "sampt_pil_resample_u8")
+            cur = dst
+        return cur
 
     @staticmethod
     def get_preprocess_shape(oldh: int, oldw: int, long_side_length: int) -> Tuple[int, int]:
@@ -252,13 +307,11 @@ class SamPredictor:
         if image_format != self.model.image_format:
             image = image[..., ::-1]
         H, W = image.shape[:2]
-        if self.transform.get_preprocess_shape(H, W, self.model.cfg.img_size) != (H, W):
-            raise NotImplementedError("set_image: the frame's longest side must equal img_size; the reference pipelines "
-                                      "resize before SamPt (configs/demo.yaml:20, configs/vos_eval_root.yaml:28)")
         self._ensure()
         t = torch.as_tensor(np.ascontiguousarray(image), device=self._dev)
+        t = self.transform.apply_image_torch(t)                      # identity when the longest side is already img_size
         feats = self.encode_frames(t[None], chw=False)
-        self.set_features(feats[0], (H, W), (H, W))     # (ClipFeatures[0] for HQ-SAM)
+        self.set_features(feats[0], (H, W), tuple(t.shape[:2]))      # (ClipFeatures[0] for HQ-SAM)
         self.stats["set_image"] += 1
 
     # -- prompt encoder + mask decoder ---------------------------------------------------------------

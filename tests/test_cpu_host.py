@@ -289,3 +289,29 @@ dist.barrier(); dist.destroy_process_group()
         os.unlink(path)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     assert "SHARDED_OK" in r.stdout
+
+
+def test_pil_bilinear_tables_bit_exact_against_pil():
+    """The fixed-point tables behind the device resize of SamPredictor.set_image reproduce PIL.Image.resize(BILINEAR)
+    bit for bit (numpy evaluation of the same integer arithmetic the HIP kernel runs), up- and down-scaling."""
+    from PIL import Image
+    from sam_pt_amd.sam_predictor import pil_bilinear_tables
+
+    def axis(img, out, ax):
+        img = np.moveaxis(img, ax, 0)
+        coef, bounds = pil_bilinear_tables(img.shape[0], out)
+        res = np.empty((out,) + img.shape[1:], np.uint8)
+        for xx in range(out):
+            x0, n = bounds[xx]
+            acc = np.full(img.shape[1:], 1 << 21, np.int64)
+            for x in range(n):
+                acc += img[x0 + x].astype(np.int64) * int(coef[xx, x])
+            res[xx] = np.clip(acc >> 22, 0, 255)
+        return np.moveaxis(res, 0, ax)
+
+    rng = np.random.default_rng(0)
+    for h, w, oh, ow in [(48, 85, 58, 102), (120, 64, 90, 48), (37, 53, 37, 106), (60, 107, 144, 256)]:
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        ref = np.asarray(Image.fromarray(img).resize((ow, oh), Image.BILINEAR))
+        got = axis(axis(img, ow, 1) if ow != w else img, oh, 0) if oh != h else axis(img, ow, 1)
+        assert np.array_equal(ref, got), (h, w, oh, ow)

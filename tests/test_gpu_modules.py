@@ -619,3 +619,35 @@ def test_predict_torch_multimask_vs_oracle(dev):
     m4, i4, l4 = pred.predict_torch(pts.to(dev), lab.to(dev), None, None, False, True)
     m5, i5, l5 = ref.predict_torch(pts, lab, None, None, False, True)
     assert max_abs(l4, l5) < 3e-4 and m4.shape == (1, 1, 144, 256)
+
+
+def test_set_image_with_resize_vs_pil_and_oracle(dev):
+    """SamPredictor.set_image on a frame whose longest side is not img_size: the device resize is bit-identical to
+    PIL.Image.resize(BILINEAR) (what upstream's ResizeLongestSide.apply_image does), and prediction at the original
+    resolution (input_size != original_size in postprocess_masks) matches the oracle."""
+    from PIL import Image
+    from oracle import sam_ref as R
+    from sam_pt_amd.sam_predictor import SamHip, SamPredictor
+    from sam_pt_amd.weights import SAM_CONFIGS, init_sam_state_dict
+    cfg = SAM_CONFIGS["vit_test"]
+    sd = init_sam_state_dict(cfg, 72)
+    pred = SamPredictor(SamHip(config=cfg, state_dict=sd, precision="f32").to(dev))
+    rng = np.random.default_rng(1)
+    for h, w in ((60, 107), (300, 200), (256, 100)):
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        nh, nw = pred.transform.get_preprocess_shape(h, w, cfg.img_size)
+        got = pred.transform.apply_image_torch(torch.as_tensor(img, device=dev))
+        ref = np.asarray(Image.fromarray(img).resize((nw, nh), Image.BILINEAR))
+        assert got.shape == (nh, nw, 3) and np.array_equal(got.cpu().numpy(), ref), (h, w)
+    frames, centres = synthetic_clip(T=1, H=144, W=256, seed=5)
+    img = np.ascontiguousarray(frames[0].permute(1, 2, 0).numpy()[::2, ::2])      # 72 x 128 -> resized to 144 x 256
+    ref_p = R.SamPredictorRef(sd, cfg)
+    ref_p.set_image(img), pred.set_image(img)
+    assert pred.original_size == (72, 128) and pred.input_size == (144, 256) == ref_p.input_size
+    assert rel_err(pred.features, ref_p.features) < 3e-5
+    pts_np = np.array([[40.0, 30.0], [80.0, 50.0], [100.0, 20.0]])
+    lab_np = np.array([1, 1, 0])
+    pc = torch.as_tensor(ref_p.transform.apply_coords(pts_np, ref_p.original_size), dtype=torch.float)[None]
+    m0, i0, l0 = ref_p.predict_torch(pc, torch.as_tensor(lab_np)[None].int(), None, None, False, True)
+    m1, i1, l1 = pred.predict(pts_np, lab_np, multimask_output=False, return_logits=True)      # numpy flavour
+    assert m1.shape == (1, 72, 128) and np.abs(m1 - m0[0].numpy()).max() < 3e-4 and np.abs(i1 - i0[0].numpy()).max() < 1e-4
