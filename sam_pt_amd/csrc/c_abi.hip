@@ -63,8 +63,10 @@ int sampt_pips_fnet_workspace_bytes(sampt_pips_t h, int nf, int H, int W, size_t
 
 int sampt_pips_fnet_f32(sampt_pips_t h, const uint8_t* frames, int nf, int H, int W, float* const pyr[4], void* ws,
                         size_t ws_bytes, sampt_stream_t stream) {
-  if (!h || !frames || !pyr || !ws || H % h->e.stride || W % h->e.stride || (H / h->e.stride) % 8 || (W / h->e.stride) % 8)
-    return fail(SAMPT_ERR_ARG, "sampt_pips_fnet_f32: bad arguments (H, W must be multiples of 8*stride)");
+  // any frame size works (feature map = floor(H / stride), pyramid levels floor-halved like avg_pool2d); the coarsest
+  // level must keep >= 2 pixels per axis because the sampler normalises by (size - 1) (pips.py:324-326)
+  if (!h || !frames || !pyr || !ws || H < 16 * h->e.stride || W < 16 * h->e.stride)
+    return fail(SAMPT_ERR_ARG, "sampt_pips_fnet_f32: bad arguments (H, W must be at least 16*stride)");
   Arena a(ws, ws_bytes);
   return h->e.fnet(frames, nf, H, W, pyr, a, (hipStream_t)stream);
 }
@@ -181,8 +183,8 @@ int sampt_pips2_fnet_workspace_bytes(sampt_pips2_t h, int nf, int H, int W, size
 
 int sampt_pips2_fnet_f32(sampt_pips2_t h, const void* frames, int frames_are_f32, int nf, int H, int W,
                          float* const pyr[4], void* ws, size_t ws_bytes, sampt_stream_t stream) {
-  if (!h || !frames || !pyr || !ws || H % (8 * h->e.stride) || W % (8 * h->e.stride))
-    return fail(SAMPT_ERR_ARG, "sampt_pips2_fnet_f32: bad arguments (H, W must be multiples of 8*stride)");
+  if (!h || !frames || !pyr || !ws || H < 16 * h->e.stride || W < 16 * h->e.stride)
+    return fail(SAMPT_ERR_ARG, "sampt_pips2_fnet_f32: bad arguments (H, W must be at least 16*stride)");
   Arena a(ws, ws_bytes);
   h->e.enc.frames_f32 = frames_are_f32 ? 1 : 0;
   return h->e.enc.fnet((const uint8_t*)frames, nf, H, W, pyr, a, (hipStream_t)stream);

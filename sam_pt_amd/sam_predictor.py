@@ -59,15 +59,16 @@ class ResizeLongestSide:
         self.target_length = target_length
         self._tables = {}
 
-    def apply_image_torch(self, image: torch.Tensor) -> torch.Tensor:
-        """(H,W,3) uint8 on the HIP device -> (new_h,new_w,3) uint8, longest side = target_length."""
-        H, W, Cc = image.shape
+    def apply_image_torch(self, image: torch.Tensor, chw: bool = False) -> torch.Tensor:
+        """uint8 frames on the HIP device, (...,H,W,3) or with ``chw`` (...,3,H,W) -> the same layout with the longest side
+        = target_length (identity if it already is)."""
+        H, W = (image.shape[-2], image.shape[-1]) if chw else (image.shape[-3], image.shape[-2])
         nh, nw = self.get_preprocess_shape(H, W, self.target_length)
         if (nh, nw) == (H, W):
             return image
         lib, dev = _lib.load(), image.device
         cur = image.contiguous()
-        for axis, (n_in, n_out) in ((1, (W, nw)), (0, (H, nh))):          # PIL: horizontal pass first, then vertical
+        for horizontal, n_in, n_out in ((True, W, nw), (False, H, nh)):    # PIL: horizontal pass first, then vertical
             if n_in == n_out:
                 continue
             key = (n_in, n_out, str(dev))
@@ -75,11 +76,12 @@ class ResizeLongestSide:
                 coef, bounds = pil_bilinear_tables(n_in, n_out)
                 self._tables[key] = (torch.from_numpy(coef).to(dev), torch.from_numpy(bounds).to(dev), coef.shape[1])
             coef_d, bounds_d, ks = self._tables[key]
-            if axis == 1:
-                outer, inner, shape = cur.shape[0], Cc, (cur.shape[0], n_out, Cc)
-            else:
-                outer, inner, shape = 1, cur.shape[1] * Cc, (n_out, cur.shape[1], Cc)
-            dst = torch.empty(shape, dtype=torch.uint8, device=dev)
+            shp = list(cur.shape)
+            ax = (len(shp) - 1 if horizontal else len(shp) - 2) if chw else (len(shp) - 2 if horizontal else len(shp) - 3)
+            outer = int(np.prod(shp[:ax])) if ax > 0 else 1
+            inner = int(np.prod(shp[ax + 1:])) if ax + 1 < len(shp) else 1
+            shp[ax] = n_out
+            dst = torch.empty(shp, dtype=torch.uint8, device=dev)
             _lib.check(lib.sampt_pil_resample_u8(_lib.ptr(cur), _lib.ptr(dst), outer, n_in, n_out, inner, _lib.ptr(coef_d),
                                                  _lib.ptr(bounds_d), ks, _lib.stream_ptr()), "sampt_pil_resample_u8")
             cur = dst
@@ -261,6 +263,7 @@ class SamPredictor:
         HQ-SAM model a ``ClipFeatures`` that also carries the per-frame HQ features (T, 16*grid*grid, 32)."""
         self._ensure()
         frames = frames.to(self._dev).contiguous()
+        frames = self.transform.apply_image_torch(frames, chw=chw)      # PIL-exact resize when the longest side != img_size
         T = frames.shape[0]
         H, W = (frames.shape[2], frames.shape[3]) if chw else (frames.shape[1], frames.shape[2])
         g, Cc = self.model.cfg.grid, self.model.cfg.out_chans
@@ -381,6 +384,7 @@ class SamPredictor:
         Results are written into out_logits (F,H,W) and out_score (F,)."""
         self._ensure()
         oh, ow = size_hw
+        ih, iw = self.transform.get_preprocess_shape(oh, ow, self.model.cfg.img_size)   # size the frames were encoded at
         hq_tokens = None
         if isinstance(feat_tokens, ClipFeatures):
             feat_tokens, hq_tokens = feat_tokens.emb, feat_tokens.hq
@@ -390,6 +394,6 @@ class SamPredictor:
         _lib.check(self._lib.sampt_sam_track_decode(self._dec, F, _lib.ptr(feat_tokens), _lib.ptr(hq_tokens),
                                                     _lib.ptr(pts), _lib.ptr(labels),
                                                     k, _lib.ptr(k_item), _lib.ptr(npos_item), pts.shape[1], n_pos_first,
-                                                    refine_iters, float(iou_thr), oh, ow,
+                                                    refine_iters, float(iou_thr), ih, iw,
                                                     oh, ow, _lib.ptr(out_logits), _lib.ptr(out_score), _lib.ptr(ws),
                                                     ws.numel(), _lib.stream_ptr()), "sampt_sam_track_decode")

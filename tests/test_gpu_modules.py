@@ -651,3 +651,42 @@ def test_set_image_with_resize_vs_pil_and_oracle(dev):
     m0, i0, l0 = ref_p.predict_torch(pc, torch.as_tensor(lab_np)[None].int(), None, None, False, True)
     m1, i1, l1 = pred.predict(pts_np, lab_np, multimask_output=False, return_logits=True)      # numpy flavour
     assert m1.shape == (1, 72, 128) and np.abs(m1 - m0[0].numpy()).max() < 3e-4 and np.abs(i1 - i0[0].numpy()).max() < 1e-4
+
+
+def test_arbitrary_frame_sizes(dev, pips_sd):
+    """Frames whose sides are not multiples of 32 and whose longest side is not the SAM input size (e.g. native 480 x 854):
+    the tracker runs at frame resolution (floor-divided feature maps / pyramid like the reference), SAM resizes with the
+    PIL-exact kernel, masks come back at frame resolution.  Tracker vs oracle; fused device path vs the call-by-call
+    protocol; the latter vs the oracle predictor driven the same way."""
+    from oracle import pips_ref as O
+    from oracle import sam_ref as R
+    from sam_pt_amd.point_tracker import PipsPointTracker
+    from sam_pt_amd.sam_predictor import SamHip, SamPredictor
+    from sam_pt_amd.sam_pt import SamPt
+    from sam_pt_amd.weights import SAM_CONFIGS, init_sam_state_dict
+    frames, centres = synthetic_clip(T=9, H=120, W=214, seed=21)
+    q = disc_queries(centres, n_pos=4, r=8.0)[None]
+    tr_ref, vi_ref = O.PipsTrackerRef(pips_sd).forward(frames[None], q)
+    trk = PipsPointTracker(state_dict=pips_sd)
+    tr, vi = trk(frames[None].to(dev), q.to(dev))
+    assert (vi.cpu() == vi_ref).all() and (tr.cpu().round() == tr_ref.round()).all() and max_abs(tr, tr_ref) < 5e-3
+    cfg = SAM_CONFIGS["vit_test"]
+    sd = init_sam_state_dict(cfg, 72)
+    pred = SamPredictor(SamHip(config=cfg, state_dict=sd, precision="f32").to(dev))
+    kw = dict(sam_iou_threshold=-1e9, positive_points_per_mask=4, negative_points_per_mask=0, iterative_refinement_iterations=2)
+    model = SamPt(trk, pred, **kw).eval()
+    video = {"image": [f for f in frames], "target_hw": (120, 214), "query_points": q}
+    out = model(video)
+    assert out["logits"][0].shape == (9, 120, 214)
+    images = frames.to(dev)
+    _, l_s, s_s = model._apply_sam_to_trajectories(images, out["trajectories"].cpu(), out["visibilities"].cpu(), None)
+    l_f = torch.stack(out["logits"]).cpu()
+    assert max_abs(l_f, l_s) < 2e-3
+    ref_pred = R.SamPredictorRef(sd, cfg)
+    ref_pred.model = torch.nn.Module()
+    ref_pred.model.device, ref_pred.model.mask_threshold = torch.device("cpu"), 0.0
+    ref = SamPt(trk, ref_pred, **kw).eval()
+    _, l_r, _ = ref._apply_sam_to_trajectories(frames, out["trajectories"].cpu(), out["visibilities"].cpu(), None)
+    assert max_abs(l_s, l_r) < 3e-3
+    for t in range(9):
+        assert iou(l_f[0, t] > 0, l_r[0, t] > 0) >= 1 - 1e-3
