@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--shard", default="sequences", choices=["sequences", "frames"],
                     help="N > 1: 'sequences' = one clip per rank (weak scaling, the default the metric uses); 'frames' = ONE "
                          "clip, its frame batches dealt over the ranks (strong scaling, BASELINE config #5)")
+    ap.add_argument("--native-480p", action="store_true",
+                    help="feed the 480x854 frames as they are (tracker at 480p, SAM resizes inside) instead of the "
+                         "reference pipelines' pre-resize to 576x1024")
     ap.add_argument("--hq", action="store_true", help="HQ-SAM decoder (reference default samhq_vit_huge; BASELINE config #5)")
     ap.add_argument("--pips-vis-bias", type=float, default=2.0,
                     help="bias of the random PIPS visibility head (weights.py default 2.0 -> sigmoid 0.88, just under the 0.9 "
@@ -205,7 +208,7 @@ def main():
     torch.set_num_threads(max(1, min(32, (os.cpu_count() or 8) // max(world, 1))))
     frames_sharded = args.shard == "frames" and world > 1
     frames, qp = bench_clip(T=args.frames, seed=72 + (0 if frames_sharded else rank), n_pos=args.points,
-                            n_objects=args.objects)
+                            n_objects=args.objects, native=args.native_480p)
     H, W = frames.shape[-2:]
     model = build_model(args, dev)
     frames_dev = frames.to(dev)
@@ -244,7 +247,7 @@ def main():
                "vs_baseline": None,
                "dtype": "f16" if args.precision == "f16" else "f32", "data": "synthetic",
                "config": {"workload": f"{'HQ-SAM' if args.hq else 'SAM'} {args.model} + {'PIPS' if args.tracker == 'pips' else 'PIPS++'}, {args.points} query points, {args.objects} object(s), "
-                                      f"{args.frames}x 480p synthetic frames upscaled to {H}x{W}, "
+                                      f"{args.frames}x 480p synthetic frames " + ("at native " if args.native_480p else "upscaled to ") + f"{H}x{W}, "
                                       f"{args.refine} refinement iterations, random-init weights (seed 72)",
                           "frames_per_step": args.frames, "parallelism": f"{'frame-batch' if frames_sharded else 'sequence'}-sharded x{world}",
                           "vit_precision": args.precision + " MFMA inputs, fp32 accumulate/LN/softmax/residual",

@@ -55,17 +55,18 @@ def upscale_to_longest_side(frames: torch.Tensor, centres: torch.Tensor, long_si
     return out, centres * s
 
 
-def bench_clip(T: int = 24, seed: int = 72, n_pos: int = 8, n_objects: int = 1):
-    """The benchmark workload: a 480x854 synthetic clip upscaled to 576x1024, 8 positive query points on one object at
-    t = 0 (BASELINE.json metric: ViT-H + PIPS, 480p, 8 pts, 1 obj)."""
+def bench_clip(T: int = 24, seed: int = 72, n_pos: int = 8, n_objects: int = 1, native: bool = False):
+    """The benchmark workload: a 480x854 synthetic clip upscaled to 576x1024 (as the reference pipelines do before SamPt:
+    configs/demo.yaml:20), 8 positive query points on one object at t = 0 (BASELINE.json metric: ViT-H + PIPS, 480p,
+    8 pts, 1 obj).  ``native`` keeps the 480x854 frames: the tracker then runs at that resolution and SAM resizes."""
     frames, centres = synthetic_clip(T=T, H=480, W=854, seed=seed, disc_r=60.0)
-    frames, centres = upscale_to_longest_side(frames, centres, 1024)
-    H, W = frames.shape[-2:]
-    # PIPS needs H/4 and W/4 divisible by 8 for the 4-level pyramid; 576x1024 satisfies it
+    scale = 854.0 / 1024.0 if native else 1.0                # query geometry is defined on the 576 x 1024 frames
+    if not native:
+        frames, centres = upscale_to_longest_side(frames, centres, 1024)
     qs = []
     for m in range(n_objects):           # object 0 = the moving disc; further objects = background patches
-        q = disc_queries(centres, n_pos=n_pos, r=36.0, t=0)
-        q[:, 1] += 260.0 * m
-        q[:, 2] += (-120.0 if m % 2 else 90.0) * (m > 0)
+        q = disc_queries(centres, n_pos=n_pos, r=36.0 * scale, t=0)
+        q[:, 1] += 260.0 * scale * m
+        q[:, 2] += (-120.0 if m % 2 else 90.0) * scale * (m > 0)
         qs.append(q)
     return frames, torch.stack(qs)
