@@ -315,3 +315,44 @@ def test_pil_bilinear_tables_bit_exact_against_pil():
         ref = np.asarray(Image.fromarray(img).resize((ow, oh), Image.BILINEAR))
         got = axis(axis(img, ow, 1) if ow != w else img, oh, 0) if oh != h else axis(img, ow, 1)
         assert np.array_equal(ref, got), (h, w, oh, ow)
+
+
+def test_c_abi_error_behaviour_without_a_gpu():
+    """Handle creation only records pointers, so the C ABI's argument / weight-table validation is testable on the CPU
+    (no kernel is launched): negative return codes, a message in sampt_last_error(), nothing thrown, no handle leaked."""
+    import ctypes as C
+    from sam_pt_amd import _lib
+    from sam_pt_amd.pack import pack_decoder, pack_pips, pack_pips2
+    from sam_pt_amd.weights import SAM_CONFIGS, init_pips2_state_dict, init_pips_state_dict, init_sam_state_dict
+    lib = _lib.load()
+    assert lib.sampt_version() >= 1
+
+    def last():
+        return lib.sampt_last_error().decode()
+
+    w = pack_pips(init_pips_state_dict(72), "cpu")
+    names, ptrs, n = _lib.name_table(w)
+    h = C.c_void_p()
+    assert lib.sampt_pips_create(names, ptrs, n, 4, 8, C.byref(h)) == 0 and h.value
+    lib.sampt_pips_destroy(h)
+    assert lib.sampt_pips_create(names, ptrs, n, 4, 7, C.byref(h)) < 0 and "S must be 8" in last()
+    w.pop("fnet.conv2.weight"), w.pop("vis_predictor.0.bias")
+    names, ptrs, n = _lib.name_table(w)
+    assert lib.sampt_pips_create(names, ptrs, n, 4, 8, C.byref(h)) < 0 and "fnet.conv2.weight" in last()
+    w2 = pack_pips2(init_pips2_state_dict(72), "cpu")
+    w2.pop("delta_block.dense.weight")
+    names, ptrs, n = _lib.name_table(w2)
+    assert lib.sampt_pips2_create(names, ptrs, n, 8, C.byref(h)) < 0 and "delta_block.dense.weight" in last()
+    cfg = SAM_CONFIGS["vit_test"]
+    wd = pack_decoder(init_sam_state_dict(cfg, 72), cfg, "cpu", 2)           # plain SAM weights ...
+    names, ptrs, n = _lib.name_table(wd)
+    assert lib.sampt_dec_create(names, ptrs, n, cfg.grid, cfg.img_size, 2, 0, C.byref(h)) == 0
+    nb = C.c_size_t()
+    assert lib.sampt_dec_workspace_bytes(h, 2, 128, 256, C.byref(nb)) == 0 and nb.value > 0       # dry run: sizes only
+    assert lib.sampt_dec_workspace_bytes(h, 3, 128, 256, C.byref(nb)) < 0                          # beyond max_frames
+    assert lib.sampt_dec_hq_workspace_bytes(h, 1, C.byref(nb)) < 0 and "HQ-SAM" in last()
+    lib.sampt_dec_destroy(h)
+    assert lib.sampt_dec_create(names, ptrs, n, cfg.grid, cfg.img_size, 2, cfg.embed_dim, C.byref(h)) < 0   # ... lack HQ keys
+    assert "hf_token" in last() or "hf_mlp" in last()
+    with pytest.raises(_lib.SamptError):
+        _lib.check(-1, "context")
