@@ -103,6 +103,9 @@ def sharded_forward(model, video, batch: int = 8):
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     T = len(video["image"])
+    batch = max(1, min(batch, -(-T // world)))          # short clips: shrink the batches so that every rank gets frames
+    if T < world:
+        raise ValueError(f"sharded_forward: {T} frames cannot be dealt over {world} ranks")
     mine = [t for r in frame_batches(T, world, rank, batch) for t in r]
     out = model({**video, "frame_ids": mine})
     logits = torch.stack(out["logits"], dim=0)                                   # (M, len(mine), H, W)
