@@ -103,13 +103,14 @@ def sharded_forward(model, video, batch: int = 8):
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     T = len(video["image"])
-    batch = max(1, min(batch, -(-T // world)))          # short clips: shrink the batches so that every rank gets frames
-    if T < world:
-        raise ValueError(f"sharded_forward: {T} frames cannot be dealt over {world} ranks")
+    batch = max(1, min(batch, -(-T // world)))          # short clips: shrink the batches so that most ranks get frames
     mine = [t for r in frame_batches(T, world, rank, batch) for t in r]
-    out = model({**video, "frame_ids": mine})
-    logits = torch.stack(out["logits"], dim=0)                                   # (M, len(mine), H, W)
-    masks = index_masks(logits)
+    if mine:
+        out = model({**video, "frame_ids": mine})
+        masks = index_masks(torch.stack(out["logits"], dim=0))                   # (len(mine), H, W) from (M, len(mine), H, W)
+    else:                                               # more ranks than frame batches: this rank only joins the gather
+        out = None
+        masks = torch.zeros((0,) + tuple(video["target_hw"]), dtype=torch.uint8, device=model.device)
     per_rank = max(len([t for r in frame_batches(T, world, k, batch) for t in r]) for k in range(world))
     gathered = gather_masks(masks, per_rank)
     if rank != 0:
