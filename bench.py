@@ -74,8 +74,8 @@ def build_model(args, dev):
 def one_step(model, video, max_frames, shard="sequences"):
     from sam_pt_amd.dist import gather_masks, index_masks, sharded_forward
     if shard == "frames":
-        full, out = sharded_forward(model, video, batch=8)
-        return index_masks(torch.stack(out["logits"], dim=0)), full
+        full, _ = sharded_forward(model, video, batch=8)     # rank 0: the assembled (T,H,W) index masks; others: None
+        return full, full
     out = model(video)
     logits = torch.stack(out["logits"], dim=0)          # (M,T,H,W) on device
     masks = index_masks(logits)                          # bg stack + softmax + argmax (eval.py:304-326)
