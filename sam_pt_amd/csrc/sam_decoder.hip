@@ -74,79 +74,115 @@ int sam_tokens(const float* out_tokens, int n_out, const float* pts, const int* 
 }
 
 // ---------------------------------------------------------------------------------------------
-// attention with many keys and few queries: one workgroup per (query, head, frame); scores stay in registers
+// attention with many keys and few queries: one workgroup per (QPW queries, head, frame); scores stay in registers.
+// K and V of a (frame, head) are streamed once per workgroup and shared by its QPW queries: with one query per
+// workgroup the token->image attention re-read them Nq times through L2 (6 TB/s of L2 traffic, L2-bandwidth bound).
+// Per-query arithmetic and reduction order do not depend on QPW.
 // ---------------------------------------------------------------------------------------------
-template <int HD>
+template <int HD, int QPW>
 __global__ __launch_bounds__(256) void k_attn_rowblock(const float* __restrict__ q, const float* __restrict__ k,
                                                        const float* __restrict__ v, float* __restrict__ out, int Nq,
                                                        int Nk, int ld, const int* __restrict__ nk_item) {
   constexpr int KPT = 16;  // keys per thread (Nk <= 4096)
-  __shared__ float red[8];
-  __shared__ float accs[4][HD];
-  const int qi = blockIdx.x, h = blockIdx.y, f = blockIdx.z;
+  __shared__ float red[QPW][8];
+  __shared__ float accs[QPW][4][HD];
+  const int q0 = blockIdx.x * QPW, h = blockIdx.y, f = blockIdx.z;
   q += (long)f * Nq * ld, out += (long)f * Nq * ld;
   k += (long)f * Nk * ld, v += (long)f * Nk * ld;
   if (nk_item) Nk = nk_item[f];   // ragged batch: only the item's valid tokens are keys (strides keep the padded Nk)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float qv[HD];
+  float qv[QPW][HD];
 #pragma unroll
-  for (int c = 0; c < HD; ++c) qv[c] = q[(long)qi * ld + h * HD + c];
+  for (int j = 0; j < QPW; ++j) {
+    const int qi = min(q0 + j, Nq - 1);      // surplus queries of the last workgroup recompute the last one (not stored)
+#pragma unroll
+    for (int c = 0; c < HD; ++c) qv[j][c] = q[(long)qi * ld + h * HD + c];
+  }
   const float inv = sqrtf((float)HD);
-  float sc[KPT];
-  float m = -INFINITY;
+  float sc[QPW][KPT];
+  float m[QPW];
+#pragma unroll
+  for (int j = 0; j < QPW; ++j) m[j] = -INFINITY;
 #pragma unroll
   for (int i = 0; i < KPT; ++i) {
     int key = tid + 256 * i;
-    sc[i] = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < QPW; ++j) sc[j][i] = -INFINITY;
     if (key < Nk) {
       const float4* kp = (const float4*)(k + (long)key * ld + h * HD);
-      float a = 0.f;
+      float a[QPW];
+#pragma unroll
+      for (int j = 0; j < QPW; ++j) a[j] = 0.f;
 #pragma unroll
       for (int c = 0; c < HD / 4; ++c) {
         float4 kk = kp[c];
-        a += qv[4 * c] * kk.x + qv[4 * c + 1] * kk.y + qv[4 * c + 2] * kk.z + qv[4 * c + 3] * kk.w;
+#pragma unroll
+        for (int j = 0; j < QPW; ++j)
+          a[j] += qv[j][4 * c] * kk.x + qv[j][4 * c + 1] * kk.y + qv[j][4 * c + 2] * kk.z + qv[j][4 * c + 3] * kk.w;
       }
-      sc[i] = a / inv;
-      m = fmaxf(m, sc[i]);
+#pragma unroll
+      for (int j = 0; j < QPW; ++j) {
+        sc[j][i] = a[j] / inv;
+        m[j] = fmaxf(m[j], sc[j][i]);
+      }
     }
   }
-  m = wave_max(m);
-  if (lane == 0) red[wave] = m;
-  __syncthreads();
-  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-  float acc[HD];
 #pragma unroll
-  for (int c = 0; c < HD; ++c) acc[c] = 0.f;
-  float sum = 0.f;
+  for (int j = 0; j < QPW; ++j) {
+    m[j] = wave_max(m[j]);
+    if (lane == 0) red[j][wave] = m[j];
+  }
+  __syncthreads();
+  float acc[QPW][HD], sum[QPW];
+#pragma unroll
+  for (int j = 0; j < QPW; ++j) {
+    m[j] = fmaxf(fmaxf(red[j][0], red[j][1]), fmaxf(red[j][2], red[j][3]));
+    sum[j] = 0.f;
+#pragma unroll
+    for (int c = 0; c < HD; ++c) acc[j][c] = 0.f;
+  }
 #pragma unroll
   for (int i = 0; i < KPT; ++i) {
     int key = tid + 256 * i;
     if (key < Nk) {
-      float p = expf(sc[i] - m);
-      sum += p;
+      float p[QPW];
+#pragma unroll
+      for (int j = 0; j < QPW; ++j) {
+        p[j] = expf(sc[j][i] - m[j]);
+        sum[j] += p[j];
+      }
       const float4* vp = (const float4*)(v + (long)key * ld + h * HD);
 #pragma unroll
       for (int c = 0; c < HD / 4; ++c) {
         float4 vv = vp[c];
-        acc[4 * c] += p * vv.x;
-        acc[4 * c + 1] += p * vv.y;
-        acc[4 * c + 2] += p * vv.z;
-        acc[4 * c + 3] += p * vv.w;
+#pragma unroll
+        for (int j = 0; j < QPW; ++j) {
+          acc[j][4 * c] += p[j] * vv.x;
+          acc[j][4 * c + 1] += p[j] * vv.y;
+          acc[j][4 * c + 2] += p[j] * vv.z;
+          acc[j][4 * c + 3] += p[j] * vv.w;
+        }
       }
     }
   }
-  sum = wave_sum(sum);
-  if (lane == 0) red[4 + wave] = sum;
 #pragma unroll
-  for (int c = 0; c < HD; ++c) {
-    float a = wave_sum(acc[c]);
-    if (lane == 0) accs[wave][c] = a;
+  for (int j = 0; j < QPW; ++j) {
+    float t = wave_sum(sum[j]);
+    if (lane == 0) red[j][4 + wave] = t;
+#pragma unroll
+    for (int c = 0; c < HD; ++c) {
+      float a = wave_sum(acc[j][c]);
+      if (lane == 0) accs[j][wave][c] = a;
+    }
   }
   __syncthreads();
-  if (tid < HD) {
-    float tot = (red[4] + red[5]) + (red[6] + red[7]);
-    float a = (accs[0][tid] + accs[1][tid]) + (accs[2][tid] + accs[3][tid]);
-    out[(long)qi * ld + h * HD + tid] = a / tot;
+  if (tid < HD * QPW) {
+    const int j = tid / HD, c = tid - j * HD;
+    if (q0 + j < Nq) {
+      float tot = (red[j][4] + red[j][5]) + (red[j][6] + red[j][7]);
+      float a = (accs[j][0][c] + accs[j][1][c]) + (accs[j][2][c] + accs[j][3][c]);
+      out[(long)(q0 + j) * ld + h * HD + c] = a / tot;
+    }
   }
 }
 
@@ -154,10 +190,16 @@ int attn_rowblock(const float* q, const float* k, const float* v, float* out, in
                   const int* nk_item, hipStream_t s) {
   if (Nk > 4096 || Nk <= 0 || Nq <= 0 || F <= 0) return SAMPT_ERR_ARG;
   int ld = heads * hd;
-  dim3 grid(Nq, heads, F);
-  if (hd == 16) hipLaunchKernelGGL(k_attn_rowblock<16>, grid, dim3(256), 0, s, q, k, v, out, Nq, Nk, ld, nk_item);
-  else if (hd == 32) hipLaunchKernelGGL(k_attn_rowblock<32>, grid, dim3(256), 0, s, q, k, v, out, Nq, Nk, ld, nk_item);
-  else return SAMPT_ERR_UNSUPPORTED;
+  if (hd == 16 && Nk > 256) {            // token -> image: long key streams, share them between 4 queries
+    hipLaunchKernelGGL((k_attn_rowblock<16, 4>), dim3(cdiv(Nq, 4), heads, F), dim3(256), 0, s, q, k, v, out, Nq, Nk, ld,
+                       nk_item);
+  } else if (hd == 16) {
+    hipLaunchKernelGGL((k_attn_rowblock<16, 1>), dim3(Nq, heads, F), dim3(256), 0, s, q, k, v, out, Nq, Nk, ld, nk_item);
+  } else if (hd == 32) {
+    hipLaunchKernelGGL((k_attn_rowblock<32, 1>), dim3(Nq, heads, F), dim3(256), 0, s, q, k, v, out, Nq, Nk, ld, nk_item);
+  } else {
+    return SAMPT_ERR_UNSUPPORTED;
+  }
   SAMPT_CHECK_LAUNCH("attn_rowblock");
   return SAMPT_OK;
 }
