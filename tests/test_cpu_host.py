@@ -11,6 +11,13 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port() -> int:
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
 def test_c_abi_exports_every_declared_symbol():
     """libsampt_hip.so loads and exports exactly the functions declared in include/sampt_hip.h."""
     from sam_pt_amd import _lib
@@ -127,14 +134,15 @@ else:
     assert out is None
 dist.barrier(); dist.destroy_process_group()
 """ % ROOT
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    port = str(_free_port())
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     import tempfile  # torch.distributed.run needs a script file
     with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:
         f.write(code)
         path = f.name
     try:
         r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                            "--master-addr", "127.0.0.1", "--master-port", "29533", path], env=env, capture_output=True,
+                            "--master-addr", "127.0.0.1", "--master-port", port, path], env=env, capture_output=True,
                            text=True, timeout=240)
     finally:
         os.unlink(path)
@@ -276,14 +284,15 @@ else:
     assert full is None
 dist.barrier(); dist.destroy_process_group()
 """ % ROOT
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+    port = str(_free_port())
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     import tempfile
     with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:
         f.write(code)
         path = f.name
     try:
         r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                            "--master-addr", "127.0.0.1", "--master-port", "29547", path], env=env, capture_output=True,
+                            "--master-addr", "127.0.0.1", "--master-port", port, path], env=env, capture_output=True,
                            text=True, timeout=600)
     finally:
         os.unlink(path)
