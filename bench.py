@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--refine", type=int, default=12)
     ap.add_argument("--precision", default="f16", choices=["f16", "f32"])
     ap.add_argument("--encode-batch", type=int, default=8)
+    ap.add_argument("--decode-batch", type=int, default=32, help="max (frame, object) items per batched decoder chain")
     ap.add_argument("--tracker", default="pips", choices=["pips", "pips_plus_plus"],
                     help="point tracker (the metric is quoted on PIPS; PIPS++ = SURVEY.md §8 row f4)")
     ap.add_argument("--shard", default="sequences", choices=["sequences", "frames"],
@@ -58,7 +59,8 @@ def build_model(args, dev):
     from sam_pt_amd.point_tracker import PipsPointTracker
     from sam_pt_amd.sam_predictor import SamHip, SamPredictor
     from sam_pt_amd.sam_pt import SamPt
-    sam = SamHip(args.model, precision=args.precision, seed=72, max_batch=args.encode_batch, hq=args.hq).to(dev)
+    sam = SamHip(args.model, precision=args.precision, seed=72, max_batch=args.encode_batch, hq=args.hq,
+                 max_decode_batch=args.decode_batch).to(dev)
     from sam_pt_amd.weights import init_pips_state_dict
     if args.tracker == "pips":
         tracker = PipsPointTracker(state_dict=init_pips_state_dict(72, vis_bias=args.pips_vis_bias), fnet_chunk=8)
