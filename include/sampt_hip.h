@@ -200,6 +200,12 @@ int sampt_index_masks(const float* logits_dev, int M, long npix, uint8_t* out_de
  * +-1e8 from its ground-truth mask on the query frame.  out_dev uint8 [T][hw]. */
 int sampt_vos_index_masks(const float* logits_dev, int M, int T, long hw, const int32_t* query_t_dev,
                           const uint8_t* gt_masks_dev, uint8_t* out_dev, sampt_stream_t stream);
+/* ... and for frames processed at (h, w) but wanted at (out_h, out_w) (eval.py:326, 340-356: softmax, bilinear resize of
+ * the probabilities with align_corners=False, argmax).  logits_dev [M][T][h][w], gt_masks_dev [M][h][w] or NULL,
+ * out_dev uint8 [T][out_h][out_w]; M <= 32. */
+int sampt_vos_index_masks_resized(const float* logits_dev, int M, int T, int h, int w, const int32_t* query_t_dev,
+                                  const uint8_t* gt_masks_dev, int out_h, int out_w, uint8_t* out_dev,
+                                  sampt_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Kernel-level entry points (used by the parity tests and the roofline bench; same kernels the engines launch).

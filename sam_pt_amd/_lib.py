@@ -68,6 +68,7 @@ _SIGS = {
     "sampt_pil_resample_u8": (c_int, [_P, _P, C.c_long, c_int, c_int, c_int, _P, _P, c_int, _P]),
     "sampt_index_masks": (c_int, [_P, c_int, C.c_long, _P, _P]),
     "sampt_vos_index_masks": (c_int, [_P, c_int, c_int, C.c_long, _P, _P, _P, _P]),
+    "sampt_vos_index_masks_resized": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, c_int, c_int, _P, _P]),
     "sampt_gemm": (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     "sampt_conv2d_nhwc": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "sampt_instance_norm_nhwc": (c_int, [_P, c_int, c_int, c_int, c_float, c_int, _P, _P, c_size_t, _P]),

@@ -385,6 +385,12 @@ int sampt_pil_resample_u8(const uint8_t* src, uint8_t* dst, long outer, int in_l
                          (hipStream_t)stream);
 }
 
+int sampt_vos_index_masks_resized(const float* logits, int M, int T, int h, int w, const int32_t* query_t,
+                                  const uint8_t* gt_masks, int oh, int ow, uint8_t* out, sampt_stream_t stream) {
+  if (!logits || !out || !query_t || T <= 0 || h <= 0 || w <= 0) return SAMPT_ERR_ARG;
+  return vos_index_masks_resized(logits, M, T, h, w, (const int*)query_t, gt_masks, oh, ow, out, (hipStream_t)stream);
+}
+
 int sampt_index_masks(const float* logits, int M, long npix, uint8_t* out, sampt_stream_t stream) {
   if (!logits || !out || npix <= 0) return SAMPT_ERR_ARG;
   return index_masks(logits, M, npix, out, (hipStream_t)stream);

@@ -510,6 +510,65 @@ __global__ void k_vos_index_masks(const float* __restrict__ logits, int M, int T
   out[i] = (uint8_t)arg;
 }
 
+// The evaluator's full tail for frames that were processed at another resolution (eval.py:326, 340-356): softmax over
+// {background, objects} at the processing resolution (h, w), bilinear resize of the PROBABILITIES to (oh, ow)
+// (F.interpolate, align_corners=False), argmax.  One thread per output pixel; M <= 32 objects.
+__global__ void k_vos_index_masks_resized(const float* __restrict__ logits, int M, int T, int h, int w,
+                                          const int* __restrict__ qt, const uint8_t* __restrict__ gt, int oh, int ow,
+                                          uint8_t* __restrict__ out) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)T * oh * ow) return;
+  const int x = (int)(i % ow), y = (int)((i / ow) % oh), t = (int)(i / ((long)ow * oh));
+  int y0, y1, x0, x1;
+  float ly, lx;
+  {
+    float sy = ((float)h / (float)oh) * ((float)y + 0.5f) - 0.5f, sx = ((float)w / (float)ow) * ((float)x + 0.5f) - 0.5f;
+    sy = sy < 0.f ? 0.f : sy, sx = sx < 0.f ? 0.f : sx;
+    y0 = min((int)sy, h - 1), x0 = min((int)sx, w - 1);
+    y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+    ly = sy - (float)y0, lx = sx - (float)x0;
+  }
+  const float wgt[4] = {(1.f - ly) * (1.f - lx), (1.f - ly) * lx, ly * (1.f - lx), ly * lx};
+  const int py[4] = {y0, y0, y1, y1}, px[4] = {x0, x1, x0, x1};
+  float prob[33];
+#pragma unroll 1
+  for (int m = 0; m <= M; ++m) prob[m] = 0.f;
+  const long hw = (long)h * w;
+  for (int c = 0; c < 4; ++c) {
+    const long p = (long)py[c] * w + px[c];
+    float v[33];
+    v[0] = 0.f;
+    float mx = 0.f;
+    for (int m = 0; m < M; ++m) {
+      float a = logits[((long)m * T + t) * hw + p];
+      if (t < qt[m]) a = -1e8f;
+      else if (t == qt[m] && gt) a = gt[(long)m * hw + p] ? 1e8f : -1e8f;
+      v[m + 1] = a;
+      mx = fmaxf(mx, a);
+    }
+    float sum = 0.f;
+    for (int m = 0; m <= M; ++m) {
+      v[m] = expf(v[m] - mx);
+      sum += v[m];
+    }
+    for (int m = 0; m <= M; ++m) prob[m] += wgt[c] * (v[m] / sum);
+  }
+  int arg = 0;
+  float best = prob[0];
+  for (int m = 1; m <= M; ++m)
+    if (prob[m] > best) best = prob[m], arg = m;
+  out[i] = (uint8_t)arg;
+}
+
+int vos_index_masks_resized(const float* logits, int M, int T, int h, int w, const int* qt, const uint8_t* gt, int oh,
+                            int ow, uint8_t* out, hipStream_t s) {
+  if (M <= 0 || M > 32 || !qt || oh <= 0 || ow <= 0) return SAMPT_ERR_ARG;
+  hipLaunchKernelGGL(k_vos_index_masks_resized, dim3(cdiv((long)T * oh * ow, 256)), dim3(256), 0, s, logits, M, T, h, w, qt,
+                     gt, oh, ow, out);
+  SAMPT_CHECK_LAUNCH("vos_index_masks_resized");
+  return SAMPT_OK;
+}
+
 int vos_index_masks(const float* logits, int M, int T, long hw, const int* qt, const uint8_t* gt, uint8_t* out,
                     hipStream_t s) {
   if (M <= 0 || M > 254 || !qt) return SAMPT_ERR_ARG;

@@ -72,6 +72,8 @@ int vos_index_masks(const float* logits, int M, int T, long hw, const int* qt, c
                     hipStream_t s);
 int pil_resample_u8(const uint8_t* src, uint8_t* dst, long outer, int in_len, int out_len, int inner, const int* coef,
                     const int* bounds, int ksize, hipStream_t s);
+int vos_index_masks_resized(const float* logits, int M, int T, int h, int w, const int* qt, const uint8_t* gt, int oh,
+                            int ow, uint8_t* out, hipStream_t s);
 int fill_rows_bias(void* out, int f16, const int* rows, int nrows, const float* bias, int N, hipStream_t s);
 // ---- PIPS++ (pips2.hip; pips_plus_plus.py:263-342, 436-546) — rows are (point, frame): row = pt*S + s
 int pips2_init(const float* trajs0, const float* fmap, int H, int W, const int* frame_idx, float stride, int S, int n,

@@ -49,12 +49,37 @@ def frame_batches(n_frames: int, world: int, rank: int, batch: int = 8) -> List[
     return [range(s, min(s + batch, n_frames)) for i, s in enumerate(starts) if i % world == rank]
 
 
-def index_masks(logits: torch.Tensor, query_timestep=None, query_masks=None) -> torch.Tensor:
+def index_masks(logits: torch.Tensor, query_timestep=None, query_masks=None, out_hw=None) -> torch.Tensor:
     """(M,T,H,W) per-object logits -> uint8 (T,H,W) object index map with background 0 (bg logit 0 stacked in front,
     softmax/argmax over objects: sam_pt/vos_eval/eval.py:304, 326, 355).  With ``query_timestep`` (M,) the evaluator's
     overrides are applied first (eval.py:318-323): object m is -1e8 before its query frame, and on the query frame its
-    logits are +-1e8 from ``query_masks`` (M,H,W) {0,1} when given (resized with ``nearest`` to (H,W) by the caller)."""
+    logits are +-1e8 from ``query_masks`` (M,H,W) {0,1} when given (resized with ``nearest`` to (H,W) by the caller).
+    ``out_hw`` = the evaluator's resize back to the original frame size (eval.py:340-356): the softmax PROBABILITIES are
+    interpolated bilinearly (align_corners=False) before the argmax."""
     M, T, H, W = logits.shape
+    if out_hw is not None and tuple(out_hw) != (H, W):
+        out_hw = (int(out_hw[0]), int(out_hw[1]))
+        qt = torch.zeros(M, dtype=torch.int32) if query_timestep is None else torch.as_tensor(query_timestep).to(torch.int32)
+        if logits.is_cuda:
+            from . import _lib
+            lib = _lib.load()
+            logits = logits.contiguous()
+            out = torch.empty((T,) + out_hw, dtype=torch.uint8, device=logits.device)
+            qt_d = qt.to(logits.device).contiguous()
+            gt = None if query_masks is None else (query_masks.to(logits.device) > 0).to(torch.uint8).contiguous()
+            _lib.check(lib.sampt_vos_index_masks_resized(_lib.ptr(logits), M, T, H, W, _lib.ptr(qt_d), _lib.ptr(gt),
+                                                         out_hw[0], out_hw[1], _lib.ptr(out), _lib.stream_ptr()),
+                       "sampt_vos_index_masks_resized")
+            return out
+        lg = logits.clone()                                                       # host-side formula (CPU tests)
+        for m in range(M):
+            t = int(qt[m])
+            lg[m, :t] = -1e8
+            if query_masks is not None:
+                lg[m, t] = torch.where(query_masks[m] > 0, 1e8, -1e8)
+        prob = torch.softmax(torch.cat([torch.zeros((1, T, H, W), dtype=lg.dtype), lg], dim=0), dim=0)   # (M+1,T,H,W)
+        prob = torch.nn.functional.interpolate(prob.permute(1, 0, 2, 3), out_hw, mode="bilinear", align_corners=False)
+        return prob.argmax(dim=1).to(torch.uint8)
     if logits.is_cuda:
         from . import _lib
         lib = _lib.load()

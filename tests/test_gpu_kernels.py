@@ -253,3 +253,22 @@ def test_vos_index_masks_overrides(lib, dev):
     got2 = index_masks(logits.to(dev), qt, None)
     assert torch.equal(got2.cpu(), ref2) and not torch.equal(ref, ref2)
     assert (ref[:2] != 2).all() and (ref[:4] != 3).all()                           # nothing before the query frame
+
+
+def test_vos_index_masks_resized(lib, dev):
+    """softmax -> bilinear resize of the probabilities -> argmax (vos_eval/eval.py:326, 340-356) fused in one kernel, with
+    and without the query-frame overrides, up- and down-scaling, against the torch formula."""
+    from sam_pt_amd.dist import index_masks
+    g = torch.Generator().manual_seed(9)
+    M, T, H, W = 3, 4, 36, 64
+    logits = torch.randn(M, T, H, W, generator=g) * 4
+    logits[2, 1] = -1e30
+    qt = torch.tensor([0, 1, 3])
+    gt = (torch.rand(M, H, W, generator=g) > 0.5).float()
+    for out_hw in ((30, 53), (72, 128), (36, 100)):
+        for q, m in ((None, None), (qt, None), (qt, gt)):
+            ref = index_masks(logits, q, m, out_hw=out_hw)
+            got = index_masks(logits.to(dev), q, None if m is None else m.to(dev), out_hw=out_hw)
+            assert got.shape == (T,) + out_hw
+            mism = (got.cpu() != ref).float().mean().item()
+            assert mism < 2e-3, (out_hw, mism)            # ties / last-ulp probability differences only
