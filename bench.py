@@ -50,12 +50,16 @@ def parse():
                     help="bias of the random PIPS visibility head (weights.py default 2.0 -> sigmoid 0.88, just under the 0.9 "
                          "link threshold: short hops, ~23 tracker rounds per clip; 4.0 behaves like a trained model on "
                          "trackable points: 7-frame hops).  Sensitivity knob only; the headline number uses the default.")
+    ap.add_argument("--fnet-exact", action="store_true",
+                    help="tracker encoder convolutions as exact fp32 MFMAs instead of the 3-term split-fp16 MFMAs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
 
 
 def build_model(args, dev):
+    if args.fnet_exact:
+        os.environ["SAMPT_FNET_F16X3"] = "0"
     from sam_pt_amd.point_tracker import PipsPointTracker
     from sam_pt_amd.sam_predictor import SamHip, SamPredictor
     from sam_pt_amd.sam_pt import SamPt
@@ -243,6 +247,10 @@ def main():
         torch.cuda.synchronize()
         insitu = model.sam_predictor.gemm_profile_end()
     if rank == 0:
+        from sam_pt_amd.pack import fnet_f16x3_enabled
+        tracker_precision = ("fp32-grade: correlation/mixer exact f32 MFMA; encoder convolutions 3-term split-fp16 MFMA "
+                             "(hi*hi + hi*lo + lo*hi, fp32 accumulate)" if fnet_f16x3_enabled(args.tracker == "pips")
+                             else "fp32 (exact f32 MFMA)")
         res = {"metric": "frames/sec end-to-end (SAM-PT: ViT + PIPS, 480p, 8 pts, 1 obj)", "value": round(fps, 3),
                "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "strong" if frames_sharded else "weak",
@@ -253,7 +261,7 @@ def main():
                                       f"{args.refine} refinement iterations, random-init weights (seed 72)",
                           "frames_per_step": args.frames, "parallelism": f"{'frame-batch' if frames_sharded else 'sequence'}-sharded x{world}",
                           "vit_precision": args.precision + " MFMA inputs, fp32 accumulate/LN/softmax/residual",
-                          "tracker_precision": "fp32 (exact f32 MFMA)", "decoder_precision": "fp32"},
+                          "tracker_precision": tracker_precision, "decoder_precision": "fp32"},
                "mask_foreground_fraction": round(float((masks > 0).float().mean()), 4),
                "published_reference_fps_unstated_hw": {"vit_h": 1.4, "vit_l": 1.8, "vit_b": 2.6}[args.model]}
         if not args.no_roofline and args.precision == "f16":

@@ -74,6 +74,7 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 struct GemmP {
   const void* A = nullptr;
   const void* W = nullptr;
+  const void* W_lo = nullptr;    // conv_f16x3 only: the lo plane of the split weights (W = hi plane)
   const float* bias = nullptr;   // [N] or null
   const float* res = nullptr;    // residual, f32, row stride ldr, or null
   void* C = nullptr;
@@ -105,5 +106,9 @@ struct GemmP {
 
 int gemm_f32(const GemmP& p, hipStream_t s);
 int gemm_f16(const GemmP& p, hipStream_t s);
+// fp32-grade convolution on the fp16 pipe: f32 NHWC activations, weights pre-split into fp16 hi/lo planes scaled by
+// 2^F16X3_WSHIFT (conv_f16x3.hip); the caller sets alpha = 2^-F16X3_WSHIFT.  Cin % 32 == 0.
+#define F16X3_WSHIFT 8
+int conv_f16x3(const GemmP& p, hipStream_t s);
 
 }  // namespace sampt

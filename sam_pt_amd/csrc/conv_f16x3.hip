@@ -1,0 +1,208 @@
+// fp32-grade NHWC convolution on the fp16 matrix pipe ("f16x3") for the tracker's feature encoder (pips.py:191-287).
+//
+// The encoder's trajectories must stay index-identical to the fp32 reference, so its convolutions cannot simply run in
+// fp16.  Instead every fp32 operand is split into two halves, x = hi + lo with hi = fp16(x), lo = fp16(x - hi) (22-23
+// significant bits together), and the product is evaluated as hi*hi + hi*lo + lo*hi with three
+// v_mfma_f32_16x16x32_f16 (exact fp16 products, fp32 accumulation); the dropped lo*lo term is below 2^-22 relative.  On
+// random data the result is closer to the fp64 convolution than an fp32 FMA chain is (tests/test_gpu_kernels.py), at 3/16
+// of the fp32 MFMA's issue cycles.
+//   * weights arrive pre-split from the host: half [2][Cout][K] (hi plane, lo plane), K = KH*KW*Cin, scaled by
+//     2^F16X3_WSHIFT so the lo plane stays in fp16's normal range; the epilogue multiplies by p.alpha = 2^-F16X3_WSHIFT;
+//   * activations are split on the fly while they are staged into LDS (post-InstanceNorm values are O(1), |x| < 65504);
+//   * requires Cin % 32 == 0, so a 32-deep K slab never straddles a filter tap: no div/mod in the main loop.
+//
+// Tile: 128 x BN (BN = 64 / 96 / 128 = the encoder's channel counts) x 32, 4 waves (2 x 2), LDS double-buffered with one
+// barrier per slab; MFMAs are issued with swapped operands so each lane owns 4 consecutive output channels (16-byte
+// stores).
+#include "common.h"
+
+namespace sampt {
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void k_conv_f16x3(GemmP p) {
+  constexpr int BK = 32, LDH = BK + 8;
+  constexpr int WTM = BM / 2, WTN = BN / 2, FM = WTM / 16, FN = WTN / 16;
+  constexpr int A_IT = BM * 8 / 256;                   // float4 (4 k) vectors per thread and slab
+  constexpr int B_VEC = BN * 4, B_IT = (B_VEC + 255) / 256;   // h8 (8 k) vectors per plane
+  static_assert(WTN % 16 == 0 && WTM % 16 == 0, "wave tile must be made of 16x16 fragments");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];   // 2 * (2 BM + 2 BN) * LDH halves (<= 80 KiB)
+  typedef half_t (*TileA)[BM][LDH];
+  typedef half_t (*TileB)[BN][LDH];
+  TileA Ah = (TileA)smem_raw, Al = Ah + 2;
+  TileB Bh = (TileB)(Al + 2), Bl = Bh + 2;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  // 1-D grid, the N tiles of one M tile adjacent in dispatch order (they share the activation tile through L2)
+  const int ntn = (p.N + BN - 1) / BN;
+  const int m0 = (int)(blockIdx.x / ntn) * BM, n0 = (int)(blockIdx.x % ntn) * BN;
+  const float* __restrict__ A = (const float*)p.A;
+  const half_t* __restrict__ Wh = (const half_t*)p.W;
+  const half_t* __restrict__ Wl = (const half_t*)p.W_lo;
+
+  int a_row[A_IT], a_kv[A_IT], a_iy0[A_IT], a_ix0[A_IT];
+  long a_off[A_IT];
+  bool a_ok[A_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const int v = tid + i * 256;
+    a_row[i] = v >> 3, a_kv[i] = (v & 7) * 4;
+    const int m = m0 + a_row[i];
+    a_ok[i] = m < p.M;
+    const int ohw = p.OH * p.OW;
+    const int img = m / ohw, rem = m - img * ohw;
+    const int oy = rem / p.OW, ox = rem - oy * p.OW;
+    a_off[i] = (long)img * p.cH * p.cW * p.cC;
+    a_iy0[i] = oy * p.cstride - p.cpad;
+    a_ix0[i] = ox * p.cstride - p.cpad;
+  }
+  // filter tap / channel offset of the slab being LOADED (uniform over the workgroup)
+  int l_ky = 0, l_kx = 0, l_ci = 0, l_k = 0;
+
+  float4 ra[A_IT];
+  h8 rbh[B_IT], rbl[B_IT];
+  auto load_slab = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int iy = a_iy0[i] + l_ky, ix = a_ix0[i] + l_kx;
+      const bool ok = a_ok[i] && iy >= 0 && iy < p.cH && ix >= 0 && ix < p.cW;
+      // branch-free: out-of-image taps read the tensor's first pixel and are zeroed afterwards (a branch per vector
+      // makes hipcc fence every load)
+      const float4 v = *(const float4*)(A + (ok ? a_off[i] + ((long)iy * p.cW + ix) * p.cC + l_ci + a_kv[i] : 0));
+      ra[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      const int v = tid + i * 256;
+      const int n = n0 + (v >> 2), k = l_k + (v & 3) * 8;
+      const bool ok = (B_VEC % 256 == 0 || v < B_VEC) && n < p.N;
+      const long off = ok ? (long)n * p.ldw + k : 0;
+      const h8 vh = *(const h8*)(Wh + off), vl = *(const h8*)(Wl + off);
+      rbh[i] = ok ? vh : (h8){0, 0, 0, 0, 0, 0, 0, 0};
+      rbl[i] = ok ? vl : (h8){0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    l_k += BK, l_ci += BK;
+    if (l_ci == p.cC) {
+      l_ci = 0;
+      if (++l_kx == p.KW) l_kx = 0, ++l_ky;
+    }
+  };
+  auto store_slab = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const float4 v = ra[i];
+      const h4 hi = {(half_t)v.x, (half_t)v.y, (half_t)v.z, (half_t)v.w};
+      const h4 lo = {(half_t)(v.x - (float)hi[0]), (half_t)(v.y - (float)hi[1]), (half_t)(v.z - (float)hi[2]),
+                     (half_t)(v.w - (float)hi[3])};
+      *(h4*)&Ah[buf][a_row[i]][a_kv[i]] = hi;
+      *(h4*)&Al[buf][a_row[i]][a_kv[i]] = lo;
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      const int v = tid + i * 256;
+      if (B_VEC % 256 == 0 || v < B_VEC) {
+        *(h8*)&Bh[buf][v >> 2][(v & 3) * 8] = rbh[i];
+        *(h8*)&Bl[buf][v >> 2][(v & 3) * 8] = rbl[i];
+      }
+    }
+  };
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / BK;
+  const int lr = lane & 15, lq = lane >> 4;
+  load_slab();
+  store_slab(0);
+  if (nk > 1) load_slab();
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      store_slab(cur ^ 1);                  // buffer cur^1 was last read before the previous barrier
+      if (kt + 2 < nk) load_slab();
+    }
+    h8 ah[FM], al[FM], bh[FN], bl[FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      ah[i] = *(const h8*)&Ah[cur][wm * WTM + i * 16 + lr][lq * 8];
+      al[i] = *(const h8*)&Al[cur][wm * WTM + i * 16 + lr][lq * 8];
+    }
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      bh[j] = *(const h8*)&Bh[cur][wn * WTN + j * 16 + lr][lq * 8];
+      bl[j] = *(const h8*)&Bl[cur][wn * WTN + j * 16 + lr][lq * 8];
+    }
+    // operands swapped: the fragment is C^T, lane (lr, lq) holds channels lq*4 .. lq*4+3 of output pixel lr
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+    __syncthreads();
+  }
+
+  // ---- epilogue: 4 consecutive channels per lane
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int row = m0 + wm * WTM + i * 16 + lr;
+    if (row >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int col = n0 + wn * WTN + j * 16 + lq * 4;
+      if (col >= p.N) continue;
+      float4 v = make_float4(acc[i][j][0] * p.alpha, acc[i][j][1] * p.alpha, acc[i][j][2] * p.alpha,
+                             acc[i][j][3] * p.alpha);
+      if (p.bias) {
+        const float4 b = *(const float4*)(p.bias + col);
+        v.x += b.x, v.y += b.y, v.z += b.z, v.w += b.w;
+      }
+      v.x = apply_act(v.x, p.act), v.y = apply_act(v.y, p.act), v.z = apply_act(v.z, p.act), v.w = apply_act(v.w, p.act);
+      if (p.res) {
+        const float4 r = *(const float4*)(p.res + (long)row * p.ldr + col);
+        v.x += r.x, v.y += r.y, v.z += r.z, v.w += r.w;
+      }
+      *(float4*)((float*)p.C + (long)row * p.ldc + col) = v;
+    }
+  }
+}
+
+int conv_f16x3(const GemmP& p_in, hipStream_t s) {
+  GemmP p = p_in;
+  if (!p.A || !p.W || !p.W_lo || !p.C || p.M <= 0 || p.N <= 0) return SAMPT_ERR_ARG;
+  if (!p.conv || p.cC % 32 || p.K != p.KH * p.KW * p.cC || p.ldw % 8 || p.N % 4 || p.ldc % 4) return SAMPT_ERR_UNSUPPORTED;
+  if (p.cpadw >= 0 || p.rowmap || p.a_rowmap || p.nb1 * p.nb2 != 1 || (p.res && p.ldr % 4)) return SAMPT_ERR_UNSUPPORTED;
+  if (((uintptr_t)p.A | (uintptr_t)p.W | (uintptr_t)p.W_lo | (uintptr_t)p.C | (uintptr_t)p.bias | (uintptr_t)p.res) & 15)
+    return SAMPT_ERR_ARG;
+  const int BN = p.N <= 64 ? 64 : (p.N <= 96 ? 96 : 128);
+  const size_t lds = (size_t)2 * (2 * 128 + 2 * BN) * (32 + 8) * sizeof(half_t);
+  static bool raised = false;
+  if (!raised) {  // 128 x 128 tiles need 80 KiB, above the default 64 KiB dynamic-LDS limit (gfx950: 160 KiB per CU)
+    if (hipFuncSetAttribute((const void*)k_conv_f16x3<128, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) !=
+            hipSuccess ||
+        hipFuncSetAttribute((const void*)k_conv_f16x3<128, 96>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) !=
+            hipSuccess ||
+        hipFuncSetAttribute((const void*)k_conv_f16x3<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) !=
+            hipSuccess)
+      return SAMPT_ERR_HIP;
+    raised = true;
+  }
+  dim3 grid((unsigned)((long)cdiv(p.N, BN) * cdiv(p.M, 128))), block(256);
+  if (BN == 64) hipLaunchKernelGGL((k_conv_f16x3<128, 64>), grid, block, lds, s, p);
+  else if (BN == 96) hipLaunchKernelGGL((k_conv_f16x3<128, 96>), grid, block, lds, s, p);
+  else hipLaunchKernelGGL((k_conv_f16x3<128, 128>), grid, block, lds, s, p);
+  SAMPT_CHECK_LAUNCH("conv_f16x3");
+  return SAMPT_OK;
+}
+
+}  // namespace sampt

@@ -48,6 +48,7 @@ struct Arena {
 struct ConvW {
   const float* w = nullptr;  // [Cout][KH*KW*Cin] (ci fastest), f32
   const float* b = nullptr;
+  const half_t* w_hl = nullptr;  // optional: the same weights split into fp16 planes [2][Cout][K] (conv_f16x3.hip)
   int cin = 0, cout = 0, k = 0, stride = 1, pad = 0;
 };
 

@@ -7,6 +7,7 @@ static int load_conv(const WeightMap& w, const std::string& name, int cin, int c
                      ConvW& c) {
   c.w = w.f(name + ".weight");
   c.b = w.f(name + ".bias");
+  c.w_hl = (cin % 32 == 0 && w.has(name + ".weight_hl")) ? w.h(name + ".weight_hl") : nullptr;
   c.cin = cin, c.cout = cout, c.k = k, c.stride = stride, c.pad = pad;
   return (c.w && c.b) ? SAMPT_OK : SAMPT_ERR_ARG;
 }
@@ -78,6 +79,11 @@ static int run_conv(const ConvW& c, const float* x, int n, int H, int W, float* 
   p.ldw = p.K, p.ldc = c.cout;
   p.conv = 1, p.cH = H, p.cW = W, p.cC = c.cin, p.KH = c.k, p.KW = c.k, p.cstride = c.stride, p.cpad = c.pad;
   p.OH = OH, p.OW = OW;
+  if (c.w_hl) {  // split-fp16 weights packed by the host: fp32-grade result on the fp16 matrix pipe
+    p.W = c.w_hl, p.W_lo = c.w_hl + (size_t)c.cout * p.K;
+    p.alpha = 1.0f / (float)(1 << F16X3_WSHIFT);
+    return conv_f16x3(p, s);
+  }
   return gemm_f32(p, s);
 }
 

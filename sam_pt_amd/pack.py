@@ -11,6 +11,7 @@ Layouts (see sam_pt_amd/csrc/engine_*.hip):
 """
 from __future__ import annotations
 
+import os
 from typing import Dict
 
 import torch
@@ -23,6 +24,36 @@ def _khwc(w: torch.Tensor, pad_cin_to: int = 0) -> torch.Tensor:
     if pad_cin_to and w.shape[-1] < pad_cin_to:
         w = torch.nn.functional.pad(w, (0, pad_cin_to - w.shape[-1]))
     return w.reshape(w.shape[0], -1).contiguous()
+
+
+F16X3_WSHIFT = 8          # csrc/common.h
+
+
+def split_f16x3(w: torch.Tensor) -> torch.Tensor:
+    """fp32 weights [Cout][K] -> half [2][Cout][K]: w * 2^8 = hi + lo with hi = fp16(.), lo = fp16(. - hi), the operand
+    format of csrc/conv_f16x3.hip (three fp16 MFMAs reproduce the fp32 product to 2^-22)."""
+    ws = w.float() * float(1 << F16X3_WSHIFT)
+    if not bool(torch.isfinite(ws).all()) or float(ws.abs().max()) >= 65504.0:
+        raise ValueError("split_f16x3: weight magnitude outside the fp16 range")
+    hi = ws.half()
+    lo = (ws - hi.float()).half()
+    return torch.stack([hi, lo]).contiguous()
+
+
+def fnet_f16x3_enabled(default: bool) -> bool:
+    """Whether the tracker encoder's convolutions run as 3-term split-fp16 MFMAs (csrc/conv_f16x3.hip) or as exact fp32
+    MFMAs.  ``SAMPT_FNET_F16X3=0|1`` overrides the per-tracker default (PIPS: on, PIPS++: off — see DESIGN.md)."""
+    v = os.environ.get("SAMPT_FNET_F16X3")
+    return default if v is None or v == "" else v != "0"
+
+
+def _add_fnet_split(out: Dict[str, torch.Tensor], sd: Dict[str, torch.Tensor], default: bool) -> None:
+    """``<conv>.weight_hl`` for every encoder convolution whose Cin is a multiple of 32 (all but the 3-channel stem)."""
+    if not fnet_f16x3_enabled(default):
+        return
+    for k, v in sd.items():
+        if k.startswith("fnet.") and k.endswith(".weight") and v.dim() == 4 and v.shape[1] % 32 == 0:
+            out[k + "_hl"] = split_f16x3(out[k])
 
 
 def pack_pips(sd: Dict[str, torch.Tensor], device, S: int = 8) -> Dict[str, torch.Tensor]:
@@ -40,6 +71,7 @@ def pack_pips(sd: Dict[str, torch.Tensor], device, S: int = 8) -> Dict[str, torc
     out["ffeat_updater.0.weight_t"] = sd["ffeat_updater.0.weight"].detach().float().t().contiguous()
     out["vis_predictor.0.weight"] = sd["vis_predictor.0.weight"].detach().float().reshape(-1).contiguous()
     out["__times"] = torch.linspace(0, S, S)  # pips.py:527
+    _add_fnet_split(out, sd, default=True)
     return {k: v.to(device) for k, v in out.items()}
 
 
@@ -61,6 +93,7 @@ def pack_pips2(sd: Dict[str, torch.Tensor], device) -> Dict[str, torch.Tensor]:
             out[k] = v.contiguous()
     omega = torch.arange(32) / 31
     out["__omega"] = (1.0 / (10000 ** omega)).float()
+    _add_fnet_split(out, sd, default=False)
     return {k: v.to(device) for k, v in out.items()}
 
 

@@ -365,3 +365,32 @@ def test_c_abi_error_behaviour_without_a_gpu():
     assert "hf_token" in last() or "hf_mlp" in last()
     with pytest.raises(_lib.SamptError):
         _lib.check(-1, "context")
+
+
+def test_split_f16x3_weights_and_per_tracker_default(monkeypatch):
+    """Host side of csrc/conv_f16x3.hip: hi + lo reproduces w * 2^8 to fp32 precision (absolute error far below one fp32
+    ulp of the layer's largest weight), out-of-range weights are refused, and the split planes are packed for PIPS by
+    default, for PIPS++ only on request (SAMPT_FNET_F16X3 overrides both)."""
+    from sam_pt_amd.pack import F16X3_WSHIFT, pack_pips, pack_pips2, split_f16x3
+    from sam_pt_amd.weights import init_pips2_state_dict, init_pips_state_dict
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(96, 864, generator=g) * 0.05
+    w[0, 0], w[0, 1], w[0, 2] = 3e-7, 180.0, -1.0
+    hl = split_f16x3(w)
+    assert hl.dtype == torch.float16 and hl.shape == (2, 96, 864)
+    rec = (hl[0].double() + hl[1].double()) / 2 ** F16X3_WSHIFT
+    err = (rec - w.double()).abs()
+    assert (err <= 2.0 ** -22 * w.double().abs() + 2.0 ** -33).all()
+    with pytest.raises(ValueError):
+        split_f16x3(torch.full((4, 32), 300.0))
+    monkeypatch.delenv("SAMPT_FNET_F16X3", raising=False)
+    sd1, sd2 = init_pips_state_dict(72), init_pips2_state_dict(72)
+    p1 = pack_pips(sd1, "cpu")
+    hl_keys = sorted(k for k in p1 if k.endswith(".weight_hl"))
+    assert len(hl_keys) == 21 and "fnet.conv1.weight_hl" not in p1            # every conv but the 3-channel stem
+    assert p1["fnet.conv2.weight_hl"].shape == (2, 256, 9 * 416)
+    assert not any(k.endswith("_hl") for k in pack_pips2(sd2, "cpu"))
+    monkeypatch.setenv("SAMPT_FNET_F16X3", "0")
+    assert not any(k.endswith("_hl") for k in pack_pips(sd1, "cpu"))
+    monkeypatch.setenv("SAMPT_FNET_F16X3", "1")
+    assert sum(k.endswith("_hl") for k in pack_pips2(sd2, "cpu")) == 21

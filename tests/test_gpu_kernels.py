@@ -79,6 +79,31 @@ def test_conv_f32(lib, dev, n, H, W, Cin, Cout, k, s, p):
     assert rel_err(y, ref) < 2e-6
 
 
+@pytest.mark.parametrize("n,H,W,Cin,Cout,k,s,p", [(2, 20, 28, 64, 64, 3, 1, 1), (2, 20, 28, 64, 96, 3, 2, 1),
+                                                  (2, 17, 23, 96, 128, 1, 2, 0), (1, 16, 24, 416, 256, 3, 1, 1),
+                                                  (3, 9, 11, 128, 128, 3, 1, 1), (1, 40, 56, 96, 96, 3, 1, 1)])
+def test_conv_f16x3(lib, dev, n, H, W, Cin, Cout, k, s, p):
+    """Split-fp16 convolution (three fp16 MFMAs per fp32 product, csrc/conv_f16x3.hip): as close to the fp64 convolution
+    as the exact-fp32 MFMA path is."""
+    from sam_pt_amd.pack import split_f16x3
+    g = torch.Generator().manual_seed(Cin * 3 + Cout)
+    x = torch.relu(torch.randn(n, Cin, H, W, generator=g)) * 1.7
+    w = torch.randn(Cout, Cin, k, k, generator=g) * (2.0 / (Cout * k * k)) ** 0.5
+    w[0, 0, 0, 0], w[1 % Cout, 1, 0, 0] = 3e-6, -37.0                              # tiny and large weights
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=s, padding=p).permute(0, 2, 3, 1)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    w2 = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous()
+    whl, wd, bd = split_f16x3(w2).to(dev), w2.to(dev), b.to(dev)
+    y, y32 = torch.empty(ref.shape, device=dev), torch.empty(ref.shape, device=dev)
+    ok(lib.sampt_conv2d_nhwc(3, P(xd), P(whl), P(bd), P(y), n, H, W, Cin, Cout, k, k, s, p, S()), "conv f16x3")
+    ok(lib.sampt_conv2d_nhwc(0, P(xd), P(wd), P(bd), P(y32), n, H, W, Cin, Cout, k, k, s, p, S()), "conv f32")
+    e3, e32 = rel_err(y, ref), rel_err(y32, ref)
+    assert e3 < max(2e-6, 1.5 * e32), (e3, e32)
+    # unsupported shapes are refused, never silently computed another way
+    assert lib.sampt_conv2d_nhwc(3, P(xd), P(whl), P(bd), P(y), n, H, W, Cin - 4, Cout, k, k, s, p, S()) == -3
+
+
 def test_conv_f16(lib, dev):
     n, H, W, Cin, Cout = 2, 16, 16, 256, 256
     g = torch.Generator().manual_seed(5)
