@@ -1,6 +1,8 @@
 // extern "C" surface of libsampt_hip.so (declared in include/sampt_hip.h).
 #include <string.h>
 
+#include <exception>
+#include <memory>
 #include <string>
 
 #include "../../include/sampt_hip.h"
@@ -21,6 +23,21 @@ static WeightMap make_map(const char* const* names, const void* const* ptrs, int
   for (int i = 0; i < n; ++i) w.m[names[i]] = ptrs[i];
   return w;
 }
+// Builds a handle; no C++ exception (allocation failure, ...) may cross the C boundary.
+template <class H, class Init>
+static int create_handle(const char* what, H** out, Init init) {
+  try {
+    std::unique_ptr<H> h(new H());
+    int rc = init(*h);
+    if (rc != SAMPT_OK) return fail(rc, h->e.error.empty() ? std::string(what) + ": initialisation failed" : h->e.error);
+    *out = h.release();
+    return SAMPT_OK;
+  } catch (const std::exception& ex) {
+    return fail(SAMPT_ERR_ARG, std::string(what) + ": " + ex.what());
+  } catch (...) {
+    return fail(SAMPT_ERR_ARG, std::string(what) + ": unknown C++ exception");
+  }
+}
 }  // namespace sampt
 
 using namespace sampt;
@@ -38,17 +55,10 @@ const char* sampt_last_error(void) { return last_error(); }
 // ------------------------------------------------------------------------------------------- PIPS
 int sampt_pips_create(const char* const* names, const void* const* ptrs, int n, int stride, int S, sampt_pips_t* out) {
   if (!names || !ptrs || !out || S != 8) return fail(SAMPT_ERR_ARG, "sampt_pips_create: bad arguments (S must be 8)");
-  sampt_pips* h = new sampt_pips();
-  h->e.S = S, h->e.stride = stride;
-  WeightMap w = make_map(names, ptrs, n);
-  int rc = h->e.init(w);
-  if (rc != SAMPT_OK) {
-    std::string m = h->e.error;
-    delete h;
-    return fail(rc, m);
-  }
-  *out = h;
-  return SAMPT_OK;
+  return create_handle<sampt_pips>("sampt_pips_create", out, [&](sampt_pips& h) {
+    h.e.S = S, h.e.stride = stride;
+    return h.e.init(make_map(names, ptrs, n));
+  });
 }
 void sampt_pips_destroy(sampt_pips_t h) { delete h; }
 
@@ -109,21 +119,13 @@ int sampt_pips_update_f32(sampt_pips_t h, const float* const pyr[4], int H0, int
 int sampt_vit_create(const sampt_vit_config* cfg, const char* const* names, const void* const* ptrs, int n,
                      int win_batches, sampt_vit_t* out) {
   if (!cfg || !names || !ptrs || !out || cfg->depth > 32) return fail(SAMPT_ERR_ARG, "sampt_vit_create: bad arguments");
-  sampt_vit* h = new sampt_vit();
   VitConfig c;
   c.D = cfg->embed_dim, c.depth = cfg->depth, c.heads = cfg->num_heads, c.grid = cfg->grid, c.window = cfg->window;
   c.patch = cfg->patch, c.out_chans = cfg->out_chans, c.mlp_ratio = cfg->mlp_ratio, c.img = cfg->img_size;
   c.global_mask = cfg->global_mask, c.f16 = cfg->f16;
   for (int i = 0; i < 3; ++i) c.mean[i] = cfg->pixel_mean[i], c.stdv[i] = cfg->pixel_std[i];
-  WeightMap w = make_map(names, ptrs, n);
-  int rc = h->e.init(w, c, win_batches);
-  if (rc != SAMPT_OK) {
-    std::string m = h->e.error;
-    delete h;
-    return fail(rc, m);
-  }
-  *out = h;
-  return SAMPT_OK;
+  return create_handle<sampt_vit>("sampt_vit_create", out,
+                                  [&](sampt_vit& h) { return h.e.init(make_map(names, ptrs, n), c, win_batches); });
 }
 void sampt_vit_destroy(sampt_vit_t h) { delete h; }
 
@@ -159,16 +161,8 @@ int sampt_vit_encode(sampt_vit_t h, const uint8_t* frames, int chw, int B, int H
 // ------------------------------------------------------------------------------------------- PIPS++
 int sampt_pips2_create(const char* const* names, const void* const* ptrs, int n, int stride, sampt_pips2_t* out) {
   if (!names || !ptrs || !out || stride <= 0) return fail(SAMPT_ERR_ARG, "sampt_pips2_create: bad arguments");
-  sampt_pips2* h = new sampt_pips2();
-  WeightMap w = make_map(names, ptrs, n);
-  int rc = h->e.init(w, stride);
-  if (rc != SAMPT_OK) {
-    std::string m = h->e.error;
-    delete h;
-    return fail(rc, m);
-  }
-  *out = h;
-  return SAMPT_OK;
+  return create_handle<sampt_pips2>("sampt_pips2_create", out,
+                                    [&](sampt_pips2& h) { return h.e.init(make_map(names, ptrs, n), stride); });
 }
 void sampt_pips2_destroy(sampt_pips2_t h) { delete h; }
 
@@ -216,20 +210,14 @@ int sampt_pips2_update_f32(sampt_pips2_t h, const float* const pyr[4], int H0, i
 // ------------------------------------------------------------------------------------------- decoder
 int sampt_dec_create(const char* const* names, const void* const* ptrs, int n, int grid, int img_size, int max_frames,
                      int vit_dim, sampt_dec_t* out) {
-  if (!names || !ptrs || !out || max_frames <= 0 || vit_dim < 0) return SAMPT_ERR_ARG;
-  sampt_dec* h = new sampt_dec();
+  if (!names || !ptrs || !out || max_frames <= 0 || vit_dim < 0)
+    return fail(SAMPT_ERR_ARG, "sampt_dec_create: bad arguments");
   DecConfig c;
   c.grid = grid, c.img = img_size, c.vit_dim = vit_dim;
-  h->e.max_frames = max_frames;
-  WeightMap w = make_map(names, ptrs, n);
-  int rc = h->e.init(w, c);
-  if (rc != SAMPT_OK) {
-    std::string m = h->e.error;
-    delete h;
-    return fail(rc, m);
-  }
-  *out = h;
-  return SAMPT_OK;
+  return create_handle<sampt_dec>("sampt_dec_create", out, [&](sampt_dec& h) {
+    h.e.max_frames = max_frames;
+    return h.e.init(make_map(names, ptrs, n), c);
+  });
 }
 void sampt_dec_destroy(sampt_dec_t h) { delete h; }
 
