@@ -377,6 +377,10 @@ class SamPredictorRef:
             self.features = image_encoder(self.sd, self.cfg, preprocess(self.cfg, x))
         self.n_set_image += 1
 
+    def reset_image(self):
+        self.features = self.hq_feat = None
+        self.original_size = self.input_size = None
+
     @torch.no_grad()
     def predict_torch(self, point_coords, point_labels, boxes=None, mask_input=None, multimask_output=True,
                       return_logits=False):

@@ -185,6 +185,10 @@ class SamPredictor:
         self.reset_image()
         self.stats = {"set_image": 0, "predict": 0, "encoded_frames": 0}
 
+    @property
+    def device(self):
+        return self.model.device
+
     def reset_image(self):
         self.is_image_set = False
         self.features = None
@@ -326,35 +330,46 @@ class SamPredictor:
         if multimask_output and self.model.hq:
             raise NotImplementedError("multimask_output=True with the HQ-SAM decoder is not built (SAM-PT never asks for "
                                       "it: sam_pt.py:787, 796, 805, 826)")
-        if point_coords is None or point_coords.shape[0] != 1:
-            raise NotImplementedError("predict_torch: exactly one prompt batch with points is supported")
+        if point_coords is None:
+            raise NotImplementedError("predict_torch: prompts without points are not supported")
         self._ensure()
         dev = self._dev
         oh, ow = self.original_size
         ih, iw = self.input_size
-        pts = point_coords[0].to(dev, torch.float32).contiguous()
-        lab = point_labels[0].to(dev, torch.int32).contiguous()
-        box = boxes.reshape(-1)[:4].to(dev, torch.float32).contiguous() if boxes is not None else None
+        B = point_coords.shape[0]                      # prompts against the current image (upstream's batch dimension)
+        pts = point_coords.to(dev, torch.float32).contiguous()
+        lab = point_labels.to(dev, torch.int32).contiguous()
+        box = boxes.reshape(B, 4).to(dev, torch.float32).contiguous() if boxes is not None else None
         L = 4 * self.model.cfg.grid
-        mi = mask_input.reshape(L, L).to(dev, torch.float32).contiguous() if mask_input is not None else None
+        mi = mask_input.reshape(B, L, L).to(dev, torch.float32).contiguous() if mask_input is not None else None
         nm = 3 if multimask_output else 1
-        logits = torch.empty((1, nm, oh, ow), dtype=torch.float32, device=dev)
-        iou = torch.empty((1, nm), dtype=torch.float32, device=dev)
-        low = torch.empty((1, nm, L, L), dtype=torch.float32, device=dev)
+        logits = torch.empty((B, nm, oh, ow), dtype=torch.float32, device=dev)
+        iou = torch.empty((B, nm), dtype=torch.float32, device=dev)
+        low = torch.empty((B, nm, L, L), dtype=torch.float32, device=dev)
         ws = self._dec_ws(oh, ow)
-        if multimask_output:
-            _lib.check(self._lib.sampt_sam_decode_multimask(self._dec, _lib.ptr(self._feat_tokens), _lib.ptr(pts), _lib.ptr(lab),
-                                                            pts.shape[0], _lib.ptr(box), _lib.ptr(mi), ih, iw, oh, ow,
-                                                            _lib.ptr(logits), _lib.ptr(iou), _lib.ptr(low), _lib.ptr(ws),
-                                                            ws.numel(), _lib.stream_ptr()), "sampt_sam_decode_multimask")
+        k = pts.shape[1]
+        for b in range(B):                             # stream-ordered, no host synchronisation between prompts
+            # every prompt gets its own (allocator-aligned) buffers, so a batch member sees exactly what a single call sees
+            one = B == 1
+            p_b, l_b = (pts[0], lab[0]) if one else (pts[b].clone(), lab[b].clone())
+            b_b = None if box is None else (box[0] if one else box[b].clone())
+            m_b = None if mi is None else (mi[0] if one else mi[b].clone())
+            lg, io, lw = (logits[0], iou[0], low[0]) if one else (torch.empty_like(logits[0]), torch.empty_like(iou[0]),
+                                                                  torch.empty_like(low[0]))
+            if multimask_output:
+                _lib.check(self._lib.sampt_sam_decode_multimask(self._dec, _lib.ptr(self._feat_tokens), _lib.ptr(p_b),
+                                                                _lib.ptr(l_b), k, _lib.ptr(b_b), _lib.ptr(m_b), ih, iw, oh, ow,
+                                                                _lib.ptr(lg), _lib.ptr(io), _lib.ptr(lw),
+                                                                _lib.ptr(ws), ws.numel(), _lib.stream_ptr()),
+                           "sampt_sam_decode_multimask")
+            else:
+                _lib.check(self._lib.sampt_sam_decode(self._dec, _lib.ptr(self._feat_tokens), _lib.ptr(self._hq_tokens),
+                                                      _lib.ptr(p_b), _lib.ptr(l_b), k, _lib.ptr(b_b), _lib.ptr(m_b), ih, iw,
+                                                      oh, ow, _lib.ptr(lg), _lib.ptr(io), _lib.ptr(lw), _lib.ptr(ws),
+                                                      ws.numel(), _lib.stream_ptr()), "sampt_sam_decode")
+            if not one:
+                logits[b].copy_(lg), iou[b].copy_(io), low[b].copy_(lw)
             self.stats["predict"] += 1
-            return (logits if return_logits else logits > self.model.mask_threshold), iou, low
-        _lib.check(self._lib.sampt_sam_decode(self._dec, _lib.ptr(self._feat_tokens), _lib.ptr(self._hq_tokens),
-                                              _lib.ptr(pts), _lib.ptr(lab),
-                                              pts.shape[0], _lib.ptr(box), _lib.ptr(mi), ih, iw, oh, ow, _lib.ptr(logits),
-                                              _lib.ptr(iou), _lib.ptr(low), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()),
-                   "sampt_sam_decode")
-        self.stats["predict"] += 1
         masks = logits if return_logits else logits > self.model.mask_threshold
         return masks, iou, low
 

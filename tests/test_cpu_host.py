@@ -394,3 +394,62 @@ def test_split_f16x3_weights_and_per_tracker_default(monkeypatch):
     assert not any(k.endswith("_hl") for k in pack_pips(sd1, "cpu"))
     monkeypatch.setenv("SAMPT_FNET_F16X3", "1")
     assert sum(k.endswith("_hl") for k in pack_pips2(sd2, "cpu")) == 21
+
+
+def test_predict_torch_batched_prompts_host_logic(monkeypatch):
+    """``SamPredictor.predict_torch`` with upstream's batch dimension (B prompts against the current image, as the
+    automatic mask generator issues them): every prompt becomes one C-ABI decode call with its own contiguous buffers and
+    its outputs land in row b.  Runs against a recording stand-in for the library (no GPU, no arithmetic)."""
+    import types
+    from sam_pt_amd import _lib, sam_predictor as SP
+    calls = []
+
+    class FakeLib:
+        def sampt_sam_decode_multimask(self, dec, feat, p, l, k, bx, mb, ih, iw, oh, ow, lg, io, lw, ws, n, stream):
+            calls.append(("multi", tuple(p.shape), tuple(l.shape), k, bx is None, mb is None, tuple(lg.shape)))
+            lg.fill_(float(p[0, 0])), io.fill_(float(p[0, 1])), lw.fill_(float(l[0]))
+            return 0
+
+        def sampt_sam_decode(self, dec, feat, hq, p, l, k, bx, mb, ih, iw, oh, ow, lg, io, lw, ws, n, stream):
+            calls.append(("single", tuple(p.shape), tuple(l.shape), k, None if bx is None else bx.tolist(),
+                          None if mb is None else float(mb[0, 0]), tuple(lg.shape)))
+            lg.fill_(float(p[-1, 0])), io.fill_(float(p[-1, 1])), lw.fill_(0.0)
+            return 0
+
+    def fake_ptr(t):
+        assert t is None or t.is_contiguous()
+        return t
+
+    monkeypatch.setattr(_lib, "ptr", fake_ptr)
+    monkeypatch.setattr(_lib, "stream_ptr", lambda: None)
+    cfg = types.SimpleNamespace(grid=4, img_size=64, out_chans=256)
+    model = types.SimpleNamespace(cfg=cfg, hq=False, mask_threshold=0.0, device=torch.device("cpu"), image_format="RGB")
+    pred = SP.SamPredictor(model)
+    pred._ensure = lambda: None
+    pred._dev, pred._lib, pred._dec = torch.device("cpu"), FakeLib(), object()
+    monkeypatch.setattr(pred, "_dec_ws", lambda oh, ow, frames=1: torch.zeros(16, dtype=torch.uint8))
+    pred.set_features(torch.zeros(16, 256), (20, 30), (40, 60))
+    assert pred.device == torch.device("cpu")
+    B = 5
+    pc = torch.arange(B * 2, dtype=torch.float64).reshape(B, 1, 2)            # prompt b = point (2b, 2b+1)
+    pl = torch.ones(B, 1, dtype=torch.int64)
+    logits, iou, low = pred.predict_torch(pc, pl, multimask_output=True, return_logits=True)
+    assert logits.shape == (B, 3, 20, 30) and iou.shape == (B, 3) and low.shape == (B, 3, 16, 16)
+    assert len(calls) == B and all(c == ("multi", (1, 2), (1,), 1, True, True, (3, 20, 30)) for c in calls)
+    for b in range(B):
+        assert bool((logits[b] == 2 * b).all()) and bool((iou[b] == 2 * b + 1).all()) and bool((low[b] == 1).all())
+    assert pred.stats["predict"] == B
+    calls.clear()
+    pc2 = torch.tensor([[[1.0, 2.0], [3.0, 4.0]], [[5.0, 6.0], [7.0, 8.0]]])
+    boxes = torch.tensor([[[0.0, 1.0, 2.0, 3.0]], [[4.0, 5.0, 6.0, 7.0]]])
+    mi = torch.stack([torch.full((1, 16, 16), 0.25), torch.full((1, 16, 16), 0.75)])
+    masks, iou, low = pred.predict_torch(pc2, torch.ones(2, 2, dtype=torch.int), boxes=boxes, mask_input=mi,
+                                         multimask_output=False, return_logits=False)
+    assert masks.dtype == torch.bool and masks.shape == (2, 1, 20, 30) and bool(masks.all())
+    assert calls == [("single", (2, 2), (2,), 2, [0.0, 1.0, 2.0, 3.0], 0.25, (1, 20, 30)),
+                     ("single", (2, 2), (2,), 2, [4.0, 5.0, 6.0, 7.0], 0.75, (1, 20, 30))]
+    assert iou[:, 0].tolist() == [4.0, 8.0]
+    calls.clear()                                                              # B = 1 keeps the direct (copy-free) path
+    m1, _, _ = pred.predict_torch(pc2[:1], torch.ones(1, 2, dtype=torch.int), boxes=boxes[:1], multimask_output=False,
+                                  return_logits=True)
+    assert len(calls) == 1 and m1.shape == (1, 1, 20, 30) and bool((m1 == 3.0).all())

@@ -690,3 +690,60 @@ def test_arbitrary_frame_sizes(dev, pips_sd):
     assert max_abs(l_s, l_r) < 3e-3
     for t in range(9):
         assert iou(l_f[0, t] > 0, l_r[0, t] > 0) >= 1 - 1e-3
+
+
+def test_predict_torch_prompt_batch_equals_single_calls(dev):
+    """Upstream's batch dimension of predict_torch (B prompts against one image, what the automatic mask generator
+    issues): row b of a batched call is bit-identical to the single call with prompt b, for both decoder flavours."""
+    from sam_pt_amd.sam_predictor import SamHip, SamPredictor
+    from sam_pt_amd.weights import SAM_CONFIGS, init_sam_state_dict
+    cfg = SAM_CONFIGS["vit_test"]
+    frames, _ = synthetic_clip(T=1, H=96, W=128, seed=9)
+    pred = SamPredictor(SamHip(config=cfg, state_dict=init_sam_state_dict(cfg, 72), precision="f32").to(dev))
+    pred.set_image(frames[0].permute(1, 2, 0).numpy())
+    g = torch.Generator().manual_seed(2)
+    B = 5
+    pts = (torch.rand(B, 2, 2, generator=g) * torch.tensor([256.0, 192.0])).to(dev)
+    lab = torch.tensor([[1, 0]] * B, dtype=torch.int, device=dev)
+    for multi in (True, False):
+        m, i, l = pred.predict_torch(pts, lab, multimask_output=multi, return_logits=True)
+        nm = 3 if multi else 1
+        assert m.shape == (B, nm, 96, 128) and i.shape == (B, nm) and l.shape == (B, nm, 64, 64)
+        for b in range(B):
+            mb, ib, lb = pred.predict_torch(pts[b:b + 1], lab[b:b + 1], multimask_output=multi, return_logits=True)
+            assert torch.equal(mb[0], m[b]) and torch.equal(ib[0], i[b]) and torch.equal(lb[0], l[b])
+    assert not torch.equal(m[0], m[1])
+
+
+def test_automatic_mask_generator_hip_vs_oracle(dev):
+    """SamAutomaticMaskGenerator (VIS adapter, row f3) on the HIP predictor: every record is one of SAM's three masks for
+    its grid point, and the record set agrees with the same generator driven by the CPU oracle predictor."""
+    from oracle import sam_ref as R
+    from sam_pt_amd import automatic_mask_generator as A
+    from sam_pt_amd.sam_predictor import SamHip, SamPredictor
+    from sam_pt_amd.weights import SAM_CONFIGS, init_sam_state_dict
+    cfg = SAM_CONFIGS["vit_test"]
+    sd = init_sam_state_dict(cfg, 72)
+    frames, _ = synthetic_clip(T=1, H=96, W=128, seed=3)
+    img = frames[0].permute(1, 2, 0).contiguous().numpy()
+    kw = dict(points_per_side=4, points_per_batch=6, pred_iou_thresh=0.0, stability_score_thresh=0.0)
+    sam = SamHip(config=cfg, state_dict=sd, precision="f32").to(dev)
+    ours = A.SamAutomaticMaskGenerator(sam, **kw).generate(img)
+    ref = A.SamAutomaticMaskGenerator(None, predictor=R.SamPredictorRef(sd, cfg), **kw).generate(img)
+    assert len(ours) > 0 and abs(len(ours) - len(ref)) <= max(1, len(ref) // 10)
+    ious_ = [r["predicted_iou"] for r in ours]
+    assert ious_ == sorted(ious_, reverse=True)
+    matched = 0
+    for r in ours:
+        assert r["segmentation"].shape == (96, 128) and r["area"] == int(r["segmentation"].sum())
+        cands = [q for q in ref if q["point_coords"] == r["point_coords"] and abs(q["predicted_iou"] - r["predicted_iou"]) < 1e-3]
+        if cands:
+            matched += 1
+            best = max(iou(torch.as_tensor(r["segmentation"]), torch.as_tensor(q["segmentation"])) for q in cands)
+            assert best >= 0.99
+    assert matched >= 0.9 * len(ours)
+    # one crop layer + small-region clean-up run end to end on the device path
+    more = A.SamAutomaticMaskGenerator(sam, points_per_side=2, points_per_batch=8, pred_iou_thresh=0.0,
+                                       stability_score_thresh=0.0, crop_n_layers=1, crop_n_points_downscale_factor=2,
+                                       min_mask_region_area=6).generate(img)
+    assert more and all(r["segmentation"].shape == (96, 128) for r in more)
