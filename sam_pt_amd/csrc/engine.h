@@ -172,6 +172,10 @@ struct DecEngine {
     const float *ee0_w, *ee0_b, *eeln_w, *eeln_b, *ee1_w, *ee1_b;  // embedding_encoder  (C -> C/4 -> C/8)
     const float *mf0_w, *mf0_b, *mfln_w, *mfln_b, *mf1_w, *mf1_b;  // embedding_maskfeature: conv3x3 [Cout][9*Cin]
   } hq;
+  // optional (opt-in, pack.pack_decoder with SAMPT_DEC_F16X3=1): split-fp16 planes [2][N][K] of the attention projection
+  // weights, keyed by the f32 weight pointer; projections over the image tokens (M = F*g*g rows) then run on the fp16
+  // matrix pipe at fp32 grade (conv_f16x3.hip as a 1x1 convolution over an [1][M][1][K] image)
+  std::unordered_map<const float*, const half_t*> w_hl;
   std::string error;
 
   bool is_hq() const { return c.vit_dim > 0; }

@@ -12,12 +12,17 @@
 
 namespace sampt {
 
-static void load_attn(const WeightMap& w, const std::string& p, int inner, DecEngine::Attn& a) {
+static void load_attn(const WeightMap& w, const std::string& p, int inner, DecEngine::Attn& a,
+                      std::unordered_map<const float*, const half_t*>& w_hl) {
   a.qw = w.f(p + ".q_proj.weight"), a.qb = w.f(p + ".q_proj.bias");
   a.kw = w.f(p + ".k_proj.weight"), a.kb = w.f(p + ".k_proj.bias");
   a.vw = w.f(p + ".v_proj.weight"), a.vb = w.f(p + ".v_proj.bias");
   a.ow = w.f(p + ".out_proj.weight"), a.ob = w.f(p + ".out_proj.bias");
   a.inner = inner;
+  const char* names[4] = {".q_proj.weight", ".k_proj.weight", ".v_proj.weight", ".out_proj.weight"};
+  const float* ptrs[4] = {a.qw, a.kw, a.vw, a.ow};
+  for (int i = 0; i < 4; ++i)
+    if (ptrs[i] && w.has(p + names[i] + "_hl")) w_hl[ptrs[i]] = w.h(p + names[i] + "_hl");
 }
 
 int DecEngine::init(const WeightMap& w, const DecConfig& cfg) {
@@ -27,9 +32,9 @@ int DecEngine::init(const WeightMap& w, const DecConfig& cfg) {
   for (int i = 0; i < c.depth; ++i) {
     std::string p = T + "layers." + std::to_string(i);
     Layer& L = layer[i];
-    load_attn(w, p + ".self_attn", c.C, L.self);
-    load_attn(w, p + ".cross_attn_token_to_image", c.C / 2, L.t2i);
-    load_attn(w, p + ".cross_attn_image_to_token", c.C / 2, L.i2t);
+    load_attn(w, p + ".self_attn", c.C, L.self, w_hl);
+    load_attn(w, p + ".cross_attn_token_to_image", c.C / 2, L.t2i, w_hl);
+    load_attn(w, p + ".cross_attn_image_to_token", c.C / 2, L.i2t, w_hl);
     L.n1w = w.f(p + ".norm1.weight"), L.n1b = w.f(p + ".norm1.bias");
     L.n2w = w.f(p + ".norm2.weight"), L.n2b = w.f(p + ".norm2.bias");
     L.n3w = w.f(p + ".norm3.weight"), L.n3b = w.f(p + ".norm3.bias");
@@ -37,7 +42,7 @@ int DecEngine::init(const WeightMap& w, const DecConfig& cfg) {
     L.m1w = w.f(p + ".mlp.lin1.weight"), L.m1b = w.f(p + ".mlp.lin1.bias");
     L.m2w = w.f(p + ".mlp.lin2.weight"), L.m2b = w.f(p + ".mlp.lin2.bias");
   }
-  load_attn(w, T + "final_attn_token_to_image", c.C / 2, fin);
+  load_attn(w, T + "final_attn_token_to_image", c.C / 2, fin, w_hl);
   nfw = w.f(T + "norm_final_attn.weight"), nfb = w.f(T + "norm_final_attn.bias");
   out_tokens = w.f("mask_decoder.__out_tokens");
   gauss = w.f("prompt_encoder.pe_layer.positional_encoding_gaussian_matrix");
@@ -92,12 +97,23 @@ struct L {
   hipStream_t s;
   float* skws;
   size_t skn;
+  const std::unordered_map<const float*, const half_t*>* w_hl = nullptr;
   int lin(const float* A, int M, int K, const float* W, const float* b, float* C, int N, int act = ACT_NONE,
           const float* res = nullptr, int lda = 0) const {
     GemmP p;
     p.A = A, p.W = W, p.bias = b, p.C = C, p.res = res;
     p.M = M, p.N = N, p.K = K, p.lda = lda ? lda : K, p.ldw = K, p.ldc = N, p.ldr = N, p.act = act;
     p.splitk_ws = skws, p.splitk_ws_floats = skn;
+    if (w_hl && M >= 2048 && !lda && K % 32 == 0 && N % 4 == 0) {     // image-token projections, split-fp16 planes packed
+      auto it = w_hl->find(W);
+      if (it != w_hl->end()) {
+        p.W = it->second, p.W_lo = it->second + (size_t)N * K;
+        p.alpha = 1.0f / (float)(1 << F16X3_WSHIFT);
+        p.conv = 1, p.cH = M, p.cW = 1, p.cC = K, p.KH = 1, p.KW = 1, p.cstride = 1, p.cpad = 0, p.OH = M, p.OW = 1;
+        p.splitk_ws = nullptr, p.splitk_ws_floats = 0;
+        return conv_f16x3(p, s);
+      }
+    }
     return gemm_f32(p, s);
   }
 };
@@ -188,7 +204,7 @@ int DecEngine::decode(int F, const float* features, const float* hq_feat, const 
   float* skws = ws.f32(skn);
   if (!ws.ok()) return SAMPT_ERR_WORKSPACE;
   if (ws.dry()) return SAMPT_OK;
-  L l{s, skws, skn};
+  L l{s, skws, skn, w_hl.empty() ? nullptr : &w_hl};
 
   // ---- prompt encoder
   SAMPT_TRY(sam_tokens(out_tokens, NO, pts, labels, k, ld_pts, box, gauss, point_emb, not_a_point, (float)c.img, F,

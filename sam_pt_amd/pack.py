@@ -199,4 +199,10 @@ def pack_decoder(sd: Dict[str, torch.Tensor], cfg: SamConfig, device, max_frames
     out["mask_decoder.output_upscaling.3.weight_packed"] = _convt_pack(sd["mask_decoder.output_upscaling.3.weight"].float())
     out["mask_decoder.__up0_map"] = _shuffle_map(cfg.grid, max_frames)
     out["mask_decoder.__up1_map"] = _shuffle_map(2 * cfg.grid, max_frames)
+    if os.environ.get("SAMPT_DEC_F16X3", "0") != "0":
+        # opt-in experiment: split-fp16 planes of the two-way transformer's attention projections; the
+        # engine uses them for the projections over the image tokens (M = frames * grid^2 rows)
+        for k in [k for k in out if k.startswith("mask_decoder.transformer.") and k.endswith("_proj.weight")]:
+            if out[k].shape[1] % 32 == 0 and out[k].shape[0] % 4 == 0:
+                out[k + "_hl"] = split_f16x3(out[k])
     return {k: v.to(device) for k, v in out.items()}

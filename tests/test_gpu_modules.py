@@ -3,6 +3,7 @@
 seeded weights and inputs.  Tolerances are stated per test; trajectories must agree in index space
 (round(traj) identical), masks within 1e-3 IoU."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -747,3 +748,27 @@ def test_automatic_mask_generator_hip_vs_oracle(dev):
                                        stability_score_thresh=0.0, crop_n_layers=1, crop_n_points_downscale_factor=2,
                                        min_mask_region_area=6).generate(img)
     assert more and all(r["segmentation"].shape == (96, 128) for r in more)
+
+
+@pytest.mark.skipif(os.environ.get("SAMPT_TEST_EXPERIMENTAL", "0") == "0",
+                    reason="opt-in experiment (SAMPT_DEC_F16X3): run with SAMPT_TEST_EXPERIMENTAL=1")
+def test_decoder_image_projections_f16x3_opt_in(dev, monkeypatch):
+    """the decoder's image-token projections through the split-fp16 convolution kernel — same tolerance
+    against the oracle as the exact-f32 decoder."""
+    from oracle import sam_ref as R
+    from sam_pt_amd.sam_predictor import SamHip, SamPredictor
+    from sam_pt_amd.weights import SAM_CONFIGS, init_sam_state_dict
+    monkeypatch.setenv("SAMPT_DEC_F16X3", "1")
+    cfg = SAM_CONFIGS["vit_test"]
+    sd = init_sam_state_dict(cfg, 72)
+    frames, centres = synthetic_clip(T=1, H=144, W=256, seed=5)
+    img = frames[0].permute(1, 2, 0).numpy()
+    pred = SamPredictor(SamHip(config=cfg, state_dict=sd, precision="f32").to(dev))
+    ref = R.SamPredictorRef(sd, cfg)
+    pred.set_image(img), ref.set_image(img)
+    q = disc_queries(centres, n_pos=3, r=9.0)[:, 1:]
+    pts = torch.as_tensor(pred.transform.apply_coords(q.numpy(), (144, 256)), dtype=torch.float)[None]
+    lab = torch.tensor([[1, 1, 0]], dtype=torch.int)
+    m0, i0, l0 = ref.predict_torch(pts, lab, None, None, False, True)
+    m1, i1, l1 = pred.predict_torch(pts.to(dev), lab.to(dev), None, None, False, True)
+    assert max_abs(l1, l0) < 3e-4 and max_abs(i1, i0) < 1e-4 and max_abs(m1, m0) < 3e-4
