@@ -740,8 +740,9 @@ def test_automatic_mask_generator_hip_vs_oracle(dev):
         cands = [q for q in ref if q["point_coords"] == r["point_coords"] and abs(q["predicted_iou"] - r["predicted_iou"]) < 1e-3]
         if cands:
             matched += 1
-            best = max(iou(torch.as_tensor(r["segmentation"]), torch.as_tensor(q["segmentation"])) for q in cands)
-            assert best >= 0.99
+            # same mask up to the pixels whose logit sits within the fp32 noise of 0 (small masks: a pixel or two)
+            diff = min(int((r["segmentation"] ^ q["segmentation"]).sum()) for q in cands)
+            assert diff <= max(3, 0.01 * r["area"]), (diff, r["area"])
     assert matched >= 0.9 * len(ours)
     # one crop layer + small-region clean-up run end to end on the device path
     more = A.SamAutomaticMaskGenerator(sam, points_per_side=2, points_per_batch=8, pred_iou_thresh=0.0,
