@@ -102,10 +102,23 @@ struct GemmP {
   int conv = 0;
   int cH = 0, cW = 0, cC = 0, KH = 0, KW = 0, cstride = 1, cpad = 0, OH = 0, OW = 0;
   int cpadw = -1;                // >= 0: padding along W differs from cpad (1-D convolutions over time: KW = 1, cpadw = 0)
+  // launch fusion around split-K (plain f32 GEMMs only, opt-in by the PIPS engine):
+  //  * defer_reduce: when the dispatcher splits K, leave the raw partial tiles [splitk][M][N] in splitk_ws and do NOT
+  //    launch k_splitk_reduce; the consumer applies the reduction + epilogue while it loads (gemm_f32_plan_splitk tells
+  //    the caller the split beforehand; with no split the normal epilogue runs as usual);
+  //  * a_nsplit > 0: A[m][k] = a_act(sum_{s < a_nsplit} A[s * a_split_stride + m * lda + k] + a_bias[k]) — exactly what
+  //    k_splitk_reduce would have stored (same order of additions), computed on the fly by the A loads.
+  int defer_reduce = 0;
+  int a_nsplit = 0;
+  long a_split_stride = 0;
+  const float* a_bias = nullptr;
+  int a_act = ACT_NONE;
 };
 
 int gemm_f32(const GemmP& p, hipStream_t s);
 int gemm_f16(const GemmP& p, hipStream_t s);
+// the split-K factor gemm_f32 will choose for this problem (1 = no split; needs p.splitk_ws / splitk_ws_floats set)
+int gemm_f32_plan_splitk(const GemmP& p);
 // fp32-grade convolution on the fp16 pipe: f32 NHWC activations, weights pre-split into fp16 hi/lo planes scaled by
 // 2^F16X3_WSHIFT (conv_f16x3.hip); the caller sets alpha = 2^-F16X3_WSHIFT.  Cin % 32 == 0.
 #define F16X3_WSHIFT 8

@@ -1,7 +1,17 @@
 // PIPS engine: fnet (BasicEncoder, pips.py:191-287) and the iterative point-update window (pips.py:439-620).
+#include <stdlib.h>
+#include <string.h>
+
 #include "engine.h"
 
 namespace sampt {
+
+// Opt-in launch fusion of the mixer's split-K reductions: SAMPT_PIPS_FUSE_REDUCE=1.  Off by default —
+// the default launch sequence is the one every parity test ran on.
+static bool fuse_reduce_enabled() {   // read per call (a getenv per window round), so one process can compare both modes
+  const char* v = getenv("SAMPT_PIPS_FUSE_REDUCE");
+  return v && *v && strcmp(v, "0") != 0;
+}
 
 static int load_conv(const WeightMap& w, const std::string& name, int cin, int cout, int k, int stride, int pad,
                      ConvW& c) {
@@ -185,6 +195,8 @@ int PipsEngine::update(const PyramidLevels& pyr, const int* frame_idx, int n, co
   float* delta = ws.f32((size_t)n * S * 130);
   const size_t skn = (size_t)8 * R * 4 * D;  // split-K partials of the weight-bandwidth-bound mixer GEMMs
   float* skws = ws.f32(skn);
+  const bool fuse = fuse_reduce_enabled();
+  float* skws_b = fuse ? ws.f32(skn) : nullptr;  // second partial buffer: producer and consumer partials are live together
   if (!ws.ok()) return SAMPT_ERR_WORKSPACE;
   if (dry) return SAMPT_OK;
   SAMPT_TRY(pips_init_state(xys, feat_init, (float)stride, S, n, coords, coords0, ffeats, s));
@@ -192,14 +204,56 @@ int PipsEngine::update(const PyramidLevels& pyr, const int* frame_idx, int n, co
     SAMPT_TRY(pips_corr_sample(pyr, frame_idx, S, n, 128, ffeats, coords, x, LDX, 128, s));
     SAMPT_TRY(pips_build_input(ffeats, coords, times, S, n, x, LDX, s));
     SAMPT_TRY(lin(x, R, LDX, LDX, in_w, in_b, hbuf, D, ACT_NONE, nullptr, s, skws, skn));
-    for (int i = 0; i < 12; ++i) {
-      const MixBlk& m = mix[i];
-      SAMPT_TRY(pips_token_mix(hbuf, hbuf2, m.ln1w, m.ln1b, m.tw1, m.tb1, m.tw2, m.tb2, n, S, D, s));
-      SAMPT_TRY(layernorm_rows(hbuf2, m.ln2w, m.ln2b, lnb, R, D, 1e-5f, nullptr, 0, ACT_NONE, s));
-      SAMPT_TRY(lin(lnb, R, D, D, m.cw1, m.cb1, hid, 4 * D, ACT_GELU, nullptr, s, skws, skn));
-      SAMPT_TRY(lin(hid, R, 4 * D, 4 * D, m.cw2, m.cb2, hbuf, D, ACT_NONE, hbuf2, s, skws, skn));
+    const float* mixed = hbuf;   // output of the 12 mixer blocks
+    if (!fuse) {
+      for (int i = 0; i < 12; ++i) {
+        const MixBlk& m = mix[i];
+        SAMPT_TRY(pips_token_mix(hbuf, hbuf2, m.ln1w, m.ln1b, m.tw1, m.tb1, m.tw2, m.tb2, n, S, D, s));
+        SAMPT_TRY(layernorm_rows(hbuf2, m.ln2w, m.ln2b, lnb, R, D, 1e-5f, nullptr, 0, ACT_NONE, s));
+        SAMPT_TRY(lin(lnb, R, D, D, m.cw1, m.cb1, hid, 4 * D, ACT_GELU, nullptr, s, skws, skn));
+        SAMPT_TRY(lin(hid, R, 4 * D, 4 * D, m.cw2, m.cb2, hbuf, D, ACT_NONE, hbuf2, s, skws, skn));
+      }
+    } else {
+      // Same arithmetic, fewer launches: a split-K GEMM leaves its raw partials and the consumer (the next GEMM's A
+      // loads / the next block's token mixing) applies sum + bias (+ GELU / + residual) while it reads them.
+      float* cur = hbuf;                 // materialised block input (null while it only exists as pending partials)
+      int pend_ns = 0;                   // > 0: block input = sum(skws_b partials) + pend_bias + pend_res
+      const float *pend_bias = nullptr, *pend_res = nullptr;
+      for (int i = 0; i < 12; ++i) {
+        const MixBlk& m = mix[i];
+        float* tm;                       // token-mixing output = residual of this block's channel mixing
+        if (pend_ns) {
+          tm = pend_res == hbuf2 ? hbuf : hbuf2;
+          SAMPT_TRY(pips_token_mix_fused_in(skws_b, pend_ns, (long)R * D, pend_bias, pend_res, tm, m.ln1w, m.ln1b, m.tw1,
+                                            m.tb1, m.tw2, m.tb2, n, S, D, s));
+        } else {
+          tm = cur == hbuf ? hbuf2 : hbuf;
+          SAMPT_TRY(pips_token_mix(cur, tm, m.ln1w, m.ln1b, m.tw1, m.tb1, m.tw2, m.tb2, n, S, D, s));
+        }
+        float* dst = tm == hbuf2 ? hbuf : hbuf2;   // where a materialised block output goes
+        SAMPT_TRY(layernorm_rows(tm, m.ln2w, m.ln2b, lnb, R, D, 1e-5f, nullptr, 0, ACT_NONE, s));
+        GemmP p1;
+        p1.A = lnb, p1.W = m.cw1, p1.bias = m.cb1, p1.C = hid, p1.act = ACT_GELU;
+        p1.M = R, p1.N = 4 * D, p1.K = D, p1.lda = D, p1.ldw = D, p1.ldc = 4 * D, p1.ldr = 4 * D;
+        p1.splitk_ws = skws, p1.splitk_ws_floats = skn;
+        const int sk1 = gemm_f32_plan_splitk(p1);
+        p1.defer_reduce = sk1 > 1;
+        SAMPT_TRY(gemm_f32(p1, s));
+        GemmP p2;
+        p2.W = m.cw2, p2.bias = m.cb2, p2.C = dst, p2.res = tm;
+        p2.M = R, p2.N = D, p2.K = 4 * D, p2.lda = 4 * D, p2.ldw = 4 * D, p2.ldc = D, p2.ldr = D;
+        p2.splitk_ws = skws_b, p2.splitk_ws_floats = skn;
+        if (sk1 > 1) p2.A = skws, p2.a_nsplit = sk1, p2.a_split_stride = (long)R * 4 * D, p2.a_bias = m.cb1, p2.a_act = ACT_GELU;
+        else p2.A = hid;
+        const int sk2 = gemm_f32_plan_splitk(p2);
+        p2.defer_reduce = sk2 > 1 && i < 11;       // the last block's output is materialised for the final LayerNorm
+        SAMPT_TRY(gemm_f32(p2, s));
+        if (p2.defer_reduce) pend_ns = sk2, pend_bias = m.cb2, pend_res = tm, cur = nullptr;
+        else pend_ns = 0, cur = dst;
+      }
+      mixed = cur;
     }
-    SAMPT_TRY(pips_ln_mean(hbuf, oln_w, oln_b, mean, n, S, D, s));
+    SAMPT_TRY(pips_ln_mean(mixed, oln_w, oln_b, mean, n, S, D, s));
     SAMPT_TRY(lin(mean, n, D, D, head_w, head_b, delta, S * 130, ACT_NONE, nullptr, s, skws, skn));
     SAMPT_TRY(pips_update(delta, gn_w, gn_b, up_wT, up_b, ffeats, coords, coords0, S, n, s));
   }

@@ -34,8 +34,9 @@ template <> struct GT<half_t> {
   __device__ static vec_t zero() { return (h8){0, 0, 0, 0, 0, 0, 0, 0}; }
 };
 
-template <typename T, int BM, int BN, int BK, bool CONV, bool W_KN>
+template <typename T, int BM, int BN, int BK, bool CONV, bool W_KN, bool A_SK = false>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
+  static_assert(!A_SK || (sizeof(T) == 4 && !CONV), "A_SK: plain f32 GEMMs only");
   typedef GT<T> G;
   typedef typename G::vec_t vec_t;
   constexpr int VEC = G::VEC, PAD = G::PAD;
@@ -102,6 +103,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
       int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
       if (iy < 0 || iy >= p.cH || ix < 0 || ix >= p.cW) return G::zero();
       return *(const vec_t*)(A + a_off[i] + ((long)iy * p.cW + ix) * p.cC + ci);
+    } else if constexpr (A_SK) {
+      // A = act(sum of the producer's split-K partials + bias): the arithmetic of k_splitk_reduce, in its order
+      float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int sp = 0; sp < p.a_nsplit; ++sp) {
+        const float4 t = *(const float4*)((const float*)A + (long)sp * p.a_split_stride + a_off[i] + k);
+        acc4.x += t.x, acc4.y += t.y, acc4.z += t.z, acc4.w += t.w;
+      }
+      if (p.a_bias) {
+        const float4 bb = *(const float4*)(p.a_bias + k);
+        acc4.x += bb.x, acc4.y += bb.y, acc4.z += bb.z, acc4.w += bb.w;
+      }
+      acc4.x = apply_act(acc4.x, p.a_act), acc4.y = apply_act(acc4.y, p.a_act);
+      acc4.z = apply_act(acc4.z, p.a_act), acc4.w = apply_act(acc4.w, p.a_act);
+      return acc4;
     } else {
       return *(const vec_t*)(A + a_off[i] + k);
     }
@@ -300,6 +315,33 @@ __global__ __launch_bounds__(256) void gemm_skinny_f32(GemmP p) {
 
 int gemm_f16_glds_launch(const GemmP& p, hipStream_t s);  // gemm_f16.hip
 
+// tile / split-K selection shared by the dispatcher and gemm_f32_plan_splitk
+static int plan_tiles_splitk(const GemmP& p, bool plain, int& BM_out, bool& big_out) {
+  const int batch = p.nb1 * p.nb2;
+  const long big_tiles = (long)cdiv(p.M, 128) * cdiv(p.N, 128) * batch;
+  const bool big = p.M > 64 && p.N > 64 && big_tiles >= 192;
+  const int BM = big ? 128 : 64;
+  const long tiles = (long)cdiv(p.M, BM) * cdiv(p.N, BM) * batch;
+  BM_out = BM, big_out = big;
+  if (plain && !p.out_f16 && p.splitk_ws && tiles < 128 && p.K >= 512) {
+    int want = (int)((255 + tiles) / tiles);
+    int maxs = p.K / 256;
+    int sk = want < maxs ? want : maxs;
+    if (sk > 16) sk = 16;
+    while (sk > 1 && (size_t)sk * p.M * p.N > p.splitk_ws_floats) --sk;
+    if (sk > 1) return sk;
+  }
+  return 1;
+}
+
+int gemm_f32_plan_splitk(const GemmP& p) {
+  const bool plain = !p.conv && !p.w_kn && p.nb1 * p.nb2 == 1 && !p.rowmap && !p.a_rowmap;
+  if (plain && p.M <= 16 && p.a_nsplit == 0) return 1;  // skinny path
+  int BM;
+  bool big;
+  return plan_tiles_splitk(p, plain, BM, big);
+}
+
 template <typename T>
 static int gemm_dispatch(const GemmP& p_in, hipStream_t s) {
   constexpr int VEC = GT<T>::VEC;
@@ -324,8 +366,11 @@ static int gemm_dispatch(const GemmP& p_in, hipStream_t s) {
   const bool plain = !p.conv && !p.w_kn && batch == 1 && !p.rowmap && !p.a_rowmap;
 
   // ---- skinny path
+  if (p.a_nsplit > 0 && (sizeof(T) != 4 || !plain || p.a_nsplit > 16 || p.a_split_stride % 4 ||
+                         ((uintptr_t)p.a_bias & 15)))
+    return SAMPT_ERR_UNSUPPORTED;
   if constexpr (sizeof(T) == 4) {
-    if (plain && p.M <= 16) {
+    if (plain && p.M <= 16 && p.a_nsplit == 0) {
       p.splitk = 1;
       dim3 grid(cdiv(p.N, 8)), block(256);
       if (p.M <= 4) hipLaunchKernelGGL(gemm_skinny_f32<4>, grid, block, 0, s, p);
@@ -335,21 +380,12 @@ static int gemm_dispatch(const GemmP& p_in, hipStream_t s) {
     }
   }
 
-  // ---- tile selection: the big tile only when it still yields enough workgroups for 256 CUs
-  const long big_tiles = (long)cdiv(p.M, 128) * cdiv(p.N, 128) * batch;
-  const bool big = p.M > 64 && p.N > 64 && big_tiles >= 192;
-  const int BM = big ? 128 : 64, BN = BM;
-  const long tiles = (long)cdiv(p.M, BM) * cdiv(p.N, BN) * batch;
+  // ---- tile selection: the big tile only when it still yields enough workgroups for 256 CUs;
   // ---- split-K for latency-bound shapes (few tiles, long K); deterministic two-stage reduction
-  p.splitk = 1;
-  if (plain && !p.out_f16 && p.splitk_ws && tiles < 128 && p.K >= 512) {
-    int want = (int)((255 + tiles) / tiles);
-    int maxs = p.K / 256;
-    int sk = want < maxs ? want : maxs;
-    if (sk > 16) sk = 16;
-    while (sk > 1 && (size_t)sk * p.M * p.N > p.splitk_ws_floats) --sk;
-    if (sk > 1) p.splitk = sk;
-  }
+  int BM;
+  bool big;
+  p.splitk = plan_tiles_splitk(p, plain, BM, big);
+  const int BN = BM;
   dim3 grid(cdiv(p.N, BN), cdiv(p.M, BM), batch * p.splitk), block(256);
 #define LAUNCH(BMv, BKv, CONVv, KNv) \
   hipLaunchKernelGGL((gemm_kernel<T, BMv, BMv, BKv, CONVv, KNv>), grid, block, 0, s, p)
@@ -358,6 +394,9 @@ static int gemm_dispatch(const GemmP& p_in, hipStream_t s) {
       if (big) LAUNCH(128, 16, false, true); else LAUNCH(64, 16, false, true);
     } else if (p.conv) {
       if (big) LAUNCH(128, 32, true, false); else LAUNCH(64, 64, true, false);
+    } else if (p.a_nsplit > 0) {
+      if (big) hipLaunchKernelGGL((gemm_kernel<float, 128, 128, 32, false, false, true>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((gemm_kernel<float, 64, 64, 64, false, false, true>), grid, block, 0, s, p);
     } else {
       if (big) LAUNCH(128, 32, false, false); else LAUNCH(64, 64, false, false);
     }
@@ -371,7 +410,7 @@ static int gemm_dispatch(const GemmP& p_in, hipStream_t s) {
   }
 #undef LAUNCH
   SAMPT_CHECK_LAUNCH("gemm");
-  if (p.splitk > 1) {
+  if (p.splitk > 1 && !p.defer_reduce) {
     long total = (long)p.M * p.N;
     hipLaunchKernelGGL(k_splitk_reduce, dim3(cdiv(total, 256)), dim3(256), 0, s, p);
     SAMPT_CHECK_LAUNCH("splitk_reduce");

@@ -90,6 +90,9 @@ int pips_init_state(const float* xys, const float* feat_init, float stride, int 
                     float* coords0, float* ffeats, hipStream_t s);
 // token-mixing PreNormResidual block of the MLP-Mixer, one workgroup per sequence (pips.py:116,120-121)
 // out of place: xo != x
+int pips_token_mix_fused_in(const float* parts, int nsplit, long split_stride, const float* bias, const float* res,
+                            float* xo, const float* lnw, const float* lnb, const float* w1, const float* b1,
+                            const float* w2, const float* b2, int nseq, int S, int D, hipStream_t s);
 int pips_token_mix(const float* x, float* xo, const float* lnw, const float* lnb, const float* w1, const float* b1,
                    const float* w2, const float* b2, int nseq, int S, int D, hipStream_t s);
 // mean over the S tokens of LN(x): out[n][D]

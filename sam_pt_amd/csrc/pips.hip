@@ -171,11 +171,17 @@ int pips_init_state(const float* xys, const float* feat_init, float stride, int 
 // K12a: token-mixing block  x = x + W2 . gelu(W1 . LN(x) + b1) + b2  over the S=8 tokens (Conv1d k=1)
 // One workgroup per sequence; the 8 x 512 activations live in LDS.
 // ---------------------------------------------------------------------------------------------
-template <int S, int D>
+// FUSED_IN: the input slab is not materialised — x points at the previous channel-mix GEMM's raw split-K partials
+// [nsplit][rows][D] and every read applies what k_splitk_reduce would have stored: sum over the partials (in order) + bias
+// + residual (launch fusion).
+template <int S, int D, bool FUSED_IN = false>
 __global__ __launch_bounds__(256) void k_pips_token_mix(const float* __restrict__ x, float* __restrict__ xo,
                                                         const float* __restrict__ lnw, const float* __restrict__ lnb,
                                                         const float* __restrict__ w1, const float* __restrict__ b1,
-                                                        const float* __restrict__ w2, const float* __restrict__ b2) {
+                                                        const float* __restrict__ w2, const float* __restrict__ b2,
+                                                        int nsplit = 0, long split_stride = 0,
+                                                        const float* __restrict__ in_bias = nullptr,
+                                                        const float* __restrict__ in_res = nullptr) {
   // grid = (sequence, D/64 channel chunks).  Every workgroup recomputes the LayerNorm statistics of the 8 tokens
   // (16 KiB of L2-resident reads) and then mixes its own 64 channels; out of place, so chunks never race.
   constexpr int H = 4 * S, CH = 64;
@@ -185,6 +191,17 @@ __global__ __launch_bounds__(256) void k_pips_token_mix(const float* __restrict_
   const float* xs = x + (long)blockIdx.x * S * D;
   float* xos = xo + (long)blockIdx.x * S * D;
   const int c0 = blockIdx.y * CH;
+  auto ld = [&](int tok, int ch) -> float {
+    if constexpr (FUSED_IN) {
+      float v = 0.f;
+      for (int sp = 0; sp < nsplit; ++sp) v += xs[(long)sp * split_stride + tok * D + ch];
+      v += in_bias[ch];
+      v += in_res[(long)blockIdx.x * S * D + tok * D + ch];
+      return v;
+    } else {
+      return xs[tok * D + ch];
+    }
+  };
   for (int i = tid; i < H * S; i += 256) {
     ((float*)sw1)[i] = w1[i];
     ((float*)sw2)[i] = w2[i];
@@ -196,7 +213,7 @@ __global__ __launch_bounds__(256) void k_pips_token_mix(const float* __restrict_
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < D / 64; ++i) {
-      v[i] = xs[tok * D + lane + 64 * i];
+      v[i] = ld(tok, lane + 64 * i);
       sum += v[i];
     }
     float mean = wave_sum(sum) / (float)D;
@@ -216,7 +233,7 @@ __global__ __launch_bounds__(256) void k_pips_token_mix(const float* __restrict_
   float xin[S], y[S];
 #pragma unroll
   for (int t = 0; t < S; ++t) {
-    xin[t] = xs[t * D + c];
+    xin[t] = ld(t, c);
     y[t] = (xin[t] - stat[t][0]) * stat[t][1] * gw + gb;
   }
   float part[S];
@@ -247,8 +264,21 @@ __global__ __launch_bounds__(256) void k_pips_token_mix(const float* __restrict_
 int pips_token_mix(const float* x, float* xo, const float* lnw, const float* lnb, const float* w1, const float* b1,
                    const float* w2, const float* b2, int nseq, int S, int D, hipStream_t s) {
   if (S != 8 || D != 512 || nseq <= 0 || x == xo) return SAMPT_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((k_pips_token_mix<8, 512>), dim3(nseq, D / 64), dim3(256), 0, s, x, xo, lnw, lnb, w1, b1, w2, b2);
+  hipLaunchKernelGGL((k_pips_token_mix<8, 512>), dim3(nseq, D / 64), dim3(256), 0, s, x, xo, lnw, lnb, w1, b1, w2, b2, 0,
+                     0L, (const float*)nullptr, (const float*)nullptr);
   SAMPT_CHECK_LAUNCH("pips_token_mix");
+  return SAMPT_OK;
+}
+
+// token mixing whose input is the previous block's un-reduced channel-mix output: x = sum_s parts[s] + bias + res
+int pips_token_mix_fused_in(const float* parts, int nsplit, long split_stride, const float* bias, const float* res,
+                            float* xo, const float* lnw, const float* lnb, const float* w1, const float* b1,
+                            const float* w2, const float* b2, int nseq, int S, int D, hipStream_t s) {
+  if (S != 8 || D != 512 || nseq <= 0 || nsplit < 1 || nsplit > 16 || !parts || !bias || !res || res == xo)
+    return SAMPT_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL((k_pips_token_mix<8, 512, true>), dim3(nseq, D / 64), dim3(256), 0, s, parts, xo, lnw, lnb, w1, b1, w2,
+                     b2, nsplit, split_stride, bias, res);
+  SAMPT_CHECK_LAUNCH("pips_token_mix_fused_in");
   return SAMPT_OK;
 }
 

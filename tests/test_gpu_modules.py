@@ -773,3 +773,20 @@ def test_decoder_image_projections_f16x3_opt_in(dev, monkeypatch):
     m0, i0, l0 = ref.predict_torch(pts, lab, None, None, False, True)
     m1, i1, l1 = pred.predict_torch(pts.to(dev), lab.to(dev), None, None, False, True)
     assert max_abs(l1, l0) < 3e-4 and max_abs(i1, i0) < 1e-4 and max_abs(m1, m0) < 3e-4
+
+
+@pytest.mark.skipif(os.environ.get("SAMPT_TEST_EXPERIMENTAL", "0") == "0",
+                    reason="opt-in experiment (SAMPT_PIPS_FUSE_REDUCE): run with SAMPT_TEST_EXPERIMENTAL=1")
+def test_pips_fused_splitk_reductions_opt_in(dev, pips_sd, clip, monkeypatch):
+    """the mixer's split-K reductions folded into their consumers (4 instead of 6 launches per block) —
+    the same additions in the same order, so trajectories and visibilities must not move."""
+    from sam_pt_amd.point_tracker import PipsPointTracker
+    frames, centres = clip
+    q = disc_queries(centres, n_pos=8, r=9.0)[None]
+    monkeypatch.delenv("SAMPT_PIPS_FUSE_REDUCE", raising=False)
+    tr0, vi0 = PipsPointTracker(state_dict=pips_sd)(frames[None].to(dev), q.to(dev))
+    monkeypatch.setenv("SAMPT_PIPS_FUSE_REDUCE", "1")
+    tr1, vi1 = PipsPointTracker(state_dict=pips_sd)(frames[None].to(dev), q.to(dev))
+    assert torch.equal(vi0, vi1) and max_abs(tr1, tr0) < 1e-3
+    assert torch.equal(torch.round(tr0), torch.round(tr1))
+    print("fused == unfused bitwise:", torch.equal(tr0, tr1))
