@@ -360,7 +360,13 @@ int gemm_f16_glds_launch(const GemmP& p, hipStream_t s) {
     q.persist = per_xcd;
     const int gen = per_xcd < 128 ? per_xcd : 128;
     hipLaunchKernelGGL((gemm_f16_glds<128, 128, 1, 64, 64, 16>), dim3(8 * gen), block, 0, s, q);
-  } else if (variant == 1 || variant == 3) hipLaunchKernelGGL((gemm_f16_glds<128, 128, 1, 64, 64, 16>), grid, block, 0, s, q);
+  } else if (variant == 1 || variant == 3) {
+    // experiment knob: SAMPT_GEMM_LDS_PAD=<bytes> of unused dynamic LDS per workgroup, e.g. 9728 makes a
+    // workgroup cost 41.5 KiB so that only 3 (not 4) fit a CU and ~35 KiB + wave slots stay free for the tracker's kernels
+    static const int lds_pad = getenv("SAMPT_GEMM_LDS_PAD") ? atoi(getenv("SAMPT_GEMM_LDS_PAD")) : 0;
+    hipLaunchKernelGGL((gemm_f16_glds<128, 128, 1, 64, 64, 16>), grid, block,
+                       (size_t)(lds_pad > 0 && lds_pad <= 32768 ? lds_pad : 0), s, q);
+  }
   else hipLaunchKernelGGL((gemm_f16_glds<128, 128, 2, 64, 64, 16>), grid, block, 0, s, q);
   SAMPT_CHECK_LAUNCH("gemm_f16_glds");
   return SAMPT_OK;

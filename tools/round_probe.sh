@@ -12,6 +12,7 @@ timeout 300 python -m pytest tests -q -m gpu > "$OUT/pytest_gpu.log" 2>&1; echo 
 timeout 120 python bench.py > "$OUT/bench_vith.log" 2>&1
 timeout 90 python bench.py --fnet-exact --no-cpu-baseline --no-roofline > "$OUT/bench_vith_fnet_exact.log" 2>&1
 SAMPT_DEC_F16X3=1 timeout 90 python bench.py --no-cpu-baseline --no-roofline > "$OUT/bench_vith_dec_f16x3.log" 2>&1
+SAMPT_GEMM_LDS_PAD=9728 timeout 90 python bench.py --no-cpu-baseline > "$OUT/bench_vith_gemm_3wg.log" 2>&1
 SAMPT_PIPS_FUSE_REDUCE=1 timeout 90 python bench.py --no-cpu-baseline --no-roofline > "$OUT/bench_vith_fuse_reduce.log" 2>&1
 SAMPT_TEST_EXPERIMENTAL=1 timeout 120 python -m pytest tests/test_gpu_modules.py -q -m gpu -s -k "opt_in" > "$OUT/pytest_experimental.log" 2>&1
 timeout 60 python tools/conv_bench.py 5 > "$OUT/conv_f16x3_microbench.log" 2>&1
