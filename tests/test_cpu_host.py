@@ -453,3 +453,25 @@ def test_predict_torch_batched_prompts_host_logic(monkeypatch):
     m1, _, _ = pred.predict_torch(pc2[:1], torch.ones(1, 2, dtype=torch.int), boxes=boxes[:1], multimask_output=False,
                                   return_logits=True)
     assert len(calls) == 1 and m1.shape == (1, 1, 20, 30) and bool((m1 == 3.0).all())
+
+
+def test_f16x3_scheme_is_fp32_grade():
+    """The arithmetic behind csrc/conv_f16x3.hip, emulated on the CPU: x = hi + lo in fp16 for both operands (weights
+    pre-scaled by 2^8), product = hi*hi + hi*lo + lo*hi with exact products and wide accumulation.  Its distance to the
+    fp64 convolution is below that of a plain fp32 convolution, for O(1) post-InstanceNorm activations and Kaiming-sized
+    weights (the encoder's regime), including a 416-channel 3x3 layer (K = 3744)."""
+    import torch.nn.functional as F
+    from sam_pt_amd.pack import F16X3_WSHIFT, split_f16x3
+    g = torch.Generator().manual_seed(0)
+    for cin, cout, k in ((64, 64, 3), (416, 256, 3), (96, 128, 1)):
+        x = torch.relu(torch.randn(1, cin, 24, 24, generator=g)) * 1.3
+        w = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cout * k * k)) ** 0.5
+        ref = F.conv2d(x.double(), w.double(), padding=k // 2)
+        f32 = F.conv2d(x, w, padding=k // 2).double()
+        xh = x.half()
+        xl = (x - xh.float()).half()
+        whl = split_f16x3(w.reshape(cout, -1)).reshape(2, cout, cin, k, k)
+        conv = lambda a, b: F.conv2d(a.double(), b.double(), padding=k // 2)
+        y3 = (conv(xl, whl[0]) + conv(xh, whl[1]) + conv(xh, whl[0])) / 2 ** F16X3_WSHIFT
+        err = lambda a: float((a - ref).abs().max() / ref.abs().max())
+        assert err(y3) < 2e-7 and err(y3) < err(f32), (cin, err(y3), err(f32))
