@@ -135,7 +135,12 @@ int sampt_vit_encode(sampt_vit_t h, const uint8_t* frames_dev, int chw, int B, i
 int sampt_dec_create(const char* const* names, const void* const* ptrs, int n, int grid, int img_size, int max_frames,
                      int vit_dim, sampt_dec_t* out);
 void sampt_dec_destroy(sampt_dec_t h);
+/* Workspace for prompts of up to 120 points (every shipped SAM-PT config with <= 7 objects per batch); for larger
+ * prompts (k <= SAMPT_DEC_MAX_POINTS: the reference accepts any k — 16 points x M objects fed to each other as
+ * negatives, sam_pt.py:737-756, or the VIS adapter's 100-mask batches) size it with the _k variant. */
+#define SAMPT_DEC_MAX_POINTS 4000
 int sampt_dec_workspace_bytes(sampt_dec_t h, int frames, int out_h, int out_w, size_t* bytes);
+int sampt_dec_workspace_bytes_k(sampt_dec_t h, int frames, int k, int out_h, int out_w, size_t* bytes);
 /* HQ-SAM only: hq_features_dev [frames][16*grid*grid][32] = embedding_encoder(features) +
  * compress_vit_feat(interm) (MaskDecoderHQ.forward), computed once per frame from sampt_vit_encode's two outputs
  * and passed to every decode pass of that frame. */
@@ -144,8 +149,8 @@ int sampt_dec_hq_features(sampt_dec_t h, int frames, const float* features_dev, 
                           float* hq_features_dev, void* workspace_dev, size_t workspace_bytes, sampt_stream_t stream);
 /* One pass, one frame.  features_dev [grid*grid][256]; hq_features_dev: sampt_dec_hq_features output for the frame
  * (HQ-SAM handles) or NULL (SAM handles); pts_dev [k][2] (input-frame pixels), labels_dev int32 [k];
- * box_dev 4 floats or NULL; mask_in_dev [4*grid][4*grid] low-res logits or NULL.  Limit: 5 (6 for HQ-SAM) output
- * tokens + k + 2 <= 128 decoder tokens, i.e. k <= 120 prompt points (SAMPT_ERR_UNSUPPORTED beyond).  Outputs: logits_out_dev
+ * box_dev 4 floats or NULL; mask_in_dev [4*grid][4*grid] low-res logits or NULL.  Limit: k <= SAMPT_DEC_MAX_POINTS prompt
+ * points (tokens-as-keys attention is tiled over the tokens; SAMPT_ERR_UNSUPPORTED beyond), workspace sized for k.  Outputs: logits_out_dev
  * [out_h][out_w], iou_out_dev [1], low_res_out_dev [4*grid][4*grid]. */
 int sampt_sam_decode(sampt_dec_t h, const float* features_dev, const float* hq_features_dev, const float* pts_dev,
                      const int32_t* labels_dev, int k, const float* box_dev, const float* mask_in_dev, int in_h, int in_w, int out_h, int out_w,

@@ -4,7 +4,9 @@ The product path has NO fallback: if the shared library is missing or a call fai
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
+import functools
 import os
 from typing import Dict, Iterable, List, Optional, Sequence, Tuple
 
@@ -56,6 +58,7 @@ _SIGS = {
     "sampt_dec_hq_features": (c_int, [_P, c_int, _P, _P, _P, _P, c_size_t, _P]),
     "sampt_dec_destroy": (None, [_P]),
     "sampt_dec_workspace_bytes": (c_int, [_P, c_int, c_int, c_int, C.POINTER(c_size_t)]),
+    "sampt_dec_workspace_bytes_k": (c_int, [_P, c_int, c_int, c_int, c_int, C.POINTER(c_size_t)]),
     "sampt_sam_decode": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_size_t,
                                  _P]),
     "sampt_sam_decode_multimask": (c_int, [_P, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_size_t, _P]),
@@ -117,8 +120,30 @@ def ptr(t: Optional[torch.Tensor]):
     return c_void_p(t.data_ptr())
 
 
-def stream_ptr():
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+def stream_ptr(device=None):
+    """torch's current stream ON `device` (default: the current device — inside ``device_guard`` that is the guarded one)."""
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def device_guard(device):
+    """The library launches on the HIP *current* device and never calls hipSetDevice itself, and ``stream_ptr()`` is
+    torch's current stream of the current device: every public entry point of the package runs inside this guard so that a
+    model living on cuda:N works whatever the caller's current device is (``SamHip().to('cuda:1')`` without
+    ``set_device``, gloo-initialised multi-GPU processes)."""
+    if device is not None and getattr(device, "type", None) == "cuda":
+        return torch.cuda.device(device)
+    return contextlib.nullcontext()
+
+
+def on_device(get_device):
+    """Decorator form of ``device_guard``: ``get_device(self, *args, **kwargs)`` names the device of the call."""
+    def deco(fn):
+        @functools.wraps(fn)
+        def wrapper(self, *args, **kwargs):
+            with device_guard(get_device(self, *args, **kwargs)):
+                return fn(self, *args, **kwargs)
+        return wrapper
+    return deco
 
 
 def name_table(named: Dict[str, torch.Tensor]):

@@ -221,14 +221,18 @@ int sampt_dec_create(const char* const* names, const void* const* ptrs, int n, i
 }
 void sampt_dec_destroy(sampt_dec_t h) { delete h; }
 
-int sampt_dec_workspace_bytes(sampt_dec_t h, int frames, int oh, int ow, size_t* bytes) {
-  if (!h || !bytes || frames <= 0 || frames > h->e.max_frames) return SAMPT_ERR_ARG;
+int sampt_dec_workspace_bytes_k(sampt_dec_t h, int frames, int k, int oh, int ow, size_t* bytes) {
+  if (!h || !bytes || frames <= 0 || frames > h->e.max_frames || k < 0 || k > SAMPT_DEC_MAX_POINTS) return SAMPT_ERR_ARG;
   Arena a(nullptr, 0);
   float dummy = 0.f;
-  int rc = h->e.track_decode(frames, &dummy, h->e.is_hq() ? &dummy : nullptr, &dummy, nullptr, 120, nullptr, nullptr, 120, 0, 1, 0.f, oh, ow,
+  int rc = h->e.track_decode(frames, &dummy, h->e.is_hq() ? &dummy : nullptr, &dummy, nullptr, k, nullptr, nullptr, k, 0, 1, 0.f, oh, ow,
                              oh, ow, nullptr, nullptr, a, nullptr);
   *bytes = a.peak + 256;
   return rc;
+}
+
+int sampt_dec_workspace_bytes(sampt_dec_t h, int frames, int oh, int ow, size_t* bytes) {
+  return sampt_dec_workspace_bytes_k(h, frames, 120, oh, ow, bytes);
 }
 
 int sampt_dec_hq_workspace_bytes(sampt_dec_t h, int frames, size_t* bytes) {

@@ -465,20 +465,24 @@ int resize_logits(const float* src, int n, int sh, int sw, float* dst, int dh, i
 }
 
 // index mask: argmax over {background logit 0, object logits 1..M} == argmax(softmax(cat(0, logits))) (softmax is
-// monotonic; first maximum wins like torch.argmax; -inf objects never win; NaN is treated as -inf)
+// monotonic; first maximum wins like torch.argmax; -inf objects never win).  A NaN logit — bilinear resizing of a rejected
+// (-inf) frame gives 0 * -inf on its border rows/columns, sam_pt.py:205-206 — makes the reference's whole softmax row NaN
+// and torch.argmax of an all-NaN row is index 0: such pixels are background.
 __global__ void k_index_masks(const float* __restrict__ logits, int M, long npix, uint8_t* __restrict__ out) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npix) return;
   float best = 0.f;
   int arg = 0;
+  bool nan = false;
   for (int m = 0; m < M; ++m) {
     float v = logits[(long)m * npix + i];
+    nan |= (v != v);
     if (v > best) {
       best = v;
       arg = m + 1;
     }
   }
-  out[i] = (uint8_t)arg;
+  out[i] = (uint8_t)(nan ? 0 : arg);
 }
 
 int index_masks(const float* logits, int M, long npix, uint8_t* out, hipStream_t s) {
@@ -498,16 +502,18 @@ __global__ void k_vos_index_masks(const float* __restrict__ logits, int M, int T
   const long p = i - (long)t * hw;
   float best = 0.f;
   int arg = 0;
+  bool nan = false;                 // after the overrides, as the evaluator applies them before the softmax
   for (int m = 0; m < M; ++m) {
     float v = logits[((long)m * T + t) * hw + p];
     if (t < qt[m]) v = -1e8f;
     else if (t == qt[m] && gt) v = gt[(long)m * hw + p] ? 1e8f : -1e8f;
+    nan |= (v != v);
     if (v > best) {
       best = v;
       arg = m + 1;
     }
   }
-  out[i] = (uint8_t)arg;
+  out[i] = (uint8_t)(nan ? 0 : arg);
 }
 
 // The evaluator's full tail for frames that were processed at another resolution (eval.py:326, 340-356): softmax over

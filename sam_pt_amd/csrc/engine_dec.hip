@@ -176,7 +176,7 @@ int DecEngine::decode(int F, const float* features, const float* hq_feat, const 
                       float* logits_out, float* iou_out, float* low_out, int* bbox_out, Arena& ws, hipStream_t s) {
   const int g = c.grid, P = g * g, C = c.C, H = c.heads, NO = n_out();
   const int nsparse = k + (box ? 2 : 1), Nt = NO + nsparse;
-  if (Nt > 128 || k > 120 || k < 0 || F <= 0 || F > max_frames) return SAMPT_ERR_UNSUPPORTED;   // (workspace is sized for 120)
+  if (Nt > 4096 || k < 0 || F <= 0 || F > max_frames) return SAMPT_ERR_UNSUPPORTED;   // attn_rowblock: <= 4096 keys
   if (is_hq() != (hq_feat != nullptr)) return SAMPT_ERR_ARG;
   const size_t FP = (size_t)F * P, FT = (size_t)F * Nt;
   Bufs b;

@@ -205,58 +205,76 @@ int attn_rowblock(const float* q, const float* k, const float* v, float* out, in
 }
 
 // ---------------------------------------------------------------------------------------------
-// attention with few keys and many queries (image -> token): one thread per (query, head), K/V in LDS
+// attention with few keys and many queries (image -> token): one thread per (query, head); K/V staged through LDS in
+// chunks of <= `chunk` keys with a running (max, sum) softmax, so the number of prompt tokens is unbounded.  With
+// Nk <= chunk (every SAM-PT prompt up to 120 points) there is exactly one chunk and no rescale.
 // ---------------------------------------------------------------------------------------------
 template <int HD>
 __global__ __launch_bounds__(256) void k_attn_fewkeys(const float* __restrict__ q, const float* __restrict__ k,
                                                       const float* __restrict__ v, float* __restrict__ out, int Nq,
-                                                      int Nk, int heads, const int* __restrict__ nk_item) {
-  extern __shared__ float kv[];  // [2][Nk][ld]
+                                                      int Nk, int heads, const int* __restrict__ nk_item, int chunk) {
+  extern __shared__ float kv[];  // [2][chunk][ld]
   const int ld = heads * HD, f = blockIdx.y;
   q += (long)f * Nq * ld, out += (long)f * Nq * ld;
   k += (long)f * Nk * ld, v += (long)f * Nk * ld;
   float* ks = kv;
-  float* vs = kv + (long)Nk * ld;
-  for (int i = threadIdx.x; i < Nk * ld; i += 256) {
-    ks[i] = k[i];
-    vs[i] = v[i];
-  }
-  __syncthreads();
-  if (nk_item) Nk = nk_item[f];   // ragged batch: mask the item's padding tokens
-  long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (long)Nq * heads) return;
-  int qi = (int)(idx / heads), h = (int)(idx % heads);
+  float* vs = kv + (long)chunk * ld;
+  const int nvalid = nk_item ? nk_item[f] : Nk;   // ragged batch: only the item's valid tokens are keys
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const bool live = idx < (long)Nq * heads;
+  const int qi = live ? (int)(idx / heads) : 0, h = live ? (int)(idx % heads) : 0;
   float qv[HD];
-  const float4* qp = (const float4*)(q + (long)qi * ld + h * HD);
+  {
+    const float4* qp = (const float4*)(q + (long)qi * ld + h * HD);
 #pragma unroll
-  for (int c = 0; c < HD / 4; ++c) {
-    float4 t = qp[c];
-    qv[4 * c] = t.x, qv[4 * c + 1] = t.y, qv[4 * c + 2] = t.z, qv[4 * c + 3] = t.w;
+    for (int c = 0; c < HD / 4; ++c) {
+      float4 t = qp[c];
+      qv[4 * c] = t.x, qv[4 * c + 1] = t.y, qv[4 * c + 2] = t.z, qv[4 * c + 3] = t.w;
+    }
   }
   const float inv = sqrtf((float)HD);
-  float m = -INFINITY;
-  for (int key = 0; key < Nk; ++key) {
-    const float* kp = ks + key * ld + h * HD;
-    float a = 0.f;
-#pragma unroll
-    for (int c = 0; c < HD; ++c) a += qv[c] * kp[c];
-    m = fmaxf(m, a / inv);
-  }
+  float m = -INFINITY, sum = 0.f;
   float acc[HD];
 #pragma unroll
   for (int c = 0; c < HD; ++c) acc[c] = 0.f;
-  float sum = 0.f;
-  for (int key = 0; key < Nk; ++key) {
-    const float* kp = ks + key * ld + h * HD;
-    const float* vp = vs + key * ld + h * HD;
-    float a = 0.f;
+  for (int c0 = 0; c0 < nvalid; c0 += chunk) {
+    const int n = min(chunk, nvalid - c0);
+    if (c0) __syncthreads();
+    for (int i = threadIdx.x; i < n * ld; i += 256) {
+      ks[i] = k[(long)c0 * ld + i];
+      vs[i] = v[(long)c0 * ld + i];
+    }
+    __syncthreads();
+    float mc = -INFINITY;
+    for (int key = 0; key < n; ++key) {
+      const float* kp = ks + key * ld + h * HD;
+      float a = 0.f;
 #pragma unroll
-    for (int c = 0; c < HD; ++c) a += qv[c] * kp[c];
-    float p = expf(a / inv - m);
-    sum += p;
+      for (int c = 0; c < HD; ++c) a += qv[c] * kp[c];
+      mc = fmaxf(mc, a / inv);
+    }
+    if (mc > m) {            // new running maximum: rescale what has been accumulated (never taken in the first chunk's
+      if (m > -INFINITY) {   // accumulation order, so a single-chunk result is bit-identical to the unchunked kernel)
+        const float r = expf(m - mc);
+        sum *= r;
 #pragma unroll
-    for (int c = 0; c < HD; ++c) acc[c] += p * vp[c];
+        for (int c = 0; c < HD; ++c) acc[c] *= r;
+      }
+      m = mc;
+    }
+    for (int key = 0; key < n; ++key) {
+      const float* kp = ks + key * ld + h * HD;
+      const float* vp = vs + key * ld + h * HD;
+      float a = 0.f;
+#pragma unroll
+      for (int c = 0; c < HD; ++c) a += qv[c] * kp[c];
+      float p = expf(a / inv - m);
+      sum += p;
+#pragma unroll
+      for (int c = 0; c < HD; ++c) acc[c] += p * vp[c];
+    }
   }
+  if (!live) return;
   float4* op = (float4*)(out + (long)qi * ld + h * HD);
 #pragma unroll
   for (int c = 0; c < HD / 4; ++c)
@@ -265,8 +283,9 @@ __global__ __launch_bounds__(256) void k_attn_fewkeys(const float* __restrict__ 
 
 int attn_fewkeys(const float* q, const float* k, const float* v, float* out, int F, int Nq, int Nk, int heads, int hd,
                  const int* nk_item, hipStream_t s) {
-  if (Nk <= 0 || Nk > 128 || hd != 16 || F <= 0) return SAMPT_ERR_UNSUPPORTED;
-  size_t sh = (size_t)2 * Nk * heads * hd * sizeof(float);
+  if (Nk <= 0 || hd != 16 || F <= 0) return SAMPT_ERR_UNSUPPORTED;
+  const int chunk = Nk < 128 ? Nk : 128;
+  size_t sh = (size_t)2 * chunk * heads * hd * sizeof(float);
   if (sh > 64 * 1024) {  // above the default dynamic-LDS limit (gfx950 has 160 KiB per workgroup)
     static bool raised = false;
     if (!raised) {
@@ -277,7 +296,7 @@ int attn_fewkeys(const float* q, const float* k, const float* v, float* out, int
     }
   }
   hipLaunchKernelGGL(k_attn_fewkeys<16>, dim3(cdiv((long)Nq * heads, 256), F), dim3(256), sh, s, q, k, v, out, Nq, Nk,
-                     heads, nk_item);
+                     heads, nk_item, chunk);
   SAMPT_CHECK_LAUNCH("attn_fewkeys");
   return SAMPT_OK;
 }

@@ -19,13 +19,13 @@ def init_from_env(backend: Optional[str] = None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available():            # one process per GPU, whatever the backend (gloo on a GPU box included)
+        torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
@@ -56,6 +56,13 @@ def index_masks(logits: torch.Tensor, query_timestep=None, query_masks=None, out
     logits are +-1e8 from ``query_masks`` (M,H,W) {0,1} when given (resized with ``nearest`` to (H,W) by the caller).
     ``out_hw`` = the evaluator's resize back to the original frame size (eval.py:340-356): the softmax PROBABILITIES are
     interpolated bilinearly (align_corners=False) before the argmax."""
+    from . import _lib
+    with _lib.device_guard(logits.device):
+        return _index_masks(logits, query_timestep, query_masks, out_hw)
+
+
+def _index_masks(logits: torch.Tensor, query_timestep=None, query_masks=None, out_hw=None) -> torch.Tensor:
+    """Implementation of ``index_masks`` (runs with the HIP device of ``logits`` current)."""
     M, T, H, W = logits.shape
     if out_hw is not None and tuple(out_hw) != (H, W):
         out_hw = (int(out_hw[0]), int(out_hw[1]))

@@ -63,6 +63,19 @@ class PointTracker(ABC, nn.Module):
         return out
 
 
+def _prepared_entry(frames: torch.Tensor, pyr):
+    """Cache entry of ``prepare``: holds the frames tensor itself (so its address cannot be recycled for another clip
+    while the entry lives) and its version counter (in-place edits invalidate the entry)."""
+    return (frames, frames.data_ptr(), tuple(frames.shape), frames._version, pyr)
+
+
+def _prepared_lookup(entry, frames: torch.Tensor):
+    if entry is not None and entry[1] == frames.data_ptr() and entry[2] == tuple(frames.shape) and \
+            entry[0]._version == entry[3] and frames._version == entry[3] and entry[0].device == frames.device:
+        return entry[4]
+    return None
+
+
 def load_pips_checkpoint(checkpoint_path: Optional[str]):
     """`saverloader.load` convention (utils/saverloader.py:30-73): newest model-*.pth in a directory, key
     'model_state_dict'.  None -> seeded random init (no checkpoints exist in this environment)."""
@@ -112,6 +125,7 @@ class PipsPointTracker(PointTracker):
                 pass
 
     # -- fnet + pyramid for a whole clip -----------------------------------------------------------
+    @_lib.on_device(lambda self, frames: frames.device)
     def compute_pyramid(self, frames: torch.Tensor):
         """frames (T,3,H,W) uint8 on device -> list of 4 NHWC f32 levels [T][H_l][W_l][128]."""
         self._ensure(frames.device)
@@ -136,7 +150,7 @@ class PipsPointTracker(PointTracker):
         """Optional: build the feature pyramid of ``frames`` (T,3,H,W) now, on the current stream; the next ``forward``
         on the same frames tensor reuses it.  Lets a caller keep the compute-bound fnet on its main stream and run only
         the latency-bound window rounds on a second stream (sam_pt_amd.SamPt)."""
-        self._prepared = ((frames.data_ptr(), tuple(frames.shape)), self.compute_pyramid(frames))
+        self._prepared = _prepared_entry(frames, self.compute_pyramid(frames))
 
     def _run_chains(self, pyr, T: int, query_points: torch.Tensor, flipped: torch.Tensor, ws):
         """query_points (N,3) CPU float = (t, x, y) in each chain's OWN time axis; ``flipped[i]`` marks chains that run on
@@ -216,6 +230,7 @@ class PipsPointTracker(PointTracker):
         return traj, vis > 0.5
 
     @torch.no_grad()
+    @_lib.on_device(lambda self, rgbs, query_points: rgbs.device)
     def forward(self, rgbs, query_points):
         if rgbs.shape[0] != 1:
             raise NotImplementedError("Batch size > 1 is not supported for PIPS yet")  # tracker.py:50-51
@@ -226,10 +241,8 @@ class PipsPointTracker(PointTracker):
         T = frames.shape[0]
         q = query_points[0].detach().float().cpu()
         N = q.shape[0]
-        prepared = getattr(self, "_prepared", None)
-        if prepared is not None and prepared[0] == (frames.data_ptr(), tuple(frames.shape)):
-            pyr = prepared[1]
-        else:
+        pyr = _prepared_lookup(getattr(self, "_prepared", None), frames)
+        if pyr is None:
             pyr = self.compute_pyramid(frames)
         nbytes = C.c_size_t()
         _lib.check(self._lib.sampt_pips_update_workspace_bytes(self._h, 2 * N, C.byref(nbytes)), "update_workspace")
@@ -298,6 +311,7 @@ class PipsPlusPlusPointTracker(PointTracker):
             except Exception:
                 pass
 
+    @_lib.on_device(lambda self, frames: frames.device)
     def compute_pyramid(self, frames: torch.Tensor):
         """frames (T,3,H,W) uint8 (or float32 in [0,255]) on device -> 4 NHWC f32 levels [T][H/8 >> l][W/8 >> l][128]."""
         self._ensure(frames.device)
@@ -319,7 +333,9 @@ class PipsPlusPlusPointTracker(PointTracker):
         return pyr
 
     def prepare(self, frames: torch.Tensor):
-        self._prepared = ((frames.data_ptr(), tuple(frames.shape)), self.compute_pyramid(frames))
+        if self.image_size is not None:        # forward() encodes the RESIZED float video: a pyramid of `frames` is unused
+            return
+        self._prepared = _prepared_entry(frames, self.compute_pyramid(frames))
 
     def _track(self, pyr, frame_ids: List[int], query_xy: torch.Tensor) -> torch.Tensor:
         """One direction (tracker.py:26-62): the clip is ``frame_ids`` (pyramid frame of every time step); chunks of
@@ -362,6 +378,8 @@ class PipsPlusPlusPointTracker(PointTracker):
                 cur = cur + self.max_sequence_length - 1
         return trajs
 
+    @torch.no_grad()
+    @_lib.on_device(lambda self, rgbs, query_points: rgbs.device)
     def forward(self, rgbs, query_points):
         if rgbs.shape[0] != 1:
             raise NotImplementedError("Only batch size 1 is supported.")          # tracker.py:83
@@ -371,14 +389,14 @@ class PipsPlusPlusPointTracker(PointTracker):
         frames = rgbs[0]
         T, _, H, W = frames.shape
         q = query_points[0].detach().float().cpu()
-        prepared = getattr(self, "_prepared", None)
+        prepared = _prepared_lookup(getattr(self, "_prepared", None), frames)
         if self.image_size is not None:                                          # tracker.py:69-78
             fr = torch.nn.functional.interpolate(frames.float() / 255.0, size=self.image_size, mode="bilinear") * 255.0
             pyr = self.compute_pyramid(fr.contiguous())
             q[:, 1] *= self.image_size[0] / H
             q[:, 2] *= self.image_size[1] / W
-        elif prepared is not None and prepared[0] == (frames.data_ptr(), tuple(frames.shape)):
-            pyr = prepared[1]
+        elif prepared is not None:
+            pyr = prepared
         else:
             pyr = self.compute_pyramid(frames)
         N = q.shape[0]

@@ -59,6 +59,7 @@ class ResizeLongestSide:
         self.target_length = target_length
         self._tables = {}
 
+    @_lib.on_device(lambda self, image, chw=False: image.device)
     def apply_image_torch(self, image: torch.Tensor, chw: bool = False) -> torch.Tensor:
         """uint8 frames on the HIP device, (...,H,W,3) or with ``chw`` (...,3,H,W) -> the same layout with the longest side
         = target_length (identity if it already is)."""
@@ -174,6 +175,8 @@ class SamHip(nn.Module):
 
 
 class SamPredictor:
+    max_prompt_points = 4000          # SAMPT_DEC_MAX_POINTS (include/sampt_hip.h)
+
     def __init__(self, sam_model: SamHip):
         self.model = sam_model
         self.transform = ResizeLongestSide(sam_model.cfg.img_size)
@@ -196,6 +199,7 @@ class SamPredictor:
         self.original_size = self.input_size = None
 
     # -- engines -------------------------------------------------------------------------------------
+    @_lib.on_device(lambda self, *a, **k: self.model.device)
     def _ensure(self):
         dev = self.model.device
         if self._vit is not None and self._dev == dev:
@@ -233,11 +237,13 @@ class SamPredictor:
         except Exception:
             pass
 
+    @_lib.on_device(lambda self, *a, **k: self.model.device)
     def gemm_profile_begin(self):
         """Start timing every fp16 GEMM launch of the image encoder with HIP events (see sampt_vit_profile_begin)."""
         self._ensure()
         _lib.check(self._lib.sampt_vit_profile_begin(self._vit), "sampt_vit_profile_begin")
 
+    @_lib.on_device(lambda self, *a, **k: self.model.device)
     def gemm_profile_end(self):
         """-> (algorithmic FLOP, kernel milliseconds, launches) since gemm_profile_begin."""
         fl, ms, n = C.c_double(), C.c_double(), C.c_int()
@@ -251,17 +257,24 @@ class SamPredictor:
             self._ws_vit = {B: torch.empty(n.value, dtype=torch.uint8, device=self._dev)}  # keep only the latest size
         return self._ws_vit[B]
 
-    def _dec_ws(self, oh: int, ow: int, frames: int = 1) -> torch.Tensor:
+    def _dec_ws(self, oh: int, ow: int, frames: int = 1, k: int = 0) -> torch.Tensor:
+        """Decoder scratch for `frames` items with up to k prompt points each (sized in steps: 120 points cover every
+        shipped SAM-PT configuration; larger prompts — many objects feeding each other negatives, the VIS adapter's
+        mask batches — grow it, the reference accepts any k)."""
         key = (oh, ow)
+        k = 120 if k <= 120 else -(-k // 256) * 256
         have = self._ws_dec.get(key)
-        if have is None or have[0] < frames:
+        if have is None or have[0] < frames or have[1] < k:
+            if have is not None:
+                frames, k = max(frames, have[0]), max(k, have[1])
             n = C.c_size_t()
-            _lib.check(self._lib.sampt_dec_workspace_bytes(self._dec, frames, oh, ow, C.byref(n)), "dec_workspace")
-            self._ws_dec = {key: (frames, torch.empty(n.value, dtype=torch.uint8, device=self._dev))}
-        return self._ws_dec[key][1]
+            _lib.check(self._lib.sampt_dec_workspace_bytes_k(self._dec, frames, k, oh, ow, C.byref(n)), "dec_workspace")
+            self._ws_dec = {key: (frames, k, torch.empty(n.value, dtype=torch.uint8, device=self._dev))}
+        return self._ws_dec[key][2]
 
     # -- image encoder -------------------------------------------------------------------------------
     @torch.no_grad()
+    @_lib.on_device(lambda self, *a, **k: self.model.device)
     def encode_frames(self, frames: torch.Tensor, chw: bool = True):
         """frames uint8 (T,3,H,W) [chw] or (T,H,W,3) on device -> token-major embeddings (T, grid*grid, 256) f32; for an
         HQ-SAM model a ``ClipFeatures`` that also carries the per-frame HQ features (T, 16*grid*grid, 32)."""
@@ -309,6 +322,7 @@ class SamPredictor:
         self.is_image_set = True
 
     @torch.no_grad()
+    @_lib.on_device(lambda self, *a, **k: self.model.device)
     def set_image(self, image: np.ndarray, image_format: str = "RGB") -> None:
         assert image_format in ("RGB", "BGR")
         if image_format != self.model.image_format:
@@ -323,6 +337,7 @@ class SamPredictor:
 
     # -- prompt encoder + mask decoder ---------------------------------------------------------------
     @torch.no_grad()
+    @_lib.on_device(lambda self, *a, **k: self.model.device)
     def predict_torch(self, point_coords, point_labels, boxes=None, mask_input=None, multimask_output: bool = True,
                       return_logits: bool = False):
         if not self.is_image_set:
@@ -346,8 +361,8 @@ class SamPredictor:
         logits = torch.empty((B, nm, oh, ow), dtype=torch.float32, device=dev)
         iou = torch.empty((B, nm), dtype=torch.float32, device=dev)
         low = torch.empty((B, nm, L, L), dtype=torch.float32, device=dev)
-        ws = self._dec_ws(oh, ow)
         k = pts.shape[1]
+        ws = self._dec_ws(oh, ow, 1, k)
         for b in range(B):                             # stream-ordered, no host synchronisation between prompts
             # every prompt gets its own (allocator-aligned) buffers, so a batch member sees exactly what a single call sees
             one = B == 1
@@ -387,6 +402,7 @@ class SamPredictor:
         return m[0].cpu().numpy(), i[0].cpu().numpy(), l[0].cpu().numpy()
 
     @torch.no_grad()
+    @_lib.on_device(lambda self, *a, **k: self.model.device)
     def track_decode(self, feat_tokens: torch.Tensor, pts: torch.Tensor, labels: torch.Tensor, k: int, n_pos_first: int,
                      refine_iters: int, iou_thr: float, size_hw, out_logits: torch.Tensor, out_score: torch.Tensor,
                      k_item: Optional[torch.Tensor] = None, npos_item: Optional[torch.Tensor] = None):
@@ -405,7 +421,7 @@ class SamPredictor:
             feat_tokens, hq_tokens = feat_tokens.emb, feat_tokens.hq
         F = feat_tokens.shape[0]
         assert F <= self.model.max_decode_batch
-        ws = self._dec_ws(oh, ow, F)
+        ws = self._dec_ws(oh, ow, F, k)
         _lib.check(self._lib.sampt_sam_track_decode(self._dec, F, _lib.ptr(feat_tokens), _lib.ptr(hq_tokens),
                                                     _lib.ptr(pts), _lib.ptr(labels),
                                                     k, _lib.ptr(k_item), _lib.ptr(npos_item), pts.shape[1], n_pos_first,

@@ -98,6 +98,15 @@ class SamPt(nn.Module):
     def forward(self, video):
         if self.training:
             raise NotImplementedError(f"{self._get_name()} does not support training...")
+        from . import _lib
+        try:
+            with _lib.device_guard(self.device):      # streams / events / launches all on the model's device
+                return self._forward_impl(video)
+        finally:                                      # never leave a clip's feature pyramid cached in the tracker
+            if hasattr(self.point_tracker, "_prepared"):
+                self.point_tracker._prepared = None
+
+    def _forward_impl(self, video):
         images = torch.stack(video["image"], dim=0) if isinstance(video["image"], (list, tuple)) else video["image"]
         n_frames, channels, height, width = images.shape
         assert images.dtype == torch.uint8, "Input images must be in uint8 format (0-255)"
@@ -122,6 +131,16 @@ class SamPt(nn.Module):
             query_points = video["query_points"]
         tracked = None
         if fused:
+            limit = getattr(self.sam_predictor, "max_prompt_points", None)
+            if limit is not None:        # fail before the clip is encoded, not after (the reference accepts any prompt size)
+                m_, p_, _ = query_points.shape
+                others = (m_ - 1) * self.positive_points_per_mask if self.add_other_objects_positive_points_as_negative_points else 0
+                if self.max_other_objects_positive_points is not None:
+                    others = min(others, self.max_other_objects_positive_points)
+                if p_ + others > limit:
+                    raise ValueError(f"prompts of up to {p_ + others} points ({m_} objects x {p_} points, other objects' "
+                                     f"positives as negatives) exceed the decoder's limit of {limit}: lower "
+                                     "point_tracker_mask_batch_size / set max_other_objects_positive_points")
             # The image encoder (compute-bound, no host syncs) and the point tracker (many small launches, one host sync
             # per round) only share the input frames: the whole clip's encoder work is enqueued on the current stream and
             # the tracker then runs on a second, high-priority stream, filling the GPU around the big GEMMs.
@@ -140,8 +159,6 @@ class SamPt(nn.Module):
                 with torch.cuda.stream(self._side_stream):
                     tracked = self._track_points(images, query_points)
                 torch.cuda.current_stream().wait_stream(self._side_stream)
-                if hasattr(self.point_tracker, "_prepared"):
-                    self.point_tracker._prepared = None
         n_masks, n_points_per_mask, _ = query_points.shape
         if query_masks is None:
             # In query_points mode the reference computes the query masks (sam_pt.py:181) but only asserts their shape
@@ -298,6 +315,12 @@ class SamPt(nn.Module):
 
     @staticmethod
     def _resize_logits(logits, target_hw):
+        from . import _lib
+        with _lib.device_guard(logits.device):
+            return SamPt._resize_logits_impl(logits, target_hw)
+
+    @staticmethod
+    def _resize_logits_impl(logits, target_hw):
         """Bilinear (align_corners=False) resize of the (M,T,H,W) logits to target_hw (sam_pt.py:205-206)."""
         if not logits.is_cuda:
             return F.interpolate(logits, size=target_hw, mode="bilinear", align_corners=False)   # reference protocol on CPU

@@ -427,7 +427,7 @@ def test_predict_torch_batched_prompts_host_logic(monkeypatch):
     pred = SP.SamPredictor(model)
     pred._ensure = lambda: None
     pred._dev, pred._lib, pred._dec = torch.device("cpu"), FakeLib(), object()
-    monkeypatch.setattr(pred, "_dec_ws", lambda oh, ow, frames=1: torch.zeros(16, dtype=torch.uint8))
+    monkeypatch.setattr(pred, "_dec_ws", lambda oh, ow, frames=1, k=0: torch.zeros(16, dtype=torch.uint8))
     pred.set_features(torch.zeros(16, 256), (20, 30), (40, 60))
     assert pred.device == torch.device("cpu")
     B = 5

@@ -259,6 +259,13 @@ def test_resize_logits_and_index_masks(lib, dev):
     idx = torch.empty(4, 36, 64, dtype=torch.uint8, device=dev)
     ok(lib.sampt_index_masks(P(ld), 3, 4 * 36 * 64, P(idx), S()), "index_masks")
     assert torch.equal(idx.cpu(), exp)
+    # NaN logits (the resized -inf map has 0 * -inf = NaN where its bilinear taps are clamped at the border): the
+    # reference's softmax row is all-NaN there and argmax gives 0 = background
+    assert torch.isnan(ref).any()
+    exp2 = torch.softmax(torch.cat([torch.zeros(1, 4, 30, 53), ref]), dim=0).argmax(dim=0).to(torch.uint8)
+    idx2 = torch.empty(4, 30, 53, dtype=torch.uint8, device=dev)
+    ok(lib.sampt_index_masks(P(out), 3, 4 * 30 * 53, P(idx2), S()), "index_masks")
+    assert torch.equal(idx2.cpu(), exp2)
 
 
 def test_vos_index_masks_overrides(lib, dev):
@@ -277,6 +284,11 @@ def test_vos_index_masks_overrides(lib, dev):
     ref2 = index_masks(logits, qt, None)
     got2 = index_masks(logits.to(dev), qt, None)
     assert torch.equal(got2.cpu(), ref2) and not torch.equal(ref, ref2)
+    lnan = logits.clone()
+    lnan[0, 1, :3] = float("nan")          # before object 1's query frame the override hides nothing of object 0's NaNs
+    lnan[1, 0, 5:9] = float("nan")         # ... but these are replaced by -1e8 (t < qt[1]) and must not matter
+    ref3 = index_masks(lnan, qt, None)
+    assert torch.equal(index_masks(lnan.to(dev), qt, None).cpu(), ref3) and (ref3[1, :3] == 0).all()
     assert (ref[:2] != 2).all() and (ref[:4] != 3).all()                           # nothing before the query frame
 
 

@@ -550,7 +550,9 @@ def test_sampt_with_pips2_tracker(dev, clip):
 
 # ------------------------------------------------------------------------------------------ limits
 def test_prompt_size_limits(dev):
-    """Largest supported prompt (120 points -> 127/128 decoder tokens) against the oracle; one more is refused loudly."""
+    """Large prompts against the oracle: 120 points (one key chunk of the image->token attention), 121 / 300 / 1700
+    points (several chunks: the reference's 16 points x M objects fed to each other as negatives, sam_pt.py:737-756, and
+    the VIS adapter's mask batches exceed 120); beyond SAMPT_DEC_MAX_POINTS the call is refused loudly."""
     from oracle import sam_ref as R
     from sam_pt_amd import _lib
     from sam_pt_amd.sam_predictor import SamHip, SamPredictor
@@ -569,9 +571,16 @@ def test_prompt_size_limits(dev):
     m0, i0, l0 = ref.predict_torch(pts, lab, box, None, False, True)
     m1, i1, l1 = pred.predict_torch(pts.to(dev), lab.to(dev), box.to(dev), None, False, True)
     assert max_abs(l1, l0) < 5e-4 and max_abs(i1, i0) < 1e-4
-    pts2, lab2 = torch.cat([pts, pts[:, :1]], 1), torch.cat([lab, lab[:, :1]], 1)
+    for k in (121, 300, 1700):
+        pts2 = (torch.rand(1, k, 2, generator=g) * torch.tensor([250.0, 140.0])).float()
+        lab2 = (torch.rand(1, k, generator=g) > 0.3).int()
+        m2, i2, l2 = ref.predict_torch(pts2, lab2, box, l0, False, True)
+        m3, i3, l3 = pred.predict_torch(pts2.to(dev), lab2.to(dev), box.to(dev), l0.to(dev), False, True)
+        assert max_abs(l3, l2) < 1e-3 and max_abs(i3, i2) < 2e-4, k
+        assert iou(m3 > 0, m2 > 0) >= 1 - 1e-3
+    pts4 = torch.zeros(1, 4100, 2)
     with pytest.raises(_lib.SamptError):
-        pred.predict_torch(pts2.to(dev), lab2.to(dev), box.to(dev), None, False, True)
+        pred.predict_torch(pts4.to(dev), torch.ones(1, 4100, dtype=torch.int).to(dev), box.to(dev), None, False, True)
 
 
 def test_single_frame_and_single_point_video(dev, pips_sd):
