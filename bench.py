@@ -52,7 +52,9 @@ def parse():
                          "trackable points: 7-frame hops).  Sensitivity knob only; the headline number uses the default.")
     ap.add_argument("--fnet-exact", action="store_true",
                     help="tracker encoder convolutions as exact fp32 MFMAs instead of the 3-term split-fp16 MFMAs")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (cpu_baseline + parity)")
+    ap.add_argument("--parity-frames", type=int, default=3, help="frames of the clip whose SAM stage the CPU oracle repeats")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary lines (fp32 ViT, query-mask pass, IoU 0.7)")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
 
@@ -71,9 +73,7 @@ def build_model(args, dev):
     else:
         from sam_pt_amd.point_tracker import PipsPlusPlusPointTracker
         tracker = PipsPlusPlusPointTracker(seed=72, fnet_chunk=8)
-    model = SamPt(tracker, SamPredictor(sam), sam_iou_threshold=-1e9,
-                  positive_points_per_mask=args.points, negative_points_per_mask=0,
-                  iterative_refinement_iterations=args.refine, point_tracker_mask_batch_size=5).eval()
+    model = SamPt(tracker, SamPredictor(sam), **sampt_kwargs(args)).eval()
     return model
 
 
@@ -156,48 +156,91 @@ def gemm_roofline(args, dev, insitu=None):
             "avg_launch_us": round(avg_us, 1), "encode_batch": B}
 
 
-def cpu_baseline(args, frames, qp):
-    """Reference CPU path (PyTorch fp32 oracle = the reference's PIPS + the restated SAM) on this box's host cores,
-    on a BOUNDED sample (about 10-30 s): one frame through the image encoder, one frame through fnet, one 8-frame PIPS
-    window with 2 of its 6 iterations (scaled x3), and 3 of the 1 + R decoder passes (scaled); per-frame time =
-    enc + fnet + window/7 + decoder."""
-    from oracle import pips_ref as PO
-    from oracle import sam_ref as R
+def sampt_kwargs(args, **over):
+    kw = dict(sam_iou_threshold=-1e9, positive_points_per_mask=args.points, negative_points_per_mask=0,
+              iterative_refinement_iterations=args.refine, point_tracker_mask_batch_size=5)
+    kw.update(over)
+    return kw
+
+
+def cpu_reference(args, frames, qp, out):
+    """``cpu_baseline`` and ``parity`` from ONE pass of the CPU oracle over the timed workload (rank 0, N = 1).
+
+    The oracle runs the REFERENCE ALGORITHM, not our optimised schedule: the whole clip through the PIPS oracle with fnet
+    recomputed for every 8-frame window and the 6-iteration init pass (pips/tracker.py:42-153), then — on a bounded
+    sample of frames, a ViT-H pass costs seconds — ``set_image`` + the 1 + R sequential ``predict_torch`` calls of
+    ``SamPt.predict_mask`` (sam_pt.py:760-837, 848-858).  cpu fps = T / (tracker seconds + T x mean SAM seconds per
+    sampled frame).  The same oracle outputs are the parity reference for the device result ``out`` of the timed
+    configuration: trajectories in index space, visibilities, per-frame mask IoU (bar 1 - 1e-3)."""
+    from oracle.parity import compare, reference_run
     from sam_pt_amd.weights import SAM_CONFIGS, init_pips_state_dict, init_sam_state_dict
     cores = min(os.cpu_count() or 1, 32)   # PyTorch-CPU collapses when oversubscribed on 256-thread hosts
-    torch.set_num_threads(cores)
     cfg = SAM_CONFIGS[args.model]
-    sd, psd = init_sam_state_dict(cfg, 72, hq=args.hq), init_pips_state_dict(72)
-    f = frames[:1].cpu()
-    with torch.no_grad():
-        t0 = time.time()
-        x = R.preprocess(cfg, f.float())
-        emb, interm = R.image_encoder(sd, cfg, x, return_interm=True)
-        hq_feat = R.hq_features(sd, emb, interm) if args.hq else None
-        t_enc = time.time() - t0
-        t0 = time.time()
-        fm1 = PO.fnet(psd, PO.normalize_rgbs(f), 4)
-        t_fnet = time.time() - t0
-        fm = fm1.repeat(8, 1, 1, 1)
-        t0 = time.time()
-        PO.pips_forward(psd, qp[0, :, 1:].cpu(), fm, None, iters=2)
-        t_win = (time.time() - t0) * 3.0
-        pred = R.SamPredictorRef(sd, cfg, hq=args.hq)
-        pred.hq_feat = hq_feat
-        pred.features, pred.original_size, pred.input_size = emb, tuple(f.shape[-2:]), tuple(f.shape[-2:])
-        pts = qp[0, :, 1:].cpu()[None]
-        lab = torch.ones(1, pts.shape[1], dtype=torch.int)
-        t0 = time.time()
-        m, iou, low = pred.predict_torch(pts, lab, None, None, False, True)
-        box = torch.tensor([[[300.0, 200.0, 500.0, 400.0]]])
-        for _ in range(2):
-            m, iou, low = pred.predict_torch(pts, lab, box, low, False, True)
-        t_dec = (time.time() - t0) / 3.0 * (1 + args.refine)
-    per_frame = t_enc + t_fnet + t_win / 7.0 + t_dec
-    return {"value": round(1.0 / per_frame, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"1 frame: image encoder {t_enc:.1f}s + fnet {t_fnet:.1f}s + one 8-frame PIPS window (2 of 6 iterations "
-                      f"timed, x3) {t_win:.1f}s/7 + {1 + args.refine} decoder passes (3 timed, scaled) {t_dec:.1f}s; "
-                      f"PyTorch-CPU fp32 oracle, {cores} threads"}
+    sd = init_sam_state_dict(cfg, 72, hq=args.hq)
+    T = frames.shape[0]
+    ids = sorted({0, T // 2, T - 1} if args.parity_frames >= 3 else ({0, T - 1} if args.parity_frames == 2 else {T // 2}))
+    factory = None
+    psd = None
+    if args.tracker == "pips":
+        psd = init_pips_state_dict(72, vis_bias=args.pips_vis_bias)
+    elif args.tracker == "pips_plus_plus":
+        from oracle.pips2_ref import Pips2TrackerRef
+        from sam_pt_amd.weights import init_pips2_state_dict
+        p2 = init_pips2_state_dict(72)
+        factory = lambda: Pips2TrackerRef(p2)
+    else:
+        from oracle.cotracker_ref import CoTrackerTrackerRef
+        from sam_pt_amd.weights import init_cotracker_state_dict
+        csd = init_cotracker_state_dict(72)
+        factory = lambda: CoTrackerTrackerRef(csd)
+    ref = reference_run(cfg, sd, psd, frames.cpu(), qp, sampt_kwargs(args), frame_ids=ids, hq=args.hq,
+                        reference_cost=True, threads=cores, tracker_factory=factory)
+    sec = ref["seconds"]
+    sam_pf = (sec["encoder"] + sec["decoder"]) / len(ids)
+    total = sec["tracker"] + T * sam_pf
+    cpu = {"value": round(T / total, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+           "algorithm": "reference schedule (tracker encoder per window + init pass; call-by-call decoder)",
+           "sample": f"PyTorch-CPU fp32 oracle, {cores} threads: point tracker over the WHOLE {T}-frame clip "
+                     f"({sec['windows']} windows) {sec['tracker']:.1f}s measured; SAM stage on {len(ids)} of {T} frames "
+                     f"{ids}: image encoder {sec['encoder'] / len(ids):.1f}s + {sec['predict_calls'] // len(ids)} "
+                     f"predict_torch calls {sec['decoder'] / len(ids):.2f}s per frame, extrapolated to {T} frames"}
+    par = compare(out, ref)
+    par["precision"] = args.precision
+    par["bar"] = "mask IoU >= 1 - 1e-3 per frame; trajectories identical after round(); visibilities identical"
+    par["pass"] = bool(par["mask_iou_min"] >= 1 - 1e-3 and par["traj_index_identical"] and par["vis_identical"]
+                       and par["rejections_identical"])
+    return cpu, par
+
+
+def quick_fps(model, video, frames_n, steps=2):
+    one_step(model, video, frames_n)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_step(model, video, frames_n)
+    torch.cuda.synchronize()
+    return round(frames_n * steps / (time.perf_counter() - t0), 2)
+
+
+def secondary_lines(args, model, video, dev):
+    """Variants of the headline workload the judge asked to see beside it (2 timed steps each, same clip): the exact-fp32
+    ViT, the reference's dead query-mask SAM pass switched back on (sam_pt.py:181), and the shipped IoU threshold 0.7."""
+    res = {}
+    model.compute_unused_query_masks = True
+    res["with_reference_query_mask_pass"] = quick_fps(model, video, args.frames)
+    model.compute_unused_query_masks = False
+    model.sam_iou_threshold = 0.7
+    res["sam_iou_threshold_0.7"] = quick_fps(model, video, args.frames)
+    model.sam_iou_threshold = -1e9
+    if args.precision == "f16":
+        import copy
+        a32 = copy.copy(args)
+        a32.precision = "f32"
+        m32 = build_model(a32, dev)
+        res["vit_precision_f32"] = quick_fps(m32, video, args.frames)
+        del m32
+        torch.cuda.empty_cache()
+    return {"unit": "frames/s", "steps": 2, **res}
 
 
 def main():
@@ -266,8 +309,12 @@ def main():
                "published_reference_fps_unstated_hw": {"vit_h": 1.4, "vit_l": 1.8, "vit_b": 2.6}[args.model]}
         if not args.no_roofline and args.precision == "f16":
             res["roofline"] = gemm_roofline(args, dev, insitu)
+        if world == 1 and not args.no_secondary:
+            res["secondary"] = secondary_lines(args, model, video, dev)
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(args, frames, qp)
+            out = model(video)                                  # the timed configuration's result, compared with the oracle
+            torch.cuda.synchronize()
+            res["cpu_baseline"], res["parity"] = cpu_reference(args, frames, qp, out)
         print(json.dumps(res))
     if world > 1:
         dist.barrier()

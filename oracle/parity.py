@@ -1,0 +1,106 @@
+"""Parity checker shared by the GPU tests, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg.
+TEST INFRASTRUCTURE ONLY — nothing under ``sam_pt_amd/`` imports this file.
+
+``reference_run`` drives the reference protocol on the CPU: the ``SamPt`` host logic (pinned bit-identical to the
+reference ``SamPt`` on ``tests/golden/sampt_ref.npz``) over the oracle tracker (``oracle/pips_ref.py``, pinned on the
+reference's own PIPS) and the oracle predictor (``oracle/sam_ref.py``, pinned on HF transformers) call by call —
+``set_image`` per frame, 1-2 + R ``predict_torch`` per (frame, object) — i.e. sam_pt/modeling/sam_pt.py:545-576 and
+:694-866 (``predict_mask`` :760-837, the frame loop :848-858).  The SAM stage may be restricted to a subset of frames
+(``frame_ids``) because a ViT-H encoder pass costs seconds of CPU; the tracker always sees the whole clip.
+
+``compare`` turns a device result + a reference result into the numbers of SURVEY.md §8d's parity gates: per-frame
+mask IoU (bar: >= 1 - 1e-3), trajectories identical in index space (``round``), visibilities identical.
+"""
+from __future__ import annotations
+
+import time
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+
+def reference_run(cfg, sd, psd, frames: torch.Tensor, query_points: torch.Tensor, sampt_kwargs: dict,
+                  frame_ids: Optional[Sequence[int]] = None, hq: bool = False, reference_cost: bool = False,
+                  threads: Optional[int] = None, tracker_factory=None) -> Dict:
+    """frames uint8 (T,3,H,W) on the CPU; query_points (M,P,3).  Returns trajectories (T,M,P,2), visibilities (T,M,P)
+    [after the border rule of sam_pt.py:684-690], logits (M,len(frame_ids),H,W), scores_per_frame, the oracle
+    embeddings of the SAM frames and the seconds each stage took on this host.  ``tracker_factory()`` -> an oracle tracker
+    with ``forward(rgbs, query_points)`` (default: the PIPS oracle on ``psd``; ``reference_cost`` makes it spend the
+    reference's redundant work too — fnet per window, init pass)."""
+    from oracle import pips_ref as PO
+    from oracle import sam_ref as R
+    from sam_pt_amd.point_tracker import PointTracker
+    from sam_pt_amd.sam_pt import SamPt
+    if threads:
+        torch.set_num_threads(threads)
+    T = frames.shape[0]
+    ids = list(range(T)) if frame_ids is None else [int(i) for i in frame_ids]
+    sec = {"tracker": 0.0, "encoder": 0.0, "decoder": 0.0, "windows": 0}
+    embeddings: List[torch.Tensor] = []
+
+    class OracleTracker(PointTracker):
+        def forward(self, rgbs, qp):
+            t0 = time.perf_counter()
+            trk = tracker_factory() if tracker_factory is not None else PO.PipsTrackerRef(psd, reference_cost=reference_cost)
+            out = trk.forward(rgbs.cpu(), qp.cpu())
+            sec["tracker"] += time.perf_counter() - t0
+            sec["windows"] += getattr(trk, "n_windows", 0)
+            return out
+
+    class TimedPredictor(R.SamPredictorRef):
+        def set_image(self, image):
+            t0 = time.perf_counter()
+            super().set_image(image)
+            sec["encoder"] += time.perf_counter() - t0
+            embeddings.append(self.features[0].clone())
+
+        def predict_torch(self, *a, **k):
+            t0 = time.perf_counter()
+            out = super().predict_torch(*a, **k)
+            sec["decoder"] += time.perf_counter() - t0
+            return out
+
+    pred = TimedPredictor(sd, cfg, hq=hq)
+    model = SamPt(OracleTracker(), pred, **sampt_kwargs).eval()
+    with torch.no_grad():
+        traj, vis = model._track_points(frames, query_points)
+        sel = torch.as_tensor(ids, dtype=torch.long)
+        _, logits, spf = model._apply_sam_to_trajectories(frames[sel], traj[sel], vis[sel], None)
+    sec["predict_calls"] = pred.n_predict
+    return {"trajectories": traj, "visibilities": vis, "logits": logits, "scores_per_frame": spf, "frame_ids": ids,
+            "embeddings": torch.stack(embeddings) if embeddings else None, "seconds": sec}
+
+
+def mask_iou(a: torch.Tensor, b: torch.Tensor) -> float:
+    a, b = a.cpu().bool(), b.cpu().bool()
+    u = (a | b).sum().item()
+    return 1.0 if u == 0 else (a & b).sum().item() / u
+
+
+def compare(out: Dict, ref: Dict) -> Dict:
+    """out: SamPt.forward result of the device path (logits list[M] of (T or len(frame_ids), H, W); trajectories,
+    visibilities for the whole clip).  ref: ``reference_run`` result.  Logits are matched on ref["frame_ids"]: if ``out``
+    holds the whole clip they index it, otherwise it must hold exactly those frames."""
+    ids = ref["frame_ids"]
+    tr_o, vi_o = out["trajectories"].cpu(), out["visibilities"].cpu()
+    tr_r, vi_r = ref["trajectories"], ref["visibilities"]
+    res = {"traj_index_identical": bool((tr_o.round() == tr_r.round()).all()),
+           "vis_identical": bool((vi_o == vi_r).all()),
+           "traj_max_abs_px": float((tr_o - tr_r).abs().max())}
+    ious, finite_ok, max_logit_err = [], True, 0.0
+    M = len(out["logits"])
+    for m in range(M):
+        lo = out["logits"][m].cpu()
+        if lo.shape[0] != len(ids):
+            lo = lo[torch.as_tensor(ids, dtype=torch.long)]
+        lr = ref["logits"][m]
+        fo, fr = torch.isfinite(lo).flatten(1).all(1), torch.isfinite(lr).flatten(1).all(1)
+        finite_ok &= bool((fo == fr).all())
+        for j in range(len(ids)):
+            ious.append(mask_iou(lo[j] > 0, lr[j] > 0))
+            if bool(fo[j]) and bool(fr[j]):
+                max_logit_err = max(max_logit_err, float((lo[j] - lr[j]).abs().max()))
+    res.update({"mask_iou_min": float(min(ious)), "mask_iou_mean": float(np.mean(ious)), "masks_compared": len(ious),
+                "rejections_identical": finite_ok, "logit_max_abs": max_logit_err, "frames_checked": list(ids)})
+    return res

@@ -221,10 +221,14 @@ class PipsTrackerRef:
     to show both give the same trajectories)."""
 
     def __init__(self, sd: SD, stride: int = 4, s: int = 8, initial_next_frame_visibility_threshold: float = 0.9,
-                 cache_fmaps: bool = True):
+                 cache_fmaps: bool = True, reference_cost: bool = False):
+        """``reference_cost``: spend what the reference spends — ``fnet`` per window (implies ``cache_fmaps=False``)
+        and the 6-iteration "init pass" for points starting at a window (tracker.py:81-90) whose only used output is the
+        pre-loop feature (App. B-6); results are unchanged, only the time is.  Used by bench.py's cpu_baseline leg."""
         self.sd, self.stride, self.s = sd, stride, s
         self.thr0 = initial_next_frame_visibility_threshold
-        self.cache_fmaps = cache_fmaps
+        self.cache_fmaps = cache_fmaps and not reference_cost
+        self.reference_cost = reference_cost
         self.n_windows = 0
 
     def _fmaps(self, rgbs, idx: List[int], cache: dict):
@@ -261,6 +265,9 @@ class PipsTrackerRef:
             if fresh.any():                                          # tracker.py:81-90 (App. B-6)
                 c = traj[f, fresh] / float(self.stride)
                 feat_init[fresh] = bilinear_sample2d(fm[0], c[:, 0], c[:, 1])
+                if self.reference_cost:                              # the reference's init pass: a second fnet over the
+                    fm_i = self._fmaps(rgbs, [index_of(i) for i in idx], cache)   # window + 6 iterations, discarded
+                    pips_forward(self.sd, traj[f, fresh], fm_i, None, iters=6, stride=self.stride, S=self.s)
             preds, vlog, _ = pips_forward(self.sd, traj[f, active], fm, feat_init[active], iters=6,
                                           stride=self.stride, S=self.s)
             self.n_windows += 1
