@@ -103,7 +103,7 @@ def gemm_roofline(args, dev, insitu=None):
     Mg = B * 4096        # windowed blocks also run their GEMMs on the real tokens only (padding rows are never multiplied)
     shapes = [  # (M, N, K, dtype(2 = f16 out, 1 = f32 out), count per encode call)
         (Mg, 3 * D, D, 2, cfg.depth), (Mg, D, D, 1, cfg.depth),
-        (Mg, 4 * D, D, 2, cfg.depth), (Mg, D, 4 * D, 1, cfg.depth), (Mg, D, 768, 1, 1), (Mg, 256, D, 1, 1)]
+        (Mg, 4 * D, D, 2, cfg.depth), (Mg, D, 4 * D, 1, cfg.depth)]   # (patch embedding and neck run in exact fp32)
     tot_flop = tot_t = 0.0
     launches = 0
     # L2-miss (HBM + Infinity Cache) bytes per launch from the committed --pmc passes (tools/gemm_traffic.py); bench.py

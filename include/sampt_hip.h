@@ -31,6 +31,7 @@ extern "C" {
 typedef void* sampt_stream_t; /* hipStream_t */
 typedef struct sampt_pips* sampt_pips_t;
 typedef struct sampt_pips2* sampt_pips2_t;
+typedef struct sampt_cotracker* sampt_cotracker_t;
 typedef struct sampt_vit* sampt_vit_t;
 typedef struct sampt_dec* sampt_dec_t;
 
@@ -93,6 +94,44 @@ int sampt_pips2_update_f32(sampt_pips2_t h, const float* const pyr_dev[4], int H
                            int n, int S, const float* trajs0_dev, int have_feat_init, float* const feats_dev[3],
                            int iters, float* trajs_out_dev, void* workspace_dev, size_t workspace_bytes,
                            sampt_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * seam 1c — CoTracker = what sam_pt.point_tracker.cotracker.CoTrackerPointTracker.forward (cotracker/tracker.py:72-170)
+ * asks of the third-party model (facebookresearch/co-tracker @ 4f297a9, built by build_cotracker from
+ * cotracker_stride_4_wind_8.pth: CoTracker(stride=4, S=8, space_depth=6, time_depth=6)).
+ * Weight names: the checkpoint's keys ("fnet.*" packed like PIPS' encoder, "updateformer.input_transform",
+ * "updateformer.{time,space}_blocks.{i}.{attn.qkv,attn.proj,mlp.fc1,mlp.fc2}", "updateformer.flow_head", "norm",
+ * "ffeat_updater.0" (+ ".weight_t"), "vis_predictor.0") plus "__times_embed" [8][456], "__ln_ones"/"__ln_zeros" [384]
+ * (sam_pt_amd/pack.py::pack_cotracker).
+ *   resize_frames_f32 : the adapter's F.interpolate(rgbs, interp_shape, mode="bilinear") (tracker.py:90-92) over `planes`
+ *                       = T*3 single-channel planes, uint8 (src_u8 != 0) or float32 input, float32 output in [0, 255].
+ *   fnet_f32          : CoTracker.fnet (the BasicEncoder of PIPS, stride 4) on every float frame + the 4-level average-pool
+ *                       pyramid of CorrBlock; each frame once per clip (InstanceNorm is per-sample), both directions share it.
+ *   track_f32         : one CoTracker.forward (one temporal direction) over T >= 8 model frames: sliding windows of 8 frames
+ *                       with step 4, `iters` UpdateFormer iterations each, the carry-over between windows on the device, no
+ *                       host synchronisation.  frame_map_dev int32 [T]: pyramid frame of model frame t (identity; T-1-t for
+ *                       the time-flipped pass of tracker.py:154-161; clamped to the last real frame for clips shorter than 8,
+ *                       tracker.py:17-21).  Points SORTED by query frame as CoTracker.forward sorts them: query_t_host /
+ *                       query_t_dev int32 [n] (same values; window membership is host control flow), query_xy_dev [n][2] px
+ *                       of the model frame size.  pos_x_dev [W0][228] / pos_y_dev [H0][228]: the 1-D tables of
+ *                       get_2d_sincos_pos_embed(456, (H0, W0)).  traj_out_dev [T][n][2] px — exact zeros where no window
+ *                       wrote (what the adapter's `== 0` back-fill keys on, tracker.py:166) — vis_out_dev [T][n] =
+ *                       sigmoid(visibility logit), 0.5 where no window wrote.
+ * --------------------------------------------------------------------------------------------------------- */
+int sampt_cotracker_create(const char* const* names, const void* const* ptrs, int n, int stride, int S,
+                           sampt_cotracker_t* out);
+void sampt_cotracker_destroy(sampt_cotracker_t h);
+int sampt_resize_frames_f32(const void* frames_dev, int src_u8, long planes, int H, int W, float* out_dev, int out_h,
+                            int out_w, sampt_stream_t stream);
+int sampt_cotracker_fnet_workspace_bytes(sampt_cotracker_t h, int nf, int H, int W, size_t* bytes);
+int sampt_cotracker_fnet_f32(sampt_cotracker_t h, const float* frames_dev, int nf, int H, int W, float* const pyr_dev[4],
+                             void* workspace_dev, size_t workspace_bytes, sampt_stream_t stream);
+int sampt_cotracker_track_workspace_bytes(sampt_cotracker_t h, int n, size_t* bytes);
+int sampt_cotracker_track_f32(sampt_cotracker_t h, const float* const pyr_dev[4], int H0, int W0, int T,
+                              const int32_t* frame_map_dev, int n, const int32_t* query_t_host,
+                              const int32_t* query_t_dev, const float* query_xy_dev, const float* pos_x_dev,
+                              const float* pos_y_dev, int iters, float* traj_out_dev, float* vis_out_dev,
+                              void* workspace_dev, size_t workspace_bytes, sampt_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * seam 2a — SAM image encoder = SamPredictor.set_image (Sam.preprocess + ImageEncoderViT, Appendix A-1..A-3).
@@ -239,6 +278,16 @@ int sampt_corr_sample_f32(const float* const pyr_dev[4], int H0, int W0, const i
 /* ViT attention on a packed qkv matrix [B*S*S][3*heads*hd] (f16), decomposed rel-pos tables (2S-1, hd) f32.
  * out_dev f16 [B*S*S][heads*hd].  The bias tables are built inside the kernel; the workspace arguments are kept for
  * ABI stability and ignored (may be NULL / 0). */
+/* The mask decoder's two small fp32 attention kernels: q [F][Nq][heads*hd], k / v [F][Nk][heads*hd], out like q;
+ * nk_item_dev (int32 [F] or NULL): per-item number of valid keys of a ragged batch.  kind 0 = one workgroup per (4
+ * queries, head, item) over up to 4096 keys (token self-attention hd 32, token->image hd 16); kind 1 = one thread per
+ * (query, head), keys staged through LDS in chunks of 128 with a running softmax (image->token, hd 16, any Nk). */
+int sampt_attention_f32(int kind, const float* q_dev, const float* k_dev, const float* v_dev, float* out_dev, int F, int Nq,
+                        int Nk, int heads, int hd, const int32_t* nk_item_dev, sampt_stream_t stream);
+/* CoTracker's UpdateFormer attention straight from packed qkv rows [rows][3*heads*hd] (timm Attention): token t of group b
+ * is row b*batch_stride_rows + t*token_stride_rows (time attention: S, 1; space attention: 1, S); out [rows][heads*hd]. */
+int sampt_cotracker_attention_f32(const float* qkv_dev, float* out_dev, int nbatch, int L, int batch_stride_rows,
+                                  int token_stride_rows, int heads, int hd, sampt_stream_t stream);
 int sampt_vit_attention_f16(const void* qkv_dev, const float* rel_h_dev, const float* rel_w_dev, void* out_dev, int B,
                             int S, int heads, int hd, void* workspace_dev, size_t workspace_bytes, sampt_stream_t stream);
 

@@ -45,6 +45,14 @@ _SIGS = {
     "sampt_pips2_update_workspace_bytes": (c_int, [_P, c_int, c_int, C.POINTER(c_size_t)]),
     "sampt_pips2_update_f32": (c_int, [_P, C.POINTER(_P), c_int, c_int, _P, c_int, c_int, _P, c_int, C.POINTER(_P), c_int, _P,
                                        _P, c_size_t, _P]),
+    "sampt_cotracker_create": (c_int, [C.POINTER(c_char_p), C.POINTER(_P), c_int, c_int, c_int, C.POINTER(_P)]),
+    "sampt_cotracker_destroy": (None, [_P]),
+    "sampt_resize_frames_f32": (c_int, [_P, c_int, C.c_long, c_int, c_int, _P, c_int, c_int, _P]),
+    "sampt_cotracker_fnet_workspace_bytes": (c_int, [_P, c_int, c_int, c_int, C.POINTER(c_size_t)]),
+    "sampt_cotracker_fnet_f32": (c_int, [_P, _P, c_int, c_int, c_int, C.POINTER(_P), _P, c_size_t, _P]),
+    "sampt_cotracker_track_workspace_bytes": (c_int, [_P, c_int, C.POINTER(c_size_t)]),
+    "sampt_cotracker_track_f32": (c_int, [_P, C.POINTER(_P), c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P, _P, c_int, _P, _P,
+                                          _P, c_size_t, _P]),
     "sampt_pips_update_workspace_bytes": (c_int, [_P, c_int, C.POINTER(c_size_t)]),
     "sampt_pips_update_f32": (c_int, [_P, C.POINTER(_P), c_int, c_int, _P, c_int, _P, _P, c_int, _P, _P, _P, c_size_t, _P]),
     "sampt_vit_create": (c_int, [C.POINTER(VitConfigC), C.POINTER(c_char_p), C.POINTER(_P), c_int, c_int, C.POINTER(_P)]),
@@ -80,6 +88,8 @@ _SIGS = {
     "sampt_resize_bilinear_nhwc": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "sampt_avgpool2x2_nhwc": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
     "sampt_corr_sample_f32": (c_int, [C.POINTER(_P), c_int, c_int, _P, c_int, c_int, _P, _P, _P, _P]),
+    "sampt_attention_f32": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "sampt_cotracker_attention_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "sampt_vit_attention_f16": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
 }
 

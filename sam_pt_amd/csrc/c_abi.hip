@@ -44,6 +44,7 @@ using namespace sampt;
 
 struct sampt_pips { PipsEngine e; };
 struct sampt_pips2 { Pips2Engine e; };
+struct sampt_cotracker { CotEngine e; };
 struct sampt_vit { VitEngine e; };
 struct sampt_dec { DecEngine e; };
 
@@ -113,6 +114,65 @@ int sampt_pips_update_f32(sampt_pips_t h, const float* const pyr[4], int H0, int
   Arena a(ws, ws_bytes);
   return h->e.update(make_pyr(pyr, H0, W0), frame_idx, n, xys, feat_init, iters, traj_out, vis_out, a,
                      (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------- CoTracker
+int sampt_cotracker_create(const char* const* names, const void* const* ptrs, int n, int stride, int S,
+                           sampt_cotracker_t* out) {
+  if (!names || !ptrs || !out || S != 8 || stride != 4)
+    return fail(SAMPT_ERR_ARG, "sampt_cotracker_create: bad arguments (the shipped checkpoint is stride 4, window 8)");
+  return create_handle<sampt_cotracker>("sampt_cotracker_create", out, [&](sampt_cotracker& h) {
+    h.e.S = S, h.e.stride = stride;
+    return h.e.init(make_map(names, ptrs, n));
+  });
+}
+void sampt_cotracker_destroy(sampt_cotracker_t h) { delete h; }
+
+int sampt_resize_frames_f32(const void* frames, int src_u8, long planes, int H, int W, float* out, int out_h, int out_w,
+                            sampt_stream_t stream) {
+  if (!frames || !out || planes <= 0 || H <= 0 || W <= 0 || out_h <= 0 || out_w <= 0)
+    return fail(SAMPT_ERR_ARG, "sampt_resize_frames_f32: bad arguments");
+  return resize_planes(frames, src_u8, planes, H, W, out, out_h, out_w, (hipStream_t)stream);
+}
+
+int sampt_cotracker_fnet_workspace_bytes(sampt_cotracker_t h, int nf, int H, int W, size_t* bytes) {
+  if (!h || !bytes) return SAMPT_ERR_ARG;
+  Arena a(nullptr, 0);
+  float* out[4] = {nullptr, nullptr, nullptr, nullptr};
+  int rc = h->e.enc.fnet(nullptr, nf, H, W, out, a, nullptr);
+  *bytes = a.peak + 256;
+  return rc;
+}
+
+int sampt_cotracker_fnet_f32(sampt_cotracker_t h, const float* frames, int nf, int H, int W, float* const pyr[4], void* ws,
+                             size_t ws_bytes, sampt_stream_t stream) {
+  if (!h || !frames || !pyr || !ws || H < 16 * h->e.stride || W < 16 * h->e.stride)
+    return fail(SAMPT_ERR_ARG, "sampt_cotracker_fnet_f32: bad arguments (H, W must be at least 16*stride)");
+  Arena a(ws, ws_bytes);
+  return h->e.enc.fnet((const uint8_t*)frames, nf, H, W, pyr, a, (hipStream_t)stream);
+}
+
+int sampt_cotracker_track_workspace_bytes(sampt_cotracker_t h, int n, size_t* bytes) {
+  if (!h || !bytes || n <= 0) return SAMPT_ERR_ARG;
+  Arena a(nullptr, 0);
+  PyramidLevels p = {};
+  int rc = h->e.track(p, 8, nullptr, n, nullptr, nullptr, nullptr, nullptr, nullptr, 6, nullptr, nullptr, a, nullptr);
+  *bytes = a.peak + 256;
+  return rc;
+}
+
+int sampt_cotracker_track_f32(sampt_cotracker_t h, const float* const pyr[4], int H0, int W0, int T,
+                              const int32_t* frame_map, int n, const int32_t* query_t_host, const int32_t* query_t,
+                              const float* query_xy, const float* pos_x, const float* pos_y, int iters, float* traj_out,
+                              float* vis_out, void* ws, size_t ws_bytes, sampt_stream_t stream) {
+  if (!h || !pyr || !frame_map || !query_t_host || !query_t || !query_xy || !pos_x || !pos_y || !traj_out || !vis_out ||
+      !ws || n <= 0 || T < h->e.S || iters <= 0)
+    return fail(SAMPT_ERR_ARG, "sampt_cotracker_track_f32: bad arguments (T must be at least the window length 8)");
+  Arena a(ws, ws_bytes);
+  int rc = h->e.track(make_pyr(pyr, H0, W0), T, (const int*)frame_map, n, (const int*)query_t_host, (const int*)query_t,
+                      query_xy, pos_x, pos_y, iters, traj_out, vis_out, a, (hipStream_t)stream);
+  if (rc == SAMPT_ERR_ARG) return fail(rc, "sampt_cotracker_track_f32: query frames must be sorted ascending and inside [0, T)");
+  return rc;
 }
 
 // ------------------------------------------------------------------------------------------- ViT
@@ -402,6 +462,20 @@ int sampt_vit_attention_f16(const void* qkv, const float* rel_h, const float* re
                             int hd, void* ws, size_t ws_bytes, sampt_stream_t stream) {
   (void)ws, (void)ws_bytes;  // the decomposed rel-pos bias is computed inside the kernel: no scratch needed any more
   return vit_flash_attention_f16((const half_t*)qkv, rel_h, rel_w, (half_t*)out, B, S, heads, hd, (hipStream_t)stream);
+}
+
+int sampt_attention_f32(int kind, const float* q, const float* k, const float* v, float* out, int F, int Nq, int Nk,
+                        int heads, int hd, const int32_t* nk_item, sampt_stream_t stream) {
+  if (!q || !k || !v || !out) return fail(SAMPT_ERR_ARG, "sampt_attention_f32: bad arguments");
+  if (kind == 0) return attn_rowblock(q, k, v, out, F, Nq, Nk, heads, hd, (const int*)nk_item, (hipStream_t)stream);
+  if (kind == 1) return attn_fewkeys(q, k, v, out, F, Nq, Nk, heads, hd, (const int*)nk_item, (hipStream_t)stream);
+  return SAMPT_ERR_UNSUPPORTED;
+}
+
+int sampt_cotracker_attention_f32(const float* qkv, float* out, int nbatch, int L, int batch_stride_rows,
+                                  int token_stride_rows, int heads, int hd, sampt_stream_t stream) {
+  if (!qkv || !out) return fail(SAMPT_ERR_ARG, "sampt_cotracker_attention_f32: bad arguments");
+  return cot_attention(qkv, out, nbatch, L, batch_stride_rows, token_stride_rows, heads, hd, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -34,16 +34,23 @@ const char* last_error();
     if (_rc != SAMPT_OK) return _rc;             \
   } while (0)
 
-enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_GELU_TANH = 3 };
 
 __device__ __forceinline__ float gelu_erf(float x) {
   // exact (erf) GELU, matching torch.nn.GELU() default
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
 
+__device__ __forceinline__ float gelu_tanh(float x) {
+  // torch.nn.GELU(approximate="tanh"): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))  (CoTracker's timm Mlp)
+  const float inner = 0.79788456080286535588f * (x + 0.044715f * x * x * x);
+  return 0.5f * x * (1.0f + tanhf(inner));
+}
+
 __device__ __forceinline__ float apply_act(float x, int act) {
   if (act == ACT_RELU) return x > 0.f ? x : 0.f;
   if (act == ACT_GELU) return gelu_erf(x);
+  if (act == ACT_GELU_TANH) return gelu_tanh(x);
   return x;
 }
 

@@ -97,6 +97,31 @@ struct Pips2Engine {
              float* const feats[3], int iters, float* trajs_out, Arena& ws, hipStream_t s);
 };
 
+// CoTracker v1: the PIPS encoder at stride 4 + the UpdateFormer (6 time + 6 space attention blocks,
+// hidden 384, 8 heads) refining sliding windows of 8 frames with step 4.
+struct CotEngine {
+  PipsEngine enc;  // fnet only
+  int S = 8, stride = 4, hidden = 384, heads = 8, depth = 6;
+  struct Blk {
+    const float *qkv_w, *qkv_b, *proj_w, *proj_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+  } tb[6], sb[6];
+  const float *in_w, *in_b, *head_w, *head_b, *gn_w, *gn_b, *up_wT, *up_b, *vis_w, *vis_b;
+  const float *times;             // [S][456] 1-D sin/cos time embedding (host-built: float64 -> f32 like upstream)
+  const float *ln_one, *ln_zero;  // affine-free LayerNorm as weight 1 / bias 0
+  std::string error;
+
+  int init(const WeightMap& w);
+  // One temporal direction of CoTracker.forward over T >= S model frames.  frame_map (device int [T]): pyramid frame of
+  // model frame t (identity, reversed for the time-flipped pass, clamped for clips shorter than S).  Points are SORTED by
+  // query frame: qt_host / qt_dev int [n] (the same values on the host — window membership is host control flow — and on
+  // the device), qxy (device [n][2], px of the model's frame size).  pos_x [W0][228] / pos_y [H0][228]: the two 1-D tables
+  // of the 2-D sin/cos position grid.  traj_out [T][n][2] px (0 where never written), vis_out [T][n] = sigmoid(logit)
+  // (0.5 where never written).
+  int track(const PyramidLevels& pyr, int T, const int* frame_map, int n, const int* qt_host, const int* qt_dev,
+            const float* qxy, const float* pos_x, const float* pos_y, int iters, float* traj_out, float* vis_out, Arena& ws,
+            hipStream_t s);
+};
+
 // -------------------------------------------------------------------------------------------------
 struct VitConfig {
   int D = 768, depth = 12, heads = 12, grid = 64, window = 14, patch = 16, out_chans = 256, mlp_ratio = 4;

@@ -13,7 +13,7 @@ int VitEngine::init(const WeightMap& w, const VitConfig& cfg, int wrb) {
   win_rows_batches = wrb;
   const std::string sfx = c.f16 ? ".f16" : "";
   const std::string e = "image_encoder.";
-  patch_w = w.get(e + "patch_embed.proj.weight" + sfx);
+  patch_w = w.get(e + "patch_embed.proj.weight");   // fp32 in both modes (see encode)
   patch_b = w.f(e + "patch_embed.proj.bias");
   pos = w.f(e + "pos_embed");
   blk.resize(c.depth);
@@ -28,9 +28,9 @@ int VitEngine::init(const WeightMap& w, const VitConfig& cfg, int wrb) {
     b.w1 = w.get(p + ".mlp.lin1.weight" + sfx), b.b1 = w.f(p + ".mlp.lin1.bias");
     b.w2 = w.get(p + ".mlp.lin2.weight" + sfx), b.b2 = w.f(p + ".mlp.lin2.bias");
   }
-  neck0_w = w.get(e + "neck.0.weight" + sfx);
+  neck0_w = w.get(e + "neck.0.weight");
   neck1w = w.f(e + "neck.1.weight"), neck1b = w.f(e + "neck.1.bias");
-  neck2_w = w.get(e + "neck.2.weight_khwc" + sfx);  // repacked [Cout][ky][kx][Cin]
+  neck2_w = w.get(e + "neck.2.weight_khwc");  // repacked [Cout][ky][kx][Cin]
   neck3w = w.f(e + "neck.3.weight"), neck3b = w.f(e + "neck.3.bias");
   win_rows = w.i("__win_rows");
   win_inv = w.i("__win_inv"), win_pad = w.i("__win_pad");
@@ -63,12 +63,13 @@ struct G {
   const VitEngine* eng = nullptr;
   // C = act(A.W^T + bias) (+ residual at the (row-mapped) destination row)
   int run(const void* A, int M, int K, const void* W, const float* bias, void* C, int N, int act, bool out_f16,
-          const float* res, int ldr, const int* rowmap, int res_mod, const int* a_rowmap = nullptr) const {
+          const float* res, int ldr, const int* rowmap, int res_mod, const int* a_rowmap = nullptr,
+          bool exact = false) const {
     GemmP p;
     p.A = A, p.W = W, p.bias = bias, p.C = C, p.res = res, p.rowmap = rowmap, p.a_rowmap = a_rowmap;
     p.M = M, p.N = N, p.K = K, p.lda = K, p.ldw = K, p.ldc = N, p.ldr = ldr, p.act = act, p.res_mod = res_mod;
     p.out_f16 = out_f16 ? 1 : 0;
-    if (!f16) return gemm_f32(p, s);
+    if (!f16 || exact) return gemm_f32(p, s);
     if (!eng || !eng->profiling) return gemm_f16(p, s);
     VitEngine::GemmEv ev;
     ev.flop = 2.0 * M * N * K;
@@ -93,7 +94,9 @@ int VitEngine::encode(const uint8_t* frames, int chw, int B, int H, int W, float
   if (B > win_rows_batches) return SAMPT_ERR_ARG;
 
   float* x = ws.f32((size_t)Mg * D);
-  void* xn = ws.get((size_t)Mmax * (D > Kp ? D : Kp) * esz);       // LN output / patch matrix / attention output
+  size_t xn_bytes = (size_t)Mmax * (D > Kp ? D : Kp) * esz;        // LN output / attention output (fp16 in the fast mode)
+  if ((size_t)Mg * Kp * 4 > xn_bytes) xn_bytes = (size_t)Mg * Kp * 4;  // ... and the fp32 patch matrix
+  void* xn = ws.get(xn_bytes);
   void* qkv = ws.get((size_t)Mmax * 3 * D * esz);
   void* att = ws.get((size_t)Mmax * D * esz);
   void* hid = ws.get((size_t)Mg * c.mlp_ratio * D * esz);
@@ -109,15 +112,16 @@ int VitEngine::encode(const uint8_t* frames, int chw, int B, int H, int W, float
     scores = ws.f32(sg > sw2 ? sg : sw2);
   }
   float* neck_a = ws.f32((size_t)Mg * c.out_chans);
-  void* neck_b = ws.get((size_t)Mg * c.out_chans * esz);
+  float* neck_b = ws.f32((size_t)Mg * c.out_chans);
   if (!ws.ok()) return SAMPT_ERR_WORKSPACE;
   if (dry) return SAMPT_OK;
   (void)Smax;
 
   G gm{c.f16 != 0, s, this};
   // ---- patch embedding: preprocess + im2col, GEMM + bias + positional embedding (broadcast over the batch)
-  SAMPT_TRY(sam_patchify(frames, chw, B, H, W, c.img, c.patch, c.mean, c.stdv, xn, c.f16, s));
-  SAMPT_TRY(gm.run(xn, (int)Mg, Kp, patch_w, patch_b, x, D, ACT_NONE, false, pos, D, nullptr, T));
+  //      (exact fp32 in both modes: first and last layers of the encoder, 0.3 % of its FLOPs)
+  SAMPT_TRY(sam_patchify(frames, chw, B, H, W, c.img, c.patch, c.mean, c.stdv, xn, 0, s));
+  SAMPT_TRY(gm.run(xn, (int)Mg, Kp, patch_w, patch_b, x, D, ACT_NONE, false, pos, D, nullptr, T, nullptr, true));
 
   const float scale = 1.0f / sqrtf((float)hd);
   bool tapped = false;
@@ -168,19 +172,16 @@ int VitEngine::encode(const uint8_t* frames, int chw, int B, int H, int W, float
     }
   }
   // ---- neck: conv1x1 (no bias) -> LayerNorm2d -> conv3x3 (no bias) -> LayerNorm2d
-  const void* xin = x;
-  if (c.f16) {
-    SAMPT_TRY(cast_f32_f16(x, (half_t*)xn, Mg * D, s));
-    xin = xn;
-  }
-  SAMPT_TRY(gm.run(xin, (int)Mg, D, neck0_w, nullptr, neck_a, c.out_chans, ACT_NONE, false, nullptr, 0, nullptr, 0));
-  SAMPT_TRY(layernorm_rows(neck_a, neck1w, neck1b, neck_b, Mg, c.out_chans, 1e-6f, nullptr, c.f16, ACT_NONE, s));
+  //      fp32 in both modes: the neck's operand roundings would land on the embedding undamped
+  SAMPT_TRY(gm.run(x, (int)Mg, D, neck0_w, nullptr, neck_a, c.out_chans, ACT_NONE, false, nullptr, 0, nullptr, 0, nullptr,
+                   true));
+  SAMPT_TRY(layernorm_rows(neck_a, neck1w, neck1b, neck_b, Mg, c.out_chans, 1e-6f, nullptr, 0, ACT_NONE, s));
   {
     GemmP p;
     p.A = neck_b, p.W = neck2_w, p.C = neck_a;
     p.M = (int)Mg, p.N = c.out_chans, p.K = 9 * c.out_chans, p.ldw = p.K, p.ldc = c.out_chans;
     p.conv = 1, p.cH = g, p.cW = g, p.cC = c.out_chans, p.KH = 3, p.KW = 3, p.cstride = 1, p.cpad = 1, p.OH = g, p.OW = g;
-    SAMPT_TRY(c.f16 ? gemm_f16(p, s) : gemm_f32(p, s));
+    SAMPT_TRY(gemm_f32(p, s));
   }
   SAMPT_TRY(layernorm_rows(neck_a, neck3w, neck3b, features, Mg, c.out_chans, 1e-6f, nullptr, 0, ACT_NONE, s));
   return SAMPT_OK;

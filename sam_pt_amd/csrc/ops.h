@@ -105,6 +105,24 @@ int pips_update(const float* delta, const float* gn_w, const float* gn_b, const 
 int pips_finalize(const float* ffeats, const float* vis_w, const float* vis_b, const float* coords, float stride,
                   int S, int n, float* traj, float* vis, hipStream_t s);
 
+// ---- cotracker.hip (CoTracker v1 windows: SURVEY.md App. A-6; layouts in the file header) -------------------------------
+int cot_prepare(const float* qxy, const int* qt, const int* frame_map, float stride, int n, int T, float* xy0, int* fidx_pt,
+                float* traj_out, float* vis_out, hipStream_t s);
+int cot_window_init(int ind, int S_local, int prev, int na, int S, const int* qt, const float* xy0, const int* frame_map,
+                    const float* coords_prev, const float* vis_prev, const float* feat_init, float* coords, float* visin,
+                    float* mask, int* fidx, float* ffeats, hipStream_t s);
+int cot_pos_embed(const float* coords, const float* pos_x, const float* pos_y, int H, int W, int E, int na, float* pos,
+                  hipStream_t s);
+int cot_build_input(const float* ffeats, const float* coords, const float* visin, const float* mask, const float* pos,
+                    const float* times, int S, int na, float* x, hipStream_t s);
+// attention over token groups taken from packed qkv rows [rows][3*heads*hd]: token t of group b = row b*bs + t*ts
+int cot_attention(const float* qkv, float* out, int nbatch, int L, int bs, int ts, int heads, int hd, hipStream_t s);
+int cot_window_store(const float* ffeats, const float* vis_w, const float* vis_b, const float* coords, float stride, int S,
+                     int na, int ind, int S_local, int n_total, float* coords_prev, float* vis_prev, float* traj_out,
+                     float* vis_out, hipStream_t s);
+// F.interpolate(bilinear, align_corners=False) of n single-channel planes (uint8 or f32) to f32
+int resize_planes(const void* src, int src_u8, long n, int sh, int sw, float* dst, int dh, int dw, hipStream_t s);
+
 // ---- sam_decoder.hip (every launcher takes the frame batch F; tensors are [F][...] contiguous) ---------------
 // decoder tokens [F][Nt][256] (Nt = 5 + k + (box ? 2 : 1)): out tokens, then the sparse prompt tokens (App. A-4).
 // pts [F][ld_pts][2] input-frame px, labels [F][ld_pts] i32, box [F][4] or null.

@@ -362,7 +362,7 @@ __global__ __launch_bounds__(128) void k_pips_update(const float* __restrict__ d
   ffeats[(long)row * C + c] += gelu_erf(a);
   if (c < 2) {
     int ci = (s * n + pt) * 2 + c;
-    coords[ci] = (s == 0) ? coords0[pt * 2 + c] : coords[ci] + d[c];
+    coords[ci] = (s == 0 && coords0) ? coords0[pt * 2 + c] : coords[ci] + d[c];   // coords0 null: no lock (CoTracker)
   }
 }
 

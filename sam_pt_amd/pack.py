@@ -75,6 +75,44 @@ def pack_pips(sd: Dict[str, torch.Tensor], device, S: int = 8) -> Dict[str, torc
     return {k: v.to(device) for k, v in out.items()}
 
 
+def sincos_1d(embed_dim: int, pos) -> torch.Tensor:
+    """CoTracker's ``get_1d_sincos_pos_embed_from_grid`` (the MAE recipe): (M,) positions -> (M, embed_dim) =
+    [sin(pos * omega), cos(pos * omega)], omega_d = 10000^(-d / (embed_dim / 2)), evaluated in float64 and cast to f32 as
+    upstream does (numpy float64 -> ``.float()``)."""
+    import numpy as np
+    omega = np.arange(embed_dim // 2, dtype=np.float64)
+    omega /= embed_dim / 2.0
+    omega = 1.0 / 10000 ** omega
+    out = np.einsum("m,d->md", np.asarray(pos, dtype=np.float64).reshape(-1), omega)
+    return torch.from_numpy(np.concatenate([np.sin(out), np.cos(out)], axis=1)).float()
+
+
+def cotracker_pos_tables(H0: int, W0: int, embed_dim: int = 456):
+    """The two 1-D tables of ``get_2d_sincos_pos_embed(embed_dim, (H0, W0))``: channels [0, E/2) of grid cell (y, x) are
+    ``pos_x[x]``, channels [E/2, E) are ``pos_y[y]`` (upstream's meshgrid puts the column grid first)."""
+    return sincos_1d(embed_dim // 2, range(W0)).contiguous(), sincos_1d(embed_dim // 2, range(H0)).contiguous()
+
+
+def pack_cotracker(sd: Dict[str, torch.Tensor], device, S: int = 8) -> Dict[str, torch.Tensor]:
+    """CoTracker v1: encoder convolutions as for PIPS; the UpdateFormer's Linear weights are used as
+    they are ([out][in] rows); ``__times_embed`` = the 1-D sin/cos embedding of the S window frames (456 channels);
+    ``__ln_ones`` / ``__ln_zeros``: the blocks' LayerNorms are affine-free."""
+    out: Dict[str, torch.Tensor] = {}
+    for k, v in sd.items():
+        v = v.detach().float()
+        if k.startswith("fnet.") and k.endswith(".weight"):
+            out[k] = _khwc(v, pad_cin_to=4 if k == "fnet.conv1.weight" else 0)
+        else:
+            out[k] = v.contiguous()
+    out["ffeat_updater.0.weight_t"] = sd["ffeat_updater.0.weight"].detach().float().t().contiguous()
+    out["vis_predictor.0.weight"] = sd["vis_predictor.0.weight"].detach().float().reshape(-1).contiguous()
+    hidden = sd["updateformer.input_transform.weight"].shape[0]
+    out["__times_embed"] = sincos_1d(sd["updateformer.input_transform.weight"].shape[1], torch.linspace(0, S - 1, S).numpy())
+    out["__ln_ones"], out["__ln_zeros"] = torch.ones(hidden), torch.zeros(hidden)
+    _add_fnet_split(out, sd, default=True)
+    return {k: v.to(device) for k, v in out.items()}
+
+
 def pack_pips2(sd: Dict[str, torch.Tensor], device) -> Dict[str, torch.Tensor]:
     """PIPS++ (pips_plus_plus.py:420-434): fnet convs as for PIPS; DeltaBlock Conv1d weights (Cout, Cin, 3) ->
     [Cout][3][Cin] (tap-major, channel fastest = the implicit-GEMM K order over an [n][S][1][C] image), the first conv's
@@ -118,7 +156,12 @@ def window_row_map(grid: int, window: int, batches: int) -> torch.Tensor:
 def pack_vit(sd: Dict[str, torch.Tensor], cfg: SamConfig, device, f16: bool, win_batches: int) -> Dict[str, torch.Tensor]:
     out: Dict[str, torch.Tensor] = {}
     e = "image_encoder."
-    gemm_keys = [e + "patch_embed.proj.weight", e + "neck.0.weight"]
+    # The two ends of the encoder stay fp32 in the fast mode too (exact f32 MFMA, 0.3 % of the FLOPs): every fp16
+    # rounding inside the 12-32 blocks is damped by the residual stream, but the neck's roundings land on the embedding
+    # directly — they were the largest single term (30 % of the error variance) of the fp16 mode's error budget
+    # (tools/f16_error_budget.py), the patch embedding another 7 %.
+    exact_keys = [e + "patch_embed.proj.weight", e + "neck.0.weight"]
+    gemm_keys = []
     for i in range(cfg.depth):
         p = f"{e}blocks.{i}."
         gemm_keys += [p + "attn.qkv.weight", p + "attn.proj.weight", p + "mlp.lin1.weight", p + "mlp.lin2.weight"]
@@ -129,8 +172,9 @@ def pack_vit(sd: Dict[str, torch.Tensor], cfg: SamConfig, device, f16: bool, win
         if k == e + "pos_embed":
             out[k] = v.reshape(-1, v.shape[-1]).contiguous()
         elif k == e + "neck.2.weight":
-            w = _khwc(v)
-            out[e + "neck.2.weight_khwc" + (".f16" if f16 else "")] = w.half() if f16 else w
+            out[e + "neck.2.weight_khwc"] = _khwc(v)
+        elif k in exact_keys:
+            out[k] = v.reshape(v.shape[0], -1).contiguous()
         elif k in gemm_keys:
             w = v.reshape(v.shape[0], -1).contiguous()
             out[k + (".f16" if f16 else "")] = w.half() if f16 else w

@@ -416,3 +416,196 @@ class PipsPlusPlusPointTracker(PointTracker):
             traj[:, :, 1] *= W / self.image_size[1]
         vis = torch.ones((1, T, N), dtype=torch.float32, device=dev)             # PIPS++ predicts no visibility (:64)
         return traj.unsqueeze(0), vis
+
+
+def load_cotracker_checkpoint(checkpoint_path: Optional[str]):
+    """``build_cotracker`` convention (co-tracker @ 4f297a9): a ``.pth`` state dict, optionally under the key 'model'."""
+    if checkpoint_path is None:
+        return None
+    with open(checkpoint_path, "rb") as f:
+        sd = torch.load(f, map_location="cpu")
+    return sd["model"] if "model" in sd else sd
+
+
+def get_points_on_a_grid(grid_size: int, interp_shape) -> torch.Tensor:
+    """Upstream's support grid (cotracker.py ``get_points_on_a_grid``): (grid_size^2, 2) = (x, y), a regular grid with a
+    margin of ``interp_shape[1] // 64`` pixels, rows first."""
+    if grid_size == 1:
+        return torch.tensor([[interp_shape[1] / 2, interp_shape[0] / 2]])
+    step = interp_shape[1] // 64
+    lin = torch.linspace(0, grid_size - 1, grid_size)
+    gy, gx = torch.meshgrid(lin, lin, indexing="ij")
+    gy = step + gy.reshape(-1) / float(grid_size - 1) * (interp_shape[0] - step * 2)
+    gx = step + gx.reshape(-1) / float(grid_size - 1) * (interp_shape[1] - step * 2)
+    return torch.stack([gx, gy], dim=-1)
+
+
+class CoTrackerPointTracker(PointTracker):
+    """CoTracker behind the constructor of ``sam_pt.point_tracker.cotracker.CoTrackerPointTracker``
+    (cotracker/tracker.py:32-66; configs/model/point_tracker/cotracker.yaml) — the reference's default tracker.
+
+    The adapter logic is the reference's: float video resized bilinearly to ``interp_shape`` and queries rescaled
+    (tracker.py:87-96), a ``support_grid_size``^2 grid of support queries every ``support_grid_every_n_frames`` frames
+    (:98-102), the model with 6 iterations (:104), the time-flipped pass filling entries that are exactly 0 (:154-170),
+    support points dropped, visibility > threshold, trajectories scaled back (:144-150); clips shorter than the window
+    are padded with their last frame (:12-24).  Different on purpose:
+
+    * the encoder runs ONCE per frame for both temporal directions (upstream re-encodes 4 new frames per window and the
+      whole clip again for the flipped pass; InstanceNorm is per-sample, so the maps are identical);
+    * a whole direction is ONE device call (``sampt_cotracker_track_f32``): window membership depends only on the query
+      frames, the window-to-window carry stays on the device, nothing synchronises with the host;
+    * the debug visualisation branch (cv2 / imageio, :107-142) is control plane and not built.
+    """
+
+    def __init__(self, checkpoint_path=None, interp_shape=(384, 512), visibility_threshold=0.7, support_grid_size=2,
+                 support_grid_every_n_frames=12, add_debug_visualisations=False,
+                 state_dict: Optional[Dict[str, torch.Tensor]] = None, seed: int = 72, fnet_chunk: int = 8, iters: int = 6):
+        super().__init__()
+        self.checkpoint_path = checkpoint_path
+        self.interp_shape = tuple(interp_shape) if interp_shape is not None else None
+        self.visibility_threshold = visibility_threshold
+        self.support_grid_size = support_grid_size
+        self.support_grid_every_n_frames = support_grid_every_n_frames
+        self.add_debug_visualisations = add_debug_visualisations
+        if add_debug_visualisations:
+            raise NotImplementedError("add_debug_visualisations (cv2 / imageio gif dump, tracker.py:107-142) is not built")
+        from .weights import init_cotracker_state_dict
+        sd = state_dict if state_dict is not None else load_cotracker_checkpoint(checkpoint_path)
+        self._sd = sd if sd is not None else init_cotracker_state_dict(seed)
+        self.fnet_chunk, self.iters = fnet_chunk, iters
+        self.s, self.stride = 8, 4
+        self._h = None
+        self._device = None
+        self._pos: Dict[Tuple[int, int], Tuple[torch.Tensor, torch.Tensor]] = {}
+        self.stats = {"windows": 0, "fnet_frames": 0, "calls": 0}
+
+    def _ensure(self, device: torch.device):
+        if self._h is not None and self._device == device:
+            return
+        if device.type != "cuda":
+            raise _lib.SamptError("CoTrackerPointTracker runs on the HIP device only (no CPU fallback); got " + str(device))
+        from .pack import pack_cotracker
+        lib = _lib.load()
+        self._w = pack_cotracker(self._sd, device, self.s)
+        names, ptrs, n = _lib.name_table(self._w)
+        h = C.c_void_p()
+        _lib.check(lib.sampt_cotracker_create(names, ptrs, n, self.stride, self.s, C.byref(h)), "sampt_cotracker_create")
+        self._h, self._device, self._lib = h, device, lib
+        self._pos = {}
+
+    def __del__(self):
+        if getattr(self, "_h", None) is not None:
+            try:
+                self._lib.sampt_cotracker_destroy(self._h)
+            except Exception:
+                pass
+
+    # -- resize + encoder for a whole clip ---------------------------------------------------------------------
+    @_lib.on_device(lambda self, frames: frames.device)
+    def compute_pyramid(self, frames: torch.Tensor):
+        """frames (T,3,H,W) uint8 / float32 on device -> 4 NHWC f32 levels [T][h/4 >> l][w/4 >> l][128] of the video resized
+        to ``interp_shape`` (h, w)."""
+        self._ensure(frames.device)
+        dev = frames.device
+        T, _, H, W = frames.shape
+        h, w = self.interp_shape if self.interp_shape is not None else (H, W)
+        frames = frames.contiguous()
+        if frames.dtype != torch.uint8:
+            frames = frames.float()
+        small = torch.empty((T, 3, h, w), dtype=torch.float32, device=dev)
+        _lib.check(self._lib.sampt_resize_frames_f32(_lib.ptr(frames), 1 if frames.dtype == torch.uint8 else 0, T * 3, H, W,
+                                                     _lib.ptr(small), h, w, _lib.stream_ptr()), "sampt_resize_frames_f32")
+        H0, W0 = h // self.stride, w // self.stride
+        pyr = [torch.empty((T, H0 >> l, W0 >> l, 128), dtype=torch.float32, device=dev) for l in range(4)]
+        chunk = min(self.fnet_chunk, T)
+        nbytes = C.c_size_t()
+        _lib.check(self._lib.sampt_cotracker_fnet_workspace_bytes(self._h, chunk, h, w, C.byref(nbytes)), "fnet_workspace")
+        ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+        for t0 in range(0, T, chunk):
+            nf = min(chunk, T - t0)
+            outs = _lib.ptr_array([p[t0:t0 + nf] for p in pyr])
+            _lib.check(self._lib.sampt_cotracker_fnet_f32(self._h, _lib.ptr(small[t0:t0 + nf]), nf, h, w, outs, _lib.ptr(ws),
+                                                          nbytes.value, _lib.stream_ptr()), "sampt_cotracker_fnet_f32")
+        self.stats["fnet_frames"] += T
+        return pyr
+
+    def prepare(self, frames: torch.Tensor):
+        """Build the (resized) clip's feature pyramid now, on the current stream; the next ``forward`` on the same frames
+        tensor reuses it (see PipsPointTracker.prepare)."""
+        self._prepared = _prepared_entry(frames, self.compute_pyramid(frames))
+
+    def _pos_tables(self, H0: int, W0: int, dev):
+        if (H0, W0) not in self._pos:
+            from .pack import cotracker_pos_tables
+            px, py = cotracker_pos_tables(H0, W0)
+            self._pos[(H0, W0)] = (px.to(dev), py.to(dev))
+        return self._pos[(H0, W0)]
+
+    def _model(self, pyr, T: int, q: torch.Tensor, flipped: bool):
+        """One ``CoTrackerForShortVideosWrapper.__call__`` (tracker.py:17-24): q (n,3) CPU = (t, x, y) in the model's own
+        time axis and frame size; ``flipped`` = the clip is time-reversed (model frame t = pyramid frame T-1-t).
+        -> traj (T,n,2), vis (T,n) on the device, in the order of q."""
+        dev = pyr[0].device
+        n = q.shape[0]
+        Tm = max(T, self.s)                                            # short clips: last frame repeated
+        t = torch.arange(Tm).clamp(max=T - 1)
+        fmap = ((T - 1 - t) if flipped else t).to(torch.int32)
+        qt = q[:, 0].long()
+        order = torch.sort(qt, stable=True).indices                    # CoTracker.forward sorts the points by query frame
+        inv = torch.argsort(order)
+        qt_s = qt[order].to(torch.int32).contiguous()
+        H0, W0 = pyr[0].shape[1:3]
+        px, py = self._pos_tables(H0, W0, dev)
+        nb = C.c_size_t()
+        _lib.check(self._lib.sampt_cotracker_track_workspace_bytes(self._h, n, C.byref(nb)), "track_workspace")
+        ws = torch.empty(nb.value, dtype=torch.uint8, device=dev)
+        traj = torch.empty((Tm, n, 2), dtype=torch.float32, device=dev)
+        vis = torch.empty((Tm, n), dtype=torch.float32, device=dev)
+        fmap_d, qt_d = fmap.to(dev).contiguous(), qt_s.to(dev)
+        qxy_d = q[order, 1:].float().contiguous().to(dev)
+        _lib.check(self._lib.sampt_cotracker_track_f32(self._h, _lib.ptr_array(pyr), H0, W0, Tm, _lib.ptr(fmap_d), n,
+                                                       C.c_void_p(qt_s.data_ptr()), _lib.ptr(qt_d), _lib.ptr(qxy_d),
+                                                       _lib.ptr(px), _lib.ptr(py), self.iters, _lib.ptr(traj), _lib.ptr(vis),
+                                                       _lib.ptr(ws), ws.numel(), _lib.stream_ptr()),
+                   "sampt_cotracker_track_f32")
+        self.stats["calls"] += 1
+        inv_d = inv.to(dev)
+        return traj[:T].index_select(1, inv_d), vis[:T].index_select(1, inv_d)
+
+    @torch.no_grad()
+    @_lib.on_device(lambda self, rgbs, query_points: rgbs.device)
+    def forward(self, rgbs, query_points):
+        if rgbs.shape[0] != 1:
+            raise NotImplementedError("Batch size > 1 is not supported for CoTracker")   # the model asserts B == 1
+        dev = rgbs.device
+        self._ensure(dev)
+        frames = rgbs[0]
+        T, _, H, W = frames.shape
+        if self.interp_shape is None:                                   # tracker.py:87-88 (kept on the object)
+            self.interp_shape = (H, W)
+        h, w = self.interp_shape
+        q = query_points[0].detach().float().cpu().clone()
+        assert q.shape[1] == 3
+        n_points = q.shape[0]
+        q[:, 1] *= w / W                                                # tracker.py:95-96
+        q[:, 2] *= h / H
+        if self.support_grid_size > 0:                                  # tracker.py:98-102
+            for i in range(0, T, self.support_grid_every_n_frames):
+                g = get_points_on_a_grid(self.support_grid_size, (h, w))
+                q = torch.cat([q, torch.cat([torch.full((g.shape[0], 1), float(i)), g], dim=1)], dim=0)
+        pyr = _prepared_lookup(getattr(self, "_prepared", None), frames)
+        if pyr is None:
+            pyr = self.compute_pyramid(frames)
+        traj, vis = self._model(pyr, T, q, False)                       # tracker.py:104
+        qf = q.clone()                                                  # _compute_backward_tracks, tracker.py:154-170
+        qf[:, 0] = T - qf[:, 0] - 1
+        traj_f, vis_f = self._model(pyr, T, qf, True)
+        traj_f, vis_f = traj_f.flip(0), vis_f.flip(0)
+        mask = traj == 0
+        traj = torch.where(mask, traj_f, traj)
+        vis = torch.where(mask[:, :, 0], vis_f, vis)
+        traj, vis = traj[:, :n_points].clone(), vis[:, :n_points].clone()     # tracker.py:144-150
+        visb = vis > self.visibility_threshold
+        traj[:, :, 0] *= W / float(w)
+        traj[:, :, 1] *= H / float(h)
+        return traj.unsqueeze(0), visb.unsqueeze(0)

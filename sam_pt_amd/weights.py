@@ -123,6 +123,64 @@ def init_pips_state_dict(seed: int = 72, S: int = PIPS_S, delta_scale: float = 0
     return w.sd
 
 
+# --------------------------------------------------------------------------------------
+# CoTracker v1 (facebookresearch/co-tracker @ 4f297a9, requirements.txt:29 — third-party, absent from the reference tree)
+# --------------------------------------------------------------------------------------
+COTRACKER_HIDDEN = 384
+COTRACKER_HEADS = 8
+COTRACKER_DEPTH = 6          # time_depth = space_depth = 6 (build_cotracker: cotracker_stride_4_wind_8.pth)
+COTRACKER_INPUT_DIM = 456    # 130 flow embedding + 196 correlation + 128 track feature + 2 (track mask, visibility)
+
+
+def init_cotracker_state_dict(seed: int = 72, delta_scale: float = 0.003, vis_bias: float = 0.0,
+                              hidden: int = COTRACKER_HIDDEN, depth: int = COTRACKER_DEPTH) -> "OrderedDict[str, torch.Tensor]":
+    """Random CoTracker weights with the key layout of ``cotracker_stride_4_wind_8.pth``: ``fnet.*`` =
+    the same BasicEncoder tree as PIPS (instance norm: no norm parameters), ``updateformer.input_transform``,
+    ``updateformer.{time,space}_blocks.{i}.{attn.qkv, attn.proj, mlp.fc1, mlp.fc2}`` (timm ``Attention`` / ``Mlp``; the
+    blocks' LayerNorms are affine-free), ``updateformer.flow_head``, ``norm`` (GroupNorm), ``ffeat_updater.0``,
+    ``vis_predictor.0``.  UpdateFormer linears are xavier-uniform with zero bias as upstream's ``initialize_weights``.
+    ``delta_scale``: see ``init_pips_state_dict`` — with xavier weights and 12 residual blocks the unscaled random
+    head moves points by pixels per iteration and the 968-rad/px flow embedding makes the model chaotic (a 1e-7 relative
+    weight perturbation moves trajectories by 2.3 px at 0.05, 0.34 px at 0.01, 6e-4 px at 0.003), so 0.003 is the
+    default.  The random visibility head already straddles the 0.7 threshold of configs/model/point_tracker/
+    cotracker.yaml:7 (logits 1.6 +- 0.8 vs logit(0.7) = 0.85: ~80 % visible), so ``vis_bias`` defaults to 0."""
+    w = _Init(seed)
+    w.conv("fnet.conv1", 64, 3, 7, 7, kaiming_fan_out=True)
+    in_planes = 64
+    for li, (dim, stride) in enumerate([(64, 1), (96, 2), (128, 2), (128, 2)], start=1):
+        for bi in range(2):
+            cin = in_planes if bi == 0 else dim
+            p = f"fnet.layer{li}.{bi}"
+            w.conv(p + ".conv1", dim, cin, 3, 3, kaiming_fan_out=True)
+            w.conv(p + ".conv2", dim, dim, 3, 3, kaiming_fan_out=True)
+            if bi == 0 and stride != 1:
+                w.conv(p + ".downsample.0", dim, cin, 1, 1, kaiming_fan_out=True)
+        in_planes = dim
+    w.conv("fnet.conv2", 2 * PIPS_LATENT, 128 + 128 + 96 + 64, 3, 3, kaiming_fan_out=True)
+    w.conv("fnet.conv3", PIPS_LATENT, 2 * PIPS_LATENT, 1, 1, kaiming_fan_out=True)
+
+    def xavier(prefix, out_f, in_f):
+        w.uniform(prefix + ".weight", (out_f, in_f), math.sqrt(6.0 / (in_f + out_f)))
+        w.sd[prefix + ".bias"] = torch.zeros(out_f)
+
+    xavier("updateformer.input_transform", hidden, COTRACKER_INPUT_DIM)
+    xavier("updateformer.flow_head", PIPS_LATENT + 2, hidden)
+    for kind in ("time_blocks", "space_blocks"):
+        for i in range(depth):
+            p = f"updateformer.{kind}.{i}"
+            xavier(p + ".attn.qkv", 3 * hidden, hidden)
+            xavier(p + ".attn.proj", hidden, hidden)
+            xavier(p + ".mlp.fc1", 4 * hidden, hidden)
+            xavier(p + ".mlp.fc2", hidden, 4 * hidden)
+    w.norm("norm", PIPS_LATENT)
+    w.linear("ffeat_updater.0", PIPS_LATENT, PIPS_LATENT)
+    w.linear("vis_predictor.0", 1, PIPS_LATENT)
+    w.sd["updateformer.flow_head.weight"] *= delta_scale
+    w.sd["updateformer.flow_head.bias"] *= delta_scale
+    w.sd["vis_predictor.0.bias"] += vis_bias
+    return w.sd
+
+
 PIPS2_KITCHEN = 3 * PIPS_CORR_LEVELS * (2 * PIPS_CORR_RADIUS + 1) ** 2 + PIPS_LATENT + 2      # 718
 PIPS2_BLOCKS = [(128, 128), (128, 128), (128, 256), (256, 256), (256, 512), (512, 512), (512, 1024), (1024, 1024)]
 

@@ -261,10 +261,15 @@ def test_resize_logits_and_index_masks(lib, dev):
     assert torch.equal(idx.cpu(), exp)
     # NaN logits (the resized -inf map has 0 * -inf = NaN where its bilinear taps are clamped at the border): the
     # reference's softmax row is all-NaN there and argmax gives 0 = background
-    assert torch.isnan(ref).any()
-    exp2 = torch.softmax(torch.cat([torch.zeros(1, 4, 30, 53), ref]), dim=0).argmax(dim=0).to(torch.uint8)
-    idx2 = torch.empty(4, 30, 53, dtype=torch.uint8, device=dev)
-    ok(lib.sampt_index_masks(P(out), 3, 4 * 30 * 53, P(idx2), S()), "index_masks")
+    # (up-scaling clamps the source coordinate at the border, which makes one interpolation weight exactly 0)
+    ref_up = F.interpolate(logits, size=(45, 80), mode="bilinear", align_corners=False)
+    assert torch.isnan(ref_up).any()
+    out_up = torch.empty(3, 4, 45, 80, device=dev)
+    ok(lib.sampt_resize_logits(P(ld), 12, 36, 64, P(out_up), 45, 80, S()), "resize_logits")
+    assert torch.equal(torch.isnan(out_up.cpu()), torch.isnan(ref_up))
+    exp2 = torch.softmax(torch.cat([torch.zeros(1, 4, 45, 80), ref_up]), dim=0).argmax(dim=0).to(torch.uint8)
+    idx2 = torch.empty(4, 45, 80, dtype=torch.uint8, device=dev)
+    ok(lib.sampt_index_masks(P(out_up), 3, 4 * 45 * 80, P(idx2), S()), "index_masks")
     assert torch.equal(idx2.cpu(), exp2)
 
 
@@ -309,3 +314,55 @@ def test_vos_index_masks_resized(lib, dev):
             assert got.shape == (T,) + out_hw
             mism = (got.cpu() != ref).float().mean().item()
             assert mism < 2e-3, (out_hw, mism)            # ties / last-ulp probability differences only
+
+
+def _mha_ref(q, k, v, heads, nk=None):
+    """q (F,Nq,D), k/v (F,Nk,D) -> softmax(q k^T / sqrt(hd)) v per head, fp64; nk[f] = valid keys of item f."""
+    F_, Nq, D = q.shape
+    hd = D // heads
+    out = torch.empty(F_, Nq, D, dtype=torch.float64)
+    for f in range(F_):
+        n = k.shape[1] if nk is None else int(nk[f])
+        qq = q[f].double().view(Nq, heads, hd).permute(1, 0, 2)
+        kk = k[f, :n].double().view(n, heads, hd).permute(1, 0, 2)
+        vv = v[f, :n].double().view(n, heads, hd).permute(1, 0, 2)
+        a = torch.softmax(qq @ kk.transpose(1, 2) / hd ** 0.5, dim=-1)
+        out[f] = (a @ vv).permute(1, 0, 2).reshape(Nq, D)
+    return out
+
+
+@pytest.mark.parametrize("kind,hd,Nq,Nk", [(1, 16, 300, 100), (1, 16, 4096, 128), (1, 16, 1000, 129), (1, 16, 517, 307),
+                                           (1, 16, 260, 1707), (0, 32, 128, 128), (0, 32, 307, 307), (0, 32, 50, 1707),
+                                           (0, 16, 307, 4096), (0, 16, 7, 200)])
+def test_decoder_attention_kernels(lib, dev, kind, hd, Nq, Nk):
+    """The mask decoder's fp32 attention kernels against an fp64 reference, incl. prompts beyond 128 tokens (chunked
+    token-key attention) and ragged batches (per-item key counts)."""
+    heads, F_ = 8, 2
+    g = torch.Generator().manual_seed(Nq * 31 + Nk)
+    D = heads * hd
+    q, k, v = (torch.randn(F_, n, D, generator=g) for n in (Nq, Nk, Nk))
+    out = torch.empty(F_, Nq, D, device=dev)
+    qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
+    ok(lib.sampt_attention_f32(kind, P(qd), P(kd), P(vd), P(out), F_, Nq, Nk, heads, hd, None, S()), "attention")
+    assert max_abs(out, _mha_ref(q, k, v, heads)) < 2e-5
+    nk = torch.tensor([Nk, max(1, Nk // 2 + 3)], dtype=torch.int32)
+    ok(lib.sampt_attention_f32(kind, P(qd), P(kd), P(vd), P(out), F_, Nq, Nk, heads, hd, P(nk.to(dev)), S()), "attention")
+    assert max_abs(out, _mha_ref(q, k, v, heads, nk)) < 2e-5
+
+
+@pytest.mark.parametrize("nb,L,time_attn", [(36, 8, True), (8, 36, False), (8, 100, False), (8, 300, False), (5, 8, True)])
+def test_cotracker_attention_kernel(lib, dev, nb, L, time_attn):
+    """CoTracker's token-group attention read straight from packed qkv rows (8 heads x 48) vs an fp64 reference."""
+    heads, hd, S_ = 8, 48, 8
+    D = heads * hd
+    g = torch.Generator().manual_seed(nb * 13 + L)
+    npts = nb if time_attn else L
+    qkv = torch.randn(npts * S_, 3 * D, generator=g)                   # rows = point * S + frame
+    x = qkv.view(npts, S_, 3, D)
+    grp = x if time_attn else x.transpose(0, 1)                        # (groups, tokens, 3, D)
+    ref = _mha_ref(grp[:, :, 0], grp[:, :, 1], grp[:, :, 2], heads)    # (groups, tokens, D)
+    ref = ref if time_attn else ref.transpose(0, 1)
+    out = torch.empty(npts * S_, D, device=dev)
+    bs, ts = (S_, 1) if time_attn else (1, S_)
+    ok(lib.sampt_cotracker_attention_f32(P(qkv.to(dev)), P(out), nb, L, bs, ts, heads, hd, S()), "cot attention")
+    assert max_abs(out.view(npts, S_, D), ref.reshape(npts, S_, D)) < 2e-5
