@@ -219,6 +219,19 @@ int sampt_sam_track_decode(sampt_dec_t h, int frames, const float* features_dev,
                            const int32_t* npos_item_dev, int ld_pts, int n_pos_first, int refine_iters, float iou_thr,
                            int in_h, int in_w, int out_h, int out_w, float* final_logits_dev, float* score_out_dev,
                            void* workspace_dev, size_t workspace_bytes, sampt_stream_t stream);
+/* The same chain replayed from a hipGraph.  The launch sequence of sampt_sam_track_decode depends only on its arguments, so
+ * it is stream-captured once per distinct argument tuple — every scalar AND every pointer: the caller keeps the inputs,
+ * outputs and workspace of a prompt bucket in persistent buffers (sam_pt_amd.SamPredictor.track_decode(graph=True)) — and
+ * replayed with one hipGraphLaunch afterwards.  First call of a tuple: plain launches; second: capture + instantiate +
+ * launch; then: launch only.  At most 64 instantiated graphs are cached per handle (least recently used one dropped).
+ * `stream` must not be the NULL stream (not capturable: falls back to plain launches).  Results are those of
+ * sampt_sam_track_decode bit for bit (same kernels, same order).  sampt_dec_graph_stats: cache size / captures / replays. */
+int sampt_sam_track_decode_graph(sampt_dec_t h, int frames, const float* features_dev, const float* hq_features_dev,
+                                 const float* pts_dev, const int32_t* labels_dev, int k, const int32_t* k_item_dev,
+                                 const int32_t* npos_item_dev, int ld_pts, int n_pos_first, int refine_iters, float iou_thr,
+                                 int in_h, int in_w, int out_h, int out_w, float* final_logits_dev, float* score_out_dev,
+                                 void* workspace_dev, size_t workspace_bytes, sampt_stream_t stream);
+int sampt_dec_graph_stats(sampt_dec_t h, long* cached, long* captures, long* launches);
 int sampt_postprocess_masks(const float* low_res_dev, int L, int img_size, int in_h, int in_w, float* out_dev, int out_h,
                             int out_w, sampt_stream_t stream);
 /* bbox_state_dev: int32[5] = {xmin, ymin, xmax, ymax, count} over logits > 0 (sam_pt.py:809-820). */

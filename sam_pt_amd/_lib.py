@@ -72,6 +72,9 @@ _SIGS = {
     "sampt_sam_decode_multimask": (c_int, [_P, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_size_t, _P]),
     "sampt_sam_track_decode": (c_int, [_P, c_int, _P, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_float, c_int, c_int, c_int,
                                        c_int, _P, _P, _P, c_size_t, _P]),
+    "sampt_sam_track_decode_graph": (c_int, [_P, c_int, _P, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_float, c_int, c_int,
+                                             c_int, c_int, _P, _P, _P, c_size_t, _P]),
+    "sampt_dec_graph_stats": (c_int, [_P, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_long)]),
     "sampt_postprocess_masks": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P]),
     "sampt_bbox_workspace_bytes": (c_size_t, [c_int, c_int]),
     "sampt_bbox_from_logits": (c_int, [_P, c_int, c_int, _P, _P, c_size_t, _P]),

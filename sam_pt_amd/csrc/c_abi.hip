@@ -4,6 +4,7 @@
 #include <exception>
 #include <memory>
 #include <string>
+#include <unordered_map>
 
 #include "../../include/sampt_hip.h"
 #include "engine.h"
@@ -46,7 +47,37 @@ struct sampt_pips { PipsEngine e; };
 struct sampt_pips2 { Pips2Engine e; };
 struct sampt_cotracker { CotEngine e; };
 struct sampt_vit { VitEngine e; };
-struct sampt_dec { DecEngine e; };
+// hipGraph cache of the per-(frame, object) decode chain (north_star: "hipGraph capture of the per-frame decode"): one
+// instantiated graph per distinct call signature (every scalar AND every pointer of sampt_sam_track_decode_graph).
+struct DecGraphKey {
+  const void *features, *hq, *pts, *labels, *k_item, *npos_item, *logits, *score, *ws;
+  size_t ws_bytes;
+  int frames, k, ld_pts, n_pos_first, refine, in_h, in_w, oh, ow;
+  float iou_thr;
+  bool operator==(const DecGraphKey& o) const { return memcmp(this, &o, sizeof(*this)) == 0; }
+};
+struct DecGraphKeyHash {
+  size_t operator()(const DecGraphKey& k) const {
+    const unsigned char* p = (const unsigned char*)&k;
+    size_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < sizeof(k); ++i) h = (h ^ p[i]) * 1099511628211ull;
+    return h;
+  }
+};
+struct DecGraphEntry {
+  hipGraphExec_t exec = nullptr;
+  int seen = 0;       // calls with this signature so far (the first one runs eagerly: lazy one-time kernel attributes)
+  long last_use = 0;
+};
+struct sampt_dec {
+  DecEngine e;
+  std::unordered_map<DecGraphKey, DecGraphEntry, DecGraphKeyHash> graphs;
+  long graph_clock = 0, graph_launches = 0, graph_captures = 0;
+  ~sampt_dec() {
+    for (auto& kv : graphs)
+      if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+  }
+};
 
 extern "C" {
 
@@ -355,6 +386,75 @@ int sampt_sam_track_decode(sampt_dec_t h, int frames, const float* features, con
     return fail(SAMPT_ERR_ARG, "sampt_sam_track_decode: npos_item needs the two-pass mode (n_pos_first >= 0)");
   return h->e.track_decode(frames, features, hq_features, pts, labels, k, k_item, npos_item, ld_pts, n_pos_first,
                            refine_iters, iou_thr, in_h, in_w, oh, ow, final_logits, score_out, a, (hipStream_t)stream);
+}
+
+int sampt_sam_track_decode_graph(sampt_dec_t h, int frames, const float* features, const float* hq_features,
+                                 const float* pts, const int32_t* labels, int k, const int32_t* k_item,
+                                 const int32_t* npos_item, int ld_pts, int n_pos_first, int refine_iters, float iou_thr,
+                                 int in_h, int in_w, int oh, int ow, float* final_logits, float* score_out, void* ws,
+                                 size_t ws_bytes, sampt_stream_t stream) {
+  if (!h) return fail(SAMPT_ERR_ARG, "sampt_sam_track_decode_graph: null handle");
+  hipStream_t s = (hipStream_t)stream;
+  if (s == nullptr)    // the legacy default stream cannot be captured
+    return sampt_sam_track_decode(h, frames, features, hq_features, pts, labels, k, k_item, npos_item, ld_pts, n_pos_first,
+                                  refine_iters, iou_thr, in_h, in_w, oh, ow, final_logits, score_out, ws, ws_bytes, stream);
+  DecGraphKey key;
+  memset(&key, 0, sizeof(key));   // padding bytes are part of the hash / comparison
+  key.features = features, key.hq = hq_features, key.pts = pts, key.labels = labels, key.k_item = k_item;
+  key.npos_item = npos_item, key.logits = final_logits, key.score = score_out, key.ws = ws, key.ws_bytes = ws_bytes;
+  key.frames = frames, key.k = k, key.ld_pts = ld_pts, key.n_pos_first = n_pos_first, key.refine = refine_iters;
+  key.in_h = in_h, key.in_w = in_w, key.oh = oh, key.ow = ow, key.iou_thr = iou_thr;
+  try {
+    DecGraphEntry& ent = h->graphs[key];
+    ent.last_use = ++h->graph_clock;
+    if (ent.exec) {
+      if (hipGraphLaunch(ent.exec, s) != hipSuccess) return fail(SAMPT_ERR_HIP, "sampt_sam_track_decode_graph: hipGraphLaunch failed");
+      ++h->graph_launches;
+      return SAMPT_OK;
+    }
+    if (ent.seen++ == 0)   // first sight of a signature: plain launches (validates the arguments, sets lazy attributes)
+      return sampt_sam_track_decode(h, frames, features, hq_features, pts, labels, k, k_item, npos_item, ld_pts,
+                                    n_pos_first, refine_iters, iou_thr, in_h, in_w, oh, ow, final_logits, score_out, ws,
+                                    ws_bytes, stream);
+    if (h->graphs.size() > 64) {   // bound the cache: drop the least recently used instantiated graph
+      auto victim = h->graphs.end();
+      for (auto it = h->graphs.begin(); it != h->graphs.end(); ++it)
+        if (it->second.exec && &it->second != &ent && (victim == h->graphs.end() || it->second.last_use < victim->second.last_use))
+          victim = it;
+      if (victim != h->graphs.end()) {
+        (void)hipGraphExecDestroy(victim->second.exec);
+        h->graphs.erase(victim);
+      }
+    }
+    DecGraphEntry& e2 = h->graphs[key];
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess)
+      return fail(SAMPT_ERR_HIP, "sampt_sam_track_decode_graph: hipStreamBeginCapture failed");
+    int rc = sampt_sam_track_decode(h, frames, features, hq_features, pts, labels, k, k_item, npos_item, ld_pts, n_pos_first,
+                                    refine_iters, iou_thr, in_h, in_w, oh, ow, final_logits, score_out, ws, ws_bytes, stream);
+    hipGraph_t g = nullptr;
+    hipError_t ce = hipStreamEndCapture(s, &g);
+    if (rc != SAMPT_OK || ce != hipSuccess || !g) {
+      if (g) (void)hipGraphDestroy(g);
+      return rc != SAMPT_OK ? rc : fail(SAMPT_ERR_HIP, "sampt_sam_track_decode_graph: stream capture failed");
+    }
+    hipGraphExec_t exec = nullptr;
+    hipError_t ie = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (ie != hipSuccess || !exec) return fail(SAMPT_ERR_HIP, "sampt_sam_track_decode_graph: hipGraphInstantiate failed");
+    e2.exec = exec;
+    ++h->graph_captures;
+    if (hipGraphLaunch(exec, s) != hipSuccess) return fail(SAMPT_ERR_HIP, "sampt_sam_track_decode_graph: hipGraphLaunch failed");
+    ++h->graph_launches;
+    return SAMPT_OK;
+  } catch (...) {
+    return fail(SAMPT_ERR_ARG, "sampt_sam_track_decode_graph: C++ exception");
+  }
+}
+
+int sampt_dec_graph_stats(sampt_dec_t h, long* cached, long* captures, long* launches) {
+  if (!h || !cached || !captures || !launches) return SAMPT_ERR_ARG;
+  *cached = (long)h->graphs.size(), *captures = h->graph_captures, *launches = h->graph_launches;
+  return SAMPT_OK;
 }
 
 int sampt_postprocess_masks(const float* low, int L, int img, int in_h, int in_w, float* out, int oh, int ow,

@@ -185,10 +185,11 @@ int DecEngine::decode(int F, const float* features, const float* hq_feat, const 
   b.qin = ws.f32(FT * C);
   b.kin = ws.f32(FP * C);
   b.keys = ws.f32(FP * C);
-  b.Q = ws.f32(FP * C);
-  b.K = ws.f32(FP * C);
-  b.V = ws.f32(FP * C);
-  b.att = ws.f32(FP * C);
+  const size_t Fmx = FP > FT ? FP : FT;   // projections run on image tokens AND on prompt tokens (Nt may exceed g*g)
+  b.Q = ws.f32(Fmx * C);
+  b.K = ws.f32(Fmx * C);
+  b.V = ws.f32(Fmx * C);
+  b.att = ws.f32(Fmx * C);
   b.hid = ws.f32(FT * c.mlp);
   b.up0 = ws.f32(4 * FP * (C / 4));
   b.up1 = ws.f32(16 * FP * (C / 8));

@@ -13,6 +13,7 @@ per-(frame, object) prompt chain of ``SamPt.predict_mask`` on device without hos
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Optional, Tuple
 
 import numpy as np
@@ -185,6 +186,9 @@ class SamPredictor:
         self._ws_vit: Dict[int, torch.Tensor] = {}
         self._ws_dec: Dict[Tuple[int, int], torch.Tensor] = {}
         self._ws_hq = None
+        self._stage: Dict[tuple, Dict[str, torch.Tensor]] = {}
+        # hipGraph replay of the per-(frame, object) decode chain (sampt_sam_track_decode_graph); SAMPT_DEC_GRAPH=0|1
+        self.use_graph = os.environ.get("SAMPT_DEC_GRAPH", "1") != "0"
         self.reset_image()
         self.stats = {"set_image": 0, "predict": 0, "encoded_frames": 0}
 
@@ -275,9 +279,12 @@ class SamPredictor:
     # -- image encoder -------------------------------------------------------------------------------
     @torch.no_grad()
     @_lib.on_device(lambda self, *a, **k: self.model.device)
-    def encode_frames(self, frames: torch.Tensor, chw: bool = True):
+    def encode_frames(self, frames: torch.Tensor, chw: bool = True, batch_events: Optional[list] = None):
         """frames uint8 (T,3,H,W) [chw] or (T,H,W,3) on device -> token-major embeddings (T, grid*grid, 256) f32; for an
-        HQ-SAM model a ``ClipFeatures`` that also carries the per-frame HQ features (T, 16*grid*grid, 32)."""
+        HQ-SAM model a ``ClipFeatures`` that also carries the per-frame HQ features (T, 16*grid*grid, 32).
+        ``batch_events``: a list that receives one ``(end_frame, torch.cuda.Event)`` per encoder batch, recorded on the
+        current stream when frames [.., end_frame) are done — lets a caller start decoding early frames on another stream
+        while later batches are still being encoded."""
         self._ensure()
         frames = frames.to(self._dev).contiguous()
         frames = self.transform.apply_image_torch(frames, chw=chw)      # PIL-exact resize when the longest side != img_size
@@ -305,6 +312,10 @@ class SamPredictor:
                 _lib.check(self._lib.sampt_dec_hq_features(self._dec, B, _lib.ptr(out[t0:t0 + B]), _lib.ptr(interm),
                                                            _lib.ptr(hq[t0:t0 + B]), _lib.ptr(wsh), wsh.numel(),
                                                            _lib.stream_ptr()), "sampt_dec_hq_features")
+            if batch_events is not None:
+                ev = torch.cuda.Event()
+                ev.record()
+                batch_events.append((t0 + B, ev))
         self.stats["encoded_frames"] += T
         return ClipFeatures(out, hq) if hq is not None else out
 
@@ -401,11 +412,39 @@ class SamPredictor:
         m, i, l = self.predict_torch(pc, pl, bx, mi, multimask_output, return_logits)
         return m[0].cpu().numpy(), i[0].cpu().numpy(), l[0].cpu().numpy()
 
+    def decode_staging(self, F: int, ld_pts: int, size_hw) -> Dict[str, torch.Tensor]:
+        """Persistent input / output buffers of one prompt bucket (F items, ld_pts point slots, frame size): a captured
+        hipGraph replays fixed pointers, so the decode chain of a bucket always reads and writes these tensors."""
+        self._ensure()
+        key = (F, ld_pts, tuple(size_hw))
+        st = self._stage.get(key)
+        if st is None:
+            g, Cc, dev = self.model.cfg.grid, self.model.cfg.out_chans, self._dev
+            st = {"feats": torch.empty((F, g * g, Cc), dtype=torch.float32, device=dev),
+                  "pts": torch.empty((F, ld_pts, 2), dtype=torch.float32, device=dev),
+                  "labels": torch.empty((F, ld_pts), dtype=torch.int32, device=dev),
+                  "k_item": torch.empty((F,), dtype=torch.int32, device=dev),
+                  "npos_item": torch.empty((F,), dtype=torch.int32, device=dev),
+                  "logits": torch.empty((F,) + tuple(size_hw), dtype=torch.float32, device=dev),
+                  "score": torch.empty((F,), dtype=torch.float32, device=dev)}
+            if self.model.hq:
+                st["hq"] = torch.empty((F, 16 * g * g, Cc // 8), dtype=torch.float32, device=dev)
+            if len(self._stage) >= 8:                       # a handful of buckets is all a clip needs
+                self._stage.pop(next(iter(self._stage)))
+            self._stage[key] = st
+        return st
+
+    def graph_stats(self):
+        """(cached graphs, captures, replays) of the decoder handle."""
+        a, b, c = C.c_long(), C.c_long(), C.c_long()
+        _lib.check(self._lib.sampt_dec_graph_stats(self._dec, C.byref(a), C.byref(b), C.byref(c)), "sampt_dec_graph_stats")
+        return a.value, b.value, c.value
+
     @torch.no_grad()
     @_lib.on_device(lambda self, *a, **k: self.model.device)
     def track_decode(self, feat_tokens: torch.Tensor, pts: torch.Tensor, labels: torch.Tensor, k: int, n_pos_first: int,
                      refine_iters: int, iou_thr: float, size_hw, out_logits: torch.Tensor, out_score: torch.Tensor,
-                     k_item: Optional[torch.Tensor] = None, npos_item: Optional[torch.Tensor] = None):
+                     k_item: Optional[torch.Tensor] = None, npos_item: Optional[torch.Tensor] = None, graph: bool = False):
         """SamPt.predict_mask (sam_pt.py:760-837) for F independent (frame, object) items that share the visible-point
         count k, as ONE batched device-side chain without host syncs.  feat_tokens (F,g*g,256); pts (F,ld,2) f32 in
         input-frame px and labels (F,ld) i32 with the first k entries valid (positives first); n_pos_first = -1 for
@@ -422,7 +461,8 @@ class SamPredictor:
         F = feat_tokens.shape[0]
         assert F <= self.model.max_decode_batch
         ws = self._dec_ws(oh, ow, F, k)
-        _lib.check(self._lib.sampt_sam_track_decode(self._dec, F, _lib.ptr(feat_tokens), _lib.ptr(hq_tokens),
+        fn = self._lib.sampt_sam_track_decode_graph if graph else self._lib.sampt_sam_track_decode
+        _lib.check(fn(self._dec, F, _lib.ptr(feat_tokens), _lib.ptr(hq_tokens),
                                                     _lib.ptr(pts), _lib.ptr(labels),
                                                     k, _lib.ptr(k_item), _lib.ptr(npos_item), pts.shape[1], n_pos_first,
                                                     refine_iters, float(iou_thr), ih, iw,

@@ -88,7 +88,9 @@ class SamPt(nn.Module):
         self.profile = {}
         self.compute_unused_query_masks = False        # fused path: see forward()
         self.overlap_tracker_and_encoder = True        # fused path only: tracker on a second HIP stream (see forward)
-        self._side_stream = None
+        self.pipeline_decoder = True                   # fused path only: decoder chains of early frames run on a third
+        self._side_stream = None                       # stream while the encoder still works on later frames
+        self._dec_stream = None
 
     @property
     def device(self):
@@ -144,21 +146,30 @@ class SamPt(nn.Module):
             # The image encoder (compute-bound, no host syncs) and the point tracker (many small launches, one host sync
             # per round) only share the input frames: the whole clip's encoder work is enqueued on the current stream and
             # the tracker then runs on a second, high-priority stream, filling the GPU around the big GEMMs.
+            # Three streams: the encoder batches go to the current stream first (the GPU never waits for the host); the
+            # tracker (its encoder, then the latency-bound window rounds with one host sync each) runs on a high-priority
+            # side stream; once the trajectories are on the host the decoder chains of the frames of encoder batch b start
+            # on a third high-priority stream as soon as batch b is done, i.e. while later batches are still encoding.
             overlap = (not self.use_point_reinit) and images.is_cuda and self.overlap_tracker_and_encoder
+            pipeline = None
             if overlap:
-                if hasattr(self.point_tracker, "prepare"):                 # compute-bound fnet stays on this stream
-                    self.point_tracker.to(self.device).prepare(images)
                 ready = torch.cuda.Event()
-                ready.record()
-            sam_images = images if frame_ids is None else images[torch.as_tensor(frame_ids, device=images.device)]
-            feats = self.sam_predictor.encode_frames(sam_images, chw=True)   # every frame exactly once, embeddings in HBM
-            if overlap:
+                ready.record()                                               # frames are valid on the caller's stream
                 if self._side_stream is None:
                     self._side_stream = torch.cuda.Stream(device=images.device, priority=-1)
+                    self._dec_stream = torch.cuda.Stream(device=images.device, priority=-1)
+            sam_images = images if frame_ids is None else images[torch.as_tensor(frame_ids, device=images.device)]
+            batch_events = [] if (overlap and self.pipeline_decoder) else None
+            feats = self.sam_predictor.encode_frames(sam_images, chw=True, batch_events=batch_events)   # embeddings in HBM
+            if overlap:
                 self._side_stream.wait_event(ready)
                 with torch.cuda.stream(self._side_stream):
+                    if hasattr(self.point_tracker, "prepare"):
+                        self.point_tracker.to(self.device).prepare(images)
                     tracked = self._track_points(images, query_points)
                 torch.cuda.current_stream().wait_stream(self._side_stream)
+                if batch_events is not None:
+                    pipeline = (batch_events, self._dec_stream)
         n_masks, n_points_per_mask, _ = query_points.shape
         if query_masks is None:
             # In query_points mode the reference computes the query masks (sam_pt.py:181) but only asserts their shape
@@ -169,12 +180,13 @@ class SamPt(nn.Module):
         assert query_masks is None or query_masks.shape == (n_masks, height, width)
         if not self.use_point_reinit:
             trajectories, visibilities = tracked if tracked is not None else self._track_points(images, query_points)
+            pl = pipeline if fused else None
             if frame_ids is None:
-                _, logits, scores_per_frame = self._apply_sam_to_trajectories(images, trajectories, visibilities, feats)
+                _, logits, scores_per_frame = self._apply_sam_to_trajectories(images, trajectories, visibilities, feats, pl)
             else:
                 ids = torch.as_tensor(frame_ids)
                 _, logits, scores_per_frame = self._apply_sam_to_trajectories(sam_images, trajectories[ids],
-                                                                                visibilities[ids], feats)
+                                                                                visibilities[ids], feats, pl)
             scores = scores_per_frame.mean(dim=0)
         else:
             trajectories, visibilities, logits, scores, scores_per_frame = self._forward_w_reinit(images, query_points, feats)
@@ -429,18 +441,29 @@ class SamPt(nn.Module):
             labels = np.concatenate([labels, np.zeros((len(others)), dtype=int)], axis=0)
         return coords, labels
 
-    def _apply_sam_to_trajectories(self, images, trajectories, visibilities, feats=None):
+    def _apply_sam_to_trajectories(self, images, trajectories, visibilities, feats=None, pipeline=None):
         n_frames, channels, height, width = images.shape
         _, n_masks, points_per_mask, _ = trajectories.shape
         assert trajectories.shape == (n_frames, n_masks, points_per_mask, 2)
         assert visibilities.shape == (n_frames, n_masks, points_per_mask)
         trajectories, visibilities = trajectories.cpu(), visibilities.cpu()
         if feats is not None:
-            return self._apply_sam_fused(images, trajectories, visibilities, feats)
+            if pipeline is None:
+                return self._apply_sam_fused(images, trajectories, visibilities, feats)
+            events, stream = pipeline
+            with torch.cuda.stream(stream):       # everything of the SAM stage is allocated, launched and synced on `stream`
+                out = self._apply_sam_fused(images, trajectories, visibilities, feats, events)
+            cur = torch.cuda.current_stream()
+            cur.wait_stream(stream)
+            out[1].record_stream(cur)             # the logits are consumed on the caller's stream from here on
+            return out
         return self._apply_sam_stepwise(images, trajectories, visibilities)
 
     # -- device-resident path --------------------------------------------------------------------------------
-    def _apply_sam_fused(self, images, trajectories, visibilities, feats):
+    def _apply_sam_fused(self, images, trajectories, visibilities, feats, batch_events=None):
+        """``batch_events``: [(end_frame, event)] of the encoder batches (``SamPredictor.encode_frames``).  When given, the
+        current stream is a decoder stream that must not wait for the whole encoder: the items are chunked per encoder
+        batch and every chunk waits only for the event of the batch that holds its frames."""
         n_frames, _, height, width = images.shape
         n_masks = trajectories.shape[1]
         dev = self.device
@@ -473,20 +496,52 @@ class SamPt(nn.Module):
         npos_all = np.array([int((l == 1).sum()) for _, l in prompts], dtype=np.int32)
         k_d, npos_d = torch.from_numpy(k_all).to(dev), torch.from_numpy(npos_all).to(dev)
         Fmax = getattr(pred.model, "max_decode_batch", 1)
-        for s0 in range(0, len(items), Fmax):
-            chunk = items[s0:s0 + Fmax]
+        chunks = []                                                               # [(items, event to wait for or None)]
+        if batch_events:
+            lo = 0
+            for end, ev in batch_events:
+                group = [i for i in items if lo <= i // n_masks < end]
+                chunks += [(group[s0:s0 + Fmax], ev) for s0 in range(0, len(group), Fmax)]
+                lo = end
+        else:
+            chunks = [(items[s0:s0 + Fmax], None) for s0 in range(0, len(items), Fmax)]
+        cur_stream = torch.cuda.current_stream() if batch_events else None
+        use_graph = bool(getattr(pred, "use_graph", False)) and hasattr(pred, "decode_staging") and images.is_cuda
+        for chunk, ev in chunks:
+            if ev is not None:
+                cur_stream.wait_event(ev)
             idx = torch.tensor(chunk, dtype=torch.long, device=dev)
             t_idx, m_idx = idx // n_masks, idx % n_masks
             F_ = idx.numel()
             ks, ps = k_all[chunk], npos_all[chunk]
             ragged = bool((ks != ks[0]).any() or (two_pass and (ps != ps[0]).any()))
-            out_l = torch.empty((F_, height, width), dtype=torch.float32, device=dev)
-            out_s = torch.empty((F_,), dtype=torch.float32, device=dev)
-            pred.track_decode(feats.index_select(0, t_idx), xy_d.index_select(0, idx).contiguous(),
-                              lab_d.index_select(0, idx).contiguous(), int(ks.max()), int(ps.max()) if two_pass else -1,
-                              int(self.iterative_refinement_iterations), float(self.sam_iou_threshold), size,
-                              out_l, out_s, k_item=k_d.index_select(0, idx).contiguous() if ragged else None,
-                              npos_item=npos_d.index_select(0, idx).contiguous() if (ragged and two_pass) else None)
+            if use_graph:
+                # a replayed hipGraph has its pointers baked in: the chunk's inputs are gathered into the bucket's
+                # persistent buffers and its outputs land there (SamPredictor.decode_staging)
+                st = pred.decode_staging(F_, xy_d.shape[1], size)
+                emb, hq = (feats.emb, feats.hq) if hasattr(feats, "emb") else (feats, None)
+                torch.index_select(emb, 0, t_idx, out=st["feats"])
+                f_in = st["feats"]
+                if hq is not None:
+                    torch.index_select(hq, 0, t_idx, out=st["hq"])
+                    f_in = type(feats)(st["feats"], st["hq"])
+                torch.index_select(xy_d, 0, idx, out=st["pts"])
+                torch.index_select(lab_d, 0, idx, out=st["labels"])
+                torch.index_select(k_d, 0, idx, out=st["k_item"])
+                torch.index_select(npos_d, 0, idx, out=st["npos_item"])
+                out_l, out_s = st["logits"], st["score"]
+                pred.track_decode(f_in, st["pts"], st["labels"], int(ks.max()), int(ps.max()) if two_pass else -1,
+                                  int(self.iterative_refinement_iterations), float(self.sam_iou_threshold), size, out_l,
+                                  out_s, k_item=st["k_item"] if ragged else None,
+                                  npos_item=st["npos_item"] if (ragged and two_pass) else None, graph=True)
+            else:
+                out_l = torch.empty((F_, height, width), dtype=torch.float32, device=dev)
+                out_s = torch.empty((F_,), dtype=torch.float32, device=dev)
+                pred.track_decode(feats.index_select(0, t_idx), xy_d.index_select(0, idx).contiguous(),
+                                  lab_d.index_select(0, idx).contiguous(), int(ks.max()), int(ps.max()) if two_pass else -1,
+                                  int(self.iterative_refinement_iterations), float(self.sam_iou_threshold), size,
+                                  out_l, out_s, k_item=k_d.index_select(0, idx).contiguous() if ragged else None,
+                                  npos_item=npos_d.index_select(0, idx).contiguous() if (ragged and two_pass) else None)
             logits[m_idx, t_idx] = out_l
             scores[idx] = out_s
         scores_cpu = scores.cpu().view(n_frames, n_masks)                        # the only sync of the SAM stage

@@ -799,3 +799,76 @@ def test_pips_fused_splitk_reductions_opt_in(dev, pips_sd, clip, monkeypatch):
     assert torch.equal(vi0, vi1) and max_abs(tr1, tr0) < 1e-3
     assert torch.equal(torch.round(tr0), torch.round(tr1))
     print("fused == unfused bitwise:", torch.equal(tr0, tr1))
+
+
+# ------------------------------------------------------------------------------------------ streams / hipGraph
+def test_track_decode_graph_replay_is_bitwise_eager(dev):
+    """north_star "hipGraph capture of the per-frame decode": the chain of sampt_sam_track_decode replayed from a captured
+    hipGraph (persistent bucket buffers, non-default stream) gives the eager chain's results bit for bit; first call of a
+    signature is eager, the second captures, later ones only replay; new inputs in the same buffers are picked up."""
+    from sam_pt_amd.sam_predictor import SamHip, SamPredictor
+    from sam_pt_amd.weights import SAM_CONFIGS
+    cfg = SAM_CONFIGS["vit_test"]
+    pred = SamPredictor(SamHip(config=cfg, seed=72, precision="f32", max_decode_batch=4).to(dev))
+    frames, _ = synthetic_clip(T=4, H=128, W=256, seed=3)
+    feats = pred.encode_frames(frames.to(dev))
+    g = torch.Generator().manual_seed(5)
+    F_, K = 4, 5
+    st = pred.decode_staging(F_, K, (128, 256))
+    side = torch.cuda.Stream(device=dev)
+
+    def fill(seed):
+        gg = torch.Generator().manual_seed(seed)
+        st["feats"].copy_(feats[torch.randperm(4, generator=gg)])
+        st["pts"].copy_((torch.rand(F_, K, 2, generator=gg) * torch.tensor([250.0, 120.0])).to(dev))
+        st["labels"].copy_((torch.rand(F_, K, generator=gg) > 0.3).int().to(dev))
+        st["k_item"].copy_(torch.tensor([5, 3, 1, 4], dtype=torch.int32).to(dev))
+
+    def run(graph, out_l, out_s):
+        pred.track_decode(st["feats"], st["pts"], st["labels"], K, -1, 3, 0.0, (128, 256), out_l, out_s,
+                          k_item=st["k_item"], graph=graph)
+
+    c0 = pred.graph_stats()
+    for it, seed in enumerate((1, 2, 3, 4)):
+        fill(seed)
+        torch.cuda.synchronize()
+        ref_l, ref_s = torch.empty_like(st["logits"]), torch.empty_like(st["score"])
+        run(False, ref_l, ref_s)                                         # eager, default stream, fresh outputs
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            run(True, st["logits"], st["score"])
+        side.synchronize()
+        assert torch.equal(st["logits"], ref_l) and torch.equal(st["score"], ref_s), f"call {it}"
+    c1 = pred.graph_stats()
+    assert c1[1] - c0[1] == 1 and c1[2] - c0[2] == 3, (c0, c1)           # 1 capture; replays on calls 2, 3, 4
+
+
+def test_pipelined_decoder_stream_equals_serial(dev, pips_sd):
+    """SamPt's three-stream schedule (decoder chains per encoder batch on their own stream, replayed from hipGraphs) vs the
+    serial schedule: same trajectories, masks within the batched-vs-unbatched tolerance."""
+    from sam_pt_amd.point_tracker import PipsPointTracker
+    from sam_pt_amd.sam_predictor import SamHip, SamPredictor
+    from sam_pt_amd.sam_pt import SamPt
+    from sam_pt_amd.weights import SAM_CONFIGS
+    cfg = SAM_CONFIGS["vit_test"]
+    frames, centres = synthetic_clip(T=11, H=128, W=256, seed=72)
+    q = torch.stack([disc_queries(centres, n_pos=4, r=9.0), disc_queries(centres, n_pos=4, r=5.0) + torch.tensor([0.0, -50.0, 20.0])])
+    outs = []
+    for pipelined in (False, True):
+        pred = SamPredictor(SamHip(config=cfg, seed=72, precision="f32", max_batch=4, max_decode_batch=8).to(dev))
+        model = SamPt(PipsPointTracker(state_dict=pips_sd), pred, sam_iou_threshold=-1e9, positive_points_per_mask=4,
+                      negative_points_per_mask=0, iterative_refinement_iterations=3).eval()
+        model.pipeline_decoder = pipelined
+        for rep in range(3 if pipelined else 1):                          # repeats exercise capture and replay
+            out = model({"image": [f.to(dev) for f in frames], "target_hw": (128, 256), "query_points": q})
+        torch.cuda.synchronize()
+        outs.append(out)
+        if pipelined:
+            assert pred.graph_stats()[2] > 0, "the pipelined schedule never replayed a graph"
+    a, b = outs
+    assert torch.equal(a["trajectories"], b["trajectories"]) and torch.equal(a["visibilities"], b["visibilities"])
+    for m in range(2):
+        assert max_abs(a["logits"][m], b["logits"][m]) < 2e-3
+        for t in range(11):
+            assert iou(a["logits"][m][t] > 0, b["logits"][m][t] > 0) >= 1 - 1e-3
+    assert np.allclose(np.array(a["scores_per_frame"]), np.array(b["scores_per_frame"]), atol=1e-4)

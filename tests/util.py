@@ -35,7 +35,7 @@ def make_fake_device_predictor(sd, cfg, max_decode_batch=3):
             self.model.max_decode_batch = max_decode_batch
             self.calls = []
 
-        def encode_frames(self, frames, chw=True):
+        def encode_frames(self, frames, chw=True, batch_events=None):
             x = R.preprocess(cfg, frames.float())
             return torch.cat([R.image_encoder(sd, cfg, x[i:i + 1]) for i in range(len(x))])
 
