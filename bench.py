@@ -37,8 +37,15 @@ def parse():
     ap.add_argument("--precision", default="f16", choices=["f16", "f32"])
     ap.add_argument("--encode-batch", type=int, default=8)
     ap.add_argument("--decode-batch", type=int, default=32, help="max (frame, object) items per batched decoder chain")
-    ap.add_argument("--tracker", default="pips", choices=["pips", "pips_plus_plus"],
-                    help="point tracker (the metric is quoted on PIPS; PIPS++ = SURVEY.md §8 row f4)")
+    ap.add_argument("--tracker", default="pips", choices=["pips", "pips_plus_plus", "cotracker"],
+                    help="point tracker (the metric is quoted on PIPS; CoTracker = BASELINE configs #3/#5, row a13; "
+                         "PIPS++ = SURVEY.md §8 row f4)")
+    ap.add_argument("--neg-points", type=int, default=0, help="negative query points per object (config #3: 8 + 8)")
+    ap.add_argument("--square", type=int, default=0, help="square synthetic frames of this size (config #5: 1024)")
+    ap.add_argument("--dec-pipeline", action="store_true",
+                    help="start the decoder chains of each encoder batch as soon as that batch is done (measured: loses)")
+    ap.add_argument("--overlap-fnet", action="store_true", help="tracker encoder on the side stream too (measured: loses)")
+    ap.add_argument("--no-dec-graph", action="store_true", help="decode chains as plain launches instead of hipGraph replays")
     ap.add_argument("--shard", default="sequences", choices=["sequences", "frames"],
                     help="N > 1: 'sequences' = one clip per rank (weak scaling, the default the metric uses); 'frames' = ONE "
                          "clip, its frame batches dealt over the ranks (strong scaling, BASELINE config #5)")
@@ -70,10 +77,18 @@ def build_model(args, dev):
     from sam_pt_amd.weights import init_pips_state_dict
     if args.tracker == "pips":
         tracker = PipsPointTracker(state_dict=init_pips_state_dict(72, vis_bias=args.pips_vis_bias), fnet_chunk=8)
+    elif args.tracker == "cotracker":
+        from sam_pt_amd.point_tracker import CoTrackerPointTracker
+        tracker = CoTrackerPointTracker(seed=72, fnet_chunk=8)            # configs/model/point_tracker/cotracker.yaml
     else:
         from sam_pt_amd.point_tracker import PipsPlusPlusPointTracker
         tracker = PipsPlusPlusPointTracker(seed=72, fnet_chunk=8)
-    model = SamPt(tracker, SamPredictor(sam), **sampt_kwargs(args)).eval()
+    pred = SamPredictor(sam)
+    if args.no_dec_graph:
+        pred.use_graph = False
+    model = SamPt(tracker, pred, **sampt_kwargs(args)).eval()
+    model.pipeline_decoder = args.dec_pipeline
+    model.overlap_tracker_encoder_fnet = args.overlap_fnet
     return model
 
 
@@ -157,7 +172,7 @@ def gemm_roofline(args, dev, insitu=None):
 
 
 def sampt_kwargs(args, **over):
-    kw = dict(sam_iou_threshold=-1e9, positive_points_per_mask=args.points, negative_points_per_mask=0,
+    kw = dict(sam_iou_threshold=-1e9, positive_points_per_mask=args.points, negative_points_per_mask=args.neg_points,
               iterative_refinement_iterations=args.refine, point_tracker_mask_batch_size=5)
     kw.update(over)
     return kw
@@ -257,7 +272,7 @@ def main():
     torch.set_num_threads(max(1, min(32, (os.cpu_count() or 8) // max(world, 1))))
     frames_sharded = args.shard == "frames" and world > 1
     frames, qp = bench_clip(T=args.frames, seed=72 + (0 if frames_sharded else rank), n_pos=args.points,
-                            n_objects=args.objects, native=args.native_480p)
+                            n_objects=args.objects, native=args.native_480p, n_neg=args.neg_points, square=args.square)
     H, W = frames.shape[-2:]
     model = build_model(args, dev)
     frames_dev = frames.to(dev)
@@ -292,14 +307,15 @@ def main():
     if rank == 0:
         from sam_pt_amd.pack import fnet_f16x3_enabled
         tracker_precision = ("fp32-grade: correlation/mixer exact f32 MFMA; encoder convolutions 3-term split-fp16 MFMA "
-                             "(hi*hi + hi*lo + lo*hi, fp32 accumulate)" if fnet_f16x3_enabled(args.tracker == "pips")
+                             "(hi*hi + hi*lo + lo*hi, fp32 accumulate)" if fnet_f16x3_enabled(args.tracker in ("pips", "cotracker"))
                              else "fp32 (exact f32 MFMA)")
         res = {"metric": "frames/sec end-to-end (SAM-PT: ViT + PIPS, 480p, 8 pts, 1 obj)", "value": round(fps, 3),
                "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "strong" if frames_sharded else "weak",
                "vs_baseline": None,
                "dtype": "f16" if args.precision == "f16" else "f32", "data": "synthetic",
-               "config": {"workload": f"{'HQ-SAM' if args.hq else 'SAM'} {args.model} + {'PIPS' if args.tracker == 'pips' else 'PIPS++'}, {args.points} query points, {args.objects} object(s), "
+               "config": {"workload": f"{'HQ-SAM' if args.hq else 'SAM'} {args.model} + { {'pips': 'PIPS', 'cotracker': 'CoTracker', 'pips_plus_plus': 'PIPS++'}[args.tracker]}, {args.points}"
+                                      f"{'+' + str(args.neg_points) if args.neg_points else ''} query points, {args.objects} object(s), "
                                       f"{args.frames}x 480p synthetic frames " + ("at native " if args.native_480p else "upscaled to ") + f"{H}x{W}, "
                                       f"{args.refine} refinement iterations, random-init weights (seed 72)",
                           "frames_per_step": args.frames, "parallelism": f"{'frame-batch' if frames_sharded else 'sequence'}-sharded x{world}",

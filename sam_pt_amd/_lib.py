@@ -120,6 +120,12 @@ def load():
     return lib
 
 
+def require_hip(device, who: str):
+    """The hot path has no CPU / PyTorch fallback: anything but a HIP device is an error."""
+    if getattr(device, "type", None) != "cuda":
+        raise SamptError(f"{who} runs on the HIP device only (no CPU fallback); got {device}")
+
+
 def check(rc: int, what: str):
     if rc != 0:
         msg = load().sampt_last_error()

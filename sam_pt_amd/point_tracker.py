@@ -108,8 +108,7 @@ class PipsPointTracker(PointTracker):
     def _ensure(self, device: torch.device):
         if self._h is not None and self._device == device:
             return
-        if device.type != "cuda":
-            raise _lib.SamptError("PipsPointTracker runs on the HIP device only (no CPU fallback); got " + str(device))
+        _lib.require_hip(device, "PipsPointTracker")
         lib = _lib.load()
         self._w = pack_pips(self._sd, device, self.s)
         names, ptrs, n = _lib.name_table(self._w)
@@ -294,8 +293,7 @@ class PipsPlusPlusPointTracker(PointTracker):
     def _ensure(self, device: torch.device):
         if self._h is not None and self._device == device:
             return
-        if device.type != "cuda":
-            raise _lib.SamptError("PipsPlusPlusPointTracker runs on the HIP device only (no CPU fallback); got " + str(device))
+        _lib.require_hip(device, "PipsPlusPlusPointTracker")
         from .pack import pack_pips2
         lib = _lib.load()
         self._w = pack_pips2(self._sd, device)
@@ -482,8 +480,7 @@ class CoTrackerPointTracker(PointTracker):
     def _ensure(self, device: torch.device):
         if self._h is not None and self._device == device:
             return
-        if device.type != "cuda":
-            raise _lib.SamptError("CoTrackerPointTracker runs on the HIP device only (no CPU fallback); got " + str(device))
+        _lib.require_hip(device, "CoTrackerPointTracker")
         from .pack import pack_cotracker
         lib = _lib.load()
         self._w = pack_cotracker(self._sd, device, self.s)

@@ -145,20 +145,39 @@ class SamHip(nn.Module):
     mask_threshold: float = 0.0
     image_format: str = "RGB"
 
-    def __init__(self, variant: str = "vit_h", checkpoint: Optional[str] = None, state_dict=None, seed: int = 72,
+    def __init__(self, variant: Optional[str] = None, checkpoint: Optional[str] = None, state_dict=None, seed: int = 72,
                  precision: str = "f16", config: Optional[SamConfig] = None, max_batch: int = 8,
-                 max_decode_batch: int = 32, hq: Optional[bool] = None, **hydra_kwargs):
+                 max_decode_batch: int = 32, hq: Optional[bool] = None, image_encoder=None, prompt_encoder=None,
+                 mask_decoder=None, pixel_mean=None, pixel_std=None, **hydra_kwargs):
         """``hq``: build the HQ-SAM decoder (sam_pt/modeling/sam.py SamHQHydra, configs/model/sam/samhq_vit_*.yaml);
-        default: inferred from the checkpoint (presence of ``mask_decoder.hf_token.weight``)."""
+        default: inferred from the checkpoint (presence of ``mask_decoder.hf_token.weight``) or from the ``mask_decoder``
+        node's ``_target_`` (``...MaskDecoderHQ``).
+
+        Hydra: this class stands in for ``sam_pt.modeling.sam.Sam*Hydra`` (sam.py:18-61) and takes the very keywords of
+        ``configs/model/sam/*.yaml``.  The geometry comes from the nested ``image_encoder`` node (``embed_dim, depth,
+        num_heads, global_attn_indexes, window_size, ...`` of configs/model/sam/image_encoder/vit_*.yaml) — a mapping when
+        the node is left un-instantiated (``+...sam_model._recursive_=false``), or upstream's
+        ``ImageEncoderViT`` object if Hydra did instantiate it; ``variant`` is only a shorthand for code that builds the
+        object by hand.  ``prompt_encoder`` / ``mask_decoder`` hyper-parameters are the fixed ones of
+        configs/model/sam/{prompt_encoder,mask_decoder}/sam.yaml and are checked, not used."""
         super().__init__()
-        self.cfg = config if config is not None else SAM_CONFIGS[variant]
+        if config is None:
+            config = self._config_from_hydra(image_encoder, mask_decoder, pixel_mean, pixel_std, hydra_kwargs)
+        if config is None:
+            config = SAM_CONFIGS[variant if variant is not None else "vit_h"]
+        elif variant is not None and (SAM_CONFIGS[variant].embed_dim, SAM_CONFIGS[variant].depth) != (config.embed_dim, config.depth):
+            raise ValueError(f"variant={variant} contradicts the image_encoder config (embed_dim {config.embed_dim}, depth {config.depth})")
+        self.cfg = config
+        if hq is None and mask_decoder is not None:
+            tgt = mask_decoder.get("_target_", "") if hasattr(mask_decoder, "get") else type(mask_decoder).__name__
+            if str(tgt).endswith("MaskDecoderHQ"):
+                hq = True if (state_dict is None and checkpoint is None) else None   # a checkpoint decides by its keys
         if state_dict is None and checkpoint is not None:
             with open(checkpoint, "rb") as f:
                 state_dict = torch.load(f, map_location="cpu")
-        if state_dict is None:
-            state_dict = init_sam_state_dict(self.cfg, seed, hq=bool(hq))
-        self.sd = state_dict
-        has_hq = "mask_decoder.hf_token.weight" in self.sd
+        # no checkpoint: seeded random weights in the upstream key layout, generated on first use (ViT-H is 2.5 GB of fp32)
+        self._sd, self._seed = state_dict, seed
+        has_hq = bool(hq) if state_dict is None else "mask_decoder.hf_token.weight" in state_dict
         self.hq = has_hq if hq is None else bool(hq)
         if self.hq and not has_hq:
             raise ValueError("hq=True but the checkpoint has no MaskDecoderHQ weights (mask_decoder.hf_token.weight ...)")
@@ -169,6 +188,49 @@ class SamHip(nn.Module):
         self.register_buffer("pixel_mean", torch.tensor(self.cfg.pixel_mean).view(-1, 1, 1), persistent=False)
         self.prompt_embed_dim, self.image_size = self.cfg.out_chans, self.cfg.img_size
         self.vit_patch_size, self.image_embedding_size = self.cfg.patch_size, self.cfg.grid
+
+    @property
+    def sd(self):
+        if self._sd is None:
+            self._sd = init_sam_state_dict(self.cfg, self._seed, hq=self.hq)
+        return self._sd
+
+    @staticmethod
+    def _config_from_hydra(image_encoder, mask_decoder, pixel_mean, pixel_std, kw) -> Optional[SamConfig]:
+        """SamConfig from the keyword arguments Hydra passes for configs/model/sam/*.yaml (None if there is no
+        ``image_encoder`` node to read)."""
+        if image_encoder is None:
+            return None
+        if hasattr(image_encoder, "get"):                                   # un-instantiated node (mapping / DictConfig)
+            ie = image_encoder
+            g = lambda k, d=None: ie.get(k, d)
+            embed_dim, depth, heads = int(g("embed_dim")), int(g("depth")), int(g("num_heads"))
+            gidx = tuple(int(i) for i in g("global_attn_indexes"))
+            window, mlp_ratio = int(g("window_size", 14)), int(g("mlp_ratio", 4))
+            img = int(g("img_size", kw.get("image_size", 1024)))
+            patch = int(g("patch_size", kw.get("vit_patch_size", 16)))
+            out_chans = int(g("out_chans", kw.get("prompt_embed_dim", 256)))
+            if not (g("use_rel_pos", True) and g("qkv_bias", True)):
+                raise ValueError("SamHip: the HIP encoder implements SAM's ViT (use_rel_pos and qkv_bias are always on)")
+        else:                                                               # upstream ImageEncoderViT instance
+            blocks = list(image_encoder.blocks)
+            embed_dim, depth = int(image_encoder.pos_embed.shape[-1]), len(blocks)
+            heads = int(blocks[0].attn.num_heads)
+            gidx = tuple(i for i, b in enumerate(blocks) if int(b.window_size) == 0)
+            window = max(int(b.window_size) for b in blocks)
+            mlp_ratio = int(blocks[0].mlp.lin1.out_features // embed_dim)
+            img, patch = int(image_encoder.img_size), int(image_encoder.patch_embed.proj.kernel_size[0])
+            out_chans = int(image_encoder.neck[0].out_channels)
+        name = {(768, 12): "vit_b", (1024, 24): "vit_l", (1280, 32): "vit_h"}.get((embed_dim, depth), f"vit_{embed_dim}x{depth}")
+        extra = {}
+        if pixel_mean is not None:
+            extra["pixel_mean"] = tuple(float(v) for v in pixel_mean)
+        if pixel_std is not None:
+            extra["pixel_std"] = tuple(float(v) for v in pixel_std)
+        if "image_embedding_size" in kw and int(kw["image_embedding_size"]) != img // patch:
+            raise ValueError("image_embedding_size must equal image_size / vit_patch_size")
+        return SamConfig(name, embed_dim, depth, heads, gidx, img_size=img, patch_size=patch, window_size=window,
+                         mlp_ratio=mlp_ratio, out_chans=out_chans, **extra)
 
     @property
     def device(self):
@@ -208,8 +270,7 @@ class SamPredictor:
         dev = self.model.device
         if self._vit is not None and self._dev == dev:
             return
-        if dev.type != "cuda":
-            raise _lib.SamptError("SamPredictor runs on the HIP device only (no CPU fallback); model is on " + str(dev))
+        _lib.require_hip(dev, "SamPredictor")
         lib = _lib.load()
         cfg, m = self.model.cfg, self.model
         f16 = m.precision == "f16"

@@ -88,8 +88,15 @@ class SamPt(nn.Module):
         self.profile = {}
         self.compute_unused_query_masks = False        # fused path: see forward()
         self.overlap_tracker_and_encoder = True        # fused path only: tracker on a second HIP stream (see forward)
-        self.pipeline_decoder = True                   # fused path only: decoder chains of early frames run on a third
-        self._side_stream = None                       # stream while the encoder still works on later frames
+        # fused path only.  The decoder chain always runs on a third (non-default, hence hipGraph-capturable) stream after
+        # the encoder; pipeline_decoder=True instead starts the chains of each encoder batch as soon as that batch is done,
+        # and overlap_tracker_encoder_fnet=True moves the tracker's own encoder to the side stream too.  Both were
+        # measured on MI355X (profiles/r2_v2_*) and LOSE: the ViT GEMMs already fill the chip, so concurrent compute-bound
+        # work only contends (fp16 GEMM 421 -> 469 us, tracker convs 2-3x longer) and 8-item decoder chains cost 1.7x the
+        # GPU time of one 24-item chain: 77.9 fps serial, 75.2 with the tracker encoder overlapped, 71.9 with both.
+        self.pipeline_decoder = False
+        self.overlap_tracker_encoder_fnet = False
+        self._side_stream = None
         self._dec_stream = None
 
     @property
@@ -146,29 +153,33 @@ class SamPt(nn.Module):
             # The image encoder (compute-bound, no host syncs) and the point tracker (many small launches, one host sync
             # per round) only share the input frames: the whole clip's encoder work is enqueued on the current stream and
             # the tracker then runs on a second, high-priority stream, filling the GPU around the big GEMMs.
-            # Three streams: the encoder batches go to the current stream first (the GPU never waits for the host); the
-            # tracker (its encoder, then the latency-bound window rounds with one host sync each) runs on a high-priority
-            # side stream; once the trajectories are on the host the decoder chains of the frames of encoder batch b start
-            # on a third high-priority stream as soon as batch b is done, i.e. while later batches are still encoding.
+            # Streams: the tracker's encoder (compute-bound) and then the SAM encoder batches go to the current stream, the
+            # tracker's latency-bound window rounds (one host sync each) run beside the SAM encoder on a high-priority
+            # side stream, and the decoder chain runs on a third stream once the trajectories are on the host and the
+            # encoder is done (see the knobs in __init__ for the measured alternatives).
             overlap = (not self.use_point_reinit) and images.is_cuda and self.overlap_tracker_and_encoder
             pipeline = None
             if overlap:
+                if hasattr(self.point_tracker, "prepare") and not self.overlap_tracker_encoder_fnet:
+                    self.point_tracker.to(self.device).prepare(images)
                 ready = torch.cuda.Event()
-                ready.record()                                               # frames are valid on the caller's stream
+                ready.record()                                               # frames (and pyramid) valid on this stream
                 if self._side_stream is None:
                     self._side_stream = torch.cuda.Stream(device=images.device, priority=-1)
                     self._dec_stream = torch.cuda.Stream(device=images.device, priority=-1)
             sam_images = images if frame_ids is None else images[torch.as_tensor(frame_ids, device=images.device)]
-            batch_events = [] if (overlap and self.pipeline_decoder) else None
+            batch_events = [] if overlap else None
             feats = self.sam_predictor.encode_frames(sam_images, chw=True, batch_events=batch_events)   # embeddings in HBM
             if overlap:
                 self._side_stream.wait_event(ready)
                 with torch.cuda.stream(self._side_stream):
-                    if hasattr(self.point_tracker, "prepare"):
+                    if hasattr(self.point_tracker, "prepare") and self.overlap_tracker_encoder_fnet:
                         self.point_tracker.to(self.device).prepare(images)
                     tracked = self._track_points(images, query_points)
                 torch.cuda.current_stream().wait_stream(self._side_stream)
-                if batch_events is not None:
+                if batch_events:
+                    if not self.pipeline_decoder:                            # one chain for the clip, after the last batch
+                        batch_events = [(batch_events[-1][0], batch_events[-1][1])]
                     pipeline = (batch_events, self._dec_stream)
         n_masks, n_points_per_mask, _ = query_points.shape
         if query_masks is None:

@@ -55,18 +55,25 @@ def upscale_to_longest_side(frames: torch.Tensor, centres: torch.Tensor, long_si
     return out, centres * s
 
 
-def bench_clip(T: int = 24, seed: int = 72, n_pos: int = 8, n_objects: int = 1, native: bool = False):
+def bench_clip(T: int = 24, seed: int = 72, n_pos: int = 8, n_objects: int = 1, native: bool = False, n_neg: int = 0,
+               square: int = 0):
     """The benchmark workload: a 480x854 synthetic clip upscaled to 576x1024 (as the reference pipelines do before SamPt:
     configs/demo.yaml:20), 8 positive query points on one object at t = 0 (BASELINE.json metric: ViT-H + PIPS, 480p,
     8 pts, 1 obj).  ``native`` keeps the 480x854 frames: the tracker then runs at that resolution and SAM resizes."""
-    frames, centres = synthetic_clip(T=T, H=480, W=854, seed=seed, disc_r=60.0)
-    scale = 854.0 / 1024.0 if native else 1.0                # query geometry is defined on the 576 x 1024 frames
-    if not native:
-        frames, centres = upscale_to_longest_side(frames, centres, 1024)
+    if square:                                               # BASELINE config #5: square input (1024 x 1024), no resize
+        frames, centres = synthetic_clip(T=T, H=square, W=square, seed=seed, disc_r=72.0 * square / 1024.0)
+        scale = square / 1024.0
+    else:
+        frames, centres = synthetic_clip(T=T, H=480, W=854, seed=seed, disc_r=60.0)
+        scale = 854.0 / 1024.0 if native else 1.0            # query geometry is defined on the 576 x 1024 frames
+        if not native:
+            frames, centres = upscale_to_longest_side(frames, centres, 1024)
     qs = []
     for m in range(n_objects):           # object 0 = the moving disc; further objects = background patches
         q = disc_queries(centres, n_pos=n_pos, r=36.0 * scale, t=0)
-        q[:, 1] += 260.0 * scale * m
+        if n_neg:                        # negatives (tail points, sam_pt.py:731-733) on a ring outside the disc
+            q = torch.cat([q, disc_queries(centres, n_pos=n_neg, r=115.0 * scale, t=0)])
+        q[:, 1] += 260.0 * scale * (m % 3) * (1 if m < 3 else -1)
         q[:, 2] += (-120.0 if m % 2 else 90.0) * scale * (m > 0)
         qs.append(q)
     return frames, torch.stack(qs)

@@ -858,7 +858,7 @@ def test_pipelined_decoder_stream_equals_serial(dev, pips_sd):
         pred = SamPredictor(SamHip(config=cfg, seed=72, precision="f32", max_batch=4, max_decode_batch=8).to(dev))
         model = SamPt(PipsPointTracker(state_dict=pips_sd), pred, sam_iou_threshold=-1e9, positive_points_per_mask=4,
                       negative_points_per_mask=0, iterative_refinement_iterations=3).eval()
-        model.pipeline_decoder = pipelined
+        model.pipeline_decoder = model.overlap_tracker_encoder_fnet = pipelined
         for rep in range(3 if pipelined else 1):                          # repeats exercise capture and replay
             out = model({"image": [f.to(dev) for f in frames], "target_hw": (128, 256), "query_points": q})
         torch.cuda.synchronize()
