@@ -133,3 +133,53 @@ def load_sam_pt():
     _link_children()
     M = importlib.import_module("sam_pt.modeling.sam_pt")
     return M.SamPt
+
+
+def load_evaluator():
+    """Returns the reference ``SamPtEvaluator`` class (sam_pt/vos_eval/evaluator.py:47-60)."""
+    load_sam_pt()
+    _ns("sam_pt.vos_eval", "/sam_pt/vos_eval")
+    import importlib
+    E = importlib.import_module("sam_pt.vos_eval.evaluator")
+    _link_children()
+    return E.SamPtEvaluator
+
+
+def load_demo():
+    """Returns the reference ``demo.demo`` module (for ``run_inference``, demo/demo.py:114-155) with its control-plane
+    imports (hydra, omegaconf, cv2, wandb, matplotlib, the visualisation helper) stubbed."""
+    import importlib
+    import importlib.machinery
+    load_sam_pt()
+
+    def stub(name, **attrs):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__path__ = []
+            m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+            sys.modules[name] = m
+        for k, v in attrs.items():
+            setattr(sys.modules[name], k, v)
+        return sys.modules[name]
+
+    if "hydra" not in sys.modules:
+        stub("hydra", main=lambda **kw: (lambda fn: fn))           # @hydra.main(...) -> identity decorator
+        stub("hydra.core")
+        stub("hydra.core.hydra_config", HydraConfig=object)
+        stub("hydra.utils", instantiate=None)
+    if "omegaconf" not in sys.modules:
+        stub("omegaconf", OmegaConf=object)
+    for name in ("cv2", "wandb"):
+        stub(name)
+    try:
+        importlib.import_module("matplotlib.pyplot")
+    except Exception:
+        stub("matplotlib")
+        stub("matplotlib.pyplot")
+        sys.modules["matplotlib"].pyplot = sys.modules["matplotlib.pyplot"]
+    util = sys.modules.get("sam_pt.utils.util")
+    if util is not None and not hasattr(util, "visualize_predictions"):
+        util.visualize_predictions = None
+    _ns("demo", "/demo")
+    D = importlib.import_module("demo.demo")
+    return D

@@ -1,0 +1,162 @@
+"""Drop-in proof on the CPU: the reference's OWN config tree
+(``configs/model/sam_pt.yaml`` + ``point_tracker/*.yaml`` + ``sam/*.yaml``) composed and instantiated with exactly the
+overrides INTEGRATION.md lists builds our seam classes; and — where /root/reference exists — the UNCHANGED reference
+``SamPt`` (sam_pt/modeling/sam_pt.py), ``demo.demo.run_inference`` (demo/demo.py:114-155) and
+``SamPtEvaluator.evaluate_video`` (sam_pt/vos_eval/evaluator.py:47-60) run over those classes, whose C-ABI layer is a
+recording fake computing with the CPU oracle (tests/fake_hip.py), and give the oracle-driven reference protocol's results.
+Hydra / OmegaConf are not installed: tests/hydra_lite.py restates the subset the model configs use."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import hydra_lite as H
+from tests.util import disc_queries, iou, synthetic_clip
+
+REF = "/root/reference"
+CONFIGS = os.path.join(REF, "configs")
+needs_ref = pytest.mark.skipif(not os.path.isdir(CONFIGS), reason="reference tree not present (GPU box)")
+
+# INTEGRATION.md §1, verbatim (Hydra CLI syntax)
+OVERRIDES = ["model.point_tracker._target_=sam_pt_amd.point_tracker.{TRACKER}",
+             "model.sam_predictor._target_=sam_pt_amd.sam_predictor.SamPredictor",
+             "model.sam_predictor.sam_model._target_=sam_pt_amd.sam_predictor.SamHip",
+             "+model.sam_predictor.sam_model._recursive_=false"]
+TEST_GEOMETRY = ["model.sam_predictor.sam_model.image_encoder.depth=2", "model.sam_predictor.sam_model.image_encoder.embed_dim=64",
+                 "model.sam_predictor.sam_model.image_encoder.num_heads=2", "model.sam_predictor.sam_model.image_encoder.window_size=6",
+                 "model.sam_predictor.sam_model.image_encoder.global_attn_indexes=[1]", "model.sam_predictor.sam_model.image_size=256",
+                 "model.sam_predictor.sam_model.image_embedding_size=16"]
+
+
+def _compose(tracker_option, sam_option, tracker_cls, extra=()):
+    cfg = {"model": H.compose(CONFIGS, "model", "sam_pt", {"point_tracker": tracker_option,
+                                                           "sam@sam_predictor.sam_model": sam_option})}
+    ov = [o.replace("{TRACKER}", tracker_cls) for o in OVERRIDES] + list(extra)
+    H.apply_overrides(cfg, ov)
+    H.apply_overrides(cfg, ["model.point_tracker.checkpoint_path=null", "model.sam_predictor.sam_model.checkpoint=null"])
+    return H.resolve(cfg, cwd="/nonexistent")["model"]
+
+
+@needs_ref
+@pytest.mark.parametrize("tracker_option,tracker_cls,sam_option,hq", [
+    ("cotracker", "CoTrackerPointTracker", "samhq_vit_huge", True),        # the shipped defaults (sam_pt.yaml:3-5)
+    ("pips", "PipsPointTracker", "sam_vit_huge", False),                   # the metric's configuration
+    ("pips_plus_plus", "PipsPlusPlusPointTracker", "sam_vit_base", False)])
+def test_reference_yaml_instantiates_our_classes(tracker_option, tracker_cls, sam_option, hq):
+    """Every keyword of the reference YAMLs is accepted; the SAM geometry comes from the nested image_encoder node."""
+    import sam_pt_amd.point_tracker as P
+    from sam_pt_amd.sam_predictor import SamHip, SamPredictor
+    from sam_pt_amd.sam_pt import SamPt
+    cfg = _compose(tracker_option, sam_option, tracker_cls, ["model._target_=sam_pt_amd.sam_pt.SamPt"])
+    model = H.instantiate(cfg)
+    assert type(model) is SamPt and type(model.point_tracker) is getattr(P, tracker_cls)
+    assert type(model.sam_predictor) is SamPredictor and type(model.sam_predictor.model) is SamHip
+    sam = model.sam_predictor.model
+    want = {"samhq_vit_huge": (1280, 32, 16, (7, 15, 23, 31)), "sam_vit_huge": (1280, 32, 16, (7, 15, 23, 31)),
+            "sam_vit_base": (768, 12, 12, (2, 5, 8, 11))}[sam_option]
+    assert (sam.cfg.embed_dim, sam.cfg.depth, sam.cfg.num_heads, sam.cfg.global_attn_indexes) == want
+    assert sam.hq is hq and sam.image_size == 1024 and sam.image_embedding_size == 64 and sam.prompt_embed_dim == 256
+    assert model.sam_iou_threshold == 0.7 and model.iterative_refinement_iterations == 12
+    assert model.positive_points_per_mask == 16 and model.negative_points_per_mask == 1
+    if tracker_option == "cotracker":
+        t = model.point_tracker
+        assert (t.interp_shape, t.visibility_threshold, t.support_grid_size, t.support_grid_every_n_frames) == ((384, 512), 0.7, 2, 12)
+    if tracker_option == "pips":
+        t = model.point_tracker
+        assert (t.stride, t.s, t.initial_next_frame_visibility_threshold) == (4, 8, 0.9)
+    model.eval()
+    assert model.device.type == "cpu"                                   # .to("cuda") is what demo.load_model adds (demo.py:111)
+
+
+def _small_setup(monkeypatch, neg):
+    """Reference config tree at the reduced test geometry + PIPS, our seam classes over the recording fake device."""
+    from tests import fake_hip
+    from sam_pt_amd.weights import SAM_CONFIGS, init_pips_state_dict, init_sam_state_dict
+    tcfg = SAM_CONFIGS["vit_test"]
+    sd, psd = init_sam_state_dict(tcfg, 72), init_pips_state_dict(72)
+    fake = fake_hip.install(monkeypatch, sd, tcfg, psd)
+    cfg = _compose("pips", "sam_vit_base", "PipsPointTracker", TEST_GEOMETRY + [
+        "model.iterative_refinement_iterations=2", "model.positive_points_per_mask=4", f"model.negative_points_per_mask={neg}",
+        "model.sam_iou_threshold=-1.0e+9", "+model.point_tracker.state_dict=null", "+model.sam_predictor.sam_model.precision=f32"])
+    cfg["point_tracker"]["state_dict"] = psd                             # no checkpoint files here: hand the weights over
+    cfg["sam_predictor"]["sam_model"]["state_dict"] = sd
+    frames, centres = synthetic_clip(T=10, H=128, W=256, seed=72)
+    q = disc_queries(centres, n_pos=4 + neg, r=9.0)
+    if neg:
+        q[4:, 1:] += torch.tensor([40.0, 30.0])
+    q2 = q.clone()
+    q2[:, 1:] += torch.tensor([-60.0, 25.0])
+    qp = torch.stack([q, q2])
+    return fake, cfg, tcfg, sd, psd, frames, qp
+
+
+def _oracle_reference(tcfg, sd, psd, frames, qp, neg):
+    from oracle.parity import reference_run
+    kw = dict(sam_iou_threshold=-1e9, positive_points_per_mask=4, negative_points_per_mask=neg,
+              iterative_refinement_iterations=2, point_tracker_mask_batch_size=5)
+    return reference_run(tcfg, sd, psd, frames, qp, kw)
+
+
+@needs_ref
+@pytest.mark.parametrize("neg", [0, 1])
+def test_unchanged_reference_sampt_runs_over_our_seam_classes(monkeypatch, neg):
+    """The reference's own SamPt class, built from its own YAML with only the two seam `_target_`s swapped, drives our
+    PipsPointTracker / SamPredictor through set_image / predict_torch / evaluate_batch and reproduces the oracle protocol."""
+    from oracle import reference_loader as RL
+    RefSamPt = RL.load_sam_pt()
+    fake, cfg, tcfg, sd, psd, frames, qp = _small_setup(monkeypatch, neg)
+    assert cfg["_target_"] == "sam_pt.modeling.sam_pt.SamPt"             # untouched: the reference class itself
+    model = H.instantiate(cfg).eval()
+    assert type(model) is RefSamPt
+    video = {"image": [f for f in frames], "target_hw": (128, 256), "query_points": qp}
+    out = model(video)
+    ref = _oracle_reference(tcfg, sd, psd, frames, qp, neg)
+    assert torch.equal(out["visibilities"], ref["visibilities"])
+    assert (out["trajectories"].round() == ref["trajectories"].round()).all()
+    assert (out["trajectories"] - ref["trajectories"]).abs().max() < 1e-3
+    for m in range(2):
+        a, b = out["logits"][m], ref["logits"][m]
+        assert (a - b).abs().max() < 1e-4
+        assert min(iou(a[t] > 0, b[t] > 0) for t in range(10)) >= 1 - 1e-3
+    assert fake.calls["vit_encode_frames"] == 12 and fake.calls["sam_decode"] == 2 * (1 + neg + 2) + 20 * (1 + (1 if neg else 0) + 2)
+    assert fake.calls["pips_fnet_frames"] == 10                         # every frame encoded once for both objects' points
+
+
+@needs_ref
+def test_reference_demo_and_evaluator_entry_points(monkeypatch):
+    """demo.demo.run_inference and SamPtEvaluator.evaluate_video (both call `model(video)` and unpack the result dict)
+    over our device-path SamPt built from the reference YAML with `model._target_` swapped too."""
+    from oracle import reference_loader as RL
+    from sam_pt_amd.sam_pt import SamPt
+    demo = RL.load_demo()
+    Evaluator = RL.load_evaluator()
+    fake, cfg, tcfg, sd, psd, frames, qp = _small_setup(monkeypatch, 0)
+    cfg["_target_"] = "sam_pt_amd.sam_pt.SamPt"
+    model = H.instantiate(cfg).eval()
+    assert type(model) is SamPt
+    logits, traj, vis, scores = demo.run_inference(model, frames, qp, (128, 256))
+    ref = _oracle_reference(tcfg, sd, psd, frames, qp, 0)
+    assert logits.shape == (10, 3, 128, 256) and (logits[:, 0] == 0).all()
+    assert torch.equal(vis, ref["visibilities"]) and (traj.round() == ref["trajectories"].round()).all()
+    for m in range(2):
+        assert min(iou(logits[t, m + 1] > 0, ref["logits"][m][t] > 0) for t in range(10)) >= 1 - 1e-3
+    assert fake.calls["sam_track_decode_items"] == 20 and fake.calls["sam_decode"] == 0      # fused device protocol
+    ev = Evaluator(cfg=None, model=model)
+    out = ev.evaluate_video({"video_name": "synthetic", "video_id": 0, "image": [f for f in frames], "target_hw": (128, 256),
+                             "query_points": qp})
+    assert set(out) == {"logits", "trajectories", "visibilities", "scores"}
+    assert torch.equal(out["visibilities"], vis) and len(out["logits"]) == 2 and len(out["scores"]) == 2
+
+
+def test_hydra_lite_interpolation_and_instantiate(tmp_path):
+    """The stand-in itself: defaults composition, package placement, override, relative interpolation, _partial_."""
+    (tmp_path / "g" / "sub").mkdir(parents=True)
+    (tmp_path / "g" / "base.yaml").write_text("defaults:\n  - sub: a\nsize: 4\nsub:\n  w: ${ ..size }\n")
+    (tmp_path / "g" / "top.yaml").write_text("defaults:\n  - base\n  - override sub: b\n  - _self_\nsize: 8\n"
+                                             "f:\n  _target_: builtins.int\n  _partial_: true\n  base: 2\n")
+    (tmp_path / "g" / "sub" / "a.yaml").write_text("name: a\n")
+    (tmp_path / "g" / "sub" / "b.yaml").write_text("name: b\nroot: ${hydra:runtime.cwd}/x\n")
+    cfg = H.resolve(H.compose(str(tmp_path), "g", "top"), cwd="/cwd")
+    assert cfg["size"] == 8 and cfg["sub"] == {"name": "b", "root": "/cwd/x", "w": 8}
+    assert H.instantiate(cfg)["f"]("101") == 5
