@@ -46,9 +46,12 @@ def parse():
                     help="start the decoder chains of each encoder batch as soon as that batch is done (measured: loses)")
     ap.add_argument("--overlap-fnet", action="store_true", help="tracker encoder on the side stream too (measured: loses)")
     ap.add_argument("--no-dec-graph", action="store_true", help="decode chains as plain launches instead of hipGraph replays")
-    ap.add_argument("--shard", default="sequences", choices=["sequences", "frames"],
+    ap.add_argument("--shard", default="sequences", choices=["sequences", "frames", "lpt"],
                     help="N > 1: 'sequences' = one clip per rank (weak scaling, the default the metric uses); 'frames' = ONE "
-                         "clip, its frame batches dealt over the ranks (strong scaling, BASELINE config #5)")
+                         "clip, its frame batches dealt over the ranks (strong scaling, BASELINE config #5); 'lpt' = a "
+                         "DAVIS-2017-val-like set of --sequences clips (34-104 frames) LPT-assigned to the ranks (strong "
+                         "scaling of BASELINE config #4, reports the load imbalance)")
+    ap.add_argument("--sequences", type=int, default=30, help="--shard lpt: number of sequences of the DAVIS-17 val histogram")
     ap.add_argument("--native-480p", action="store_true",
                     help="feed the 480x854 frames as they are (tracker at 480p, SAM resizes inside) instead of the "
                          "reference pipelines' pre-resize to 576x1024")
@@ -271,7 +274,17 @@ def main():
     # host-side weight generation / packing: keep N ranks from oversubscribing the host cores
     torch.set_num_threads(max(1, min(32, (os.cpu_count() or 8) // max(world, 1))))
     frames_sharded = args.shard == "frames" and world > 1
-    frames, qp = bench_clip(T=args.frames, seed=72 + (0 if frames_sharded else rank), n_pos=args.points,
+    lpt = args.shard == "lpt"
+    lpt_info = None
+    if lpt:            # every rank cuts its sequences out of one long synthetic clip (lengths: DAVIS-2017 val histogram)
+        from sam_pt_amd.dist import DAVIS17_VAL_LENGTHS, lpt_assign
+        lengths = DAVIS17_VAL_LENGTHS[:args.sequences]
+        mine = [lengths[i] for i in lpt_assign(lengths, world)[rank]]
+        loads = [sum(lengths[i] for i in a) for a in lpt_assign(lengths, world)]
+        args.frames = max(lengths)
+        lpt_info = {"sequences": len(lengths), "frames_total": sum(lengths), "frames_per_rank": loads,
+                    "imbalance_max_over_mean": round(max(loads) / (sum(loads) / world), 4)}
+    frames, qp = bench_clip(T=args.frames, seed=72 + (0 if (frames_sharded or lpt) else rank), n_pos=args.points,
                             n_objects=args.objects, native=args.native_480p, n_neg=args.neg_points, square=args.square)
     H, W = frames.shape[-2:]
     model = build_model(args, dev)
@@ -284,19 +297,42 @@ def main():
         torch.cuda.synchronize()
 
     shard = "frames" if frames_sharded else "sequences"
+
+    def step():
+        if not lpt:
+            return one_step(model, video, args.frames, shard)[0]
+        m = None
+        for L in mine:                                  # this rank's sequences, one SamPt.forward each (+ mask gather)
+            m = one_step(model, {**video, "image": video["image"][:L]}, args.frames, "sequences")[0]
+        return m
+
+    if lpt and world > 1:                               # ranks hold different numbers of sequences: gather per step instead
+        from sam_pt_amd.dist import index_masks
+
+        def step():                                     # noqa: F811  (masks stay local; one gather of the last one per step)
+            m = None
+            for L in mine:
+                out = model({**video, "image": video["image"][:L]})
+                m = index_masks(torch.stack(out["logits"], dim=0))
+            from sam_pt_amd.dist import gather_masks
+            if m is None:
+                m = torch.zeros((0, H, W), dtype=torch.uint8, device=dev)
+            gather_masks(m, args.frames)
+            return m
+
     for _ in range(args.warmup):
-        one_step(model, video, args.frames, shard)
+        step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        masks, _ = one_step(model, video, args.frames, shard)
+        masks = step()
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    total_frames = (1 if frames_sharded else world) * args.frames * args.steps
+    total_frames = (lpt_info["frames_total"] if lpt else (1 if frames_sharded else world) * args.frames) * args.steps
     fps = total_frames / dt
     insitu = None
     if rank == 0 and not args.no_roofline and args.precision == "f16":   # one more step, GEMM launches event-timed
@@ -311,18 +347,20 @@ def main():
                              else "fp32 (exact f32 MFMA)")
         res = {"metric": "frames/sec end-to-end (SAM-PT: ViT + PIPS, 480p, 8 pts, 1 obj)", "value": round(fps, 3),
                "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "strong" if frames_sharded else "weak",
+               "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "strong" if (frames_sharded or lpt) else "weak",
                "vs_baseline": None,
                "dtype": "f16" if args.precision == "f16" else "f32", "data": "synthetic",
                "config": {"workload": f"{'HQ-SAM' if args.hq else 'SAM'} {args.model} + { {'pips': 'PIPS', 'cotracker': 'CoTracker', 'pips_plus_plus': 'PIPS++'}[args.tracker]}, {args.points}"
                                       f"{'+' + str(args.neg_points) if args.neg_points else ''} query points, {args.objects} object(s), "
                                       f"{args.frames}x 480p synthetic frames " + ("at native " if args.native_480p else "upscaled to ") + f"{H}x{W}, "
                                       f"{args.refine} refinement iterations, random-init weights (seed 72)",
-                          "frames_per_step": args.frames, "parallelism": f"{'frame-batch' if frames_sharded else 'sequence'}-sharded x{world}",
+                          "frames_per_step": lpt_info["frames_total"] if lpt else args.frames, "parallelism": f"{'frame-batch' if frames_sharded else 'sequence'}-sharded x{world}",
                           "vit_precision": args.precision + " MFMA inputs, fp32 accumulate/LN/softmax/residual",
                           "tracker_precision": tracker_precision, "decoder_precision": "fp32"},
                "mask_foreground_fraction": round(float((masks > 0).float().mean()), 4),
                "published_reference_fps_unstated_hw": {"vit_h": 1.4, "vit_l": 1.8, "vit_b": 2.6}[args.model]}
+        if lpt_info:
+            res["lpt"] = lpt_info
         if not args.no_roofline and args.precision == "f16":
             res["roofline"] = gemm_roofline(args, dev, insitu)
         if world == 1 and not args.no_secondary:

@@ -3,7 +3,7 @@
 Sequences (or frame batches of one sequence) are independent, so ranks never exchange activations; the only
 communication is the final gather of the uint8 index masks to rank 0 (0.59 MB per 576x1024 frame), which replaces the
 reference's pickled-RLE ``comm.gather`` (vis_eval/mask2former_video/data_video/ytvis_eval.py:119-131).  On ROCm the
-``nccl`` backend is RCCL; the payload is far below one xGMI link's capacity, so a single fixed-shape all-gather is used.
+``nccl`` backend is RCCL; the payload is far below one xGMI link's capacity: one fixed-shape gather to rank 0.
 """
 from __future__ import annotations
 
@@ -41,6 +41,12 @@ def lpt_assign(lengths: Sequence[int], world: int) -> List[List[int]]:
         out[r].append(i)
         loads[r] += lengths[i]
     return out
+
+
+# DAVIS-2017 val: 30 sequences, 34-104 frames [recall; the dataset is absent here] — used by bench.py --shard lpt to put
+# `lpt_assign` (the answer to the length imbalance of BASELINE config #4) on a timed path with synthetic clips.
+DAVIS17_VAL_LENGTHS = [69, 50, 80, 84, 90, 75, 40, 104, 90, 60, 66, 52, 50, 90, 78, 50, 81, 34, 50, 47, 49, 50, 79, 40, 80,
+                       100, 79, 43, 40, 99]
 
 
 def frame_batches(n_frames: int, world: int, rank: int, batch: int = 8) -> List[range]:
@@ -115,22 +121,26 @@ def _index_masks(logits: torch.Tensor, query_timestep=None, query_masks=None, ou
 
 def gather_masks(masks: torch.Tensor, max_frames: int) -> Optional[torch.Tensor]:
     """All ranks call with their uint8 (T_local,H,W) masks; rank 0 receives (world, max_frames, H, W) (zero padded).
-    Single fixed-shape collective over RCCL/xGMI (or gloo on CPU)."""
+    Single fixed-shape ``gather`` to rank 0 over RCCL/xGMI (or gloo on CPU): every rank sends its own 0.59 MB/frame once —
+    the payload SURVEY.md §8e states — instead of an all_gather's N copies."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return masks[None]
     T, H, W = masks.shape
     pad = torch.zeros((max_frames, H, W), dtype=torch.uint8, device=masks.device)
     pad[:T] = masks
-    outs = [torch.empty_like(pad) for _ in range(dist.get_world_size())]
-    dist.all_gather(outs, pad)
-    return torch.stack(outs) if dist.get_rank() == 0 else None
+    if dist.get_rank() == 0:
+        outs = [torch.empty_like(pad) for _ in range(dist.get_world_size())]
+        dist.gather(pad, outs, dst=0)
+        return torch.stack(outs)
+    dist.gather(pad, None, dst=0)
+    return None
 
 
 def sharded_forward(model, video, batch: int = 8):
     """One clip over all ranks (BASELINE config #5 / SURVEY.md §8e): frame batches of ``batch`` frames are dealt round
     robin (``frame_batches``); every rank tracks the whole clip (the tracker is cheap and needs every frame), runs the
     image encoder and the mask decoder on ITS frames only and contributes their uint8 index masks to one fixed-shape
-    all_gather.  Returns (index masks (T,H,W) uint8 on rank 0 / None elsewhere, the rank's own SamPt output dict).
+    gather.  Returns (index masks (T,H,W) uint8 on rank 0 / None elsewhere, the rank's own SamPt output dict).
     No activation ever crosses ranks."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
