@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--square", type=int, default=0, help="square synthetic frames of this size (config #5: 1024)")
     ap.add_argument("--dec-pipeline", action="store_true",
                     help="start the decoder chains of each encoder batch as soon as that batch is done (measured: loses)")
+    ap.add_argument("--dec-split", type=int, default=0,
+                    help="two decoder chains: frames of the first N encoder batches as soon as they are encoded, then the rest")
     ap.add_argument("--overlap-fnet", action="store_true", help="tracker encoder on the side stream too (measured: loses)")
     ap.add_argument("--no-dec-graph", action="store_true", help="decode chains as plain launches instead of hipGraph replays")
     ap.add_argument("--shard", default="sequences", choices=["sequences", "frames", "lpt"],
@@ -90,7 +92,7 @@ def build_model(args, dev):
     if args.no_dec_graph:
         pred.use_graph = False
     model = SamPt(tracker, pred, **sampt_kwargs(args)).eval()
-    model.pipeline_decoder = args.dec_pipeline
+    model.pipeline_decoder = args.dec_split if args.dec_split else args.dec_pipeline
     model.overlap_tracker_encoder_fnet = args.overlap_fnet
     return model
 

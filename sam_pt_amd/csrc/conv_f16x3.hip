@@ -169,7 +169,8 @@ __global__ __launch_bounds__(256) void k_conv_f16x3(GemmP p) {
       }
       v.x = apply_act(v.x, p.act), v.y = apply_act(v.y, p.act), v.z = apply_act(v.z, p.act), v.w = apply_act(v.w, p.act);
       if (p.res) {
-        const float4 r = *(const float4*)(p.res + (long)row * p.ldr + col);
+        const long rrow = p.res_mod > 0 ? row % p.res_mod : row;      // broadcast residual (positional embedding)
+        const float4 r = *(const float4*)(p.res + rrow * p.ldr + col);
         v.x += r.x, v.y += r.y, v.z += r.z, v.w += r.w;
       }
       *(float4*)((float*)p.C + (long)row * p.ldc + col) = v;

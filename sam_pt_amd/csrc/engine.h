@@ -139,6 +139,7 @@ struct VitEngine {
   };
   std::vector<Blk> blk;
   const void *patch_w, *neck0_w, *neck2_w;
+  const half_t *patch_hl = nullptr, *neck0_hl = nullptr, *neck2_hl = nullptr;   // split-fp16 planes (fast mode)
   const float *patch_b, *pos, *neck1w, *neck1b, *neck3w, *neck3b;
   const int* win_rows;  // [Bmax * nwin * window^2] -> token row or -1
   const int* win_inv;   // [Bmax * grid^2] token row -> window-order row

@@ -13,7 +13,11 @@ int VitEngine::init(const WeightMap& w, const VitConfig& cfg, int wrb) {
   win_rows_batches = wrb;
   const std::string sfx = c.f16 ? ".f16" : "";
   const std::string e = "image_encoder.";
-  patch_w = w.get(e + "patch_embed.proj.weight");   // fp32 in both modes (see encode)
+  // the encoder's two ends are fp32-grade in both modes (see encode): exact f32 weights, or their split-fp16 planes
+  patch_hl = c.f16 ? w.h(e + "patch_embed.proj.weight_hl") : nullptr;
+  neck0_hl = c.f16 ? w.h(e + "neck.0.weight_hl") : nullptr;
+  neck2_hl = c.f16 ? w.h(e + "neck.2.weight_khwc_hl") : nullptr;
+  patch_w = c.f16 ? nullptr : w.get(e + "patch_embed.proj.weight");
   patch_b = w.f(e + "patch_embed.proj.bias");
   pos = w.f(e + "pos_embed");
   blk.resize(c.depth);
@@ -28,9 +32,9 @@ int VitEngine::init(const WeightMap& w, const VitConfig& cfg, int wrb) {
     b.w1 = w.get(p + ".mlp.lin1.weight" + sfx), b.b1 = w.f(p + ".mlp.lin1.bias");
     b.w2 = w.get(p + ".mlp.lin2.weight" + sfx), b.b2 = w.f(p + ".mlp.lin2.bias");
   }
-  neck0_w = w.get(e + "neck.0.weight");
+  neck0_w = c.f16 ? nullptr : w.get(e + "neck.0.weight");
   neck1w = w.f(e + "neck.1.weight"), neck1b = w.f(e + "neck.1.bias");
-  neck2_w = w.get(e + "neck.2.weight_khwc");  // repacked [Cout][ky][kx][Cin]
+  neck2_w = c.f16 ? nullptr : w.get(e + "neck.2.weight_khwc");  // repacked [Cout][ky][kx][Cin]
   neck3w = w.f(e + "neck.3.weight"), neck3b = w.f(e + "neck.3.bias");
   win_rows = w.i("__win_rows");
   win_inv = w.i("__win_inv"), win_pad = w.i("__win_pad");
@@ -64,11 +68,17 @@ struct G {
   // C = act(A.W^T + bias) (+ residual at the (row-mapped) destination row)
   int run(const void* A, int M, int K, const void* W, const float* bias, void* C, int N, int act, bool out_f16,
           const float* res, int ldr, const int* rowmap, int res_mod, const int* a_rowmap = nullptr,
-          bool exact = false) const {
+          bool exact = false, const half_t* hl = nullptr) const {
     GemmP p;
     p.A = A, p.W = W, p.bias = bias, p.C = C, p.res = res, p.rowmap = rowmap, p.a_rowmap = a_rowmap;
     p.M = M, p.N = N, p.K = K, p.lda = K, p.ldw = K, p.ldc = N, p.ldr = ldr, p.act = act, p.res_mod = res_mod;
     p.out_f16 = out_f16 ? 1 : 0;
+    if (exact && hl) {   // fp32-grade on the fp16 pipe: the GEMM as a 1x1 convolution over an [1][M][1][K] image
+      p.W = hl, p.W_lo = hl + (size_t)N * K;
+      p.alpha = 1.0f / (float)(1 << F16X3_WSHIFT);
+      p.conv = 1, p.cH = M, p.cW = 1, p.cC = K, p.KH = 1, p.KW = 1, p.cstride = 1, p.cpad = 0, p.OH = M, p.OW = 1;
+      return conv_f16x3(p, s);
+    }
     if (!f16 || exact) return gemm_f32(p, s);
     if (!eng || !eng->profiling) return gemm_f16(p, s);
     VitEngine::GemmEv ev;
@@ -121,7 +131,7 @@ int VitEngine::encode(const uint8_t* frames, int chw, int B, int H, int W, float
   // ---- patch embedding: preprocess + im2col, GEMM + bias + positional embedding (broadcast over the batch)
   //      (exact fp32 in both modes: first and last layers of the encoder, 0.3 % of its FLOPs)
   SAMPT_TRY(sam_patchify(frames, chw, B, H, W, c.img, c.patch, c.mean, c.stdv, xn, 0, s));
-  SAMPT_TRY(gm.run(xn, (int)Mg, Kp, patch_w, patch_b, x, D, ACT_NONE, false, pos, D, nullptr, T, nullptr, true));
+  SAMPT_TRY(gm.run(xn, (int)Mg, Kp, patch_w, patch_b, x, D, ACT_NONE, false, pos, D, nullptr, T, nullptr, true, patch_hl));
 
   const float scale = 1.0f / sqrtf((float)hd);
   bool tapped = false;
@@ -174,14 +184,20 @@ int VitEngine::encode(const uint8_t* frames, int chw, int B, int H, int W, float
   // ---- neck: conv1x1 (no bias) -> LayerNorm2d -> conv3x3 (no bias) -> LayerNorm2d
   //      fp32 in both modes: the neck's operand roundings would land on the embedding undamped
   SAMPT_TRY(gm.run(x, (int)Mg, D, neck0_w, nullptr, neck_a, c.out_chans, ACT_NONE, false, nullptr, 0, nullptr, 0, nullptr,
-                   true));
+                   true, neck0_hl));
   SAMPT_TRY(layernorm_rows(neck_a, neck1w, neck1b, neck_b, Mg, c.out_chans, 1e-6f, nullptr, 0, ACT_NONE, s));
   {
     GemmP p;
     p.A = neck_b, p.W = neck2_w, p.C = neck_a;
     p.M = (int)Mg, p.N = c.out_chans, p.K = 9 * c.out_chans, p.ldw = p.K, p.ldc = c.out_chans;
     p.conv = 1, p.cH = g, p.cW = g, p.cC = c.out_chans, p.KH = 3, p.KW = 3, p.cstride = 1, p.cpad = 1, p.OH = g, p.OW = g;
-    SAMPT_TRY(gemm_f32(p, s));
+    if (neck2_hl) {
+      p.W = neck2_hl, p.W_lo = neck2_hl + (size_t)p.N * p.K;
+      p.alpha = 1.0f / (float)(1 << F16X3_WSHIFT);
+      SAMPT_TRY(conv_f16x3(p, s));
+    } else {
+      SAMPT_TRY(gemm_f32(p, s));
+    }
   }
   SAMPT_TRY(layernorm_rows(neck_a, neck3w, neck3b, features, Mg, c.out_chans, 1e-6f, nullptr, 0, ACT_NONE, s));
   return SAMPT_OK;

@@ -156,7 +156,7 @@ def window_row_map(grid: int, window: int, batches: int) -> torch.Tensor:
 def pack_vit(sd: Dict[str, torch.Tensor], cfg: SamConfig, device, f16: bool, win_batches: int) -> Dict[str, torch.Tensor]:
     out: Dict[str, torch.Tensor] = {}
     e = "image_encoder."
-    # The two ends of the encoder stay fp32 in the fast mode too (exact f32 MFMA, 0.3 % of the FLOPs): every fp16
+    # The two ends of the encoder stay fp32-grade in the fast mode too (3-term split-fp16 MFMAs, 0.3 % of the FLOPs): every fp16
     # rounding inside the 12-32 blocks is damped by the residual stream, but the neck's roundings land on the embedding
     # directly — they were the largest single term (30 % of the error variance) of the fp16 mode's error budget
     # (tools/f16_error_budget.py), the patch embedding another 7 %.
@@ -172,9 +172,17 @@ def pack_vit(sd: Dict[str, torch.Tensor], cfg: SamConfig, device, f16: bool, win
         if k == e + "pos_embed":
             out[k] = v.reshape(-1, v.shape[-1]).contiguous()
         elif k == e + "neck.2.weight":
-            out[e + "neck.2.weight_khwc"] = _khwc(v)
+            w = _khwc(v)
+            if f16:      # fast mode: fp32-grade on the fp16 matrix pipe (3-term split, csrc/conv_f16x3.hip)
+                out[e + "neck.2.weight_khwc_hl"] = split_f16x3(w)
+            else:
+                out[e + "neck.2.weight_khwc"] = w
         elif k in exact_keys:
-            out[k] = v.reshape(v.shape[0], -1).contiguous()
+            w = v.reshape(v.shape[0], -1).contiguous()
+            if f16:
+                out[k + "_hl"] = split_f16x3(w)
+            else:
+                out[k] = w
         elif k in gemm_keys:
             w = v.reshape(v.shape[0], -1).contiguous()
             out[k + (".f16" if f16 else "")] = w.half() if f16 else w
@@ -243,9 +251,10 @@ def pack_decoder(sd: Dict[str, torch.Tensor], cfg: SamConfig, device, max_frames
     out["mask_decoder.output_upscaling.3.weight_packed"] = _convt_pack(sd["mask_decoder.output_upscaling.3.weight"].float())
     out["mask_decoder.__up0_map"] = _shuffle_map(cfg.grid, max_frames)
     out["mask_decoder.__up1_map"] = _shuffle_map(2 * cfg.grid, max_frames)
-    if os.environ.get("SAMPT_DEC_F16X3", "0") != "0":
-        # opt-in experiment: split-fp16 planes of the two-way transformer's attention projections; the
-        # engine uses them for the projections over the image tokens (M = frames * grid^2 rows)
+    if os.environ.get("SAMPT_DEC_F16X3", "1") != "0":
+        # split-fp16 planes of the two-way transformer's attention projections: the engine runs the projections over the
+        # image tokens (M = frames * grid^2 >= 2048 rows) as 3-term split-fp16 MFMAs, fp32-grade at 2.25x the f32 MFMA rate
+        # (measured +1.4 % end to end, profiles/r2_v0_bench_vith_dec_f16x3.log; SAMPT_DEC_F16X3=0 restores the f32 MFMAs)
         for k in [k for k in out if k.startswith("mask_decoder.transformer.") and k.endswith("_proj.weight")]:
             if out[k].shape[1] % 32 == 0 and out[k].shape[0] % 4 == 0:
                 out[k + "_hl"] = split_f16x3(out[k])

@@ -180,6 +180,11 @@ class SamPt(nn.Module):
                 if batch_events:
                     if not self.pipeline_decoder:                            # one chain for the clip, after the last batch
                         batch_events = [(batch_events[-1][0], batch_events[-1][1])]
+                    elif isinstance(self.pipeline_decoder, int) and not isinstance(self.pipeline_decoder, bool) \
+                            and 0 < self.pipeline_decoder < len(batch_events):
+                        # two chains: the frames of the first `pipeline_decoder` encoder batches, then the rest
+                        cut = self.pipeline_decoder
+                        batch_events = [batch_events[cut - 1], batch_events[-1]]
                     pipeline = (batch_events, self._dec_stream)
         n_masks, n_points_per_mask, _ = query_points.shape
         if query_masks is None:
