@@ -176,6 +176,74 @@ def gemm_roofline(args, dev, insitu=None):
             "avg_launch_us": round(avg_us, 1), "encode_batch": B}
 
 
+def secondary_rooflines(args, dev):
+    """The other kernels north_star names, each alone on an idle GPU through its kernel-level C-ABI entry point at the
+    shape the timed workload launches it with (HIP events, 10 launches): the fused correlation sampler against HBM
+    bandwidth (algorithmic bytes: SURVEY.md §8d, 33.5 KB per (frame, point, level)), both flash-attention kernels and a
+    tracker-encoder convolution against the dense fp16 MFMA peak (the 3-term split issues 3 MFMAs per product, so its
+    fp32-equivalent ceiling is a third of 2.5 PF)."""
+    from sam_pt_amd import _lib
+    from sam_pt_amd.pack import split_f16x3
+    from sam_pt_amd.weights import SAM_CONFIGS
+    lib = _lib.load()
+    cfg = SAM_CONFIGS[args.model]
+    g = torch.Generator(device="cpu").manual_seed(1)
+
+    def timed(fn, reps=10):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e-3
+
+    out = []
+    # correlation sampler: n = 2 x points chains (both directions batched), S = 8 frames, 4 levels
+    n, S_ = 2 * args.points * args.objects, 8
+    H0, W0 = 144, 256
+    pyr = [torch.randn(S_, H0 >> l, W0 >> l, 128, generator=g).to(dev) for l in range(4)]
+    fidx = torch.arange(S_, dtype=torch.int32).repeat(n, 1).contiguous().to(dev)
+    ff = torch.randn(n, S_, 128, generator=g).to(dev)
+    co = (torch.rand(S_, n, 2, generator=g) * torch.tensor([W0 - 20.0, H0 - 20.0]) + 10).to(dev)
+    xo = torch.empty(n, S_, 196, device=dev)
+    t = timed(lambda: lib.sampt_corr_sample_f32(_lib.ptr_array(pyr), H0, W0, _lib.ptr(fidx), S_, n, _lib.ptr(ff), _lib.ptr(co),
+                                                _lib.ptr(xo), _lib.stream_ptr()))
+    nbytes = S_ * n * 4 * (8 * 8 * 128 * 4 + 512 + 196)
+    out.append({"kernel": "k_pips_corr_sample (fused correlation + 7x7 sampler)", "bound": "hbm", "achieved": round(nbytes / t / 1e9, 1),
+                "peak": 8000.0, "unit": "GB/s", "frac": round(nbytes / t / 8e12, 4), "launch_us": round(t * 1e6, 2),
+                "algorithmic_bytes_per_launch": nbytes, "note": f"{S_ * n * 4} wave-sized units per launch: launch-latency bound at this size"})
+    # flash attention, global and windowed blocks (encode batch frames)
+    heads, hd, D = cfg.num_heads, cfg.head_dim, cfg.embed_dim
+    for name, B, S2 in (("global (64x64 tokens)", args.encode_batch, 64), ("windowed (14x14 tokens)", args.encode_batch * 25, 14)):
+        N = S2 * S2
+        qkv = (torch.randn(B * N, 3 * D, generator=g) * 0.5).half().to(dev)
+        rh = (torch.randn(2 * S2 - 1, hd, generator=g) * 0.1).to(dev)
+        rw = (torch.randn(2 * S2 - 1, hd, generator=g) * 0.1).to(dev)
+        ao = torch.empty(B * N, D, dtype=torch.float16, device=dev)
+        t = timed(lambda: lib.sampt_vit_attention_f16(_lib.ptr(qkv), _lib.ptr(rh), _lib.ptr(rw), _lib.ptr(ao), B, S2, heads, hd,
+                                                      None, 0, _lib.stream_ptr()))
+        fl = 4.0 * B * heads * N * N * hd
+        out.append({"kernel": f"k_flash_f16, {name}", "bound": "mfma", "achieved": round(fl / t / 1e12, 1), "peak": 2500.0,
+                    "unit": "TFLOP/s", "frac": round(fl / t / 2.5e15, 4), "launch_us": round(t * 1e6, 1)})
+        del qkv, ao
+    # tracker encoder: the 64 -> 64 3x3 convolution at half resolution (the most frequent fnet layer), 3-term split-fp16
+    nimg, Hc, Wc, ci, cc = 8, 288, 512, 64, 64
+    x = torch.relu(torch.randn(nimg, Hc, Wc, ci, generator=g)).to(dev)
+    w = torch.randn(cc, 9 * ci, generator=g) * (2.0 / (cc * 9)) ** 0.5
+    whl, b = split_f16x3(w).to(dev), torch.zeros(cc, device=dev)
+    y = torch.empty(nimg, Hc, Wc, cc, device=dev)
+    t = timed(lambda: lib.sampt_conv2d_nhwc(3, _lib.ptr(x), _lib.ptr(whl), _lib.ptr(b), _lib.ptr(y), nimg, Hc, Wc, ci, cc, 3, 3, 1, 1,
+                                            _lib.stream_ptr()), reps=5)
+    fl = 2.0 * nimg * Hc * Wc * cc * 9 * ci
+    out.append({"kernel": "k_conv_f16x3<128,64> (fnet 64->64 3x3 @288x512, 8 frames)", "bound": "mfma", "achieved": round(fl / t / 1e12, 1),
+                "peak": 833.3, "unit": "TFLOP/s fp32-equivalent (3 fp16 MFMAs per product: 2500 / 3)", "frac": round(fl / t / 833.3e12, 4),
+                "launch_us": round(t * 1e6, 1)})
+    return out
+
+
 def sampt_kwargs(args, **over):
     kw = dict(sam_iou_threshold=-1e9, positive_points_per_mask=args.points, negative_points_per_mask=args.neg_points,
               iterative_refinement_iterations=args.refine, point_tracker_mask_batch_size=5)
@@ -365,6 +433,7 @@ def main():
             res["lpt"] = lpt_info
         if not args.no_roofline and args.precision == "f16":
             res["roofline"] = gemm_roofline(args, dev, insitu)
+            res["roofline"]["secondary"] = secondary_rooflines(args, dev)
         if world == 1 and not args.no_secondary:
             res["secondary"] = secondary_lines(args, model, video, dev)
         if world == 1 and not args.no_cpu_baseline:

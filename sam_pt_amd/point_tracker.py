@@ -125,8 +125,9 @@ class PipsPointTracker(PointTracker):
 
     # -- fnet + pyramid for a whole clip -----------------------------------------------------------
     @_lib.on_device(lambda self, frames: frames.device)
-    def compute_pyramid(self, frames: torch.Tensor):
-        """frames (T,3,H,W) uint8 on device -> list of 4 NHWC f32 levels [T][H_l][W_l][128]."""
+    def compute_pyramid(self, frames: torch.Tensor, chunk_events: Optional[list] = None):
+        """frames (T,3,H,W) uint8 on device -> list of 4 NHWC f32 levels [T][H_l][W_l][128].  ``chunk_events``: a list that
+        receives one ``(first_frame, end_frame, torch.cuda.Event)`` per encoder chunk, recorded on the current stream."""
         self._ensure(frames.device)
         T, _, H, W = frames.shape
         H0, W0 = H // self.stride, W // self.stride
@@ -141,6 +142,10 @@ class PipsPointTracker(PointTracker):
             outs = _lib.ptr_array([p[t0:t0 + nf] for p in pyr])
             _lib.check(self._lib.sampt_pips_fnet_f32(self._h, _lib.ptr(frames[t0:t0 + nf]), nf, H, W, outs, _lib.ptr(ws),
                                                      nbytes.value, _lib.stream_ptr()), "sampt_pips_fnet_f32")
+            if chunk_events is not None:
+                ev = torch.cuda.Event()
+                ev.record()
+                chunk_events.append((t0, t0 + nf, ev))
         self.stats["fnet_frames"] += T
         return pyr
 
@@ -148,10 +153,16 @@ class PipsPointTracker(PointTracker):
     def prepare(self, frames: torch.Tensor):
         """Optional: build the feature pyramid of ``frames`` (T,3,H,W) now, on the current stream; the next ``forward``
         on the same frames tensor reuses it.  Lets a caller keep the compute-bound fnet on its main stream and run only
-        the latency-bound window rounds on a second stream (sam_pt_amd.SamPt)."""
-        self._prepared = _prepared_entry(frames, self.compute_pyramid(frames))
+        the latency-bound window rounds on a second stream (sam_pt_amd.SamPt).  One event per encoder chunk is kept: a
+        ``forward`` running on ANOTHER stream makes every window round wait only for the chunks that hold its frames
+        (``chunk_events_on_other_stream``), so the first rounds start while later frames are still being encoded."""
+        evs: list = []
+        self._prepared = _prepared_entry(frames, self.compute_pyramid(frames, evs))
+        self._prepared_events = evs
 
-    def _run_chains(self, pyr, T: int, query_points: torch.Tensor, flipped: torch.Tensor, ws):
+    chunk_events_on_other_stream = True      # SamPt: the side stream needs no event for the whole pyramid
+
+    def _run_chains(self, pyr, T: int, query_points: torch.Tensor, flipped: torch.Tensor, ws, chunk_events=None):
         """query_points (N,3) CPU float = (t, x, y) in each chain's OWN time axis; ``flipped[i]`` marks chains that run on
         the time-reversed clip (direction frame d = original frame T-1-d).  Returns CPU (T,N,2), (T,N) bool in each
         chain's own time axis.
@@ -177,6 +188,7 @@ class PipsPointTracker(PointTracker):
         cur = start.clone()
         thr0 = float(self.initial_next_frame_visibility_threshold)
         pyr_ptrs = _lib.ptr_array(pyr)
+        pending = list(chunk_events) if chunk_events else []
 
         def orig(d, fl):                       # direction frame -> original frame index
             return torch.where(fl, T - 1 - d, d)
@@ -190,7 +202,13 @@ class PipsPointTracker(PointTracker):
             hi = torch.clamp(T - f, max=S)                      # frames available in the window (S - n_missing)
             win = f[:, None] + torch.arange(S)[None, :]
             win = torch.minimum(win, (f + hi - 1)[:, None])    # repeat the last frame (tracker.py:73-78)
-            fidx = orig(win, flipped[act][:, None]).to(torch.int32).to(dev).contiguous()        # [n][S]
+            used = orig(win, flipped[act][:, None])
+            if pending:                                         # pyramid chunks this round reads (prepare() on another stream)
+                lo, hi_f = int(used.min()), int(used.max())
+                for c in [c for c in pending if c[0] <= hi_f and c[1] > lo]:
+                    torch.cuda.current_stream().wait_event(c[2])
+                    pending.remove(c)
+            fidx = used.to(torch.int32).to(dev).contiguous()        # [n][S]
             xys_cpu = traj[f, act]                              # (n,2)
             xys = xys_cpu.to(dev).contiguous()
             fresh = ~have_feat[act]
@@ -241,6 +259,7 @@ class PipsPointTracker(PointTracker):
         q = query_points[0].detach().float().cpu()
         N = q.shape[0]
         pyr = _prepared_lookup(getattr(self, "_prepared", None), frames)
+        chunk_events = getattr(self, "_prepared_events", None) if pyr is not None else None
         if pyr is None:
             pyr = self.compute_pyramid(frames)
         nbytes = C.c_size_t()
@@ -250,7 +269,9 @@ class PipsPointTracker(PointTracker):
         qf = q.clone()
         qf[:, 0] = T - qf[:, 0] - 1
         flipped = torch.cat([torch.zeros(N, dtype=torch.bool), torch.ones(N, dtype=torch.bool)])
-        tr_all, vi_all = self._run_chains(pyr, T, torch.cat([q, qf]), flipped, ws)
+        tr_all, vi_all = self._run_chains(pyr, T, torch.cat([q, qf]), flipped, ws, chunk_events)
+        for c in (chunk_events or []):                          # chunks no round touched: still order this stream after them
+            torch.cuda.current_stream().wait_event(c[2])
         tr_r, vi_r = tr_all[:, :N], vi_all[:, :N]
         tr_l, vi_l = tr_all[:, N:].flip(0), vi_all[:, N:].flip(0)
         traj, vis = tr_r.clone(), vi_r.clone()

@@ -114,6 +114,7 @@ class SamPt(nn.Module):
         finally:                                      # never leave a clip's feature pyramid cached in the tracker
             if hasattr(self.point_tracker, "_prepared"):
                 self.point_tracker._prepared = None
+                self.point_tracker._prepared_events = None
 
     def _forward_impl(self, video):
         images = torch.stack(video["image"], dim=0) if isinstance(video["image"], (list, tuple)) else video["image"]
@@ -160,10 +161,13 @@ class SamPt(nn.Module):
             overlap = (not self.use_point_reinit) and images.is_cuda and self.overlap_tracker_and_encoder
             pipeline = None
             if overlap:
+                ready = torch.cuda.Event()
+                ready.record()                                               # frames valid on this stream
                 if hasattr(self.point_tracker, "prepare") and not self.overlap_tracker_encoder_fnet:
                     self.point_tracker.to(self.device).prepare(images)
-                ready = torch.cuda.Event()
-                ready.record()                                               # frames (and pyramid) valid on this stream
+                    if not getattr(self.point_tracker, "chunk_events_on_other_stream", False):
+                        ready = torch.cuda.Event()       # tracker without per-chunk events: wait for the whole pyramid
+                        ready.record()
                 if self._side_stream is None:
                     self._side_stream = torch.cuda.Stream(device=images.device, priority=-1)
                     self._dec_stream = torch.cuda.Stream(device=images.device, priority=-1)
