@@ -39,7 +39,9 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64, OCC) void gemm_f16_gl
   half_t* Bs0 = lds + BM * BK;
   constexpr int BUF = (BM + BN) * BK;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // `wave` is wave-uniform but derived from threadIdx: tell the compiler (readfirstlane), otherwise every LDS destination
+  // of the DMA (M0 values) and every per-wave base lives in a VECTOR register and is re-broadcast before each use
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / NWN, wn = wave % NWN;
   // Persistent mode (p.persist): the grid is one generation of workgroups (4 per CU) and each walks its XCD's tile
   // sequence with a stride of one generation, so the ~128 tiles co-resident on an XCD start together and stay within a
@@ -75,10 +77,11 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64, OCC) void gemm_f16_gl
   const half_t* __restrict__ A = (const half_t*)p.A;
   const half_t* __restrict__ W = (const half_t*)p.W;
 
-  // per-lane DMA source pointers (row clamped, chunk XOR-swizzled); piece i of this wave = tile rows (wave*IT+i)*8..+8
+  // per-lane DMA source offsets (row clamped, chunk XOR-swizzled); piece i of this wave = tile rows (wave*IT+i)*8..+8.
+  // One 32-bit BYTE offset per piece against the uniform operand base (operands are < 4 GiB): half the registers of a
+  // pointer per piece, and the address is formed by the load's own scalar-base + vector-offset mode.
   const int sub = lane >> 3;
-  const half_t* a_src[A_IT];
-  const half_t* b_src[B_IT];
+  unsigned a_boff[A_IT], b_boff[B_IT];
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
     const int trow = (wave * A_IT + i) * 8 + sub;               // row inside the tile
@@ -86,25 +89,36 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64, OCC) void gemm_f16_gl
     int row = m0 + trow;
     if (row > p.M - 1) row = p.M - 1;
     if (p.a_rowmap) row = p.a_rowmap[row];
-    a_src[i] = A + (long)row * p.lda + chunk * 8;
+    a_boff[i] = ((unsigned)row * (unsigned)p.lda + (unsigned)(chunk * 8)) * 2u;
   }
+  // BUNI (the 160-wide tile; its launcher guarantees N % BN == 0, so no row is ever clamped): the pieces of a wave are 8
+  // weight rows apart and (trow & 7) == sub for every piece, so ONE vector offset serves all of them and the piece stride
+  // goes into the scalar base — B_IT - 1 registers less in a kernel that has none to spare
+  constexpr bool BUNI = BN == 160;
 #pragma unroll
   for (int i = 0; i < B_IT; ++i) {
     const int trow = (wave * B_IT + i) * 8 + sub;
     const int chunk = (lane & 7) ^ (MF == 16 ? (trow & 7) : ((trow >> 1) & 7));
     int row = n0 + trow;
     if (row > p.N - 1) row = p.N - 1;
-    b_src[i] = W + (long)row * p.ldw + chunk * 8;
+    b_boff[i] = ((unsigned)row * (unsigned)p.ldw + (unsigned)(chunk * 8)) * 2u;
   }
+  const size_t b_piece = (size_t)8 * p.ldw * 2;                 // bytes between consecutive pieces (uniform)
   auto issue = [&](int kt, int buf) {
     half_t* ab = As0 + buf * BUF + wave * A_IT * 8 * BK;
     half_t* bb = Bs0 + buf * BUF + wave * B_IT * 8 * BK;
+    const char* Ak = (const char*)A + (size_t)kt * (BK * 2);    // uniform
+    const char* Wk = (const char*)W + (size_t)kt * (BK * 2);
 #pragma unroll
     for (int i = 0; i < A_IT; ++i)
-      __builtin_amdgcn_global_load_lds((glb_void*)(a_src[i] + kt * BK), (lds_void*)(ab + i * 8 * BK), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void*)(Ak + a_boff[i]), (lds_void*)(ab + i * 8 * BK), 16, 0, 0);
 #pragma unroll
-    for (int i = 0; i < B_IT; ++i)
-      __builtin_amdgcn_global_load_lds((glb_void*)(b_src[i] + kt * BK), (lds_void*)(bb + i * 8 * BK), 16, 0, 0);
+    for (int i = 0; i < B_IT; ++i) {
+      if constexpr (BUNI)
+        __builtin_amdgcn_global_load_lds((glb_void*)(Wk + i * b_piece + b_boff[0]), (lds_void*)(bb + i * 8 * BK), 16, 0, 0);
+      else
+        __builtin_amdgcn_global_load_lds((glb_void*)(Wk + b_boff[i]), (lds_void*)(bb + i * 8 * BK), 16, 0, 0);
+    }
   };
 
   acc_t acc[FM][FN];
@@ -143,6 +157,24 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64, OCC) void gemm_f16_gl
 #pragma unroll
     for (int kk = 0; kk < 8 / KQ; ++kk) {
       const int pos = ((kk * KQ + lq) ^ sw) * 8;
+      if constexpr (FN > 4) {
+        // wide wave tiles (FN = 5): keep the A fragments of the K-step and ONE B fragment (plus the next one in flight)
+        // live instead of all FN — the 80 accumulator registers leave no room for 9 operand fragments under the
+        // 128-register budget of 4 workgroups per CU (the scheduler barrier keeps the compiler from hoisting the loads)
+        h8 a[FM];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) a[i] = *(const h8*)(base + a_off[i] + pos);
+        h8 bc = *(const h8*)(base + b_off[0] + pos);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          h8 bn = bc;
+          if (j + 1 < FN) bn = *(const h8*)(base + b_off[j + 1] + pos);
+#pragma unroll
+          for (int i = 0; i < FM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bc, a[i], acc[i][j], 0, 0, 0);
+          bc = bn;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
       h8 a[FM], b[FN];
 #pragma unroll
       for (int i = 0; i < FM; ++i) a[i] = *(const h8*)(base + a_off[i] + pos);
@@ -155,6 +187,7 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64, OCC) void gemm_f16_gl
           if constexpr (MF == 16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[j], a[i], acc[i][j], 0, 0, 0);
           else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[j], a[i], acc[i][j], 0, 0, 0);
         }
+      }
     }
   }
 
@@ -331,6 +364,7 @@ int gemm_f16_glds_launch(const GemmP& p, hipStream_t s) {
     grid = dim3(8 * per_xcd * R * nt_n, 1, 1);
   }
   static const int variant = getenv("SAMPT_GEMM_VARIANT") ? atoi(getenv("SAMPT_GEMM_VARIANT")) : 1;
+  static const bool bn160 = getenv("SAMPT_GEMM_BN160") && atoi(getenv("SAMPT_GEMM_BN160")) != 0;
   if ((variant == 4 || variant == 5 || variant == 7) && swz && p.M >= 256 && p.N >= 256) {
     // 256 x 256 tile, 8 waves of 128 x 64, two 64 KiB LDS stages (1 workgroup per CU): a K-slab is 64 MFMAs per wave, so
     // the DMA of the next slab has ~2000 cycles to land and LDS traffic per FLOP halves against the 128 x 128 tile
@@ -342,6 +376,17 @@ int gemm_f16_glds_launch(const GemmP& p, hipStream_t s) {
     if (variant == 7) hipLaunchKernelGGL((gemm_f16_glds<256, 256, 2, 128, 128, 16, 1>), grid, dim3(256), 0, s, q);
     else if (variant == 4) hipLaunchKernelGGL((gemm_f16_glds<256, 256, 2, 128, 64, 16>), grid, dim3(512), 0, s, q);
     else hipLaunchKernelGGL((gemm_f16_glds<256, 256, 2, 128, 64, 32>), grid, dim3(512), 0, s, q);
+  } else if ((variant == 10 || (variant == 1 && bn160)) && swz && p.N % 160 == 0) {
+    // 128 x 160 tile (4 waves x (64 x 80)): the ViT-H / ViT-L widths are multiples of 160, and with 160-wide column tiles
+    // every encoder GEMM is a whole number of generations of 1024 resident workgroups (N = 1280: 2048 tiles = 2.0
+    // generations instead of 2.5; 3840: 6.0 instead of 7.5; 5120: 8.0 instead of 10.0) — no half-empty last wave; LDS is
+    // 36 KiB per workgroup, still 4 per CU; a wave's slab costs 18 KiB of fragment reads per 40 MFMAs instead of 16 per 32.
+    const int nt_m = cdiv(p.M, 128), nt_n = p.N / 160;
+    int R = 8;
+    while (R > 1 && cdiv(nt_m, R) < 16) R /= 2;
+    q.xcd_swizzle = R;
+    grid = dim3(8 * cdiv(cdiv(nt_m, R), 8) * R * nt_n, 1, 1);
+    hipLaunchKernelGGL((gemm_f16_glds<128, 160, 1, 64, 80, 16>), grid, block, 0, s, q);
   } else if (variant == 6) {
     hipLaunchKernelGGL((gemm_f16_glds<128, 128, 1, 64, 64, 32>), grid, block, 0, s, q);
   } else if (variant == 3 && swz && p.M >= 256) {

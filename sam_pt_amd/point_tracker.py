@@ -124,7 +124,7 @@ class PipsPointTracker(PointTracker):
                 pass
 
     # -- fnet + pyramid for a whole clip -----------------------------------------------------------
-    @_lib.on_device(lambda self, frames: frames.device)
+    @_lib.on_device(lambda self, frames, *a, **k: frames.device)
     def compute_pyramid(self, frames: torch.Tensor, chunk_events: Optional[list] = None):
         """frames (T,3,H,W) uint8 on device -> list of 4 NHWC f32 levels [T][H_l][W_l][128].  ``chunk_events``: a list that
         receives one ``(first_frame, end_frame, torch.cuda.Event)`` per encoder chunk, recorded on the current stream."""
@@ -142,7 +142,7 @@ class PipsPointTracker(PointTracker):
             outs = _lib.ptr_array([p[t0:t0 + nf] for p in pyr])
             _lib.check(self._lib.sampt_pips_fnet_f32(self._h, _lib.ptr(frames[t0:t0 + nf]), nf, H, W, outs, _lib.ptr(ws),
                                                      nbytes.value, _lib.stream_ptr()), "sampt_pips_fnet_f32")
-            if chunk_events is not None:
+            if chunk_events is not None and frames.is_cuda:
                 ev = torch.cuda.Event()
                 ev.record()
                 chunk_events.append((t0, t0 + nf, ev))
@@ -330,7 +330,7 @@ class PipsPlusPlusPointTracker(PointTracker):
             except Exception:
                 pass
 
-    @_lib.on_device(lambda self, frames: frames.device)
+    @_lib.on_device(lambda self, frames, *a, **k: frames.device)
     def compute_pyramid(self, frames: torch.Tensor):
         """frames (T,3,H,W) uint8 (or float32 in [0,255]) on device -> 4 NHWC f32 levels [T][H/8 >> l][W/8 >> l][128]."""
         self._ensure(frames.device)
@@ -519,7 +519,7 @@ class CoTrackerPointTracker(PointTracker):
                 pass
 
     # -- resize + encoder for a whole clip ---------------------------------------------------------------------
-    @_lib.on_device(lambda self, frames: frames.device)
+    @_lib.on_device(lambda self, frames, *a, **k: frames.device)
     def compute_pyramid(self, frames: torch.Tensor):
         """frames (T,3,H,W) uint8 / float32 on device -> 4 NHWC f32 levels [T][h/4 >> l][w/4 >> l][128] of the video resized
         to ``interp_shape`` (h, w)."""

@@ -160,3 +160,25 @@ def test_hydra_lite_interpolation_and_instantiate(tmp_path):
     cfg = H.resolve(H.compose(str(tmp_path), "g", "top"), cwd="/cwd")
     assert cfg["size"] == 8 and cfg["sub"] == {"name": "b", "root": "/cwd/x", "w": 8}
     assert H.instantiate(cfg)["f"]("101") == 5
+
+
+def test_prepared_pyramid_path_on_the_fake_device(monkeypatch):
+    """PipsPointTracker.prepare() + forward() (the split SamPt's stream schedule uses: pyramid first, window rounds later)
+    gives the plain forward()'s result, reuses the pyramid (every frame encoded once) and drops a stale cache entry."""
+    from tests import fake_hip
+    from sam_pt_amd.point_tracker import PipsPointTracker
+    from sam_pt_amd.weights import init_pips_state_dict
+    psd = init_pips_state_dict(72)
+    fake = fake_hip.install(monkeypatch, pips_sd=psd)
+    frames, centres = synthetic_clip(T=9, H=128, W=256, seed=72)
+    q = torch.cat([disc_queries(centres, n_pos=3, r=9.0, t=0), disc_queries(centres, n_pos=1, r=4.0, t=6)])[None]
+    trk = PipsPointTracker(state_dict=psd, fnet_chunk=4)
+    tr0, vi0 = trk(frames[None], q)
+    assert fake.calls["pips_fnet_frames"] == 9
+    rgbs = frames[None].clone()
+    trk.prepare(rgbs[0])
+    tr1, vi1 = trk(rgbs, q)
+    assert fake.calls["pips_fnet_frames"] == 18 and torch.equal(tr0, tr1) and torch.equal(vi0, vi1)
+    rgbs[0, 0, 0, 0, 0] += 1                                         # in-place edit: the cached pyramid is stale
+    trk(rgbs, q)
+    assert fake.calls["pips_fnet_frames"] == 27

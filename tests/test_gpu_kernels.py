@@ -50,7 +50,8 @@ def test_gemm_f32(lib, dev, M, N, K, act):
 
 
 @pytest.mark.parametrize("M,N,K,dtype", [(256, 256, 128, 1), (4900, 3840, 1280, 2), (100, 72, 64, 1), (4096, 768, 768, 2),
-                                           (300, 200, 192, 1), (129, 129, 64, 2)])
+                                           (300, 200, 192, 1), (129, 129, 64, 2), (1000, 1280, 320, 1),
+                                           (4096, 5120, 1280, 2), (777, 320, 128, 1)])
 def test_gemm_f16(lib, dev, M, N, K, dtype):
     g = torch.Generator().manual_seed(M + N)
     A = torch.randn(M, K, generator=g).half()
