@@ -110,7 +110,7 @@ def one_step(model, video, max_frames, shard="sequences"):
 
 
 def gemm_roofline(args, dev, insitu=None):
-    """Dominant kernel = the fp16 MFMA GEMM of the ViT encoder (gemm_f16_glds<128,128,1>).
+    """Dominant kernel = the fp16 MFMA GEMM of the ViT encoder (gemm_f16_glds<128,160,1> for ViT-H, <128,128,1> otherwise).
     ``achieved`` / ``avg_launch_us`` are IN SITU: one extra (untimed) step of the very same workload runs with every GEMM
     launch of the encoder bracketed by HIP events on its launching stream (sampt_vit_profile_begin/end), so the figure is
     the real launches' algorithmic FLOP / their summed duration, tracker overlap included, and matches the rocprofv3
@@ -164,7 +164,7 @@ def gemm_roofline(args, dev, insitu=None):
     ach, avg_us, n_launch = iso, tot_t / launches * 1e6, launches
     if insitu is not None and insitu[2] > 0:
         ach, avg_us, n_launch = insitu[0] / (insitu[1] * 1e-3) / 1e12, insitu[1] * 1e3 / insitu[2], insitu[2]
-    return {"bound": "mfma", "kernel": "gemm_f16_glds<128,128,1> (ViT qkv/proj/MLP/patch/neck GEMMs, LDS-DMA fp16 MFMA)",
+    return {"bound": "mfma", "kernel": "gemm_f16_glds<128,160,1> / <128,128,1> (ViT qkv / proj / MLP GEMMs, LDS-DMA fp16 MFMA; 160-wide tiles when N % 160 == 0)",
             "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
             "measured": "in situ: HIP events around every GEMM launch of one extra step" if insitu else "isolated shapes",
             "launches_timed": n_launch, "isolated_achieved": round(iso, 1),
@@ -425,7 +425,8 @@ def main():
                                       f"{args.frames}x 480p synthetic frames " + ("at native " if args.native_480p else "upscaled to ") + f"{H}x{W}, "
                                       f"{args.refine} refinement iterations, random-init weights (seed 72)",
                           "frames_per_step": lpt_info["frames_total"] if lpt else args.frames, "parallelism": f"{'frame-batch' if frames_sharded else 'sequence'}-sharded x{world}",
-                          "vit_precision": args.precision + " MFMA inputs, fp32 accumulate/LN/softmax/residual",
+                          "vit_precision": args.precision + " MFMA inputs, fp32 accumulate/LN/softmax/residual"
+                                           + ("; patch embedding and neck fp32-grade (3-term split-fp16 MFMA)" if args.precision == "f16" else ""),
                           "tracker_precision": tracker_precision, "decoder_precision": "fp32"},
                "mask_foreground_fraction": round(float((masks > 0).float().mean()), 4),
                "published_reference_fps_unstated_hw": {"vit_h": 1.4, "vit_l": 1.8, "vit_b": 2.6}[args.model]}

@@ -364,7 +364,9 @@ int gemm_f16_glds_launch(const GemmP& p, hipStream_t s) {
     grid = dim3(8 * per_xcd * R * nt_n, 1, 1);
   }
   static const int variant = getenv("SAMPT_GEMM_VARIANT") ? atoi(getenv("SAMPT_GEMM_VARIANT")) : 1;
-  static const bool bn160 = getenv("SAMPT_GEMM_BN160") && atoi(getenv("SAMPT_GEMM_BN160")) != 0;
+  // 128 x 160 tiles wherever N is a multiple of 160 (every ViT-H GEMM): measured +3.6 .. +4.8 % per shape and +1 % end to
+  // end over the 128 x 128 tile (profiles/r2_v4_gemm_microbench_{default,bn160}.log); SAMPT_GEMM_BN160=0 disables it
+  static const bool bn160 = !(getenv("SAMPT_GEMM_BN160") && atoi(getenv("SAMPT_GEMM_BN160")) == 0);
   if ((variant == 4 || variant == 5 || variant == 7) && swz && p.M >= 256 && p.N >= 256) {
     // 256 x 256 tile, 8 waves of 128 x 64, two 64 KiB LDS stages (1 workgroup per CU): a K-slab is 64 MFMAs per wave, so
     // the DMA of the next slab has ~2000 cycles to land and LDS traffic per FLOP halves against the 128 x 128 tile
