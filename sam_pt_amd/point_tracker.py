@@ -173,78 +173,101 @@ class PipsPointTracker(PointTracker):
         advances by one window per round, all of them batched into one ``sampt_pips_update_f32`` call with per-point
         window frames.  Results are identical per point; the number of device calls drops from one per distinct anchor
         to max-windows-per-chain, and the MFMA GEMMs of the mixer always see all active points."""
+        import numpy as np
         dev = pyr[0].device
         N = query_points.shape[0]
         H0, W0 = pyr[0].shape[1:3]
         S = self.s
-        traj = torch.zeros(T, N, 2)
-        vis = torch.zeros(T, N)
-        start = query_points[:, 0].long()
-        ar = torch.arange(N)
+        # Host state in numpy: a round's bookkeeping is a few dozen tiny array operations and the tracker stream idles while
+        # the host does them (23 rounds per benchmark clip), so their per-call overhead matters.  Arithmetic that decides
+        # anything (visibility thresholds) stays float32, as in the reference's torch code.
+        qp = query_points.numpy().astype(np.float32)
+        traj = np.zeros((T, N, 2), np.float32)
+        vis = np.zeros((T, N), np.float32)
+        start = qp[:, 0].astype(np.int64)
+        ar = np.arange(N)
         vis[start, ar] = 1.0
-        traj[start, ar] = query_points[:, 1:]
+        traj[start, ar] = qp[:, 1:]
+        flip = flipped.numpy().astype(bool)
         feat_init = torch.zeros(N, 128, device=dev)
-        have_feat = torch.zeros(N, dtype=torch.bool)
-        cur = start.clone()
-        thr0 = float(self.initial_next_frame_visibility_threshold)
+        have_feat = np.zeros(N, bool)
+        cur = start.copy()
+        thr0 = np.float32(self.initial_next_frame_visibility_threshold)
+        step = np.float32(0.02)
         pyr_ptrs = _lib.ptr_array(pyr)
         pending = list(chunk_events) if chunk_events else []
-
-        def orig(d, fl):                       # direction frame -> original frame index
-            return torch.where(fl, T - 1 - d, d)
+        pin = dev.type == "cuda"
+        sw = np.arange(S)[None, :]
 
         while True:
-            act = (cur < T - 1).nonzero().flatten()            # tracker.py:67: anchors range over n_frames-1
-            if act.numel() == 0:
+            act = np.nonzero(cur < T - 1)[0]                    # tracker.py:67: anchors range over n_frames-1
+            if act.size == 0:
                 break
-            n = act.numel()
+            n = int(act.size)
             f = cur[act]                                        # (n,) anchor frame of each active chain
-            hi = torch.clamp(T - f, max=S)                      # frames available in the window (S - n_missing)
-            win = f[:, None] + torch.arange(S)[None, :]
-            win = torch.minimum(win, (f + hi - 1)[:, None])    # repeat the last frame (tracker.py:73-78)
-            used = orig(win, flipped[act][:, None])
+            hi = np.minimum(T - f, S)                           # frames available in the window (S - n_missing)
+            win = np.minimum(f[:, None] + sw, (f + hi - 1)[:, None])   # repeat the last frame (tracker.py:73-78)
+            used = np.where(flip[act][:, None], T - 1 - win, win)      # direction frame -> original frame index
             if pending:                                         # pyramid chunks this round reads (prepare() on another stream)
                 lo, hi_f = int(used.min()), int(used.max())
                 for c in [c for c in pending if c[0] <= hi_f and c[1] > lo]:
                     torch.cuda.current_stream().wait_event(c[2])
                     pending.remove(c)
-            fidx = used.to(torch.int32).to(dev).contiguous()        # [n][S]
-            xys_cpu = traj[f, act]                              # (n,2)
-            xys = xys_cpu.to(dev).contiguous()
+            xys_np = traj[f, act]                               # (n,2)
             fresh = ~have_feat[act]
-            if fresh.any():                                     # tracker.py:81-90 == App. B-6: feature at the query frame
-                fa = act[fresh]
-                xy = (xys_cpu[fresh] / float(self.stride)).to(dev).contiguous()
-                fr = fidx[fresh.to(dev), 0].contiguous()
-                out = torch.empty(fa.numel(), 128, device=dev)
-                _lib.check(self._lib.sampt_pips_sample_feat_f32(_lib.ptr(pyr[0]), H0, W0, _lib.ptr(fr), _lib.ptr(xy),
-                                                                fa.numel(), _lib.ptr(out), _lib.stream_ptr()),
-                           "sampt_pips_sample_feat_f32")
-                feat_init[fa.to(dev)] = out
-                have_feat[fa] = True
-            fi = feat_init[act.to(dev)].contiguous()
-            tr_o = torch.empty(S, n, 2, device=dev)
-            vi_o = torch.empty(S, n, device=dev)
+            nf = int(fresh.sum())
+            # ONE upload per round: [window frames n*S | chain ids n | fresh chain ids nf | fresh frames nf] as int32 and
+            # [anchor positions n*2 | fresh positions / stride nf*2] as float32 behind them (bit-cast)
+            ints = np.concatenate([used.reshape(-1), act, act[fresh], used[fresh, 0]]).astype(np.int32)
+            flts = np.concatenate([xys_np.reshape(-1), (xys_np[fresh] / np.float32(self.stride)).reshape(-1)]).astype(np.float32)
+            host = torch.from_numpy(np.concatenate([ints, flts.view(np.int32)]))
+            if pin:
+                host = host.pin_memory()
+            stage = host.to(dev, non_blocking=True)
+            o = 0
+            fidx = stage[o:o + n * S].view(n, S); o += n * S
+            act_d = stage[o:o + n].long(); o += n
+            fa_d = stage[o:o + nf].long(); o += nf
+            fr = stage[o:o + nf]; o += nf
+            xys = stage[o:o + 2 * n].view(torch.float32).view(n, 2); o += 2 * n
+            if nf:                                              # tracker.py:81-90 == App. B-6: feature at the query frame
+                xy = stage[o:o + 2 * nf].view(torch.float32).view(nf, 2)
+                out = torch.empty(nf, 128, device=dev)
+                _lib.check(self._lib.sampt_pips_sample_feat_f32(_lib.ptr(pyr[0]), H0, W0, _lib.ptr(fr), _lib.ptr(xy), nf,
+                                                                _lib.ptr(out), _lib.stream_ptr()), "sampt_pips_sample_feat_f32")
+                feat_init[fa_d] = out
+                have_feat[act[fresh]] = True
+            fi = feat_init.index_select(0, act_d)
+            res = torch.empty(S * n * 3, device=dev)            # ONE download per round: [trajectories S*n*2 | visibilities S*n]
+            tr_o, vi_o = res[:S * n * 2].view(S, n, 2), res[S * n * 2:].view(S, n)
             _lib.check(self._lib.sampt_pips_update_f32(self._h, pyr_ptrs, H0, W0, _lib.ptr(fidx), n, _lib.ptr(xys),
                                                        _lib.ptr(fi), 6, _lib.ptr(tr_o), _lib.ptr(vi_o), _lib.ptr(ws),
                                                        ws.numel(), _lib.stream_ptr()), "sampt_pips_update_f32")
             self.stats["windows"] += 1
             self.stats["point_windows"] = self.stats.get("point_windows", 0) + n
-            tr_c, vi_c = tr_o.cpu(), vi_o.cpu()                 # linking below is data-dependent host control flow
-            for j in range(n):                                  # write frames 1..hi-1 of each chain (tracker.py:104-109)
-                p, fj, hj = int(act[j]), int(f[j]), int(hi[j])
-                vis[fj + 1:fj + hj, p] = vi_c[1:hj, j]
-                traj[fj + 1:fj + hj, p] = tr_c[1:hj, j]
+            res_c = res.cpu().numpy()                           # linking below is data-dependent host control flow
+            tr_c, vi_c = res_c[:S * n * 2].reshape(S, n, 2), res_c[S * n * 2:].reshape(S, n)
+            # write frames 1..hi-1 of each chain (tracker.py:104-109)
+            ss = np.arange(1, S)[:, None]                       # (S-1, 1) window slots
+            ok = ss < hi[None, :]                               # (S-1, n)
+            rows = (f[None, :] + ss)[ok]
+            cols = np.broadcast_to(act[None, :], ok.shape)[ok]
+            vis[rows, cols] = vi_c[1:][ok]
+            traj[rows, cols] = tr_c[1:][ok]
             # trajectory linking per chain (tracker.py:111-148)
-            thr = torch.full((n,), thr0)
+            thr = np.full(n, thr0, np.float32)
             earliest, last = f + 1, f + hi - 1
-            nxt = last.clone()
-            while (vis[nxt, act] <= thr).any():
-                nxt = torch.where(vis[nxt, act] <= thr, nxt - 1, nxt)
-                thr = torch.where(nxt < earliest, thr - 0.02, thr)
-                nxt = torch.where(nxt < earliest, last, nxt)
+            nxt = last.copy()
+            while True:
+                low = vis[nxt, act] <= thr
+                if not low.any():
+                    break
+                nxt = np.where(low, nxt - 1, nxt)
+                wrap = nxt < earliest
+                thr = np.where(wrap, thr - step, thr)
+                nxt = np.where(wrap, last, nxt)
             cur[act] = nxt
-        return traj, vis > 0.5
+        return torch.from_numpy(traj), torch.from_numpy(vis > 0.5)
 
     @torch.no_grad()
     @_lib.on_device(lambda self, rgbs, query_points: rgbs.device)
