@@ -129,7 +129,10 @@ def gemm_roofline(args, dev, insitu=None):
     # L2-miss (HBM + Infinity Cache) bytes per launch from the committed --pmc passes (tools/gemm_traffic.py); bench.py
     # cannot run rocprofv3 on itself, so the figure is looked up per shape and is null for shapes that were not profiled
     traffic_tab, tot_traffic, tot_alg_bytes = {}, 0.0, 0.0
-    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_gemm_hbm_traffic.json")
+    pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    tpath = os.path.join(pdir, "r2_gemm_hbm_traffic.json")        # PMC passes of the shipped kernel (tools/gemm_traffic.py)
+    if not os.path.exists(tpath):
+        tpath = os.path.join(pdir, "r1_gemm_hbm_traffic.json")
     if os.path.exists(tpath):
         with open(tpath) as fh:
             traffic_tab = json.load(fh)["per_launch"]
