@@ -247,7 +247,7 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64, OCC) void gemm_f16_gl
 __global__ __launch_bounds__(256, 4) void gemm_f16_glds_bk32(GemmP p) {
   constexpr int BM = 128, BN = 128, BK = 32, FM = 4, FN = 4, BUF = (BM + BN) * BK;
   __shared__ __attribute__((aligned(1024))) half_t lds[2 * BUF];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int nt_m = (p.M + BM - 1) / BM, nt_n = (p.N + BN - 1) / BN;
   const int R = p.xcd_swizzle, nstrips = (nt_m + R - 1) / R, per_strip = R * nt_n;

@@ -196,7 +196,6 @@ class PipsPointTracker(PointTracker):
         step = np.float32(0.02)
         pyr_ptrs = _lib.ptr_array(pyr)
         pending = list(chunk_events) if chunk_events else []
-        pin = dev.type == "cuda"
         sw = np.arange(S)[None, :]
 
         while True:
@@ -220,10 +219,7 @@ class PipsPointTracker(PointTracker):
             # [anchor positions n*2 | fresh positions / stride nf*2] as float32 behind them (bit-cast)
             ints = np.concatenate([used.reshape(-1), act, act[fresh], used[fresh, 0]]).astype(np.int32)
             flts = np.concatenate([xys_np.reshape(-1), (xys_np[fresh] / np.float32(self.stride)).reshape(-1)]).astype(np.float32)
-            host = torch.from_numpy(np.concatenate([ints, flts.view(np.int32)]))
-            if pin:
-                host = host.pin_memory()
-            stage = host.to(dev, non_blocking=True)
+            stage = torch.from_numpy(np.concatenate([ints, flts.view(np.int32)])).to(dev)
             o = 0
             fidx = stage[o:o + n * S].view(n, S); o += n * S
             act_d = stage[o:o + n].long(); o += n
