@@ -197,6 +197,7 @@ struct DecEngine {
     const float *cv0_w, *cv0_b, *cvln_w, *cvln_b, *cv1_w, *cv1_b;  // compress_vit_feat  (vit_dim -> C -> C/8)
     const float *ee0_w, *ee0_b, *eeln_w, *eeln_b, *ee1_w, *ee1_b;  // embedding_encoder  (C -> C/4 -> C/8)
     const float *mf0_w, *mf0_b, *mfln_w, *mfln_b, *mf1_w, *mf1_b;  // embedding_maskfeature: conv3x3 [Cout][9*Cin]
+    const half_t *mf0_hl = nullptr, *mf1_hl = nullptr;             // their split-fp16 planes (optional)
   } hq;
   // optional (opt-in, pack.pack_decoder with SAMPT_DEC_F16X3=1): split-fp16 planes [2][N][K] of the attention projection
   // weights, keyed by the f32 weight pointer; projections over the image tokens (M = F*g*g rows) then run on the fp16

@@ -84,6 +84,8 @@ int DecEngine::init(const WeightMap& w, const DecConfig& cfg) {
     seq("compress_vit_feat", hq.cv0_w, hq.cv0_b, hq.cvln_w, hq.cvln_b, hq.cv1_w, hq.cv1_b);
     seq("embedding_encoder", hq.ee0_w, hq.ee0_b, hq.eeln_w, hq.eeln_b, hq.ee1_w, hq.ee1_b);
     seq("embedding_maskfeature", hq.mf0_w, hq.mf0_b, hq.mfln_w, hq.mfln_b, hq.mf1_w, hq.mf1_b);
+    if (w.has(M + "embedding_maskfeature.0.weight_packed_hl")) hq.mf0_hl = w.h(M + "embedding_maskfeature.0.weight_packed_hl");
+    if (w.has(M + "embedding_maskfeature.3.weight_packed_hl")) hq.mf1_hl = w.h(M + "embedding_maskfeature.3.weight_packed_hl");
   }
   if (!w.missing.empty()) {
     error = "DecEngine: missing weights: " + w.missing;
@@ -280,13 +282,23 @@ int DecEngine::decode(int F, const float* features, const float* hq_feat, const 
     p.A = b.up1, p.W = hq.mf0_w, p.bias = hq.mf0_b, p.C = uh0;
     p.M = (int)(16 * FP), p.N = C / 4, p.K = 9 * (C / 8), p.ldw = p.K, p.ldc = C / 4;
     p.conv = 1, p.cH = Lr, p.cW = Lr, p.cC = C / 8, p.KH = 3, p.KW = 3, p.cstride = 1, p.cpad = 1, p.OH = Lr, p.OW = Lr;
-    SAMPT_TRY(gemm_f32(p, s));
+    if (hq.mf0_hl) {   // 3-term split-fp16 MFMAs: fp32-grade, 2.25x the f32 MFMA rate (the two convs are 4.8 of an HQ pass's 8.6 GFLOP)
+      p.W = hq.mf0_hl, p.W_lo = hq.mf0_hl + (size_t)p.N * p.K, p.alpha = 1.0f / (float)(1 << F16X3_WSHIFT);
+      SAMPT_TRY(conv_f16x3(p, s));
+    } else {
+      SAMPT_TRY(gemm_f32(p, s));
+    }
     SAMPT_TRY(layernorm_rows(uh0, hq.mfln_w, hq.mfln_b, uh0, 16L * FP, C / 4, 1e-6f, nullptr, 0, ACT_GELU, s));
     GemmP q;
     q.A = uh0, q.W = hq.mf1_w, q.bias = hq.mf1_b, q.C = uh1, q.res = hq_feat;
     q.M = (int)(16 * FP), q.N = C / 8, q.K = 9 * (C / 4), q.ldw = q.K, q.ldc = C / 8, q.ldr = C / 8;
     q.conv = 1, q.cH = Lr, q.cW = Lr, q.cC = C / 4, q.KH = 3, q.KW = 3, q.cstride = 1, q.cpad = 1, q.OH = Lr, q.OW = Lr;
-    SAMPT_TRY(gemm_f32(q, s));
+    if (hq.mf1_hl) {
+      q.W = hq.mf1_hl, q.W_lo = hq.mf1_hl + (size_t)q.N * q.K, q.alpha = 1.0f / (float)(1 << F16X3_WSHIFT);
+      SAMPT_TRY(conv_f16x3(q, s));
+    } else {
+      SAMPT_TRY(gemm_f32(q, s));
+    }
     const float* hq_tok = queries + 5 * C;
     SAMPT_TRY(l.lin(hq_tok, F, C, hq.mlp_w[0], hq.mlp_b[0], b.t0, C, ACT_RELU, nullptr, Nt * C));
     SAMPT_TRY(l.lin(b.t0, F, C, hq.mlp_w[1], hq.mlp_b[1], b.t1, C, ACT_RELU));

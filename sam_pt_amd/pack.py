@@ -242,6 +242,9 @@ def pack_decoder(sd: Dict[str, torch.Tensor], cfg: SamConfig, device, max_frames
             w = sd[f"mask_decoder.embedding_maskfeature.{i}.weight"].float()
             out[f"mask_decoder.embedding_maskfeature.{i}.weight_packed"] = \
                 w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
+            if os.environ.get("SAMPT_DEC_F16X3", "1") != "0":                  # fp32-grade on the fp16 pipe (Cin 32 / 64)
+                out[f"mask_decoder.embedding_maskfeature.{i}.weight_packed_hl"] = \
+                    split_f16x3(out[f"mask_decoder.embedding_maskfeature.{i}.weight_packed"])
     out["mask_decoder.__out_tokens"] = torch.cat(toks, dim=0).float().contiguous()
     out["prompt_encoder.__point_embeddings"] = torch.cat(
         [sd[f"prompt_encoder.point_embeddings.{i}.weight"] for i in range(4)], dim=0).float().contiguous()

@@ -1,8 +1,13 @@
 set -u
-R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/r2_v6; mkdir -p $OUT; cd $R
-for v in 1 9 4 7 3; do
-  SAMPT_GEMM_BN160=0 SAMPT_GEMM_VARIANT=$v timeout 100 python tools/gemm_bench.py 8 > $OUT/gemm_v$v.log 2>&1
-done
-timeout 100 python tools/gemm_bench.py 8 > $OUT/gemm_bn160.log 2>&1
-for v in 1 9 4 7 3 bn160; do echo "== variant $v"; grep "M= 32768" $OUT/gemm_v$v.log $OUT/gemm_$v.log 2>/dev/null | cut -d: -f2- | cut -c1-100; done
-timeout 90 python tools/stage_times.py > $OUT/stage_times.log 2>&1; tail -1 $OUT/stage_times.log
+R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/r2_final; mkdir -p $OUT; cd $R
+timeout 1100 python -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
+timeout 200 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1
+timeout 500 python bench.py --steps 20 --warmup 5 > $OUT/bench_vith.log 2>&1
+timeout 200 python bench.py --no-cpu-baseline --no-secondary --no-roofline --hq --tracker cotracker --points 16 --objects 5 --square 1024 --frames 24 > $OUT/bench_cfg5_hq_cotracker.log 2>&1
+timeout 200 python bench.py --no-cpu-baseline --no-secondary --no-roofline --hq > $OUT/bench_hq_pips.log 2>&1
+tail -4 $OUT/pytest_gpu.log; tail -1 $OUT/smoke.log; tail -1 $OUT/bench_vith.log | cut -c1-250; tail -1 $OUT/bench_cfg5_hq_cotracker.log | cut -c1-200; tail -1 $OUT/bench_hq_pips.log | cut -c1-200
+tail -1 $OUT/bench_vith.log | python -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+for k in ('value','ms_per_step','secondary','parity','cpu_baseline'): print(k, json.dumps(d.get(k))[:400])
+"
