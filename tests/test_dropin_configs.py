@@ -182,3 +182,40 @@ def test_prepared_pyramid_path_on_the_fake_device(monkeypatch):
     rgbs[0, 0, 0, 0, 0] += 1                                         # in-place edit: the cached pyramid is stale
     trk(rgbs, q)
     assert fake.calls["pips_fnet_frames"] == 27
+
+
+def test_checkpoint_files_load_through_the_reference_conventions(tmp_path, monkeypatch):
+    """`checkpoint` / `checkpoint_path` constructor arguments: SAM `.pth` state dict (sam.py:21-24), PIPS directory with
+    `model-*.pth` holding 'model_state_dict' (utils/saverloader.py:30-73), CoTracker `.pth` optionally wrapped in 'model'
+    (build_cotracker) — the weights that reach the packer are the file's, and HQ-SAM is recognised by its keys."""
+    from tests import fake_hip
+    from sam_pt_amd.point_tracker import CoTrackerPointTracker, PipsPointTracker
+    from sam_pt_amd.sam_predictor import SamHip, SamPredictor
+    from sam_pt_amd.weights import SAM_CONFIGS, init_cotracker_state_dict, init_pips_state_dict, init_sam_state_dict
+    cfg = SAM_CONFIGS["vit_test"]
+    sd = init_sam_state_dict(cfg, 5, hq=True)
+    torch.save(sd, tmp_path / "sam_hq_vit_test.pth")
+    sam = SamHip(config=cfg, checkpoint=str(tmp_path / "sam_hq_vit_test.pth"), precision="f32")
+    assert sam.hq and all(torch.equal(sam.sd[k], v) for k, v in sd.items())
+    plain = {k: v for k, v in sd.items() if not any(t in k for t in ("hf_token", "hf_mlp", "compress_vit_feat",
+                                                                        "embedding_encoder", "embedding_maskfeature"))}
+    torch.save(plain, tmp_path / "sam_vit_test.pth")
+    assert not SamHip(config=cfg, checkpoint=str(tmp_path / "sam_vit_test.pth")).hq
+    with pytest.raises(ValueError):
+        SamHip(config=cfg, checkpoint=str(tmp_path / "sam_vit_test.pth"), hq=True)
+    psd = init_pips_state_dict(9)
+    (tmp_path / "pips").mkdir()
+    torch.save({"model_state_dict": init_pips_state_dict(8)}, tmp_path / "pips" / "model-000000001.pth")
+    torch.save({"model_state_dict": psd}, tmp_path / "pips" / "model-000200000.pth")          # the newest one wins
+    trk = PipsPointTracker(checkpoint_path=str(tmp_path / "pips"))
+    assert all(torch.equal(trk._sd[k], v) for k, v in psd.items())
+    csd = init_cotracker_state_dict(3)
+    torch.save({"model": csd}, tmp_path / "cotracker_stride_4_wind_8.pth")
+    ctrk = CoTrackerPointTracker(checkpoint_path=str(tmp_path / "cotracker_stride_4_wind_8.pth"))
+    assert all(torch.equal(ctrk._sd[k], v) for k, v in csd.items())
+    # ... and they reach the device-side packer unchanged in value (fake device: the packed dict is what *_create receives)
+    fake = fake_hip.install(monkeypatch, plain, cfg, psd)
+    pred = SamPredictor(SamHip(config=cfg, checkpoint=str(tmp_path / "sam_vit_test.pth"), precision="f32"))
+    pred._ensure()
+    assert torch.equal(pred._wv["image_encoder.blocks.0.attn.qkv.weight"], plain["image_encoder.blocks.0.attn.qkv.weight"])
+    assert torch.equal(pred._wd["mask_decoder.iou_prediction_head.layers.2.weight"], plain["mask_decoder.iou_prediction_head.layers.2.weight"])
