@@ -161,6 +161,20 @@ int sampt_vit_profile_end(sampt_vit_t h, double* flop, double* ms, int* launches
  * global-attention block — HQ-SAM's interm_embeddings[0] (configs/model/sam/samhq_vit_*.yaml, MaskDecoderHQ). */
 int sampt_vit_encode(sampt_vit_t h, const uint8_t* frames_dev, int chw, int B, int H, int W, float* features_dev,
                      float* interm_out_dev, void* workspace_dev, size_t workspace_bytes, sampt_stream_t stream);
+/* The same result (bit for bit) with the frame-independent part of the work done once per frame geometry.  Sam.preprocess
+ * (sam.py: normalise, then zero-pad to img_size^2) leaves the token rows below a landscape frame — 28 of 64 rows for 16:9
+ * video — without any pixel; until the first global-attention block such a token only ever meets tokens of its own
+ * window, so whole window rows of them evolve identically in every frame.
+ *   sampt_vit_live_rows: *live_rows = the token rows that can depend on the frame before the first global block
+ *     (ceil(H/patch) completed to whole windows), == grid when nothing can be skipped (portrait / square frames, a
+ *     global block first); *cache_bytes = size of the dead-row cache [(grid - live_rows) * grid][embed_dim] f32.
+ *   sampt_vit_encode_live(build=1): fills dead_cache_dev from ONE frame of that geometry (frames_dev[0]; features_dev /
+ *     interm_out_dev unused).  build=0: encodes B frames, running the blocks before the first global one on the live
+ *     rows only and taking the other rows from dead_cache_dev.  Workspace: sampt_vit_encode_workspace_bytes. */
+int sampt_vit_live_rows(sampt_vit_t h, int H, int W, int* live_rows, size_t* cache_bytes);
+int sampt_vit_encode_live(sampt_vit_t h, const uint8_t* frames_dev, int chw, int B, int H, int W, float* features_dev,
+                          float* interm_out_dev, float* dead_cache_dev, int build, void* workspace_dev,
+                          size_t workspace_bytes, sampt_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * seam 2b — prompt encoder + mask decoder + postprocess = SamPredictor.predict_torch(multimask_output=False,

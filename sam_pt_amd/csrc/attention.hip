@@ -369,13 +369,13 @@ int vit_flash_attention_f16(const half_t* qkv, const float* relh, const float* r
   const int N = S * S;
   const float scale = 1.0f / sqrtf((float)hd);
   static const int dbg = getenv("SAMPT_FLASH_DBG") ? atoi(getenv("SAMPT_FLASH_DBG")) : 0;
-  static const bool nw7 = getenv("SAMPT_FLASH_NW7") && atoi(getenv("SAMPT_FLASH_NW7")) != 0;
 #define FL(HDv, NWv, SGv)                                                                                        \
   hipLaunchKernelGGL((k_flash_f16<HDv, NWv, SGv>), dim3(cdiv(N, NWv * 32), heads, B), dim3(NWv * 64), 0, s, qkv, \
                      relh, relw, out, N, heads, scale, dbg)
   if (S == 64 && hd == 80) FL(80, 4, 64);
   else if (S == 64 && hd == 64) FL(64, 4, 64);
-  else if (S == 14 && hd == 80 && nw7) FL(80, 7, 14);   // experiment: one 7-wave workgroup per (window, head): 224 query slots
+  // (a 7-wave workgroup per (window, head) — 224 query slots for the 196 tokens instead of 2 x 128 — measured 4 % slower,
+  //  profiles/r2_v7_attn_nw7.log: the K/V staging is the same and 188 VGPRs leave one workgroup per SIMD set)
   else if (S == 14 && hd == 80) FL(80, 4, 14);
   else if (S == 14 && hd == 64) FL(64, 4, 14);
   else if (S == 16 && hd == 32) FL(32, 4, 16);   // reduced test geometry (vit_test)

@@ -234,8 +234,32 @@ int sampt_vit_encode_workspace_bytes(sampt_vit_t h, int B, size_t* bytes) {
   if (!h || !bytes || B <= 0) return SAMPT_ERR_ARG;
   Arena a(nullptr, 0);
   int rc = h->e.encode(nullptr, 1, B, h->e.c.img, h->e.c.img, nullptr, nullptr, a, nullptr);
-  *bytes = a.peak + 256;
+  // + the compact live-row stream of sampt_vit_encode_live (at most one more copy of the residual stream)
+  *bytes = a.peak + 512 + (size_t)B * h->e.c.grid * h->e.c.grid * h->e.c.D * sizeof(float);
   return rc;
+}
+
+int sampt_vit_live_rows(sampt_vit_t h, int H, int W, int* live_rows, size_t* cache_bytes) {
+  if (!h || !live_rows || !cache_bytes) return SAMPT_ERR_ARG;
+  const int g = h->e.c.grid, lh = h->e.live_rows(H, W);
+  *live_rows = lh;
+  *cache_bytes = (size_t)(g - lh) * g * h->e.c.D * sizeof(float);
+  return SAMPT_OK;
+}
+
+int sampt_vit_encode_live(sampt_vit_t h, const uint8_t* frames, int chw, int B, int H, int W, float* features,
+                          float* interm_out, float* dead_cache, int build, void* ws, size_t ws_bytes,
+                          sampt_stream_t stream) {
+  if (!h || !frames || !dead_cache || !ws || B <= 0 || (!build && !features))
+    return fail(SAMPT_ERR_ARG, "sampt_vit_encode_live: bad arguments");
+  if (H > h->e.c.img || W > h->e.c.img || (H != h->e.c.img && W != h->e.c.img))
+    return fail(SAMPT_ERR_UNSUPPORTED, "sampt_vit_encode_live: the frame's longest side must equal img_size");
+  if (h->e.live_rows(H, W) >= h->e.c.grid)
+    return fail(SAMPT_ERR_UNSUPPORTED,
+                "sampt_vit_encode_live: this frame geometry has no frame-independent token rows (sampt_vit_live_rows)");
+  Arena a(ws, ws_bytes);
+  return h->e.encode(frames, chw, build ? 1 : B, H, W, features, interm_out, a, (hipStream_t)stream, dead_cache,
+                     build ? 1 : 2);
 }
 
 int sampt_vit_encode(sampt_vit_t h, const uint8_t* frames, int chw, int B, int H, int W, float* features,

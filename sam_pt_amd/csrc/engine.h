@@ -144,6 +144,8 @@ struct VitEngine {
   const int* win_rows;  // [Bmax * nwin * window^2] -> token row or -1
   const int* win_inv;   // [Bmax * grid^2] token row -> window-order row
   const int* win_pad;   // [Bmax * npad] window-order rows that are zero padding
+  const int* win_inv_live[8] = {};   // the same two maps for the compact live grids of k+1 window rows x grid columns
+  const int* win_pad_live[8] = {};
   int win_rows_batches = 0;
   std::string error;
   // Optional in-situ timing of the fp16 GEMM launches (bench.py's roofline): HIP events on the launching stream around
@@ -160,8 +162,12 @@ struct VitEngine {
   // frames: uint8 (B,3,H,W) if chw else (B,H,W,3); features out: [B][grid*grid][out_chans] f32 (NHWC);
   // interm_out (optional): [B][grid*grid][D] f32 = token stream after the first global-attention block (HQ-SAM's
   // interm_embeddings[0])
+  // dead_mode 0: full computation.  1: B == 1, computes `dead_cache` [(grid - live_rows) * grid][D] f32 (the residual
+  // stream of the frame-independent padding tokens at the input of the first global block) and returns.  2: blocks before
+  // the first global one run on the live rows only, the dead rows come from `dead_cache` (see encode()).
   int encode(const uint8_t* frames, int chw, int B, int H, int W, float* features, float* interm_out, Arena& ws,
-             hipStream_t s);
+             hipStream_t s, float* dead_cache = nullptr, int dead_mode = 0);
+  int live_rows(int H, int W) const;   // token rows that depend on the frame before the first global block (grid = all)
 };
 
 // -------------------------------------------------------------------------------------------------

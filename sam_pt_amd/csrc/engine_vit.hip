@@ -38,6 +38,11 @@ int VitEngine::init(const WeightMap& w, const VitConfig& cfg, int wrb) {
   neck3w = w.f(e + "neck.3.weight"), neck3b = w.f(e + "neck.3.bias");
   win_rows = w.i("__win_rows");
   win_inv = w.i("__win_inv"), win_pad = w.i("__win_pad");
+  for (int k = 0; k < 8; ++k) {   // window maps of the compact live grids (k+1 window rows x full width), optional
+    const std::string sk = std::to_string(k + 1);
+    win_inv_live[k] = w.has("__win_inv_live" + sk) ? w.i("__win_inv_live" + sk) : nullptr;
+    win_pad_live[k] = w.has("__win_pad_live" + sk) ? w.i("__win_pad_live" + sk) : nullptr;
+  }
   if (!w.missing.empty()) {
     error = "VitEngine: missing weights: " + w.missing;
     return SAMPT_ERR_ARG;
@@ -93,8 +98,20 @@ struct G {
 };
 }  // namespace
 
+int VitEngine::live_rows(int H, int W) const {
+  // Token rows that can depend on the frame before the first global-attention block: the rows holding pixels, completed to
+  // whole windows.  Only for landscape / square-width frames (the live tokens are then a contiguous prefix of every frame).
+  int g0 = 0;
+  while (g0 < c.depth && !((c.global_mask >> g0) & 1)) ++g0;
+  if (g0 == 0 || W != c.img) return c.grid;
+  const int h_tok = (H + c.patch - 1) / c.patch;
+  const int lh = ((h_tok + c.window - 1) / c.window) * c.window;
+  if (lh >= c.grid || lh / c.window > 8 || !win_inv_live[lh / c.window - 1]) return c.grid;
+  return lh;
+}
+
 int VitEngine::encode(const uint8_t* frames, int chw, int B, int H, int W, float* features, float* interm_out, Arena& ws,
-                      hipStream_t s) {
+                      hipStream_t s, float* dead_cache, int dead_mode) {
   const bool dry = ws.dry();
   const int g = c.grid, T = g * g, D = c.D, ws_ = c.window, hd = D / c.heads;
   const int gp = ((g + ws_ - 1) / ws_) * ws_, nw1 = gp / ws_, nwin = nw1 * nw1, wt = ws_ * ws_;
@@ -103,6 +120,22 @@ int VitEngine::encode(const uint8_t* frames, int chw, int B, int H, int W, float
   const int Kp = 3 * c.patch * c.patch;
   if (B > win_rows_batches) return SAMPT_ERR_ARG;
 
+  // ---- frames whose height is not the padded square's: the token rows below the picture (zero padding after
+  //      Sam.preprocess, 28 of 64 rows for 16:9 video) hold the same values in EVERY frame until the first global-attention
+  //      block mixes them with picture tokens — their patch embedding is bias + pos_embed and the windowed blocks only mix
+  //      tokens of one window.  Blocks before the first global one therefore run on a compact stream of the live rows only
+  //      (dead_mode 2) and the dead rows' residual stream is taken from a cache computed once per frame geometry (dead_mode
+  //      1: one zero frame through the full path).  Bit-identical to the full computation: GEMM rows, LayerNorm rows and
+  //      attention windows are independent of which other rows / windows share the launch.
+  int g0 = 0;
+  while (g0 < c.depth && !((c.global_mask >> g0) & 1)) ++g0;
+  const int lh = live_rows(H, W);
+  const bool rect = dead_mode == 2 && lh < g;
+  if (dead_mode != 0 && (lh >= g || !dead_cache)) return SAMPT_ERR_ARG;
+  if (dead_mode == 1 && B != 1) return SAMPT_ERR_ARG;
+  const int Tl = lh * g, nwin_l = (lh / ws_) * nw1;
+  const long Ml = (long)B * Tl;
+  float* xl = rect ? ws.f32((size_t)Ml * D) : nullptr;
   float* x = ws.f32((size_t)Mg * D);
   size_t xn_bytes = (size_t)Mmax * (D > Kp ? D : Kp) * esz;        // LN output / attention output (fp16 in the fast mode)
   if ((size_t)Mg * Kp * 4 > xn_bytes) xn_bytes = (size_t)Mg * Kp * 4;  // ... and the fp32 patch matrix
@@ -135,13 +168,39 @@ int VitEngine::encode(const uint8_t* frames, int chw, int B, int H, int W, float
 
   const float scale = 1.0f / sqrtf((float)hd);
   bool tapped = false;
+  float* const x_full = x;
+  const long Mg_full = Mg;
+  if (rect) {   // gather the live rows of every frame into the compact stream
+    if (hipMemcpy2DAsync(xl, (size_t)Tl * D * 4, x_full, (size_t)T * D * 4, (size_t)Tl * D * 4, B, hipMemcpyDeviceToDevice, s) !=
+        hipSuccess)
+      return SAMPT_ERR_HIP;
+  }
   for (int i = 0; i < c.depth; ++i) {
     const Blk& b = blk[i];
     const bool glob = (c.global_mask >> i) & 1;
+    const bool compact = rect && i < g0;
+    if (i == g0 && (rect || dead_mode == 1)) {
+      if (dead_mode == 1) {   // the zero frame went through the full path: keep its dead rows, done
+        if (hipMemcpyAsync(dead_cache, x_full + (size_t)Tl * D, (size_t)(T - Tl) * D * 4, hipMemcpyDeviceToDevice, s) != hipSuccess)
+          return SAMPT_ERR_HIP;
+        return SAMPT_OK;
+      }
+      // back to the full token grid: live rows from the compact stream, dead rows from the cache
+      if (hipMemcpy2DAsync(x_full, (size_t)T * D * 4, xl, (size_t)Tl * D * 4, (size_t)Tl * D * 4, B, hipMemcpyDeviceToDevice, s) !=
+          hipSuccess)
+        return SAMPT_ERR_HIP;
+      for (int f = 0; f < B; ++f)
+        if (hipMemcpyAsync(x_full + ((size_t)f * T + Tl) * D, dead_cache, (size_t)(T - Tl) * D * 4, hipMemcpyDeviceToDevice, s) !=
+            hipSuccess)
+          return SAMPT_ERR_HIP;
+    }
+    float* const x = compact ? xl : x_full;               // (shadows: everything below works on the active stream)
+    const long Mg = compact ? Ml : Mg_full;
     const int S = glob ? g : ws_, N = S * S;
-    const int Bw = glob ? B : B * nwin;
+    const int Bw = glob ? B : B * (compact ? nwin_l : nwin);
     const long M = (long)Bw * N;
-    const int* inv = glob ? nullptr : win_inv;
+    const int* inv = glob ? nullptr : (compact ? win_inv_live[lh / ws_ - 1] : win_inv);
+    const int* win_pad = compact ? win_pad_live[lh / ws_ - 1] : this->win_pad;
     // norm1; the window partition (zero padding AFTER the norm, App. A-3) is a row scatter of the qkv GEMM: only the
     // real tokens go through the GEMM, the padded rows' qkv is the bias alone
     SAMPT_TRY(layernorm_rows(x, b.ln1w, b.ln1b, xn, Mg, D, 1e-6f, nullptr, c.f16, ACT_NONE, s));
@@ -181,6 +240,7 @@ int VitEngine::encode(const uint8_t* frames, int chw, int B, int H, int W, float
       tapped = true;
     }
   }
+  if (dead_mode == 1) return SAMPT_ERR_ARG;   // (no global block: live_rows() already refused)
   // ---- neck: conv1x1 (no bias) -> LayerNorm2d -> conv3x3 (no bias) -> LayerNorm2d
   //      fp32 in both modes: the neck's operand roundings would land on the embedding undamped
   SAMPT_TRY(gm.run(x, (int)Mg, D, neck0_w, nullptr, neck_a, c.out_chans, ACT_NONE, false, nullptr, 0, nullptr, 0, nullptr,

@@ -135,20 +135,24 @@ def pack_pips2(sd: Dict[str, torch.Tensor], device) -> Dict[str, torch.Tensor]:
     return {k: v.to(device) for k, v in out.items()}
 
 
-def window_row_map(grid: int, window: int, batches: int) -> torch.Tensor:
+def window_row_map(grid: int, window: int, batches: int, rows: int = 0) -> torch.Tensor:
     """Row map of SAM's window_partition (App. A-3): entry ((b*nwin + w)*window^2 + i) = source token row
-    b*grid^2 + y*grid + x, or -1 where the window hangs over the zero padding."""
+    b*grid^2 + y*grid + x, or -1 where the window hangs over the zero padding.  `rows` > 0 (a multiple of `window`):
+    the map of a token stream that holds only the first `rows` token rows of every frame (rows x grid tokens per frame,
+    rows/window x ceil(grid/window) windows) — the compact stream of the encoder's dead-row skipping."""
     n1 = (grid + window - 1) // window
+    gh = rows if rows > 0 else grid
+    ny = (gh + window - 1) // window
     ys = torch.arange(n1 * window).view(n1, window)
-    m = torch.full((n1, n1, window, window), -1, dtype=torch.int64)
-    for wy in range(n1):
+    m = torch.full((ny, n1, window, window), -1, dtype=torch.int64)
+    for wy in range(ny):
         for wx in range(n1):
             yy = ys[wy].view(window, 1).expand(window, window)
             xx = ys[wx].view(1, window).expand(window, window)
-            ok = (yy < grid) & (xx < grid)
+            ok = (yy < gh) & (xx < grid)
             m[wy, wx] = torch.where(ok, yy * grid + xx, torch.full_like(yy, -1))
     m = m.reshape(1, -1).repeat(batches, 1)
-    off = (torch.arange(batches) * grid * grid).view(batches, 1)
+    off = (torch.arange(batches) * gh * grid).view(batches, 1)
     m = torch.where(m >= 0, m + off, m)
     return m.reshape(-1).to(torch.int32)
 
@@ -197,6 +201,18 @@ def pack_vit(sd: Dict[str, torch.Tensor], cfg: SamConfig, device, f16: bool, win
     inv[rows[valid].long()] = valid.to(torch.int32)
     out["__win_inv"] = inv
     out["__win_pad"] = (rows < 0).nonzero().flatten().to(torch.int32)
+    # the same two maps for the compact streams of frames that fill only k window rows of the padded square (16:9 video:
+    # k = 3 of 5) — VitEngine::encode runs the blocks before the first global one on those rows only
+    for k in range(1, min(8, cfg.grid // cfg.window_size) + 1):
+        lh = k * cfg.window_size
+        if lh >= cfg.grid:
+            break
+        r = window_row_map(cfg.grid, cfg.window_size, win_batches, rows=lh)
+        v = (r >= 0).nonzero().flatten()
+        iv = torch.empty(win_batches * lh * cfg.grid, dtype=torch.int32)
+        iv[r[v].long()] = v.to(torch.int32)
+        out[f"__win_inv_live{k}"] = iv
+        out[f"__win_pad_live{k}"] = (r < 0).nonzero().flatten().to(torch.int32)
     return {k: v.to(device) for k, v in out.items()}
 
 

@@ -251,6 +251,9 @@ class SamPredictor:
         self._stage: Dict[tuple, Dict[str, torch.Tensor]] = {}
         # hipGraph replay of the per-(frame, object) decode chain (sampt_sam_track_decode_graph); SAMPT_DEC_GRAPH=0|1
         self.use_graph = os.environ.get("SAMPT_DEC_GRAPH", "1") != "0"
+        # skip the frame-independent padding rows of landscape frames in the blocks before the first global one (exact)
+        self.skip_dead_rows = os.environ.get("SAMPT_VIT_SKIP_DEAD", "1") != "0"
+        self._dead_cache = {}
         self.reset_image()
         self.stats = {"set_image": 0, "predict": 0, "encoded_frames": 0}
 
@@ -322,6 +325,25 @@ class SamPredictor:
             self._ws_vit = {B: torch.empty(n.value, dtype=torch.uint8, device=self._dev)}  # keep only the latest size
         return self._ws_vit[B]
 
+    def _dead_rows(self, frames: torch.Tensor, chw: bool, H: int, W: int, ws: torch.Tensor) -> Optional[torch.Tensor]:
+        """Residual stream of the token rows no pixel of an (H, W) frame reaches (the zero padding of Sam.preprocess below
+        a landscape frame) at the input of the first global-attention block: the same in every frame, computed once per
+        geometry from the first frame that has it (sampt_vit_encode_live, include/sampt_hip.h).  None: nothing to skip."""
+        key = (H, W)
+        if key not in self._dead_cache:
+            lh, nb = C.c_int(), C.c_size_t()
+            _lib.check(self._lib.sampt_vit_live_rows(self._vit, H, W, C.byref(lh), C.byref(nb)), "sampt_vit_live_rows")
+            cache = None
+            if nb.value:
+                cache = torch.empty(nb.value // 4, dtype=torch.float32, device=self._dev)
+                _lib.check(self._lib.sampt_vit_encode_live(self._vit, _lib.ptr(frames[:1]), 1 if chw else 0, 1, H, W, None,
+                                                           None, _lib.ptr(cache), 1, _lib.ptr(ws), ws.numel(),
+                                                           _lib.stream_ptr()), "sampt_vit_encode_live(build)")
+            if len(self._dead_cache) >= 8:
+                self._dead_cache.clear()
+            self._dead_cache[key] = cache
+        return self._dead_cache[key]
+
     def _dec_ws(self, oh: int, ow: int, frames: int = 1, k: int = 0) -> torch.Tensor:
         """Decoder scratch for `frames` items with up to k prompt points each (sized in steps: 120 points cover every
         shipped SAM-PT configuration; larger prompts — many objects feeding each other negatives, the VIS adapter's
@@ -358,12 +380,19 @@ class SamPredictor:
         if self.model.hq:
             hq = torch.empty((T, 16 * g * g, Cc // 8), dtype=torch.float32, device=self._dev)
             interm = torch.empty((min(Bm, T), g * g, self.model.cfg.embed_dim), dtype=torch.float32, device=self._dev)
+        dead = self._dead_rows(frames, chw, H, W, self._vit_ws(min(Bm, T))) if self.skip_dead_rows else None
         for t0 in range(0, T, Bm):
             B = min(Bm, T - t0)
             ws = self._vit_ws(B)
-            _lib.check(self._lib.sampt_vit_encode(self._vit, _lib.ptr(frames[t0:t0 + B]), 1 if chw else 0, B, H, W,
-                                                  _lib.ptr(out[t0:t0 + B]), _lib.ptr(interm), _lib.ptr(ws), ws.numel(),
-                                                  _lib.stream_ptr()), "sampt_vit_encode")
+            if dead is not None:
+                _lib.check(self._lib.sampt_vit_encode_live(self._vit, _lib.ptr(frames[t0:t0 + B]), 1 if chw else 0, B, H, W,
+                                                           _lib.ptr(out[t0:t0 + B]), _lib.ptr(interm), _lib.ptr(dead), 0,
+                                                           _lib.ptr(ws), ws.numel(), _lib.stream_ptr()),
+                           "sampt_vit_encode_live")
+            else:
+                _lib.check(self._lib.sampt_vit_encode(self._vit, _lib.ptr(frames[t0:t0 + B]), 1 if chw else 0, B, H, W,
+                                                      _lib.ptr(out[t0:t0 + B]), _lib.ptr(interm), _lib.ptr(ws), ws.numel(),
+                                                      _lib.stream_ptr()), "sampt_vit_encode")
             if hq is not None:      # the ViT tap is consumed batch by batch: only the 32-channel HQ features stay resident
                 if self._ws_hq is None or self._ws_hq[0] < B:
                     n = C.c_size_t()

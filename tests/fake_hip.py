@@ -116,6 +116,12 @@ class FakeHip:
         _set(out, 256)
         return 0
 
+    def sampt_vit_live_rows(self, h, H, W, live, nbytes):
+        # the skipping of frame-independent padding rows is an exact device-side optimisation: the fake has nothing to skip
+        live._obj.value = self.cfg.grid
+        _set(nbytes, 0)
+        return 0
+
     def sampt_vit_encode(self, h, frames, chw, B, H, W, out, interm, ws, nbytes, stream):
         from oracle import sam_ref as R
         self.calls["vit_encode_frames"] += B

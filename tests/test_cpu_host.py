@@ -67,6 +67,21 @@ def test_window_row_map_matches_window_partition():
         assert torch.equal(window_row_map(grid, ws, B).long(), expect)
 
 
+def test_live_window_row_map_is_the_restriction_of_the_full_one():
+    """The compact stream of the encoder's dead-row skipping holds the first `rows` token rows of every frame: its window
+    map must list, window by window, the same tokens as the full map's first rows/window window rows."""
+    from sam_pt_amd.pack import window_row_map
+    for grid, ws, B, rows in [(16, 6, 2, 12), (16, 6, 1, 6), (64, 14, 2, 42), (64, 14, 1, 14)]:
+        n1 = -(-grid // ws)
+        full = window_row_map(grid, ws, B).view(B, n1, n1, ws * ws).long()
+        live = window_row_map(grid, ws, B, rows=rows).view(B, rows // ws, n1, ws * ws).long()
+        for b in range(B):
+            f = full[b, :rows // ws]
+            tok = torch.where(f >= 0, f - b * grid * grid, f)              # token index inside the frame
+            assert (tok < rows * grid).all()
+            assert torch.equal(torch.where(tok >= 0, tok + b * rows * grid, tok), live[b])
+
+
 def test_pixel_shuffle_maps_match_conv_transpose():
     from sam_pt_amd.pack import _convt_pack, _shuffle_map
     g = torch.Generator().manual_seed(0)

@@ -124,6 +124,38 @@ def test_vit_b_encoder_vs_oracle(dev, precision, tol):
     assert rel_err(got, ref) < tol
 
 
+@pytest.mark.parametrize("variant,precision,hw,T", [("vit_test", "f32", (144, 256), 3), ("vit_test", "f16", (100, 256), 3),
+                                                     ("vit_b", "f16", (576, 1024), 3), ("vit_b", "f32", (480, 1024), 1)])
+def test_vit_dead_row_skipping_is_exact(dev, variant, precision, hw, T):
+    """Landscape frames: the blocks before the first global one run on the token rows a pixel can reach, the rest comes
+    from the per-geometry cache (sampt_vit_encode_live) — bit-identical to the full computation, odd batch tail included."""
+    frames, _ = synthetic_clip(T=T, H=hw[0], W=hw[1], seed=11, disc_r=hw[0] // 8)
+    pred = _sam(variant, precision, max_batch=2)
+    assert pred.skip_dead_rows
+    a = pred.encode_frames(frames.to(dev)).clone()
+    assert pred._dead_cache[hw] is not None, "geometry should have frame-independent rows"
+    b = pred.encode_frames(frames.flip(0).to(dev)).flip(0)     # cache reused by a second clip, other frame first
+    pred.skip_dead_rows = False
+    full = pred.encode_frames(frames.to(dev))
+    assert torch.equal(a, full) and torch.equal(b, full)
+    # portrait / square frames have nothing to skip and take the plain entry point
+    pred.skip_dead_rows = True
+    sq, _ = synthetic_clip(T=1, H=hw[1], W=hw[1], seed=3, disc_r=20)
+    pred.encode_frames(sq.to(dev))
+    assert pred._dead_cache[(hw[1], hw[1])] is None
+
+
+def test_hq_features_with_dead_row_skipping(dev):
+    """The HQ-SAM tap (first global block's output) sits after the re-expansion: identical with and without skipping."""
+    from sam_pt_amd.sam_predictor import SamHip, SamPredictor
+    frames, _ = synthetic_clip(T=2, H=144, W=256, seed=5)
+    pred = SamPredictor(SamHip("vit_test", precision="f32", seed=72, max_batch=2, hq=True).cuda())
+    a = pred.encode_frames(frames.to(dev))
+    pred.skip_dead_rows = False
+    b = pred.encode_frames(frames.to(dev))
+    assert torch.equal(a.emb, b.emb) and torch.equal(a.hq, b.hq)
+
+
 def test_predict_torch_vs_oracle(dev):
     """SamPredictor.set_image / predict_torch (points; points+mask; points+box+mask) on ViT-B in exact-f32 mode."""
     from oracle import sam_ref as R
