@@ -311,6 +311,13 @@ int sampt_corr_sample_f32(const float* const pyr_dev[4], int H0, int W0, const i
  * (query, head), keys staged through LDS in chunks of 128 with a running softmax (image->token, hd 16, any Nk). */
 int sampt_attention_f32(int kind, const float* q_dev, const float* k_dev, const float* v_dev, float* out_dev, int F, int Nq,
                         int Nk, int heads, int hd, const int32_t* nk_item_dev, sampt_stream_t stream);
+/* The decoder's token -> image attention (8 heads x 16 channels: q [F][Nq][128], k / v [F][Nk][128]) as the engine runs
+ * it: the keys of a frame are split over workgroups that each read their K / V rows once, fully coalesced, for all heads
+ * and up to 8 queries (running softmax), and a second launch merges the splits.  Same result as kind 0 above up to fp32
+ * re-association. */
+int sampt_attention_t2i_workspace_bytes(int F, int Nq, int Nk, size_t* bytes);
+int sampt_attention_t2i_f32(const float* q_dev, const float* k_dev, const float* v_dev, float* out_dev, int F, int Nq, int Nk,
+                            void* workspace_dev, size_t workspace_bytes, sampt_stream_t stream);
 /* CoTracker's UpdateFormer attention straight from packed qkv rows [rows][3*heads*hd] (timm Attention): token t of group b
  * is row b*batch_stride_rows + t*token_stride_rows (time attention: S, 1; space attention: 1, S); out [rows][heads*hd]. */
 int sampt_cotracker_attention_f32(const float* qkv_dev, float* out_dev, int nbatch, int L, int batch_stride_rows,

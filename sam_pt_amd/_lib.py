@@ -61,6 +61,8 @@ _SIGS = {
     "sampt_vit_profile_begin": (c_int, [_P]),
     "sampt_vit_profile_end": (c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_int)]),
     "sampt_vit_encode": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, c_size_t, _P]),
+    "sampt_attention_t2i_workspace_bytes": (c_int, [c_int, c_int, c_int, C.POINTER(c_size_t)]),
+    "sampt_attention_t2i_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_size_t, _P]),
     "sampt_vit_live_rows": (c_int, [_P, c_int, c_int, C.POINTER(c_int), C.POINTER(c_size_t)]),
     "sampt_vit_encode_live": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, c_size_t, _P]),
     "sampt_dec_create": (c_int, [C.POINTER(c_char_p), C.POINTER(_P), c_int, c_int, c_int, c_int, c_int, C.POINTER(_P)]),

@@ -596,6 +596,18 @@ int sampt_attention_f32(int kind, const float* q, const float* k, const float* v
   return SAMPT_ERR_UNSUPPORTED;
 }
 
+int sampt_attention_t2i_workspace_bytes(int F, int Nq, int Nk, size_t* bytes) {
+  if (!bytes || F <= 0 || Nq <= 0 || Nk <= 0) return SAMPT_ERR_ARG;
+  *bytes = attn_t2i_workspace_floats(F, Nq, Nk) * sizeof(float) + 16;
+  return SAMPT_OK;
+}
+
+int sampt_attention_t2i_f32(const float* q, const float* k, const float* v, float* out, int F, int Nq, int Nk, void* ws,
+                            size_t ws_bytes, sampt_stream_t stream) {
+  if (!q || !k || !v || !out) return fail(SAMPT_ERR_ARG, "sampt_attention_t2i_f32: bad arguments");
+  return attn_t2i(q, k, v, out, F, Nq, Nk, (float*)ws, ws_bytes / sizeof(float), (hipStream_t)stream);
+}
+
 int sampt_cotracker_attention_f32(const float* qkv, float* out, int nbatch, int L, int batch_stride_rows,
                                   int token_stride_rows, int heads, int hd, sampt_stream_t stream) {
   if (!qkv || !out) return fail(SAMPT_ERR_ARG, "sampt_cotracker_attention_f32: bad arguments");

@@ -94,6 +94,10 @@ struct GemmP {
   long sA1 = 0, sA2 = 0, sW1 = 0, sW2 = 0, sC1 = 0, sC2 = 0;
   long sRowmap1 = 0;             // rowmap offset per z1
   int res_mod = 0;               // >0: residual row = row % res_mod (broadcast, e.g. positional embedding)
+  // conv_f16x3 only — ConvTranspose2d(k=2, s=2) as ONE GEMM: the N = 4 * shuf_n columns are (dy, dx, channel); GEMM row
+  // f*g*g + y*g + x, column block z = 2*dy + dx goes to output pixel row f*4*g*g + (2y+dy)*2g + 2x+dx (C / res have
+  // shuf_n columns, bias has shuf_n entries).  shuf_g = g (0: off)
+  int shuf_g = 0, shuf_n = 0;
   int act = ACT_NONE;
   int out_f16 = 0;               // C is half (only when the input type is half)
   int w_kn = 0;                  // W stored [K][N]

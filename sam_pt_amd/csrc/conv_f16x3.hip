@@ -163,17 +163,25 @@ __global__ __launch_bounds__(256) void k_conv_f16x3(GemmP p) {
       if (col >= p.N) continue;
       float4 v = make_float4(acc[i][j][0] * p.alpha, acc[i][j][1] * p.alpha, acc[i][j][2] * p.alpha,
                              acc[i][j][3] * p.alpha);
+      long orow = row;       // destination pixel row and channel (pixel shuffle of a transposed convolution, see GemmP)
+      int ocol = col;
+      if (p.shuf_g) {
+        const int z = col / p.shuf_n, g = p.shuf_g, P = g * g;
+        ocol = col - z * p.shuf_n;
+        const int f = row / P, rem = row - f * P, y = rem / g, x = rem - y * g;
+        orow = (long)f * 4 * P + (long)(2 * y + (z >> 1)) * 2 * g + 2 * x + (z & 1);
+      }
       if (p.bias) {
-        const float4 b = *(const float4*)(p.bias + col);
+        const float4 b = *(const float4*)(p.bias + ocol);
         v.x += b.x, v.y += b.y, v.z += b.z, v.w += b.w;
       }
       v.x = apply_act(v.x, p.act), v.y = apply_act(v.y, p.act), v.z = apply_act(v.z, p.act), v.w = apply_act(v.w, p.act);
       if (p.res) {
-        const long rrow = p.res_mod > 0 ? row % p.res_mod : row;      // broadcast residual (positional embedding)
-        const float4 r = *(const float4*)(p.res + rrow * p.ldr + col);
+        const long rrow = p.res_mod > 0 ? orow % p.res_mod : orow;    // broadcast residual (positional embedding)
+        const float4 r = *(const float4*)(p.res + rrow * p.ldr + ocol);
         v.x += r.x, v.y += r.y, v.z += r.z, v.w += r.w;
       }
-      *(float4*)((float*)p.C + (long)row * p.ldc + col) = v;
+      *(float4*)((float*)p.C + orow * p.ldc + ocol) = v;
     }
   }
 }
@@ -182,6 +190,7 @@ int conv_f16x3(const GemmP& p_in, hipStream_t s) {
   GemmP p = p_in;
   if (!p.A || !p.W || !p.W_lo || !p.C || p.M <= 0 || p.N <= 0) return SAMPT_ERR_ARG;
   if (!p.conv || p.cC % 32 || p.K != p.KH * p.KW * p.cC || p.ldw % 8 || p.N % 4 || p.ldc % 4) return SAMPT_ERR_UNSUPPORTED;
+  if (p.shuf_g && (p.shuf_n <= 0 || p.shuf_n % 4 || p.N != 4 * p.shuf_n || p.M % (p.shuf_g * p.shuf_g))) return SAMPT_ERR_ARG;
   if (p.cpadw >= 0 || p.rowmap || p.a_rowmap || p.nb1 * p.nb2 != 1 || (p.res && p.ldr % 4)) return SAMPT_ERR_UNSUPPORTED;
   if (((uintptr_t)p.A | (uintptr_t)p.W | (uintptr_t)p.W_lo | (uintptr_t)p.C | (uintptr_t)p.bias | (uintptr_t)p.res) & 15)
     return SAMPT_ERR_ARG;

@@ -193,6 +193,15 @@ struct DecEngine {
   const float *gauss, *point_emb, *not_a_point, *no_mask, *dense_pe;
   MaskEmbedW me;
   const float *up0_w, *up0_b, *upln_w, *upln_b, *up1_w, *up1_b;  // ConvT weights packed [(dy,dx)][cout][cin]
+  const half_t *up0_hl = nullptr, *up1_hl = nullptr;             // their split-fp16 planes [2][4*cout][cin] (optional)
+  // Fused image-side projections (pack.py): per layer W = [t2i.k_proj; t2i.v_proj; i2t.q_proj] (384 x C), bias likewise,
+  // pe = dense_pe @ [Wk; 0; Wq]^T (P x 384) — (keys + pe) W^T = keys W^T + pe W^T, so the positional term is a constant
+  // added in the epilogue and the image tokens are read ONCE per layer; final attention: [k_proj; v_proj] (256 x C).
+  struct FusedProj {
+    const float *w = nullptr, *b = nullptr, *pe = nullptr;
+    const half_t* hl = nullptr;
+    int n = 0;
+  } kvq[4], fin_kv;
   const int *up0_map, *up1_map;                  // pixel-shuffle row maps [4][max_frames*g*g], [4][max_frames*4*g*g]
   const float *hyp_w[3], *hyp_b[3], *iou_w[3], *iou_b[3];         // hypernetwork MLP 0 and IoU head
   const float *hypx_w[3][3], *hypx_b[3][3];                       // hypernetwork MLPs 1..3 (multimask_output=True)
@@ -204,6 +213,7 @@ struct DecEngine {
     const float *ee0_w, *ee0_b, *eeln_w, *eeln_b, *ee1_w, *ee1_b;  // embedding_encoder  (C -> C/4 -> C/8)
     const float *mf0_w, *mf0_b, *mfln_w, *mfln_b, *mf1_w, *mf1_b;  // embedding_maskfeature: conv3x3 [Cout][9*Cin]
     const half_t *mf0_hl = nullptr, *mf1_hl = nullptr;             // their split-fp16 planes (optional)
+    const half_t *cv0_hl = nullptr, *cv1_hl = nullptr, *ee0_hl = nullptr, *ee1_hl = nullptr;
   } hq;
   // optional (opt-in, pack.pack_decoder with SAMPT_DEC_F16X3=1): split-fp16 planes [2][N][K] of the attention projection
   // weights, keyed by the f32 weight pointer; projections over the image tokens (M = F*g*g rows) then run on the fp16

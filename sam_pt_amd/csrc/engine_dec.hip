@@ -43,6 +43,12 @@ int DecEngine::init(const WeightMap& w, const DecConfig& cfg) {
     L.m2w = w.f(p + ".mlp.lin2.weight"), L.m2b = w.f(p + ".mlp.lin2.bias");
   }
   load_attn(w, T + "final_attn_token_to_image", c.C / 2, fin, w_hl);
+  auto fused = [&](const std::string& k, int n, FusedProj& f) {
+    f.w = w.f(k + "_w"), f.b = w.f(k + "_b"), f.pe = w.f(k + "_pe"), f.n = n;
+    if (w.has(k + "_w_hl")) f.hl = w.h(k + "_w_hl");
+  };
+  for (int i = 0; i < c.depth; ++i) fused(T + "layers." + std::to_string(i) + ".__kvq", 3 * (c.C / 2), kvq[i]);
+  fused(T + "__fin_kv", 2 * (c.C / 2), fin_kv);
   nfw = w.f(T + "norm_final_attn.weight"), nfb = w.f(T + "norm_final_attn.bias");
   out_tokens = w.f("mask_decoder.__out_tokens");
   gauss = w.f("prompt_encoder.pe_layer.positional_encoding_gaussian_matrix");
@@ -59,6 +65,8 @@ int DecEngine::init(const WeightMap& w, const DecConfig& cfg) {
   upln_w = w.f(U + "1.weight"), upln_b = w.f(U + "1.bias");
   up1_w = w.f(U + "3.weight_packed"), up1_b = w.f(U + "3.bias");
   up0_map = w.i("mask_decoder.__up0_map"), up1_map = w.i("mask_decoder.__up1_map");
+  if (w.has(U + "0.weight_packed_hl")) up0_hl = w.h(U + "0.weight_packed_hl");
+  if (w.has(U + "3.weight_packed_hl")) up1_hl = w.h(U + "3.weight_packed_hl");
   for (int i = 0; i < 3; ++i) {
     hyp_w[i] = w.f("mask_decoder.output_hypernetworks_mlps.0.layers." + std::to_string(i) + ".weight");
     hyp_b[i] = w.f("mask_decoder.output_hypernetworks_mlps.0.layers." + std::to_string(i) + ".bias");
@@ -84,6 +92,9 @@ int DecEngine::init(const WeightMap& w, const DecConfig& cfg) {
     seq("compress_vit_feat", hq.cv0_w, hq.cv0_b, hq.cvln_w, hq.cvln_b, hq.cv1_w, hq.cv1_b);
     seq("embedding_encoder", hq.ee0_w, hq.ee0_b, hq.eeln_w, hq.eeln_b, hq.ee1_w, hq.ee1_b);
     seq("embedding_maskfeature", hq.mf0_w, hq.mf0_b, hq.mfln_w, hq.mfln_b, hq.mf1_w, hq.mf1_b);
+    auto opt = [&](const std::string& k) { return w.has(M + k) ? w.h(M + k) : nullptr; };
+    hq.cv0_hl = opt("compress_vit_feat.0.weight_packed_hl"), hq.cv1_hl = opt("compress_vit_feat.3.weight_packed_hl");
+    hq.ee0_hl = opt("embedding_encoder.0.weight_packed_hl"), hq.ee1_hl = opt("embedding_encoder.3.weight_packed_hl");
     if (w.has(M + "embedding_maskfeature.0.weight_packed_hl")) hq.mf0_hl = w.h(M + "embedding_maskfeature.0.weight_packed_hl");
     if (w.has(M + "embedding_maskfeature.3.weight_packed_hl")) hq.mf1_hl = w.h(M + "embedding_maskfeature.3.weight_packed_hl");
   }
@@ -121,9 +132,33 @@ struct L {
 };
 
 struct Bufs {
-  float *tokens, *qin, *kin, *keys, *Q, *K, *V, *att, *hid, *up0, *up1, *t0, *t1, *t2, *me0, *me1;
+  float *tokens, *qin, *keys, *Q, *K, *V, *att, *hid, *up0, *up1, *t0, *t1, *t2, *me0, *me1;
+  float* part = nullptr;      // split-key partial states of the token -> image attention (attn_t2i)
+  size_t part_floats = 0;
+  float* kvq = nullptr;       // fused image-side projections [F*P][K | V | Q']
 };
 }  // namespace
+
+// fused image-side projection: out [M][f.n] = A W^T + b + pe[row % P]   (see DecEngine::FusedProj)
+static int fused_proj(const L& l, const DecEngine::FusedProj& f, const float* A, long M, int C, int P, float* out) {
+  GemmP p;
+  p.A = A, p.bias = f.b, p.C = out, p.res = f.pe, p.res_mod = P;
+  p.M = (int)M, p.N = f.n, p.K = C, p.lda = C, p.ldw = C, p.ldc = f.n, p.ldr = f.n;
+  if (f.hl && C % 32 == 0) {
+    p.W = f.hl, p.W_lo = f.hl + (size_t)f.n * C, p.alpha = 1.0f / (float)(1 << F16X3_WSHIFT);
+    p.conv = 1, p.cH = (int)M, p.cW = 1, p.cC = C, p.KH = 1, p.KW = 1, p.cstride = 1, p.cpad = 0, p.OH = (int)M, p.OW = 1;
+    return conv_f16x3(p, l.s);
+  }
+  p.W = f.w;
+  return gemm_f32(p, l.s);
+}
+
+// tail of an attention block: out = LN(resid + out_proj(att))
+static int attn_tail(const L& l, const DecEngine::Attn& a, int C, long rows, const float* att, const float* resid, float* out,
+                     const float* lnw, const float* lnb, hipStream_t s) {
+  SAMPT_TRY(l.lin(att, (int)rows, a.inner, a.ow, a.ob, out, C, ACT_NONE, resid));
+  return layernorm_rows(out, lnw, lnb, out, rows, C, 1e-5f, nullptr, 0, ACT_NONE, s);
+}
 
 // attention block over F frames: out = LN(resid + out_proj(attn(q_in Wq, k_in Wk, v_in Wv)))  (resid null: replace)
 static int attn_block(const L& l, const DecEngine::Attn& a, int heads, int C, int F, const float* q_in, int Nq,
@@ -134,6 +169,8 @@ static int attn_block(const L& l, const DecEngine::Attn& a, int heads, int C, in
   SAMPT_TRY(l.lin(v_in, F * Nk, C, a.vw, a.vb, b.V, a.inner));
   const int hd = a.inner / heads;
   if (few_keys) SAMPT_TRY(attn_fewkeys(b.Q, b.K, b.V, b.att, F, Nq, Nk, heads, hd, nk_item, s));
+  else if (hd == 16 && heads == 8 && Nk > 256 && !nk_item)     // token -> image: the K / V stream decides, read it once
+    SAMPT_TRY(attn_t2i(b.Q, b.K, b.V, b.att, F, Nq, Nk, b.part, b.part_floats, s));
   else SAMPT_TRY(attn_rowblock(b.Q, b.K, b.V, b.att, F, Nq, Nk, heads, hd, nk_item, s));
   SAMPT_TRY(l.lin(b.att, F * Nq, a.inner, a.ow, a.ob, out, C, ACT_NONE, resid));
   return layernorm_rows(out, lnw, lnb, out, (long)F * Nq, C, 1e-5f, nullptr, 0, ACT_NONE, s);
@@ -143,8 +180,26 @@ static int attn_block(const L& l, const DecEngine::Attn& a, int heads, int C, in
 // optionally applies `act` and adds `res` (same layout as out):  x [F*P][K0] -> mid [F*4P][N0] -> out [F*16P][N1]
 static int convt_pair(const DecEngine& e, int F, const float* x, int K0, const float* w0, const float* b0, int N0,
                       const float* lnw, const float* lnb, const float* w1, const float* b1, int N1, int act,
-                      const float* res, float* mid, float* out, float* skws, size_t skn, hipStream_t s) {
+                      const float* res, float* mid, float* out, float* skws, size_t skn, hipStream_t s,
+                      const half_t* w0_hl = nullptr, const half_t* w1_hl = nullptr) {
   const long FP = (long)F * e.c.grid * e.c.grid, P = (long)e.c.grid * e.c.grid;
+  if (w0_hl && w1_hl && K0 % 32 == 0 && N0 % 32 == 0 && N1 % 4 == 0) {
+    // Each stage as ONE 3-term split-fp16 GEMM over all four (dy, dx) sub-pixels (N = 4 * cout): the input is read once
+    // instead of four times and the pixel shuffle is address arithmetic in the epilogue (conv_f16x3.hip, GemmP::shuf_g).
+    auto stage = [&](const float* A, long M, int K, const half_t* hl, const float* bias, int nsub, int g, float* C, int a,
+                     const float* r) {
+      GemmP p;
+      p.A = A, p.W = hl, p.W_lo = hl + (size_t)4 * nsub * K, p.bias = bias, p.C = C, p.res = r, p.act = a;
+      p.alpha = 1.0f / (float)(1 << F16X3_WSHIFT);
+      p.M = (int)M, p.N = 4 * nsub, p.K = K, p.ldw = K, p.ldc = nsub, p.ldr = nsub;
+      p.conv = 1, p.cH = (int)M, p.cW = 1, p.cC = K, p.KH = 1, p.KW = 1, p.cstride = 1, p.cpad = 0, p.OH = (int)M, p.OW = 1;
+      p.shuf_g = g, p.shuf_n = nsub;
+      return conv_f16x3(p, s);
+    };
+    SAMPT_TRY(stage(x, FP, K0, w0_hl, b0, N0, e.c.grid, mid, ACT_NONE, nullptr));
+    SAMPT_TRY(layernorm_rows(mid, lnw, lnb, mid, 4L * FP, N0, 1e-6f, nullptr, 0, ACT_GELU, s));
+    return stage(mid, 4 * FP, N0, w1_hl, b1, N1, 2 * e.c.grid, out, act, res);
+  }
   GemmP p;
   p.A = x, p.W = w0, p.bias = b0, p.C = mid, p.rowmap = e.up0_map;
   p.M = (int)FP, p.N = N0, p.K = K0, p.lda = K0, p.ldw = K0, p.ldc = N0;
@@ -168,9 +223,9 @@ int DecEngine::hq_features(int F, const float* features, const float* interm, fl
   if (ws.dry()) return SAMPT_OK;
   // out = compress_vit_feat(interm) ; out += embedding_encoder(features)
   SAMPT_TRY(convt_pair(*this, F, interm, c.vit_dim, hq.cv0_w, hq.cv0_b, C, hq.cvln_w, hq.cvln_b, hq.cv1_w, hq.cv1_b, C / 8,
-                       ACT_NONE, nullptr, mid, out, nullptr, 0, s));
+                       ACT_NONE, nullptr, mid, out, nullptr, 0, s, hq.cv0_hl, hq.cv1_hl));
   return convt_pair(*this, F, features, C, hq.ee0_w, hq.ee0_b, C / 4, hq.eeln_w, hq.eeln_b, hq.ee1_w, hq.ee1_b, C / 8,
-                    ACT_NONE, out, mid, out, nullptr, 0, s);
+                    ACT_NONE, out, mid, out, nullptr, 0, s, hq.ee0_hl, hq.ee1_hl);
 }
 
 int DecEngine::decode(int F, const float* features, const float* hq_feat, const float* pts, const int* labels, int k,
@@ -185,7 +240,7 @@ int DecEngine::decode(int F, const float* features, const float* hq_feat, const 
   b.tokens = ws.f32(FT * C);
   float* queries = ws.f32(FT * C);
   b.qin = ws.f32(FT * C);
-  b.kin = ws.f32(FP * C);
+  b.kvq = ws.f32(FP * 3 * (C / 2));
   b.keys = ws.f32(FP * C);
   const size_t Fmx = FP > FT ? FP : FT;   // projections run on image tokens AND on prompt tokens (Nt may exceed g*g)
   b.Q = ws.f32(Fmx * C);
@@ -193,6 +248,8 @@ int DecEngine::decode(int F, const float* features, const float* hq_feat, const 
   b.V = ws.f32(Fmx * C);
   b.att = ws.f32(Fmx * C);
   b.hid = ws.f32(FT * c.mlp);
+  b.part_floats = attn_t2i_workspace_floats(F, Nt, P);
+  b.part = ws.f32(b.part_floats ? b.part_floats : 4);
   b.up0 = ws.f32(4 * FP * (C / 4));
   b.up1 = ws.f32(16 * FP * (C / 8));
   b.t0 = ws.f32((size_t)F * C), b.t1 = ws.f32((size_t)F * C), b.t2 = ws.f32((size_t)F * C);
@@ -218,7 +275,9 @@ int DecEngine::decode(int F, const float* features, const float* hq_feat, const 
 
   // ---- two-way transformer: query PE = the prompt tokens, key PE = dense positional encoding
   const float* qpe = b.tokens;
-  const long nT = (long)FT * C, nP = (long)FP * C, pe_mod = (long)P * C;
+  const long nT = (long)FT * C;
+  const int inner = C / 2;
+  if (inner != 16 * H || inner != 128) return SAMPT_ERR_UNSUPPORTED;   // attn_t2i / attn_fewkeys: 8 heads x 16 channels
   for (int i = 0; i < c.depth; ++i) {
     const Layer& Ly = layer[i];
     if (i == 0) {
@@ -229,28 +288,34 @@ int DecEngine::decode(int F, const float* features, const float* hq_feat, const 
       SAMPT_TRY(attn_block(l, Ly.self, H, C, F, b.qin, Nt, b.qin, queries, Nt, false, nkt, b, queries, queries, Ly.n1w,
                            Ly.n1b, s));
     }
-    // tokens -> image
+    // tokens -> image.  K = (keys + pe) Wk, V = keys Wv and the image -> token query (keys + pe) Wq' below all read the
+    // same image tokens: one fused projection, kvq [F*P][K | V | Q'], the positional terms folded into its epilogue
     SAMPT_TRY(add_bcast(queries, qpe, b.qin, nT, nT, s));
-    SAMPT_TRY(add_bcast(b.keys, dense_pe, b.kin, nP, pe_mod, s));
-    SAMPT_TRY(attn_block(l, Ly.t2i, H, C, F, b.qin, Nt, b.kin, b.keys, P, false, nullptr, b, queries, queries, Ly.n2w,
-                         Ly.n2b, s));
+    SAMPT_TRY(fused_proj(l, kvq[i], b.keys, (long)FP, C, P, b.kvq));
+    SAMPT_TRY(l.lin(b.qin, (int)FT, C, Ly.t2i.qw, Ly.t2i.qb, b.Q, inner));
+    SAMPT_TRY(attn_t2i(b.Q, b.kvq, b.kvq + inner, b.att, F, Nt, P, b.part, b.part_floats, s, 3 * inner));
+    SAMPT_TRY(attn_tail(l, Ly.t2i, C, (long)FT, b.att, queries, queries, Ly.n2w, Ly.n2b, s));
     // MLP (ReLU)
     SAMPT_TRY(l.lin(queries, (int)FT, C, Ly.m1w, Ly.m1b, b.hid, c.mlp, ACT_RELU));
     SAMPT_TRY(l.lin(b.hid, (int)FT, c.mlp, Ly.m2w, Ly.m2b, queries, C, ACT_NONE, queries));
     SAMPT_TRY(layernorm_rows(queries, Ly.n3w, Ly.n3b, queries, (long)FT, C, 1e-5f, nullptr, 0, ACT_NONE, s));
-    // image -> tokens
+    // image -> tokens (queries: the Q' slice of kvq)
     SAMPT_TRY(add_bcast(queries, qpe, b.qin, nT, nT, s));
-    SAMPT_TRY(attn_block(l, Ly.i2t, H, C, F, b.kin, P, b.qin, queries, Nt, true, nkt, b, b.keys, b.keys, Ly.n4w, Ly.n4b,
-                         s));
+    SAMPT_TRY(l.lin(b.qin, (int)FT, C, Ly.i2t.kw, Ly.i2t.kb, b.K, inner));
+    SAMPT_TRY(l.lin(queries, (int)FT, C, Ly.i2t.vw, Ly.i2t.vb, b.V, inner));
+    SAMPT_TRY(attn_fewkeys(b.kvq + 2 * inner, b.K, b.V, b.att, F, P, Nt, H, inner / H, nkt, s, 3 * inner));
+    SAMPT_TRY(attn_tail(l, Ly.i2t, C, (long)FP, b.att, b.keys, b.keys, Ly.n4w, Ly.n4b, s));
   }
   SAMPT_TRY(add_bcast(queries, qpe, b.qin, nT, nT, s));
-  SAMPT_TRY(add_bcast(b.keys, dense_pe, b.kin, nP, pe_mod, s));
-  SAMPT_TRY(attn_block(l, fin, H, C, F, b.qin, Nt, b.kin, b.keys, P, false, nullptr, b, queries, queries, nfw, nfb, s));
+  SAMPT_TRY(fused_proj(l, fin_kv, b.keys, (long)FP, C, P, b.kvq));
+  SAMPT_TRY(l.lin(b.qin, (int)FT, C, fin.qw, fin.qb, b.Q, inner));
+  SAMPT_TRY(attn_t2i(b.Q, b.kvq, b.kvq + inner, b.att, F, Nt, P, b.part, b.part_floats, s, 2 * inner));
+  SAMPT_TRY(attn_tail(l, fin, C, (long)FT, b.att, queries, queries, nfw, nfb, s));
 
   // ---- upscaling: ConvT2x2s2 (C -> C/4) + LN2d + GELU ; ConvT2x2s2 (C/4 -> C/8) + GELU   (pixel shuffle via row maps
   //      that cover max_frames frames: map[(dy,dx)][f*P + p] = f*4P + (2y+dy)*2g + 2x+dx)
   SAMPT_TRY(convt_pair(*this, F, b.keys, C, up0_w, up0_b, C / 4, upln_w, upln_b, up1_w, up1_b, C / 8, ACT_GELU, nullptr,
-                       b.up0, b.up1, nullptr, 0, s));
+                       b.up0, b.up1, nullptr, 0, s, up0_hl, up1_hl));
   if (multimask) {
     // multimask_output=True (MaskDecoder.forward: mask_slice = slice(1, None)): masks and IoUs of mask tokens 1..3;
     // low_out [3][4g][4g], logits_out [3][oh][ow], iou_out [3]

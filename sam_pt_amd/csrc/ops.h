@@ -135,8 +135,13 @@ int sam_tokens(const float* out_tokens /*[n_out][256]*/, int n_out, const float*
 int attn_rowblock(const float* q, const float* k, const float* v, float* out, int F, int Nq, int Nk, int heads, int hd,
                   const int* nk_item, hipStream_t s);
 // small f32 attention with few keys (Nk <= 64): one thread per (query, head)
+// token -> image attention, 8 heads x 16 channels (q/k/v/out rows of 128 floats), any Nq / Nk: keys split over workgroups,
+// partial softmax states merged by a second launch; ws: attn_t2i_workspace_floats(F, Nq, Nk) floats (0: none needed)
+size_t attn_t2i_workspace_floats(int F, int Nq, int Nk);
+int attn_t2i(const float* q, const float* k, const float* v, float* out, int F, int Nq, int Nk, float* ws, size_t ws_floats,
+             hipStream_t s, int ldkv = 128 /* row stride of k and v in floats (slices of a fused projection) */);
 int attn_fewkeys(const float* q, const float* k, const float* v, float* out, int F, int Nq, int Nk, int heads, int hd,
-                 const int* nk_item, hipStream_t s);
+                 const int* nk_item, hipStream_t s, int ldq = 0 /* row stride of q in floats (0: heads*hd) */);
 // low_res[f][p] = <hyper[f][0:C], up[f][p][0:C]>
 int sam_mask_dot(const float* up, const float* hyper, int ld_hyper, const float* up2 /*or null*/, const float* hyper2,
                  int ld_hyper2, float* low_res, int F, int npix, int C, hipStream_t s);

@@ -205,6 +205,184 @@ int attn_rowblock(const float* q, const float* k, const float* v, float* out, in
 }
 
 // ---------------------------------------------------------------------------------------------
+// token -> image attention of the two-way transformer (8 heads x 16 channels, 10-20 prompt tokens against the 4096 image
+// tokens of every frame): HBM-bound on K and V, which every frame reads exactly once.
+//   * the keys of a frame are split over KS workgroups (F alone would leave most CUs idle), each handling up to 16
+//     queries and ALL heads: a wave's lane owns one float4 of a 512-byte K/V row (lane -> half-wave = key parity, head =
+//     (lane & 31) >> 2, quarter = lane & 3), so every global load is a fully coalesced 1 KiB and nothing is re-read per
+//     head or per query (k_attn_rowblock re-read each row through L2 once per head and per 4 queries, 64 bytes at a time);
+//   * flash-style running softmax per (query, head) over chunks of 4 keys; the quarter-dots are summed with two DPP
+//     row shuffles; partial (max, sum, acc) states go to a workspace and k_attn_t2i_merge combines the KS splits.
+// ---------------------------------------------------------------------------------------------
+namespace {
+constexpr int T2I_NQ = 8;           // queries per workgroup (their running softmax states live in registers)
+constexpr int T2I_REC = 128 + 16;   // floats per (split, query): acc[128] + max[8] + sum[8]
+constexpr float T2I_SCALE = 0.25f * 1.4426950408889634f;   // scores are kept in log2 units: softmax via v_exp_f32 alone
+#define T2I_EXP(x) __builtin_amdgcn_exp2f(x)
+constexpr float T2I_MIN = -1e30f;   // "no key yet" running maximum (finite: exp(T2I_MIN - m) = 0 without inf - inf)
+
+__device__ __forceinline__ float quad_sum(float v) {      // sum over the 4 lanes of a quad, result in all 4 (DPP, no LDS)
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+  return v;
+}
+}  // namespace
+
+__global__ __launch_bounds__(256) void k_attn_t2i_part(const float* __restrict__ q, const float* __restrict__ k,
+                                                       const float* __restrict__ v, float* __restrict__ part,
+                                                       float* __restrict__ out, int Nq, int Nk, int kper, int ldkv) {
+  constexpr int NQ = T2I_NQ;
+  __shared__ float4 s_acc[8][NQ][32];   // one partial state per (wave, key parity)
+  __shared__ float4 s_q[NQ][32];        // the queries stay in LDS (broadcast reads) instead of 4 NQ registers per lane
+  __shared__ float s_m[8][NQ][8], s_s[8][NQ][8];
+  const int ks = blockIdx.x, qb = blockIdx.y, f = blockIdx.z, KS = gridDim.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, hp = lane & 31;
+  q += (long)f * Nq * 128, k += (long)f * Nk * ldkv, v += (long)f * Nk * ldkv;   // k / v rows: 128 floats, stride ldkv
+  const int q0 = qb * NQ;
+  for (int e = tid; e < NQ * 32; e += 256)
+    s_q[e >> 5][e & 31] = *(const float4*)(q + (long)min(q0 + (e >> 5), Nq - 1) * 128 + (e & 31) * 4);
+  __syncthreads();
+  float m[NQ], sum[NQ];
+  float4 acc[NQ];
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) m[j] = T2I_MIN, sum[j] = 0.f, acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int k0 = ks * kper, k1 = min(Nk, k0 + kper);
+  // a wave takes 8 consecutive keys per step (4 per half-wave): rows k0 + 32 i + 8 wave + {0..7}; byte offsets inside
+  // a frame's K / V fit 32 bits (checked by the launcher)
+  const char* kc = (const char*)k;
+  const char* vc = (const char*)v;
+  auto load = [&](int kb, float4* kk, float4* vv) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int key = kb + 2 * c + half;
+      const unsigned off = (unsigned)(key < k1 ? key : k0) * ((unsigned)ldkv * 4u) + (unsigned)hp * 16u;
+      kk[c] = *(const float4*)(kc + off);
+      vv[c] = *(const float4*)(vc + off);
+    }
+  };
+  auto step = [&](int kb, const float4* kk, const float4* vv) {
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+      float sc[4];
+      const float4 qj = s_q[j][hp];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float d = qj.x * kk[c].x + qj.y * kk[c].y + qj.z * kk[c].z + qj.w * kk[c].w;
+        d = quad_sum(d) * T2I_SCALE;                          // / sqrt(16), in the base-2 domain of T2I_EXP
+        sc[c] = kb + 2 * c + half < k1 ? d : -INFINITY;
+      }
+      const float mn = fmaxf(fmaxf(m[j], fmaxf(sc[0], sc[1])), fmaxf(sc[2], sc[3]));
+      const float r = T2I_EXP(m[j] - mn);
+      m[j] = mn;
+      float s_ = sum[j] * r;
+      float4 a = make_float4(acc[j].x * r, acc[j].y * r, acc[j].z * r, acc[j].w * r);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float pr = T2I_EXP(sc[c] - mn);
+        s_ += pr;
+        a.x += pr * vv[c].x, a.y += pr * vv[c].y, a.z += pr * vv[c].z, a.w += pr * vv[c].w;
+      }
+      sum[j] = s_, acc[j] = a;
+    }
+  };
+  // (two resident waves per SIMD overlap one wave's loads with the other's arithmetic; an explicit register ping-pong
+  //  only made hipcc re-order the loads against the in-order vmcnt counter)
+  for (int kb = k0 + wave * 8; kb < k1; kb += 32) {
+    float4 kk[4], vv[4];
+    load(kb, kk, vv);
+    step(kb, kk, vv);
+  }
+  // ---- merge the 8 partial streams of the workgroup through LDS
+  const int st_ = wave * 2 + half;
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    s_acc[st_][j][hp] = acc[j];
+    if ((hp & 3) == 0) s_m[st_][j][hp >> 2] = m[j], s_s[st_][j][hp >> 2] = sum[j];
+  }
+  __syncthreads();
+  for (int e = tid; e < NQ * 32; e += 256) {
+    const int j = e >> 5, c4 = e & 31, h = c4 >> 2;
+    if (q0 + j >= Nq) continue;
+    float mn = T2I_MIN;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) mn = fmaxf(mn, s_m[w][j][h]);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    float st = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+      const float r = T2I_EXP(s_m[w][j][h] - mn);
+      const float4 t = s_acc[w][j][c4];
+      a.x += t.x * r, a.y += t.y * r, a.z += t.z * r, a.w += t.w * r;
+      st += s_s[w][j][h] * r;
+    }
+    if (KS == 1) {
+      *(float4*)(out + ((long)f * Nq + q0 + j) * 128 + c4 * 4) = make_float4(a.x / st, a.y / st, a.z / st, a.w / st);
+    } else {
+      float* rec = part + (((long)f * Nq + q0 + j) * KS + ks) * T2I_REC;
+      *(float4*)(rec + c4 * 4) = a;
+      if ((c4 & 3) == 0) rec[128 + h] = mn, rec[136 + h] = st;
+    }
+  }
+}
+
+// out[f][q][h*16 + c] = sum_ks acc * exp(m_ks - M) / sum_ks sum * exp(m_ks - M): one thread per (f, q, float4)
+__global__ void k_attn_t2i_merge(const float* __restrict__ part, float* __restrict__ out, long nrows, int KS) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nrows * 32) return;
+  const long row = e >> 5;
+  const int c4 = (int)(e & 31), h = c4 >> 2;
+  const float* rec = part + row * KS * T2I_REC;
+  float mn = T2I_MIN;
+  for (int s = 0; s < KS; ++s) mn = fmaxf(mn, rec[(long)s * T2I_REC + 128 + h]);
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  float st = 0.f;
+  for (int s = 0; s < KS; ++s) {
+    const float* rs = rec + (long)s * T2I_REC;
+    const float r = T2I_EXP(rs[128 + h] - mn);
+    const float4 t = *(const float4*)(rs + c4 * 4);
+    a.x += t.x * r, a.y += t.y * r, a.z += t.z * r, a.w += t.w * r;
+    st += rs[136 + h] * r;
+  }
+  *(float4*)(out + row * 128 + c4 * 4) = make_float4(a.x / st, a.y / st, a.z / st, a.w / st);
+}
+
+// key split: enough workgroups to fill the chip (>= ~512), at least 64 keys each, at most 32 splits
+static void attn_t2i_plan(int F, int Nq, int Nk, int& qblocks, int& KS, int& kper) {
+  qblocks = cdiv(Nq, T2I_NQ);
+  const long wg = (long)F * qblocks;
+  int want = (int)((512 + wg - 1) / wg);
+  want = want < 1 ? 1 : (want > 32 ? 32 : want);
+  const int most = Nk / 64 > 0 ? Nk / 64 : 1;
+  if (want > most) want = most;
+  kper = cdiv(cdiv(Nk, want), 32) * 32;
+  KS = cdiv(Nk, kper);
+}
+
+size_t attn_t2i_workspace_floats(int F, int Nq, int Nk) {
+  // F * Nq * KS records with KS <= 512 / (F * qblocks) + 1 and Nq / qblocks <= T2I_NQ: a bound that grows with F and Nq,
+  // so a workspace sized for the largest batch / prompt also covers every smaller one
+  (void)Nk;
+  return ((size_t)512 * T2I_NQ + (size_t)F * Nq) * T2I_REC;
+}
+
+int attn_t2i(const float* q, const float* k, const float* v, float* out, int F, int Nq, int Nk, float* ws, size_t ws_floats,
+             hipStream_t s, int ldkv) {
+  if (Nk <= 0 || Nq <= 0 || F <= 0 || ldkv < 128 || ldkv % 4 || (long)Nk * ldkv * 4 >= (1L << 32)) return SAMPT_ERR_ARG;
+  int qb, KS, kper;
+  attn_t2i_plan(F, Nq, Nk, qb, KS, kper);
+  if (KS > 1 && (!ws || ws_floats < (size_t)F * Nq * KS * T2I_REC)) return SAMPT_ERR_WORKSPACE;
+  hipLaunchKernelGGL(k_attn_t2i_part, dim3(KS, qb, F), dim3(256), 0, s, q, k, v, ws, out, Nq, Nk, kper, ldkv);
+  SAMPT_CHECK_LAUNCH("attn_t2i_part");
+  if (KS > 1) {
+    const long nrows = (long)F * Nq;
+    hipLaunchKernelGGL(k_attn_t2i_merge, dim3((unsigned)cdiv(nrows * 32, 256)), dim3(256), 0, s, ws, out, nrows, KS);
+    SAMPT_CHECK_LAUNCH("attn_t2i_merge");
+  }
+  return SAMPT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // attention with few keys and many queries (image -> token): one thread per (query, head); K/V staged through LDS in
 // chunks of <= `chunk` keys with a running (max, sum) softmax, so the number of prompt tokens is unbounded.  With
 // Nk <= chunk (every SAM-PT prompt up to 120 points) there is exactly one chunk and no rescale.
@@ -212,10 +390,11 @@ int attn_rowblock(const float* q, const float* k, const float* v, float* out, in
 template <int HD>
 __global__ __launch_bounds__(256) void k_attn_fewkeys(const float* __restrict__ q, const float* __restrict__ k,
                                                       const float* __restrict__ v, float* __restrict__ out, int Nq,
-                                                      int Nk, int heads, const int* __restrict__ nk_item, int chunk) {
+                                                      int Nk, int heads, const int* __restrict__ nk_item, int chunk,
+                                                      int ldq) {
   extern __shared__ float kv[];  // [2][chunk][ld]
   const int ld = heads * HD, f = blockIdx.y;
-  q += (long)f * Nq * ld, out += (long)f * Nq * ld;
+  q += (long)f * Nq * ldq, out += (long)f * Nq * ld;
   k += (long)f * Nk * ld, v += (long)f * Nk * ld;
   float* ks = kv;
   float* vs = kv + (long)chunk * ld;
@@ -225,7 +404,7 @@ __global__ __launch_bounds__(256) void k_attn_fewkeys(const float* __restrict__ 
   const int qi = live ? (int)(idx / heads) : 0, h = live ? (int)(idx % heads) : 0;
   float qv[HD];
   {
-    const float4* qp = (const float4*)(q + (long)qi * ld + h * HD);
+    const float4* qp = (const float4*)(q + (long)qi * ldq + h * HD);
 #pragma unroll
     for (int c = 0; c < HD / 4; ++c) {
       float4 t = qp[c];
@@ -282,8 +461,10 @@ __global__ __launch_bounds__(256) void k_attn_fewkeys(const float* __restrict__ 
 }
 
 int attn_fewkeys(const float* q, const float* k, const float* v, float* out, int F, int Nq, int Nk, int heads, int hd,
-                 const int* nk_item, hipStream_t s) {
+                 const int* nk_item, hipStream_t s, int ldq) {
   if (Nk <= 0 || hd != 16 || F <= 0) return SAMPT_ERR_UNSUPPORTED;
+  if (ldq == 0) ldq = heads * hd;
+  if (ldq < heads * hd || ldq % 4) return SAMPT_ERR_ARG;
   const int chunk = Nk < 128 ? Nk : 128;
   size_t sh = (size_t)2 * chunk * heads * hd * sizeof(float);
   if (sh > 64 * 1024) {  // above the default dynamic-LDS limit (gfx950 has 160 KiB per workgroup)
@@ -296,7 +477,7 @@ int attn_fewkeys(const float* q, const float* k, const float* v, float* out, int
     }
   }
   hipLaunchKernelGGL(k_attn_fewkeys<16>, dim3(cdiv((long)Nq * heads, 256), F), dim3(256), sh, s, q, k, v, out, Nq, Nk,
-                     heads, nk_item, chunk);
+                     heads, nk_item, chunk, ldq);
   SAMPT_CHECK_LAUNCH("attn_fewkeys");
   return SAMPT_OK;
 }
@@ -330,9 +511,45 @@ __global__ void k_sam_mask_dot(const float* __restrict__ up, const float* __rest
   low[(long)f * npix + p] = a;
 }
 
+// C == 32 (every SAM variant: transformer_dim / 8): 8 lanes per pixel, one float4 each, so a wave reads 1 KiB of
+// consecutive bytes per load (one thread per pixel strides the lanes 128 bytes apart: 4x slower); the 8 partial dots are
+// summed with three DPP steps (quad_perm, quad_perm, row_half_mirror)
+__device__ __forceinline__ float oct_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xf, 0xf, true));   // row_half_mirror
+  return v;
+}
+
+__global__ void k_sam_mask_dot32(const float* __restrict__ up, const float* __restrict__ hyper, int ld_hyper,
+                                 const float* __restrict__ up2, const float* __restrict__ hyper2, int ld_hyper2,
+                                 float* __restrict__ low, int npix) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int f = blockIdx.y, part = (int)(idx & 7);
+  const long p = idx >> 3;
+  const bool live = p < npix;                      // (npix * 8 is a multiple of the block: whole octets are live or dead)
+  const long pe = ((long)f * npix + (live ? p : 0)) * 32 + part * 4;
+  const float4 t = *(const float4*)(up + pe);
+  const float4 h = *(const float4*)(hyper + (long)f * ld_hyper + part * 4);
+  float a = oct_sum(h.x * t.x + h.y * t.y + h.z * t.z + h.w * t.w);
+  if (up2) {
+    const float4 t2 = *(const float4*)(up2 + pe);
+    const float4 h2 = *(const float4*)(hyper2 + (long)f * ld_hyper2 + part * 4);
+    a += oct_sum(h2.x * t2.x + h2.y * t2.y + h2.z * t2.z + h2.w * t2.w);
+  }
+  if (live && part == 0) low[(long)f * npix + p] = a;
+}
+
 int sam_mask_dot(const float* up, const float* hyper, int ld_hyper, const float* up2, const float* hyper2, int ld_hyper2,
                  float* low_res, int F, int npix, int C, hipStream_t s) {
   if (C % 4) return SAMPT_ERR_ARG;
+  if (C == 32 && ld_hyper % 4 == 0 && (!up2 || ld_hyper2 % 4 == 0) &&
+      !(((uintptr_t)hyper | (uintptr_t)hyper2 | (uintptr_t)up | (uintptr_t)up2) & 15)) {
+    hipLaunchKernelGGL(k_sam_mask_dot32, dim3(cdiv((long)npix * 8, 256), F), dim3(256), 0, s, up, hyper, ld_hyper, up2,
+                       hyper2, ld_hyper2, low_res, npix);
+    SAMPT_CHECK_LAUNCH("sam_mask_dot32");
+    return SAMPT_OK;
+  }
   hipLaunchKernelGGL(k_sam_mask_dot, dim3(cdiv(npix, 256), F), dim3(256), 0, s, up, hyper, ld_hyper, up2, hyper2,
                      ld_hyper2, low_res, npix, C);
   SAMPT_CHECK_LAUNCH("sam_mask_dot");
@@ -534,24 +751,26 @@ __global__ void k_mask_down(const float* __restrict__ in, int ih, int iw, const 
 }
 
 // stage C: src[f][p][c] = feat[f][p][c] + b2[c] + sum_k w2[c][k] * e[f][p][k]
+constexpr int MEO_PIX = 32;
 __global__ void k_mask_embed_out(const float* __restrict__ e, int C2, const float* __restrict__ w2,
                                  const float* __restrict__ b2, const float* __restrict__ feat, float* __restrict__ src,
                                  long npix_total) {
-  // 256 threads = output channels; 4 pixels per workgroup
-  __shared__ float es[4][16];
+  // 256 threads = output channels; MEO_PIX pixels per workgroup (each thread loads its 16 weights once per workgroup: at
+  // 4 pixels per workgroup the weight re-reads through L2 were 4x the kernel's HBM traffic)
+  __shared__ float es[MEO_PIX][16];
   const int c = threadIdx.x;
-  const long p0 = (long)blockIdx.x * 4;
-  if (c < 4 * C2) {
-    long p = p0 + c / C2;
-    es[c / C2][c % C2] = p < npix_total ? e[p * C2 + c % C2] : 0.f;
+  const long p0 = (long)blockIdx.x * MEO_PIX;
+  for (int i = c; i < MEO_PIX * C2; i += 256) {
+    long p = p0 + i / C2;
+    es[i / C2][i % C2] = p < npix_total ? e[p * C2 + i % C2] : 0.f;
   }
   __syncthreads();
   float wr[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) wr[k] = k < C2 ? w2[c * C2 + k] : 0.f;
   const float bb = b2[c];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
+#pragma unroll 4
+  for (int i = 0; i < MEO_PIX; ++i) {
     long p = p0 + i;
     if (p >= npix_total) break;
     float a = bb;
@@ -571,7 +790,7 @@ int sam_mask_embed_src(const float* mask, int g, int F, const MaskEmbedW& w, con
                      w.ln1w, w.ln1b, tmp1);
   SAMPT_CHECK_LAUNCH("mask_down1");
   long npix = (long)F * g * g;
-  hipLaunchKernelGGL(k_mask_embed_out, dim3(cdiv(npix, 4)), dim3(256), 0, s, tmp1, 16, w.w2, w.b2, feat, src, npix);
+  hipLaunchKernelGGL(k_mask_embed_out, dim3(cdiv(npix, MEO_PIX)), dim3(256), 0, s, tmp1, 16, w.w2, w.b2, feat, src, npix);
   SAMPT_CHECK_LAUNCH("mask_embed_out");
   return SAMPT_OK;
 }

@@ -268,6 +268,34 @@ def pack_decoder(sd: Dict[str, torch.Tensor], cfg: SamConfig, device, max_frames
     out["prompt_encoder.__dense_pe"] = dense_pe(g, cfg.grid)
     out["mask_decoder.output_upscaling.0.weight_packed"] = _convt_pack(sd["mask_decoder.output_upscaling.0.weight"].float())
     out["mask_decoder.output_upscaling.3.weight_packed"] = _convt_pack(sd["mask_decoder.output_upscaling.3.weight"].float())
+    if os.environ.get("SAMPT_DEC_F16X3", "1") != "0":
+        # the transposed convolutions as ONE split-fp16 GEMM per stage over all four sub-pixels: planes [2][4*cout][cin]
+        names = ["output_upscaling"] + (["compress_vit_feat", "embedding_encoder"] if hq else [])
+        for nme in names:
+            for i in (0, 3):
+                wp = out[f"mask_decoder.{nme}.{i}.weight_packed"]
+                if wp.shape[2] % 32 == 0 and wp.shape[1] % 4 == 0:
+                    out[f"mask_decoder.{nme}.{i}.weight_packed_hl"] = split_f16x3(wp.reshape(-1, wp.shape[2]))
+    # Fused image-side projections of the two-way transformer (csrc/engine.h DecEngine::FusedProj): the token -> image keys
+    # (keys + pe) Wk, values keys Wv and the image -> token queries (keys + pe) Wq' of a layer read the same image tokens, so
+    # they run as one GEMM with W = [Wk; Wv; Wq'] and the constant pe [Wk; 0; Wq']^T added in its epilogue.
+    tr = "mask_decoder.transformer."
+    pe64 = out["prompt_encoder.__dense_pe"].double()
+
+    def fuse(key, mats, with_pe):
+        W = torch.cat([out[m + ".weight"] for m in mats], dim=0)
+        out[key + "_w"] = W.contiguous()
+        out[key + "_b"] = torch.cat([out[m + ".bias"] for m in mats], dim=0).contiguous()
+        Wpe = torch.cat([out[m + ".weight"] if u else torch.zeros_like(out[m + ".weight"]) for m, u in zip(mats, with_pe)], dim=0)
+        out[key + "_pe"] = (pe64 @ Wpe.double().t()).float().contiguous()
+        if os.environ.get("SAMPT_DEC_F16X3", "1") != "0" and W.shape[1] % 32 == 0:
+            out[key + "_w_hl"] = split_f16x3(W)
+
+    for i in range(cfg.dec_depth):
+        lp = f"{tr}layers.{i}."
+        fuse(lp + "__kvq", [lp + "cross_attn_token_to_image.k_proj", lp + "cross_attn_token_to_image.v_proj",
+                            lp + "cross_attn_image_to_token.q_proj"], [True, False, True])
+    fuse(tr + "__fin_kv", [tr + "final_attn_token_to_image.k_proj", tr + "final_attn_token_to_image.v_proj"], [True, False])
     out["mask_decoder.__up0_map"] = _shuffle_map(cfg.grid, max_frames)
     out["mask_decoder.__up1_map"] = _shuffle_map(2 * cfg.grid, max_frames)
     if os.environ.get("SAMPT_DEC_F16X3", "1") != "0":

@@ -24,6 +24,7 @@ restated ``rgb2lab`` (skimage absent: that one function is parity unpinned).
 """
 from __future__ import annotations
 
+import time
 from enum import IntEnum
 from typing import List, Optional
 
@@ -98,6 +99,7 @@ class SamPt(nn.Module):
         self.overlap_tracker_encoder_fnet = False
         self._side_stream = None
         self._dec_stream = None
+        self.timeline = None      # measurement hook: a dict that forward() fills with timed CUDA events / host stamps
 
     @property
     def device(self):
@@ -160,6 +162,7 @@ class SamPt(nn.Module):
             # encoder is done (see the knobs in __init__ for the measured alternatives).
             overlap = (not self.use_point_reinit) and images.is_cuda and self.overlap_tracker_and_encoder
             pipeline = None
+            self._mark("start")
             if overlap:
                 ready = torch.cuda.Event()
                 ready.record()                                               # frames valid on this stream
@@ -173,13 +176,16 @@ class SamPt(nn.Module):
                     self._dec_stream = torch.cuda.Stream(device=images.device, priority=-1)
             sam_images = images if frame_ids is None else images[torch.as_tensor(frame_ids, device=images.device)]
             batch_events = [] if overlap else None
+            self._mark("prepared")
             feats = self.sam_predictor.encode_frames(sam_images, chw=True, batch_events=batch_events)   # embeddings in HBM
+            self._mark("encoded")
             if overlap:
                 self._side_stream.wait_event(ready)
                 with torch.cuda.stream(self._side_stream):
                     if hasattr(self.point_tracker, "prepare") and self.overlap_tracker_encoder_fnet:
                         self.point_tracker.to(self.device).prepare(images)
                     tracked = self._track_points(images, query_points)
+                    self._mark("tracked")
                 torch.cuda.current_stream().wait_stream(self._side_stream)
                 if batch_events:
                     if not self.pipeline_decoder:                            # one chain for the clip, after the last batch
@@ -208,6 +214,7 @@ class SamPt(nn.Module):
                 _, logits, scores_per_frame = self._apply_sam_to_trajectories(sam_images, trajectories[ids],
                                                                                 visibilities[ids], feats, pl)
             scores = scores_per_frame.mean(dim=0)
+            self._mark("decoded")
         else:
             trajectories, visibilities, logits, scores, scores_per_frame = self._forward_w_reinit(images, query_points, feats)
 
@@ -222,6 +229,12 @@ class SamPt(nn.Module):
         assert visibilities.shape == (n_frames, n_masks, n_points_per_mask)
         return {"logits": [m for m in logits], "scores": scores.tolist(), "scores_per_frame": scores_per_frame.tolist(),
                 "trajectories": trajectories, "visibilities": visibilities}
+
+    def _mark(self, name):
+        if self.timeline is not None and torch.cuda.is_available():
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()                                   # on the stream that is current where the mark sits
+            self.timeline[name] = (ev, time.perf_counter())
 
     def extract_query_points(self, images, query_masks, query_points_timestep):
         """Query points (M, P+ + P-, 3) = (t, x, y) from masks: positives from the mask, negatives from its complement

@@ -351,6 +351,24 @@ def test_decoder_attention_kernels(lib, dev, kind, hd, Nq, Nk):
     assert max_abs(out, _mha_ref(q, k, v, heads, nk)) < 2e-5
 
 
+@pytest.mark.parametrize("F_,Nq,Nk", [(24, 15, 4096), (2, 16, 4096), (1, 7, 4096), (3, 21, 1000), (1, 300, 4096), (40, 9, 257),
+                                      (2, 5, 333)])
+def test_token_to_image_attention_kernel(lib, dev, F_, Nq, Nk):
+    """The split-key token -> image attention (8 heads x 16) vs an fp64 reference: full and ragged key ranges, several
+    query blocks, splits with and without the merge launch."""
+    heads, D = 8, 128
+    g = torch.Generator().manual_seed(F_ * 1000 + Nq * 10 + Nk)
+    q, k, v = (torch.randn(F_, n, D, generator=g) for n in (Nq, Nk, Nk))
+    q = q * 3.0                                                            # peaked softmax rows as well as flat ones
+    out = torch.full((F_, Nq, D), float("nan"), device=dev)
+    n = C.c_size_t()
+    ok(lib.sampt_attention_t2i_workspace_bytes(F_, Nq, Nk, C.byref(n)), "t2i workspace")
+    ws = torch.empty(n.value, dtype=torch.uint8, device=dev)
+    qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)                          # (kept alive: the call only takes pointers)
+    ok(lib.sampt_attention_t2i_f32(P(qd), P(kd), P(vd), P(out), F_, Nq, Nk, P(ws), ws.numel(), S()), "t2i attention")
+    assert max_abs(out, _mha_ref(q, k, v, heads)) < 2e-5
+
+
 @pytest.mark.parametrize("nb,L,time_attn", [(36, 8, True), (8, 36, False), (8, 100, False), (8, 300, False), (5, 8, True)])
 def test_cotracker_attention_kernel(lib, dev, nb, L, time_attn):
     """CoTracker's token-group attention read straight from packed qkv rows (8 heads x 48) vs an fp64 reference."""
