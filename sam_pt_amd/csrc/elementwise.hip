@@ -88,9 +88,71 @@ __global__ void k_instnorm_final(const double* __restrict__ part, int nchunks, l
   mean_rstd[(img * C + c) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
+// C % 4 == 0: a thread owns 4 channels (16-byte loads, two pixels in flight per iteration) — the scalar kernel above
+// ran at half the bandwidth of k_instnorm_apply although it only reads.  Same partial layout, sums in fp64.
+__global__ __launch_bounds__(256) void k_instnorm_partial_v4(const float* __restrict__ x, long hw, int C, int ny,
+                                                             double* __restrict__ part) {
+  extern __shared__ double sh[];  // [ny][C][2]
+  const int c4n = C >> 2, tid = threadIdx.x;
+  const int cq = tid % c4n, ty = tid / c4n;
+  const long img = blockIdx.y, chunk = blockIdx.x;
+  long p0 = chunk * IN_PIX_PER_BLOCK, p1 = p0 + IN_PIX_PER_BLOCK;
+  if (p1 > hw) p1 = hw;
+  double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+  if (ty < ny) {
+    const float* base = x + img * hw * C + cq * 4;
+    long p = p0 + ty;
+    for (; p + ny < p1; p += 2 * ny) {
+      const float4 a = *(const float4*)(base + p * C), b = *(const float4*)(base + (p + ny) * C);
+      const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const double u = (double)av[j], w = (double)bv[j];
+        s1[j] += u, s2[j] += u * u;
+        s1[j] += w, s2[j] += w * w;
+      }
+    }
+    if (p < p1) {
+      const float4 a = *(const float4*)(base + p * C);
+      const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const double u = (double)av[j];
+        s1[j] += u, s2[j] += u * u;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      sh[(ty * C + cq * 4 + j) * 2] = s1[j];
+      sh[(ty * C + cq * 4 + j) * 2 + 1] = s2[j];
+    }
+  }
+  __syncthreads();
+  if (tid < C) {
+    double t1 = 0.0, t2 = 0.0;
+    for (int j = 0; j < ny; ++j) {
+      t1 += sh[(j * C + tid) * 2];
+      t2 += sh[(j * C + tid) * 2 + 1];
+    }
+    double* o = part + ((img * gridDim.x + chunk) * C + tid) * 2;
+    o[0] = t1;
+    o[1] = t2;
+  }
+}
+
 int instnorm_stats(const float* x, int nimg, long hw, int C, float eps, double* partials, float* mean_rstd,
                    hipStream_t s) {
   if (C > 1024 || C <= 0) return SAMPT_ERR_ARG;
+  if (C % 4 == 0 && C <= 256 && !((uintptr_t)x & 15)) {
+    const int nyv = 256 / (C / 4) > 16 ? 16 : 256 / (C / 4);
+    const int nch = cdiv(hw, IN_PIX_PER_BLOCK);
+    hipLaunchKernelGGL(k_instnorm_partial_v4, dim3(nch, nimg), dim3(256), (size_t)nyv * C * 2 * sizeof(double), s, x, hw, C,
+                       nyv, partials);
+    SAMPT_CHECK_LAUNCH("instnorm_partial_v4");
+    hipLaunchKernelGGL(k_instnorm_final, dim3(nimg), dim3(C), 0, s, partials, nch, hw, C, eps, mean_rstd);
+    SAMPT_CHECK_LAUNCH("instnorm_final");
+    return SAMPT_OK;
+  }
   int ny = 256 / C;
   if (ny < 1) ny = 1;
   int nchunks = cdiv(hw, IN_PIX_PER_BLOCK);
@@ -322,9 +384,40 @@ __global__ __launch_bounds__(256) void k_layernorm_rows_v4(const float* __restri
   }
 }
 
+// D == 64 (LayerNorm2d between the decoder's two transposed convolutions, 1.6 M pixel rows per pass): 16 lanes per row, one
+// float4 each, 16 rows per workgroup; the row sums stay inside a DPP row (quad_perm x2, row_half_mirror, row_mirror)
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xf, 0xf, true));   // row_half_mirror
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xf, 0xf, true));   // row_mirror
+  return v;
+}
+
+__global__ __launch_bounds__(256) void k_layernorm_rows_d64(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ b, float* __restrict__ y, long M,
+                                                            float eps, int act) {
+  const long row = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int c = (threadIdx.x & 15) * 4;
+  const bool live = row < M;
+  const float4 v = *(const float4*)(x + (live ? row : 0) * 64 + c);
+  const float mean = row16_sum((v.x + v.y) + (v.z + v.w)) * (1.0f / 64.0f);
+  const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+  const float rstd = 1.0f / sqrtf(row16_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) * (1.0f / 64.0f) + eps);
+  if (!live) return;
+  const float4 wv = *(const float4*)(w + c), bv = *(const float4*)(b + c);
+  *(float4*)(y + row * 64 + c) = make_float4(apply_act(d0 * rstd * wv.x + bv.x, act), apply_act(d1 * rstd * wv.y + bv.y, act),
+                                             apply_act(d2 * rstd * wv.z + bv.z, act), apply_act(d3 * rstd * wv.w + bv.w, act));
+}
+
 int layernorm_rows(const float* x, const float* w, const float* b, void* y, long M, int D, float eps,
                    const int* src_rows, int out_f16, int act, hipStream_t s) {
   if (D <= 0 || D > 2048 || M <= 0) return SAMPT_ERR_ARG;
+  if (D == 64 && !src_rows && !out_f16 && ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)w | (uintptr_t)b) & 15) == 0)) {
+    hipLaunchKernelGGL(k_layernorm_rows_d64, dim3((unsigned)cdiv(M, 16)), dim3(256), 0, s, x, w, b, (float*)y, M, eps, act);
+    SAMPT_CHECK_LAUNCH("layernorm_rows_d64");
+    return SAMPT_OK;
+  }
   dim3 grid(cdiv(M, 4)), block(256);
   if (D % 256 == 0 && D <= 1536 && ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)w | (uintptr_t)b) & 15) == 0)) {
 #define LNV(NVv) hipLaunchKernelGGL(k_layernorm_rows_v4<NVv>, grid, block, 0, s, x, w, b, y, M, D, eps, src_rows, out_f16, act)

@@ -387,7 +387,10 @@ int attn_t2i(const float* q, const float* k, const float* v, float* out, int F, 
 // chunks of <= `chunk` keys with a running (max, sum) softmax, so the number of prompt tokens is unbounded.  With
 // Nk <= chunk (every SAM-PT prompt up to 120 points) there is exactly one chunk and no rescale.
 // ---------------------------------------------------------------------------------------------
-template <int HD>
+// STAGE (heads * HD == 128): the 32 query rows of a workgroup go through LDS both ways — global loads and stores are whole
+// 512-byte rows, the (query, head) threads pick their 64-byte slices from LDS (direct slices put the 64 lanes of a load on
+// 64 different cache lines, 16 bytes each: the kernel was bound by that, not by its arithmetic).
+template <int HD, bool STAGE>
 __global__ __launch_bounds__(256) void k_attn_fewkeys(const float* __restrict__ q, const float* __restrict__ k,
                                                       const float* __restrict__ v, float* __restrict__ out, int Nq,
                                                       int Nk, int heads, const int* __restrict__ nk_item, int chunk,
@@ -398,12 +401,27 @@ __global__ __launch_bounds__(256) void k_attn_fewkeys(const float* __restrict__ 
   k += (long)f * Nk * ld, v += (long)f * Nk * ld;
   float* ks = kv;
   float* vs = kv + (long)chunk * ld;
+  constexpr int SLD = 132;                        // staged row stride in floats (128 + 4: rows start on different banks)
+  float* stage = kv + 2L * chunk * ld;            // STAGE: [32][SLD]
   const int nvalid = nk_item ? nk_item[f] : Nk;   // ragged batch: only the item's valid tokens are keys
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   const bool live = idx < (long)Nq * heads;
   const int qi = live ? (int)(idx / heads) : 0, h = live ? (int)(idx % heads) : 0;
+  const int q0 = blockIdx.x * 32, ql = threadIdx.x >> 3;          // STAGE: first query of the workgroup, local query
   float qv[HD];
-  {
+  if (STAGE) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = threadIdx.x + i * 256, r = e >> 5, c4 = e & 31;
+      *(float4*)(stage + r * SLD + c4 * 4) = *(const float4*)(q + (long)min(q0 + r, Nq - 1) * ldq + c4 * 4);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < HD / 4; ++c) {
+      float4 t = *(const float4*)(stage + ql * SLD + h * HD + c * 4);
+      qv[4 * c] = t.x, qv[4 * c + 1] = t.y, qv[4 * c + 2] = t.z, qv[4 * c + 3] = t.w;
+    }
+  } else {
     const float4* qp = (const float4*)(q + (long)qi * ldq + h * HD);
 #pragma unroll
     for (int c = 0; c < HD / 4; ++c) {
@@ -411,7 +429,8 @@ __global__ __launch_bounds__(256) void k_attn_fewkeys(const float* __restrict__ 
       qv[4 * c] = t.x, qv[4 * c + 1] = t.y, qv[4 * c + 2] = t.z, qv[4 * c + 3] = t.w;
     }
   }
-  const float inv = sqrtf((float)HD);
+  static_assert(HD == 16, "the score scale below is written as an exact reciprocal of sqrt(16)");
+  const float rinv = 0.25f;        // 1 / sqrt(HD): a power of two, so the product equals the division bit for bit
   float m = -INFINITY, sum = 0.f;
   float acc[HD];
 #pragma unroll
@@ -419,9 +438,23 @@ __global__ __launch_bounds__(256) void k_attn_fewkeys(const float* __restrict__ 
   for (int c0 = 0; c0 < nvalid; c0 += chunk) {
     const int n = min(chunk, nvalid - c0);
     if (c0) __syncthreads();
-    for (int i = threadIdx.x; i < n * ld; i += 256) {
-      ks[i] = k[(long)c0 * ld + i];
-      vs[i] = v[(long)c0 * ld + i];
+    {   // stage the chunk: 16-byte loads, up to 4 K and 4 V vectors in flight per thread before the first LDS store
+      const float4* k4 = (const float4*)(k + (long)c0 * ld);
+      const float4* v4 = (const float4*)(v + (long)c0 * ld);
+      const int n4 = n * (ld >> 2);
+      for (int i0 = threadIdx.x; i0 < n4; i0 += 4 * 256) {
+        float4 kr[4], vr[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u * 256;
+          if (i < n4) kr[u] = k4[i], vr[u] = v4[i];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u * 256;
+          if (i < n4) ((float4*)ks)[i] = kr[u], ((float4*)vs)[i] = vr[u];
+        }
+      }
     }
     __syncthreads();
     float mc = -INFINITY;
@@ -430,7 +463,7 @@ __global__ __launch_bounds__(256) void k_attn_fewkeys(const float* __restrict__ 
       float a = 0.f;
 #pragma unroll
       for (int c = 0; c < HD; ++c) a += qv[c] * kp[c];
-      mc = fmaxf(mc, a / inv);
+      mc = fmaxf(mc, a * rinv);
     }
     if (mc > m) {            // new running maximum: rescale what has been accumulated (never taken in the first chunk's
       if (m > -INFINITY) {   // accumulation order, so a single-chunk result is bit-identical to the unchunked kernel)
@@ -447,11 +480,25 @@ __global__ __launch_bounds__(256) void k_attn_fewkeys(const float* __restrict__ 
       float a = 0.f;
 #pragma unroll
       for (int c = 0; c < HD; ++c) a += qv[c] * kp[c];
-      float p = expf(a / inv - m);
+      float p = expf(a * rinv - m);
       sum += p;
 #pragma unroll
       for (int c = 0; c < HD; ++c) acc[c] += p * vp[c];
     }
+  }
+  if (STAGE) {
+    __syncthreads();                                // every thread has taken its query slice out of `stage`
+#pragma unroll
+    for (int c = 0; c < HD / 4; ++c)
+      *(float4*)(stage + ql * SLD + h * HD + c * 4) =
+          make_float4(acc[4 * c] / sum, acc[4 * c + 1] / sum, acc[4 * c + 2] / sum, acc[4 * c + 3] / sum);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = threadIdx.x + i * 256, r = e >> 5, c4 = e & 31;
+      if (q0 + r < Nq) *(float4*)(out + (long)(q0 + r) * ld + c4 * 4) = *(const float4*)(stage + r * SLD + c4 * 4);
+    }
+    return;
   }
   if (!live) return;
   float4* op = (float4*)(out + (long)qi * ld + h * HD);
@@ -460,24 +507,104 @@ __global__ __launch_bounds__(256) void k_attn_fewkeys(const float* __restrict__ 
     op[c] = make_float4(acc[4 * c] / sum, acc[4 * c + 1] / sum, acc[4 * c + 2] / sum, acc[4 * c + 3] / sum);
 }
 
+// 8 heads x 16 channels (the image -> token attention of every SAM decoder): wave = head, lane = query.  The K / V slice
+// of a (frame, head) is then the same for all 64 lanes of a wave, so it is read with SCALAR loads (s_load_dwordx16 per key
+// row) and enters the FMAs as an SGPR operand: no LDS staging of the keys at all — the (query, head)-per-thread kernel
+// above read every key from LDS once per thread and was bound by LDS bandwidth (1.1 ms per launch at 87 prompt tokens x
+// 32 items).  Any number of keys, no chunking; the 64 query rows of a workgroup go through LDS both ways so that global
+// loads and stores are whole 512-byte rows.
+__global__ __launch_bounds__(512) void k_attn_fewkeys_s(const float* __restrict__ q, const float* __restrict__ k,
+                                                        const float* __restrict__ v, float* __restrict__ out, int Nq,
+                                                        int Nk, const int* __restrict__ nk_item, int ldq) {
+  constexpr int HD = 16, LD = 128, SLD = 132;
+  __shared__ float stage[64 * SLD];
+  const int f = blockIdx.y, q0 = blockIdx.x * 64, tid = threadIdx.x;
+  const int h = __builtin_amdgcn_readfirstlane(tid >> 6), ql = tid & 63;
+  q += (long)f * Nq * ldq, out += (long)f * Nq * LD;
+  // wave-uniform pointers in the constant address space: hipcc then always selects scalar loads for them (K and V are
+  // written by earlier launches only)
+  typedef const __attribute__((address_space(4))) float* cptr;
+  const cptr kh = (cptr)(uintptr_t)(k + (long)f * Nk * LD + h * HD);
+  const cptr vh = (cptr)(uintptr_t)(v + (long)f * Nk * LD + h * HD);
+  // ragged batch: only the item's valid tokens are keys (uniform over the workgroup)
+  const int nvalid = __builtin_amdgcn_readfirstlane(nk_item ? nk_item[f] : Nk);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int e = tid + i * 512, r = e >> 5, c4 = e & 31;
+    *(float4*)(stage + r * SLD + c4 * 4) = *(const float4*)(q + (long)min(q0 + r, Nq - 1) * ldq + c4 * 4);
+  }
+  __syncthreads();
+  float qv[HD];
+#pragma unroll
+  for (int c = 0; c < HD / 4; ++c) {
+    const float4 t = *(const float4*)(stage + ql * SLD + h * HD + c * 4);
+    qv[4 * c] = t.x, qv[4 * c + 1] = t.y, qv[4 * c + 2] = t.z, qv[4 * c + 3] = t.w;
+  }
+  float m = -INFINITY;
+  for (int key = 0; key < nvalid; ++key) {
+    const cptr kp = kh + (long)key * LD;
+    float a = 0.f;
+#pragma unroll
+    for (int c = 0; c < HD; ++c) a += qv[c] * kp[c];
+    m = fmaxf(m, a * 0.25f);                                         // / sqrt(16)
+  }
+  float sum = 0.f, acc[HD];
+#pragma unroll
+  for (int c = 0; c < HD; ++c) acc[c] = 0.f;
+  for (int key = 0; key < nvalid; ++key) {
+    const cptr kp = kh + (long)key * LD;
+    const cptr vp = vh + (long)key * LD;
+    float a = 0.f;
+#pragma unroll
+    for (int c = 0; c < HD; ++c) a += qv[c] * kp[c];
+    const float p = expf(a * 0.25f - m);
+    sum += p;
+#pragma unroll
+    for (int c = 0; c < HD; ++c) acc[c] += p * vp[c];
+  }
+  __syncthreads();                                  // every thread has taken its query slice out of `stage`
+#pragma unroll
+  for (int c = 0; c < HD / 4; ++c)
+    *(float4*)(stage + ql * SLD + h * HD + c * 4) =
+        make_float4(acc[4 * c] / sum, acc[4 * c + 1] / sum, acc[4 * c + 2] / sum, acc[4 * c + 3] / sum);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int e = tid + i * 512, r = e >> 5, c4 = e & 31;
+    if (q0 + r < Nq) *(float4*)(out + (long)(q0 + r) * LD + c4 * 4) = *(const float4*)(stage + r * SLD + c4 * 4);
+  }
+}
+
 int attn_fewkeys(const float* q, const float* k, const float* v, float* out, int F, int Nq, int Nk, int heads, int hd,
                  const int* nk_item, hipStream_t s, int ldq) {
   if (Nk <= 0 || hd != 16 || F <= 0) return SAMPT_ERR_UNSUPPORTED;
   if (ldq == 0) ldq = heads * hd;
   if (ldq < heads * hd || ldq % 4) return SAMPT_ERR_ARG;
+  if (heads == 8 && hd == 16) {
+    hipLaunchKernelGGL(k_attn_fewkeys_s, dim3(cdiv(Nq, 64), F), dim3(512), 0, s, q, k, v, out, Nq, Nk, nk_item, ldq);
+    SAMPT_CHECK_LAUNCH("attn_fewkeys_s");
+    return SAMPT_OK;
+  }
   const int chunk = Nk < 128 ? Nk : 128;
-  size_t sh = (size_t)2 * chunk * heads * hd * sizeof(float);
+  const bool stage = heads * hd == 128;
+  size_t sh = ((size_t)2 * chunk * heads * hd + (stage ? 32 * 132 : 0)) * sizeof(float);
   if (sh > 64 * 1024) {  // above the default dynamic-LDS limit (gfx950 has 160 KiB per workgroup)
     static bool raised = false;
     if (!raised) {
-      if (hipFuncSetAttribute((const void*)k_attn_fewkeys<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) !=
-          hipSuccess)
+      if (hipFuncSetAttribute((const void*)k_attn_fewkeys<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              152 * 1024) != hipSuccess ||
+          hipFuncSetAttribute((const void*)k_attn_fewkeys<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              144 * 1024) != hipSuccess)
         return SAMPT_ERR_HIP;
       raised = true;
     }
   }
-  hipLaunchKernelGGL(k_attn_fewkeys<16>, dim3(cdiv((long)Nq * heads, 256), F), dim3(256), sh, s, q, k, v, out, Nq, Nk,
-                     heads, nk_item, chunk, ldq);
+  if (stage)
+    hipLaunchKernelGGL((k_attn_fewkeys<16, true>), dim3(cdiv((long)Nq * heads, 256), F), dim3(256), sh, s, q, k, v, out, Nq,
+                       Nk, heads, nk_item, chunk, ldq);
+  else
+    hipLaunchKernelGGL((k_attn_fewkeys<16, false>), dim3(cdiv((long)Nq * heads, 256), F), dim3(256), sh, s, q, k, v, out, Nq,
+                       Nk, heads, nk_item, chunk, ldq);
   SAMPT_CHECK_LAUNCH("attn_fewkeys");
   return SAMPT_OK;
 }

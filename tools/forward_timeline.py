@@ -8,7 +8,8 @@ import bench
 args = bench.parse()
 dev = torch.device("cuda:0")
 from sam_pt_amd.synth import bench_clip
-frames, qp = bench_clip(T=args.frames, seed=72, n_pos=args.points, n_objects=args.objects)
+frames, qp = bench_clip(T=args.frames, seed=72, n_pos=args.points, n_objects=args.objects, native=args.native_480p,
+                        n_neg=args.neg_points, square=args.square)
 model = bench.build_model(args, dev)
 video = {"image": [f for f in frames.to(dev)], "target_hw": tuple(frames.shape[-2:]), "query_points": qp}
 for _ in range(3):
