@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--refine", type=int, default=12)
     ap.add_argument("--precision", default="f16", choices=["f16", "f32"])
     ap.add_argument("--encode-batch", type=int, default=8)
-    ap.add_argument("--decode-batch", type=int, default=32, help="max (frame, object) items per batched decoder chain")
+    ap.add_argument("--decode-batch", type=int, default=128, help="max (frame, object) items per batched decoder chain")
     ap.add_argument("--tracker", default="pips", choices=["pips", "pips_plus_plus", "cotracker"],
                     help="point tracker (the metric is quoted on PIPS; CoTracker = BASELINE configs #3/#5, row a13; "
                          "PIPS++ = SURVEY.md §8 row f4)")

@@ -194,7 +194,7 @@ int conv_f16x3(const GemmP& p_in, hipStream_t s) {
   if (p.cpadw >= 0 || p.rowmap || p.a_rowmap || p.nb1 * p.nb2 != 1 || (p.res && p.ldr % 4)) return SAMPT_ERR_UNSUPPORTED;
   if (((uintptr_t)p.A | (uintptr_t)p.W | (uintptr_t)p.W_lo | (uintptr_t)p.C | (uintptr_t)p.bias | (uintptr_t)p.res) & 15)
     return SAMPT_ERR_ARG;
-  const int BN = p.N <= 64 ? 64 : (p.N <= 96 ? 96 : 128);
+  const int BN = p.N <= 32 ? 32 : (p.N <= 64 ? 64 : (p.N <= 96 ? 96 : 128));
   const size_t lds = (size_t)2 * (2 * 128 + 2 * BN) * (32 + 8) * sizeof(half_t);
   static bool raised = false;
   if (!raised) {  // 128 x 128 tiles need 80 KiB, above the default 64 KiB dynamic-LDS limit (gfx950: 160 KiB per CU)
@@ -208,7 +208,8 @@ int conv_f16x3(const GemmP& p_in, hipStream_t s) {
     raised = true;
   }
   dim3 grid((unsigned)((long)cdiv(p.N, BN) * cdiv(p.M, 128))), block(256);
-  if (BN == 64) hipLaunchKernelGGL((k_conv_f16x3<128, 64>), grid, block, lds, s, p);
+  if (BN == 32) hipLaunchKernelGGL((k_conv_f16x3<128, 32>), grid, block, lds, s, p);   // (51 KiB: under the default limit)
+  else if (BN == 64) hipLaunchKernelGGL((k_conv_f16x3<128, 64>), grid, block, lds, s, p);
   else if (BN == 96) hipLaunchKernelGGL((k_conv_f16x3<128, 96>), grid, block, lds, s, p);
   else hipLaunchKernelGGL((k_conv_f16x3<128, 128>), grid, block, lds, s, p);
   SAMPT_CHECK_LAUNCH("conv_f16x3");

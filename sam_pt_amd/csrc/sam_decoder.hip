@@ -186,10 +186,85 @@ __global__ __launch_bounds__(256) void k_attn_rowblock(const float* __restrict__
   }
 }
 
+// Self-attention among the prompt tokens (8 heads x 32 channels, 7 .. a few hundred tokens): one wave per (64 queries,
+// head, item), lane = query.  K and V rows of a (head, item) are wave-uniform, so they are read with scalar loads and used
+// as SGPR operands (k_attn_rowblock spent a 256-thread workgroup and two block reductions per query: 236 us per launch at
+// 87 tokens x 32 items).
+template <int HD>
+__global__ __launch_bounds__(256) void k_attn_tokens_s(const float* __restrict__ q, const float* __restrict__ k,
+                                                       const float* __restrict__ v, float* __restrict__ out, int Nq,
+                                                       int Nk, int ld, const int* __restrict__ nk_item, float rscale) {
+  // 4 waves share the 64 queries of the workgroup and split the keys (key % 4 == wave): the loop is a chain of scalar-load
+  // latencies, so four short chains beat one long one; maxima, sums and accumulators meet in LDS
+  __shared__ float s_max[4][64];
+  __shared__ float s_acc[4][64][HD + 1];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = blockIdx.y, f = blockIdx.z;
+  const int qi = blockIdx.x * 64 + lane;
+  const long qrow = ((long)f * Nq + min(qi, Nq - 1)) * ld + h * HD;
+  float qv[HD];
+#pragma unroll
+  for (int c = 0; c < HD / 4; ++c) {
+    const float4 t = *(const float4*)(q + qrow + c * 4);
+    qv[4 * c] = t.x, qv[4 * c + 1] = t.y, qv[4 * c + 2] = t.z, qv[4 * c + 3] = t.w;
+  }
+  typedef const __attribute__((address_space(4))) float* cptr;     // constant address space: scalar loads (see above)
+  const cptr kh = (cptr)(uintptr_t)(k + (long)f * Nk * ld + h * HD);
+  const cptr vh = (cptr)(uintptr_t)(v + (long)f * Nk * ld + h * HD);
+  const int nvalid = __builtin_amdgcn_readfirstlane(nk_item ? nk_item[f] : Nk);
+  float m = -INFINITY;
+  for (int key = w; key < nvalid; key += 4) {
+    const cptr kp = kh + (long)key * ld;
+    float a = 0.f;
+#pragma unroll
+    for (int c = 0; c < HD; ++c) a += qv[c] * kp[c];
+    m = fmaxf(m, a * rscale);
+  }
+  s_max[w][lane] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(s_max[0][lane], s_max[1][lane]), fmaxf(s_max[2][lane], s_max[3][lane]));
+  float sum = 0.f, acc[HD];
+#pragma unroll
+  for (int c = 0; c < HD; ++c) acc[c] = 0.f;
+  for (int key = w; key < nvalid; key += 4) {
+    const cptr kp = kh + (long)key * ld;
+    const cptr vp = vh + (long)key * ld;
+    float a = 0.f;
+#pragma unroll
+    for (int c = 0; c < HD; ++c) a += qv[c] * kp[c];
+    const float p = expf(a * rscale - m);
+    sum += p;
+#pragma unroll
+    for (int c = 0; c < HD; ++c) acc[c] += p * vp[c];
+  }
+#pragma unroll
+  for (int c = 0; c < HD; ++c) s_acc[w][lane][c] = acc[c];
+  s_acc[w][lane][HD] = sum;
+  __syncthreads();
+  if (qi >= Nq) return;
+  const float tot = (s_acc[0][lane][HD] + s_acc[1][lane][HD]) + (s_acc[2][lane][HD] + s_acc[3][lane][HD]);
+  constexpr int CW = HD / 4;                                        // channels finished by each wave
+  float o[CW];
+#pragma unroll
+  for (int c = 0; c < CW; ++c) {
+    const int cc = w * CW + c;
+    o[c] = ((s_acc[0][lane][cc] + s_acc[1][lane][cc]) + (s_acc[2][lane][cc] + s_acc[3][lane][cc])) / tot;
+  }
+#pragma unroll
+  for (int c = 0; c < CW / 4; ++c)
+    *(float4*)(out + qrow + w * CW + c * 4) = make_float4(o[4 * c], o[4 * c + 1], o[4 * c + 2], o[4 * c + 3]);
+}
+
 int attn_rowblock(const float* q, const float* k, const float* v, float* out, int F, int Nq, int Nk, int heads, int hd,
                   const int* nk_item, hipStream_t s) {
   if (Nk > 4096 || Nk <= 0 || Nq <= 0 || F <= 0) return SAMPT_ERR_ARG;
   int ld = heads * hd;
+  if (hd == 32 && ld % 16 == 0 && !(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15)) {
+    hipLaunchKernelGGL((k_attn_tokens_s<32>), dim3(cdiv(Nq, 64), heads, F), dim3(256), 0, s, q, k, v, out, Nq, Nk, ld, nk_item,
+                       1.0f / sqrtf(32.0f));
+    SAMPT_CHECK_LAUNCH("attn_tokens_s");
+    return SAMPT_OK;
+  }
   if (hd == 16 && Nk > 256) {            // token -> image: long key streams, share them between 4 queries
     hipLaunchKernelGGL((k_attn_rowblock<16, 4>), dim3(cdiv(Nq, 4), heads, F), dim3(256), 0, s, q, k, v, out, Nq, Nk, ld,
                        nk_item);

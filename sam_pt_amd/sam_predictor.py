@@ -147,7 +147,7 @@ class SamHip(nn.Module):
 
     def __init__(self, variant: Optional[str] = None, checkpoint: Optional[str] = None, state_dict=None, seed: int = 72,
                  precision: str = "f16", config: Optional[SamConfig] = None, max_batch: int = 8,
-                 max_decode_batch: int = 32, hq: Optional[bool] = None, image_encoder=None, prompt_encoder=None,
+                 max_decode_batch: int = 128, hq: Optional[bool] = None, image_encoder=None, prompt_encoder=None,
                  mask_decoder=None, pixel_mean=None, pixel_std=None, **hydra_kwargs):
         """``hq``: build the HQ-SAM decoder (sam_pt/modeling/sam.py SamHQHydra, configs/model/sam/samhq_vit_*.yaml);
         default: inferred from the checkpoint (presence of ``mask_decoder.hf_token.weight``) or from the ``mask_decoder``

@@ -13,7 +13,7 @@ F = int(sys.argv[2]) if len(sys.argv) > 2 else 24
 K = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 hq = len(sys.argv) > 4 and sys.argv[4] == "1"
 R, size = 12, ((int(sys.argv[5]), int(sys.argv[6])) if len(sys.argv) > 6 else (576, 1024))
-pred = SamPredictor(SamHip("vit_b", seed=72, precision="f16", max_decode_batch=32, hq=hq).to(dev))   # decoder identical for B/L/H
+pred = SamPredictor(SamHip("vit_b", seed=72, precision="f16", max_decode_batch=128, hq=hq).to(dev))   # decoder identical for B/L/H
 pred._ensure()
 st = pred.decode_staging(F, K, size)
 g = torch.Generator().manual_seed(0)

@@ -9,7 +9,7 @@ from sam_pt_amd.weights import SAM_CONFIGS
 
 dev = torch.device("cuda:0")
 F, K, R, size = 24, 8, 12, (576, 1024)
-pred = SamPredictor(SamHip("vit_b", seed=72, precision="f16", max_decode_batch=32).to(dev))   # decoder identical for B/L/H
+pred = SamPredictor(SamHip("vit_b", seed=72, precision="f16", max_decode_batch=128).to(dev))   # decoder identical for B/L/H
 pred._ensure()
 st = pred.decode_staging(F, K, size)
 g = torch.Generator().manual_seed(0)
