@@ -7,6 +7,7 @@ import sys
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -111,6 +112,73 @@ def test_weight_layouts_and_packing():
     assert s["image_encoder.blocks.2.attn.rel_pos_h"].shape == (127, 64)   # global block: 2*64-1
     assert s["image_encoder.blocks.0.attn.rel_pos_h"].shape == (27, 64)    # windowed: 2*14-1
     assert s["mask_decoder.output_upscaling.0.weight"].shape == (256, 64, 2, 2)
+
+
+def _unsplit(hl):
+    """inverse of pack.split_f16x3: half [2][N][K] -> fp32 [N][K] (exact up to the dropped 2^-22 tail)"""
+    from sam_pt_amd.pack import F16X3_WSHIFT
+    return (hl[0].double() + hl[1].double()).float() / float(1 << F16X3_WSHIFT)
+
+
+def test_decoder_fused_projection_packing():
+    """pack_decoder's fused image-side projections: keys @ W^T + b + pe-term must equal the three separate projections of
+    the two-way transformer — (keys + pe) Wk, keys Wv, (keys + pe) Wq' (SAM TwoWayAttentionBlock) — and the final
+    attention's K | V pair."""
+    from sam_pt_amd.pack import pack_decoder
+    from sam_pt_amd.weights import SAM_CONFIGS, init_sam_state_dict
+    cfg = SAM_CONFIGS["vit_test"]
+    sd = init_sam_state_dict(cfg, 3)
+    p = pack_decoder(sd, cfg, "cpu", 2)
+    g = torch.Generator().manual_seed(0)
+    P = cfg.grid * cfg.grid
+    keys = torch.randn(2 * P, 256, generator=g)
+    pe = p["prompt_encoder.__dense_pe"].repeat(2, 1)
+    tr = "mask_decoder.transformer."
+
+    def lin(x, name):
+        return x.double() @ sd[name + ".weight"].double().t() + sd[name + ".bias"].double()
+
+    for i in range(cfg.dec_depth):
+        lp = f"{tr}layers.{i}."
+        want = torch.cat([lin(keys + pe, lp + "cross_attn_token_to_image.k_proj"), lin(keys, lp + "cross_attn_token_to_image.v_proj"),
+                          lin(keys + pe, lp + "cross_attn_image_to_token.q_proj")], dim=1)
+        got = keys.double() @ p[lp + "__kvq_w"].double().t() + p[lp + "__kvq_b"].double() + p[lp + "__kvq_pe"].double().repeat(2, 1)
+        assert got.shape == (2 * P, 384) and (got - want).abs().max() < 2e-5
+        assert (_unsplit(p[lp + "__kvq_w_hl"]) - p[lp + "__kvq_w"]).abs().max() < 1e-6       # the planes the GPU multiplies
+    want = torch.cat([lin(keys + pe, tr + "final_attn_token_to_image.k_proj"), lin(keys, tr + "final_attn_token_to_image.v_proj")], dim=1)
+    got = keys.double() @ p[tr + "__fin_kv_w"].double().t() + p[tr + "__fin_kv_b"].double() + p[tr + "__fin_kv_pe"].double().repeat(2, 1)
+    assert got.shape == (2 * P, 256) and (got - want).abs().max() < 2e-5
+
+
+def test_transposed_convolution_as_one_gemm_with_pixel_shuffle():
+    """The decoder's ConvTranspose2d(k=2, s=2) stages run as ONE GEMM over N = 4*Cout columns (dy, dx, channel) whose
+    epilogue scatters GEMM row f*g*g + y*g + x, column block z = 2*dy + dx to pixel row f*4*g*g + (2y+dy)*2g + 2x+dx
+    (csrc/conv_f16x3.hip, GemmP::shuf_g).  This restates that address arithmetic on the packed planes and checks it
+    against torch's conv_transpose2d."""
+    from sam_pt_amd.pack import pack_decoder
+    from sam_pt_amd.weights import SAM_CONFIGS, init_sam_state_dict
+    cfg = SAM_CONFIGS["vit_test"]
+    sd = init_sam_state_dict(cfg, 5, hq=True)
+    p = pack_decoder(sd, cfg, "cpu", 2, hq=True)
+    gen = torch.Generator().manual_seed(1)
+    for name, g in [("output_upscaling.0", 5), ("output_upscaling.3", 6), ("embedding_encoder.0", 4), ("compress_vit_feat.3", 3)]:
+        w, b = sd[f"mask_decoder.{name}.weight"], sd[f"mask_decoder.{name}.bias"]
+        cin, cout = w.shape[0], w.shape[1]
+        F_ = 2
+        x = torch.randn(F_, cin, g, g, generator=gen)
+        ref = F.conv_transpose2d(x.double(), w.double(), b.double(), stride=2).permute(0, 2, 3, 1).reshape(F_ * 4 * g * g, cout)
+        hl = p[f"mask_decoder.{name}.weight_packed_hl"]
+        assert hl.shape == (2, 4 * cout, cin)
+        rows = x.permute(0, 2, 3, 1).reshape(F_ * g * g, cin).double()
+        acc = rows @ _unsplit(hl).double().t()                              # [F*g*g][4*cout], columns z*cout + c
+        out = torch.zeros_like(ref)
+        r = torch.arange(F_ * g * g)
+        f, rem = r // (g * g), r % (g * g)
+        y, xx = rem // g, rem % g
+        for z in range(4):
+            orow = f * 4 * g * g + (2 * y + (z >> 1)) * 2 * g + 2 * xx + (z & 1)
+            out[orow] = acc[:, z * cout:(z + 1) * cout] + b.double()
+        assert (out - ref).abs().max() < 1e-5, name
 
 
 def test_sharding_helpers():
