@@ -244,6 +244,23 @@ def secondary_rooflines(args, dev):
     out.append({"kernel": "k_conv_f16x3<128,64> (fnet 64->64 3x3 @288x512, 8 frames)", "bound": "mfma", "achieved": round(fl / t / 1e12, 1),
                 "peak": 833.3, "unit": "TFLOP/s fp32-equivalent (3 fp16 MFMAs per product: 2500 / 3)", "frac": round(fl / t / 833.3e12, 4),
                 "launch_us": round(t * 1e6, 1)})
+    # mask decoder, token -> image attention of one pass over the clip's (frame, object) items: K and V of every item are
+    # read once (algorithmic bytes = 2 x items x 4096 x 128 x 4), queries / outputs are a few KB
+    import ctypes as C
+    items, nq = args.frames * args.objects, 7 + args.points + args.neg_points
+    q = torch.randn(items, nq, 128, generator=g).to(dev)
+    kk = torch.randn(items, 4096, 128, generator=g).to(dev)
+    vv = torch.randn(items, 4096, 128, generator=g).to(dev)
+    oo = torch.empty(items, nq, 128, device=dev)
+    nb = C.c_size_t()
+    _lib.check(lib.sampt_attention_t2i_workspace_bytes(items, nq, 4096, C.byref(nb)), "t2i workspace")
+    wsb = torch.empty(nb.value, dtype=torch.uint8, device=dev)
+    t = timed(lambda: lib.sampt_attention_t2i_f32(_lib.ptr(q), _lib.ptr(kk), _lib.ptr(vv), _lib.ptr(oo), items, nq, 4096,
+                                                  _lib.ptr(wsb), wsb.numel(), _lib.stream_ptr()))
+    nbytes = 2 * items * 4096 * 128 * 4
+    out.append({"kernel": f"k_attn_t2i_part + _merge (decoder token->image attention, {items} items x {nq} tokens)", "bound": "hbm",
+                "achieved": round(nbytes / t / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(nbytes / t / 8e12, 4),
+                "launch_us": round(t * 1e6, 1), "algorithmic_bytes_per_launch": nbytes})
     return out
 
 

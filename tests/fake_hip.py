@@ -117,10 +117,28 @@ class FakeHip:
         return 0
 
     def sampt_vit_live_rows(self, h, H, W, live, nbytes):
-        # the skipping of frame-independent padding rows is an exact device-side optimisation: the fake has nothing to skip
-        live._obj.value = self.cfg.grid
-        _set(nbytes, 0)
+        # The skipping of frame-independent padding rows is an exact device-side optimisation.  By default the fake reports
+        # nothing to skip; with ``model_live_rows`` set it follows the engine's rule (VitEngine::live_rows) so that the host
+        # logic around sampt_vit_encode_live — one cache per frame geometry, built from the first frame — runs on the CPU.
+        c = self.cfg
+        lh = c.grid
+        first_global = min(c.global_attn_indexes) if c.global_attn_indexes else c.depth
+        if getattr(self, "model_live_rows", False) and first_global > 0 and W == c.img_size:
+            h_tok = -(-H // c.patch_size)
+            lh = min(c.grid, -(-h_tok // c.window_size) * c.window_size)
+        live._obj.value = lh
+        _set(nbytes, (c.grid - lh) * c.grid * c.embed_dim * 4)
         return 0
+
+    def sampt_vit_encode_live(self, h, frames, chw, B, H, W, out, interm, cache, build, ws, nbytes, stream):
+        if build:
+            self.calls["vit_dead_cache_builds"] += 1
+            assert B == 1 and out is None and cache is not None
+            cache.fill_(float(H * 10000 + W))                                  # marker: which geometry the cache belongs to
+            return 0
+        assert float(cache[0]) == float(H * 10000 + W), "dead-row cache of another frame geometry"
+        self.calls["vit_encode_live_frames"] += B
+        return self.sampt_vit_encode(h, frames, chw, B, H, W, out, interm, ws, nbytes, stream)
 
     def sampt_vit_encode(self, h, frames, chw, B, H, W, out, interm, ws, nbytes, stream):
         from oracle import sam_ref as R

@@ -184,6 +184,36 @@ def test_prepared_pyramid_path_on_the_fake_device(monkeypatch):
     assert fake.calls["pips_fnet_frames"] == 27
 
 
+def test_dead_row_cache_host_logic_on_the_fake_device(monkeypatch):
+    """SamPredictor.encode_frames around sampt_vit_encode_live: one cache per frame geometry, built once from the first frame
+    of that size and reused by later clips; square frames (nothing to skip) take the plain entry point; the embeddings equal
+    the plain path's (the fake computes both with the oracle encoder)."""
+    from sam_pt_amd.sam_predictor import SamHip, SamPredictor
+    from sam_pt_amd.weights import SAM_CONFIGS, init_sam_state_dict
+    from tests import fake_hip
+    cfg = SAM_CONFIGS["vit_test"]
+    sd = init_sam_state_dict(cfg, 72)
+    fake = fake_hip.install(monkeypatch, sd, cfg, None)
+    fake.model_live_rows = True
+    pred = SamPredictor(SamHip(config=cfg, state_dict=sd, precision="f32"))
+    land, _ = synthetic_clip(T=3, H=144, W=256, seed=5)
+    a = pred.encode_frames(land)                                   # 9 token rows -> 12 live rows of 16
+    assert fake.calls["vit_dead_cache_builds"] == 1 and fake.calls["vit_encode_live_frames"] == 3
+    pred.encode_frames(land[:2])                                   # second clip, same geometry: cache reused
+    assert fake.calls["vit_dead_cache_builds"] == 1 and fake.calls["vit_encode_live_frames"] == 5
+    low, _ = synthetic_clip(T=1, H=80, W=256, seed=6)
+    pred.encode_frames(low)                                        # another geometry: its own cache
+    assert fake.calls["vit_dead_cache_builds"] == 2
+    sq, _ = synthetic_clip(T=1, H=256, W=256, seed=7)
+    n_plain = fake.calls["vit_encode_frames"]
+    pred.encode_frames(sq)                                         # square: nothing to skip, plain entry point
+    assert fake.calls["vit_dead_cache_builds"] == 2 and fake.calls["vit_encode_live_frames"] == 6
+    assert fake.calls["vit_encode_frames"] == n_plain + 1
+    pred.skip_dead_rows = False
+    b = pred.encode_frames(land)
+    assert fake.calls["vit_encode_live_frames"] == 6 and torch.equal(a, b)
+
+
 def test_checkpoint_files_load_through_the_reference_conventions(tmp_path, monkeypatch):
     """`checkpoint` / `checkpoint_path` constructor arguments: SAM `.pth` state dict (sam.py:21-24), PIPS directory with
     `model-*.pth` holding 'model_state_dict' (utils/saverloader.py:30-73), CoTracker `.pth` optionally wrapped in 'model'
