@@ -18,7 +18,9 @@
 
 namespace sampt {
 
-template <int BM, int BN>
+// PF = prefetch distance in K slabs: the global loads of slab kt + PF are issued while slab kt is multiplied (PF register
+// sets; the split into fp16 planes happens when a set is stored to LDS, one slab ahead of its use).
+template <int BM, int BN, int PF>
 __global__ __launch_bounds__(256) void k_conv_f16x3(GemmP p) {
   constexpr int BK = 32, LDH = BK + 8;
   constexpr int WTM = BM / 2, WTN = BN / 2, FM = WTM / 16, FN = WTN / 16;
@@ -59,9 +61,9 @@ __global__ __launch_bounds__(256) void k_conv_f16x3(GemmP p) {
   // filter tap / channel offset of the slab being LOADED (uniform over the workgroup)
   int l_ky = 0, l_kx = 0, l_ci = 0, l_k = 0;
 
-  float4 ra[A_IT];
-  h8 rbh[B_IT], rbl[B_IT];
-  auto load_slab = [&]() {
+  float4 ra0[A_IT], ra1[PF > 1 ? A_IT : 1];
+  h8 rbh0[B_IT], rbl0[B_IT], rbh1[PF > 1 ? B_IT : 1], rbl1[PF > 1 ? B_IT : 1];
+  auto load_slab = [&](float4* ra, h8* rbh, h8* rbl) {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       const int iy = a_iy0[i] + l_ky, ix = a_ix0[i] + l_kx;
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(256) void k_conv_f16x3(GemmP p) {
       if (++l_kx == p.KW) l_kx = 0, ++l_ky;
     }
   };
-  auto store_slab = [&](int buf) {
+  auto store_slab = [&](int buf, const float4* ra, const h8* rbh, const h8* rbl) {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       const float4 v = ra[i];
@@ -115,15 +117,23 @@ __global__ __launch_bounds__(256) void k_conv_f16x3(GemmP p) {
 
   const int nk = p.K / BK;
   const int lr = lane & 15, lq = lane >> 4;
-  load_slab();
-  store_slab(0);
-  if (nk > 1) load_slab();
+  // slab s travels in register set s % PF; iteration kt stores slab kt + 1 to LDS buffer (kt + 1) & 1 (last read before the
+  // previous barrier) and re-uses its registers for slab kt + 1 + PF
+  load_slab(ra0, rbh0, rbl0);
+  if (PF > 1 && nk > 1) load_slab(ra1, rbh1, rbl1);
+  store_slab(0, ra0, rbh0, rbl0);
+  if (nk > PF) load_slab(ra0, rbh0, rbl0);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) {
-      store_slab(cur ^ 1);                  // buffer cur^1 was last read before the previous barrier
-      if (kt + 2 < nk) load_slab();
+      if (PF == 1 || (kt & 1)) {            // slab kt + 1 is even (or the only set): set 0
+        store_slab(cur ^ 1, ra0, rbh0, rbl0);
+        if (kt + 1 + PF < nk) load_slab(ra0, rbh0, rbl0);
+      } else {
+        store_slab(cur ^ 1, ra1, rbh1, rbl1);
+        if (kt + 1 + PF < nk) load_slab(ra1, rbh1, rbl1);
+      }
     }
     h8 ah[FM], al[FM], bh[FN], bl[FN];
 #pragma unroll
@@ -196,22 +206,30 @@ int conv_f16x3(const GemmP& p_in, hipStream_t s) {
     return SAMPT_ERR_ARG;
   const int BN = p.N <= 32 ? 32 : (p.N <= 64 ? 64 : (p.N <= 96 ? 96 : 128));
   const size_t lds = (size_t)2 * (2 * 128 + 2 * BN) * (32 + 8) * sizeof(half_t);
+  // SAMPT_CONV_PF=2: two slabs in flight (two register sets).  Measured slower everywhere — decode chain 24.70 vs 24.34 ms,
+  // tracker-encoder pass 6.54 vs 6.08 ms, 93.9 vs 95.0 fps end to end (profiles/r2_v16_*): these kernels are not bound by
+  // the latency of their global loads, and the extra 30 registers cost the 64- and 96-column tiles a resident wave.
+  static const int pf = getenv("SAMPT_CONV_PF") ? atoi(getenv("SAMPT_CONV_PF")) : 1;
   static bool raised = false;
   if (!raised) {  // 128 x 128 tiles need 80 KiB, above the default 64 KiB dynamic-LDS limit (gfx950: 160 KiB per CU)
-    if (hipFuncSetAttribute((const void*)k_conv_f16x3<128, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) !=
-            hipSuccess ||
-        hipFuncSetAttribute((const void*)k_conv_f16x3<128, 96>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) !=
-            hipSuccess ||
-        hipFuncSetAttribute((const void*)k_conv_f16x3<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) !=
-            hipSuccess)
-      return SAMPT_ERR_HIP;
+    const void* fns[] = {(const void*)k_conv_f16x3<128, 64, 1>,  (const void*)k_conv_f16x3<128, 96, 1>,
+                         (const void*)k_conv_f16x3<128, 128, 1>, (const void*)k_conv_f16x3<128, 64, 2>,
+                         (const void*)k_conv_f16x3<128, 96, 2>,  (const void*)k_conv_f16x3<128, 128, 2>};
+    for (const void* f : fns)
+      if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) return SAMPT_ERR_HIP;
     raised = true;
   }
   dim3 grid((unsigned)((long)cdiv(p.N, BN) * cdiv(p.M, 128))), block(256);
-  if (BN == 32) hipLaunchKernelGGL((k_conv_f16x3<128, 32>), grid, block, lds, s, p);   // (51 KiB: under the default limit)
-  else if (BN == 64) hipLaunchKernelGGL((k_conv_f16x3<128, 64>), grid, block, lds, s, p);
-  else if (BN == 96) hipLaunchKernelGGL((k_conv_f16x3<128, 96>), grid, block, lds, s, p);
-  else hipLaunchKernelGGL((k_conv_f16x3<128, 128>), grid, block, lds, s, p);
+#define CONV_LAUNCH(BNv)                                                                              \
+  do {                                                                                                \
+    if (pf >= 2) hipLaunchKernelGGL((k_conv_f16x3<128, BNv, 2>), grid, block, lds, s, p);            \
+    else hipLaunchKernelGGL((k_conv_f16x3<128, BNv, 1>), grid, block, lds, s, p);                    \
+  } while (0)
+  if (BN == 32) CONV_LAUNCH(32);   // (51 KiB: under the default limit)
+  else if (BN == 64) CONV_LAUNCH(64);
+  else if (BN == 96) CONV_LAUNCH(96);
+  else CONV_LAUNCH(128);
+#undef CONV_LAUNCH
   SAMPT_CHECK_LAUNCH("conv_f16x3");
   return SAMPT_OK;
 }
