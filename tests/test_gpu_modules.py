@@ -792,15 +792,16 @@ def test_automatic_mask_generator_hip_vs_oracle(dev):
     assert more and all(r["segmentation"].shape == (96, 128) for r in more)
 
 
-@pytest.mark.skipif(os.environ.get("SAMPT_TEST_EXPERIMENTAL", "0") == "0",
-                    reason="opt-in experiment (SAMPT_DEC_F16X3): run with SAMPT_TEST_EXPERIMENTAL=1")
-def test_decoder_image_projections_f16x3_opt_in(dev, monkeypatch):
-    """the decoder's image-token projections through the split-fp16 convolution kernel — same tolerance
-    against the oracle as the exact-f32 decoder."""
+@pytest.mark.parametrize("f16x3", ["0", "1"])
+def test_decoder_image_side_gemms_both_arithmetics(dev, monkeypatch, f16x3):
+    """The decoder's GEMMs over the image tokens (fused K|V|Q' projections with the folded positional term, out-projection,
+    the two transposed convolutions) run as 3-term split-fp16 MFMAs by default and as exact-f32 MFMAs with
+    SAMPT_DEC_F16X3=0 (row-mapped transposed convolutions, broadcast residual in gemm_f32): same tolerance against the
+    oracle either way."""
     from oracle import sam_ref as R
     from sam_pt_amd.sam_predictor import SamHip, SamPredictor
     from sam_pt_amd.weights import SAM_CONFIGS, init_sam_state_dict
-    monkeypatch.setenv("SAMPT_DEC_F16X3", "1")
+    monkeypatch.setenv("SAMPT_DEC_F16X3", f16x3)
     cfg = SAM_CONFIGS["vit_test"]
     sd = init_sam_state_dict(cfg, 72)
     frames, centres = synthetic_clip(T=1, H=144, W=256, seed=5)
