@@ -454,19 +454,22 @@ class SamPt(nn.Module):
 
     def _prepare_points(self, trajectories, visibilities, frame_idx, mask_idx, n_masks):
         """Prompt assembly of sam_pt.py:726-758: visible points (== 1), tail points negative, the other objects'
-        visible positives appended as negatives."""
-        point_coords = trajectories[frame_idx, mask_idx, :, :]
+        visible positives appended as negatives.  ``trajectories`` / ``visibilities``: torch tensors, or — the fused path
+        converts once per clip, per-item torch indexing was 0.1 ms per (frame, object) — numpy arrays (T, M, P, 2) float and
+        (T, M, P) bool."""
+        if isinstance(trajectories, torch.Tensor):
+            trajectories, visibilities = trajectories.numpy(), (visibilities == 1).numpy()
+        point_coords = trajectories[frame_idx, mask_idx]
         point_labels = np.ones((len(point_coords)), dtype=int)
         if self.negative_points_per_mask > 0:
             point_labels[self.positive_points_per_mask:] = 0
-        vmask = (visibilities[frame_idx, mask_idx, :] == 1).numpy()
-        coords = point_coords.numpy()[vmask]
+        vmask = visibilities[frame_idx, mask_idx]
+        coords = point_coords[vmask]
         labels = point_labels[vmask]
         if n_masks > 1 and self.add_other_objects_positive_points_as_negative_points:
-            others = [trajectories[frame_idx, o, :self.positive_points_per_mask, :][
-                visibilities[frame_idx, o, :self.positive_points_per_mask] == 1, :]
-                for o in range(n_masks) if o != mask_idx]
-            others = torch.cat(others, dim=0).numpy()
+            pp = self.positive_points_per_mask
+            keep = np.arange(n_masks) != mask_idx
+            others = trajectories[frame_idx, keep, :pp][visibilities[frame_idx, keep, :pp]]   # object-major, like the cat
             if self.max_other_objects_positive_points is not None and len(others) > self.max_other_objects_positive_points:
                 idx = np.random.choice(len(others), self.max_other_objects_positive_points, replace=False)
                 others = others[idx, :]
@@ -504,9 +507,10 @@ class SamPt(nn.Module):
         size = (height, width)
         prompts = []
         kmax = 1
+        traj_np, vis_np = trajectories.numpy(), (visibilities == 1).numpy()
         for t in range(n_frames):
             for m in range(n_masks):
-                c, l = self._prepare_points(trajectories, visibilities, t, m, n_masks)
+                c, l = self._prepare_points(traj_np, vis_np, t, m, n_masks)
                 if len(c):
                     c = pred.transform.apply_coords(c, size)
                 prompts.append((c, l))

@@ -181,6 +181,33 @@ def test_transposed_convolution_as_one_gemm_with_pixel_shuffle():
         assert (out - ref).abs().max() < 1e-5, name
 
 
+def test_prompt_assembly_numpy_equals_the_reference_formulation():
+    """SamPt._prepare_points on numpy inputs (the fused path converts once per clip) against the reference's per-item torch
+    formulation (sam_pt.py:726-758): own visible points, tail points negative, the other objects' visible positives
+    appended object by object as negatives."""
+    from sam_pt_amd.sam_pt import SamPt
+    for nm, npos, nneg in [(1, 8, 0), (5, 16, 0), (3, 8, 2), (2, 4, 4)]:
+        m = SamPt.__new__(SamPt)
+        m.positive_points_per_mask, m.negative_points_per_mask = npos, nneg
+        m.add_other_objects_positive_points_as_negative_points, m.max_other_objects_positive_points = True, None
+        g = torch.Generator().manual_seed(nm * 10 + npos)
+        traj = torch.rand(6, nm, npos + nneg, 2, generator=g) * 500
+        vis = (torch.rand(6, nm, npos + nneg, generator=g) > 0.3).float()
+        tn, vn = traj.numpy(), (vis == 1).numpy()
+        for t in range(6):
+            for o in range(nm):
+                pl = np.ones(npos + nneg, dtype=int)
+                pl[npos:] = 0
+                vm = (vis[t, o] == 1).numpy()
+                c_ref, l_ref = traj[t, o].numpy()[vm], pl[vm]
+                if nm > 1:
+                    oth = torch.cat([traj[t, q, :npos][vis[t, q, :npos] == 1] for q in range(nm) if q != o]).numpy()
+                    c_ref, l_ref = np.concatenate([c_ref, oth]), np.concatenate([l_ref, np.zeros(len(oth), dtype=int)])
+                for args in ((tn, vn), (traj, vis)):                       # numpy fast path and the tensor entry
+                    c, l = m._prepare_points(args[0], args[1], t, o, nm)
+                    assert np.array_equal(c, c_ref) and np.array_equal(l, l_ref)
+
+
 def test_sharding_helpers():
     from sam_pt_amd.dist import frame_batches, index_masks, lpt_assign
     lengths = [104, 34, 50, 80, 69, 40, 90, 75, 60, 45]
