@@ -306,9 +306,11 @@ int sampt_corr_sample_f32(const float* const pyr_dev[4], int H0, int W0, const i
  * out_dev f16 [B*S*S][heads*hd].  The bias tables are built inside the kernel; the workspace arguments are kept for
  * ABI stability and ignored (may be NULL / 0). */
 /* The mask decoder's two small fp32 attention kernels: q [F][Nq][heads*hd], k / v [F][Nk][heads*hd], out like q;
- * nk_item_dev (int32 [F] or NULL): per-item number of valid keys of a ragged batch.  kind 0 = one workgroup per (4
- * queries, head, item) over up to 4096 keys (token self-attention hd 32, token->image hd 16); kind 1 = one thread per
- * (query, head), keys staged through LDS in chunks of 128 with a running softmax (image->token, hd 16, any Nk). */
+ * nk_item_dev (int32 [F] or NULL): per-item number of valid keys of a ragged batch.  kind 0 = few queries against up to
+ * 4096 keys: hd 32 (token self-attention) runs wave = (64 queries, head) with scalar-loaded key rows split over 4 waves,
+ * hd 16 one workgroup per (4 queries, head, item) — the engine's token->image attention is sampt_attention_t2i_f32 below;
+ * kind 1 = many queries against few keys (image->token, hd 16, any Nk): with 8 heads wave = head, lane = query and the
+ * K / V rows are scalar loads, otherwise one thread per (query, head) with keys staged through LDS in chunks of 128. */
 int sampt_attention_f32(int kind, const float* q_dev, const float* k_dev, const float* v_dev, float* out_dev, int F, int Nq,
                         int Nk, int heads, int hd, const int32_t* nk_item_dev, sampt_stream_t stream);
 /* The decoder's token -> image attention (8 heads x 16 channels: q [F][Nq][128], k / v [F][Nk][128]) as the engine runs
