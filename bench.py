@@ -65,7 +65,9 @@ def parse():
     ap.add_argument("--fnet-exact", action="store_true",
                     help="tracker encoder convolutions as exact fp32 MFMAs instead of the 3-term split-fp16 MFMAs")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (cpu_baseline + parity)")
-    ap.add_argument("--parity-frames", type=int, default=3, help="frames of the clip whose SAM stage the CPU oracle repeats")
+    ap.add_argument("--parity-frames", type=int, default=24,
+                    help="frames of the clip whose SAM stage the CPU oracle repeats (evenly spaced; default: every frame of the "
+                         "24-frame clip, ~10 s of host time per ViT-H frame)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary lines (fp32 ViT, query-mask pass, IoU 0.7)")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -286,7 +288,8 @@ def cpu_reference(args, frames, qp, out):
     cfg = SAM_CONFIGS[args.model]
     sd = init_sam_state_dict(cfg, 72, hq=args.hq)
     T = frames.shape[0]
-    ids = sorted({0, T // 2, T - 1} if args.parity_frames >= 3 else ({0, T - 1} if args.parity_frames == 2 else {T // 2}))
+    n_par = max(1, min(args.parity_frames, T))
+    ids = sorted({int(round(i * (T - 1) / max(n_par - 1, 1))) for i in range(n_par)}) if n_par > 1 else [T // 2]
     factory = None
     psd = None
     if args.tracker == "pips":
@@ -351,8 +354,25 @@ def secondary_lines(args, model, video, dev):
     return {"unit": "frames/s", "steps": 2, **res}
 
 
+def self_launch(args):
+    """``python bench.py --gpus N`` with N > 1 and no rendezvous in the environment: re-exec this very command line under
+    ``torch.distributed.run`` (one rank per GPU, RCCL), exactly as the documented launch line does."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     from sam_pt_amd.dist import init_from_env
     from sam_pt_amd.synth import bench_clip
     rank, world, local = init_from_env()
@@ -432,10 +452,20 @@ def main():
         insitu = model.sam_predictor.gemm_profile_end()
     if rank == 0:
         from sam_pt_amd.pack import fnet_f16x3_enabled
-        tracker_precision = ("fp32-grade: correlation/mixer exact f32 MFMA; encoder convolutions 3-term split-fp16 MFMA "
-                             "(hi*hi + hi*lo + lo*hi, fp32 accumulate)" if fnet_f16x3_enabled(args.tracker in ("pips", "cotracker"))
-                             else "fp32 (exact f32 MFMA)")
-        res = {"metric": "frames/sec end-to-end (SAM-PT: ViT + PIPS, 480p, 8 pts, 1 obj)", "value": round(fps, 3),
+        tracker_precision = ("fp32-grade: mixer / update GEMMs exact f32 MFMA, correlation sampler fp32 VALU dot products (wave "
+                             "shuffles, no MFMA); encoder convolutions 3-term split-fp16 MFMA (hi*hi + hi*lo + lo*hi, fp32 "
+                             "accumulate)" if fnet_f16x3_enabled(args.tracker in ("pips", "cotracker"))
+                             else "fp32 (GEMMs / convolutions exact f32 MFMA, correlation sampler fp32 VALU)")
+        # BASELINE.json's metric string verbatim when the run IS that configuration; otherwise the same sentence with this run's
+        # model / tracker / prompt so that a non-headline line cannot be mistaken for the headline
+        headline = (args.model == "vit_h" and args.tracker == "pips" and args.points == 8 and args.objects == 1
+                    and args.neg_points == 0 and not args.hq and not args.square)
+        trk_name = {"pips": "PIPS", "cotracker": "CoTracker", "pips_plus_plus": "PIPS++"}[args.tracker]
+        mdl_name = ("HQ-SAM " if args.hq else "") + {"vit_h": "ViT-H", "vit_l": "ViT-L", "vit_b": "ViT-B"}[args.model]
+        metric = ("frames/sec end-to-end (ViT-H + PIPS, 480p, 8 pts, 1 obj) at 1/2/4/8 MI355X" if headline else
+                  f"frames/sec end-to-end ({mdl_name} + {trk_name}, {'%d^2' % args.square if args.square else '480p'}, "
+                  f"{args.points}{'+' + str(args.neg_points) if args.neg_points else ''} pts, {args.objects} obj) at 1/2/4/8 MI355X")
+        res = {"metric": metric, "value": round(fps, 3),
                "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "strong" if (frames_sharded or lpt) else "weak",
                "vs_baseline": None,

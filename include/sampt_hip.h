@@ -285,6 +285,12 @@ int sampt_vos_index_masks_resized(const float* logits_dev, int M, int T, int h, 
  * 2 = f16 in / f16 out.  act: 0 none, 1 relu, 2 gelu(erf). */
 int sampt_gemm(int dtype, const void* A_dev, const void* W_dev, const float* bias_dev, const float* res_dev,
                void* C_dev, int M, int N, int K, int act, float alpha, sampt_stream_t stream);
+/* The same GEMM with the row maps the ViT engine uses: rowmap[m] = destination row of C / res for GEMM row m (-1 drops the
+ * row; C must hold max(rowmap)+1 rows), a_rowmap[m] = row of A read by GEMM row m (gather), res_mod > 0: the residual row
+ * is (destination row) % res_mod (broadcast over the batch, e.g. a positional embedding), ldr = row stride of res (0: N). */
+int sampt_gemm_ex(int dtype, const void* A_dev, const void* W_dev, const float* bias_dev, const float* res_dev,
+                  void* C_dev, int M, int N, int K, int act, float alpha, const int32_t* rowmap_dev,
+                  const int32_t* a_rowmap_dev, int res_mod, int ldr, sampt_stream_t stream);
 /* NHWC convolution as implicit GEMM: x [n][H][W][Cin], w [Cout][KH][KW][Cin], y [n][OH][OW][Cout] (f32 out).
  * dtype 3 = fp32-grade result on the fp16 matrix pipe: x is f32, w_dev is half [2][Cout][KH*KW*Cin] = the weights times
  * 2^8 split as hi = fp16(w), lo = fp16(w - hi) (sam_pt_amd/pack.py:split_f16x3); Cin % 32 == 0, Cout % 4 == 0. */

@@ -337,7 +337,13 @@ int sampt_dec_create(const char* const* names, const void* const* ptrs, int n, i
 void sampt_dec_destroy(sampt_dec_t h) { delete h; }
 
 int sampt_dec_workspace_bytes_k(sampt_dec_t h, int frames, int k, int oh, int ow, size_t* bytes) {
-  if (!h || !bytes || frames <= 0 || frames > h->e.max_frames || k < 0 || k > SAMPT_DEC_MAX_POINTS) return SAMPT_ERR_ARG;
+  if (!h || !bytes) return fail(SAMPT_ERR_ARG, "sampt_dec_workspace_bytes_k: null handle / output");
+  if (frames <= 0 || frames > h->e.max_frames)
+    return fail(SAMPT_ERR_ARG, "sampt_dec_workspace_bytes_k: frames " + std::to_string(frames) + " outside 1.." +
+                                   std::to_string(h->e.max_frames) + " (max_frames of sampt_dec_create)");
+  if (k < 0 || k > SAMPT_DEC_MAX_POINTS)
+    return fail(SAMPT_ERR_ARG, "sampt_dec_workspace_bytes_k: k = " + std::to_string(k) + " prompt points outside 0.." +
+                                   std::to_string(SAMPT_DEC_MAX_POINTS) + " (SAMPT_DEC_MAX_POINTS)");
   Arena a(nullptr, 0);
   float dummy = 0.f;
   int rc = h->e.track_decode(frames, &dummy, h->e.is_hq() ? &dummy : nullptr, &dummy, nullptr, k, nullptr, nullptr, k, 0, 1, 0.f, oh, ow,
@@ -431,6 +437,14 @@ int sampt_sam_track_decode_graph(sampt_dec_t h, int frames, const float* feature
   try {
     DecGraphEntry& ent = h->graphs[key];
     ent.last_use = ++h->graph_clock;
+    while (h->graphs.size() > 64) {   // bound the cache: drop the least recently used signature, captured or only seen
+      auto victim = h->graphs.end();
+      for (auto it = h->graphs.begin(); it != h->graphs.end(); ++it)
+        if (&it->second != &ent && (victim == h->graphs.end() || it->second.last_use < victim->second.last_use)) victim = it;
+      if (victim == h->graphs.end()) break;
+      if (victim->second.exec) (void)hipGraphExecDestroy(victim->second.exec);
+      h->graphs.erase(victim);       // (references to other elements of an unordered_map stay valid)
+    }
     if (ent.exec) {
       if (hipGraphLaunch(ent.exec, s) != hipSuccess) return fail(SAMPT_ERR_HIP, "sampt_sam_track_decode_graph: hipGraphLaunch failed");
       ++h->graph_launches;
@@ -440,16 +454,6 @@ int sampt_sam_track_decode_graph(sampt_dec_t h, int frames, const float* feature
       return sampt_sam_track_decode(h, frames, features, hq_features, pts, labels, k, k_item, npos_item, ld_pts,
                                     n_pos_first, refine_iters, iou_thr, in_h, in_w, oh, ow, final_logits, score_out, ws,
                                     ws_bytes, stream);
-    if (h->graphs.size() > 64) {   // bound the cache: drop the least recently used instantiated graph
-      auto victim = h->graphs.end();
-      for (auto it = h->graphs.begin(); it != h->graphs.end(); ++it)
-        if (it->second.exec && &it->second != &ent && (victim == h->graphs.end() || it->second.last_use < victim->second.last_use))
-          victim = it;
-      if (victim != h->graphs.end()) {
-        (void)hipGraphExecDestroy(victim->second.exec);
-        h->graphs.erase(victim);
-      }
-    }
     DecGraphEntry& e2 = h->graphs[key];
     if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess)
       return fail(SAMPT_ERR_HIP, "sampt_sam_track_decode_graph: hipStreamBeginCapture failed");
@@ -500,6 +504,17 @@ int sampt_gemm(int dtype, const void* A, const void* W, const float* bias, const
   GemmP p;
   p.A = A, p.W = W, p.bias = bias, p.res = res, p.C = C;
   p.M = M, p.N = N, p.K = K, p.lda = K, p.ldw = K, p.ldc = N, p.ldr = N, p.act = act, p.alpha = alpha;
+  p.out_f16 = dtype == 2;
+  return dtype == 0 ? gemm_f32(p, (hipStream_t)stream) : gemm_f16(p, (hipStream_t)stream);
+}
+
+int sampt_gemm_ex(int dtype, const void* A, const void* W, const float* bias, const float* res, void* C, int M, int N, int K,
+                  int act, float alpha, const int32_t* rowmap, const int32_t* a_rowmap, int res_mod, int ldr,
+                  sampt_stream_t stream) {
+  GemmP p;
+  p.A = A, p.W = W, p.bias = bias, p.res = res, p.C = C, p.rowmap = rowmap, p.a_rowmap = a_rowmap;
+  p.M = M, p.N = N, p.K = K, p.lda = K, p.ldw = K, p.ldc = N, p.ldr = ldr > 0 ? ldr : N, p.act = act, p.alpha = alpha;
+  p.res_mod = res_mod;
   p.out_f16 = dtype == 2;
   return dtype == 0 ? gemm_f32(p, (hipStream_t)stream) : gemm_f16(p, (hipStream_t)stream);
 }

@@ -346,8 +346,15 @@ __global__ __launch_bounds__(256, 4) void gemm_f16_glds_bk32(GemmP p) {
   }
 }
 
+int gemm_f16_p8_launch(const GemmP& p, hipStream_t s);   // gemm_f16_p8.hip
+
 // returns SAMPT_ERR_UNSUPPORTED when the shape does not fit this kernel (caller falls back to gemm_kernel)
 int gemm_f16_glds_launch(const GemmP& p, hipStream_t s) {
+  static const int p8 = getenv("SAMPT_GEMM_P8") ? atoi(getenv("SAMPT_GEMM_P8")) : 1;
+  if (p8) {
+    int rc = gemm_f16_p8_launch(p, s);
+    if (rc != SAMPT_ERR_UNSUPPORTED) return rc;
+  }
   if (p.conv || p.w_kn || p.nb1 * p.nb2 != 1 || p.K % 64 || p.M < 128 || p.N < 128) return SAMPT_ERR_UNSUPPORTED;
   if ((p.lda % 8) || (p.ldw % 8) || (((uintptr_t)p.A | (uintptr_t)p.W) & 15)) return SAMPT_ERR_UNSUPPORTED;
   if ((p.N % 4) || (p.ldc % 4) || (p.res && (p.ldr % 4))) return SAMPT_ERR_UNSUPPORTED;   // vector epilogue only

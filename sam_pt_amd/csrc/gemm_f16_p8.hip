@@ -1,0 +1,326 @@
+// fp16 MFMA GEMM for the ViT image encoder: 256 x 256 x 64 tiles, 8 waves, 8-phase LDS-DMA pipeline, persistent workgroups.
+//
+//   C[M][N] = epi(A[M][K] . W[N][K]^T + bias) (+ residual)        A, W fp16 K-contiguous; fp32 accumulate
+//
+// One workgroup (512 threads = 8 waves as 2 (M) x 4 (N), each wave a 128 x 64 patch = 8 x 4 fragments of
+// v_mfma_f32_16x16x32_f16, 128 accumulator registers) per CU walks a list of output tiles.  The operand stream never
+// stops at a tile boundary: K-tiles of the NEXT output tile are already in flight while the accumulators of the current
+// one are written out.
+//
+// LDS (128 KiB): two K-tile buffers x four 16-KiB "half tiles" (128 rows x 64 halfs):
+//     A0 = A rows {wm*128 +      0..63 }   A1 = A rows {wm*128 + 64..127}          (wm = 0, 1)
+//     B0 = W rows {wn*64  +      0..31 }   B1 = W rows {wn*64  + 32..63 }          (wn = 0..3)
+// so that every wave reads the quadrant (ha, hb) of its own 128 x 64 patch from half tiles (A ha, B hb).  Half tiles go
+// HBM -> LDS with two `global_load_lds_dwordx4` per wave (no VGPR staging).  The LDS image of one instruction is linear
+// (M0 base + lane*16), so the bank swizzle is applied to the SOURCE address: lane l fetches, for tile row r, the 16-byte
+// chunk (l&7) ^ (r&7); fragment reads apply the same XOR (conflict-free for ds_read_b128's 16-lane groups).
+//
+// A K-tile is four phases, one quadrant of 16 MFMAs each, in the order (a0,b0) (a0,b1) (a1,b1) (a1,b0):
+//     phase   ds_read            last read of   stage issued (after the phase's first barrier)
+//     P1      B0 (4) + A0 (8)    A0             B0 of K-tile +1  (other buffer; its last read was the previous P4)
+//     P2      B1 (4)             B1             A0 of K-tile +2  (this buffer)
+//     P3      A1 (8)             A1             B1 of K-tile +2
+//     P4      B0 (4)             B0             A1 of K-tile +2
+// i.e. 7 half tiles are staged ahead of the one being multiplied.  `s_waitcnt vmcnt(4)` in P4's read segment (two half
+// tiles may stay in flight ACROSS the barriers) retires the whole next K-tile; it is read from the next phase on.  The two
+// wave rows run staggered by one barrier: while wm = 0 multiplies, wm = 1 (the other wave of each SIMD) reads fragments.
+//
+// Ordering (what makes it correct, not just fast):
+//   RAW  LDS-DMA data is visible to a ds_read only after the ISSUING wave's vmcnt wait and a barrier both pass: the wait
+//        sits before P4's first barrier in every wave (wm = 1 executes it one barrier later), the first read of that data
+//        is in the next phase's read segment of wm = 0 - one more barrier in between.
+//   WAR  a half tile is re-staged one phase after its last ds_read: all reads of a phase feed that phase's MFMAs, so they
+//        have returned before the phase's second barrier in every wave; the stage is issued after the NEXT phase's first
+//        barrier (wm = 1's second barrier of the reading phase is at or before it).
+//
+// Tile order: strips of R row panels, column-major inside a strip; XCD x (= blockIdx.x & 7, each XCD has a private 4 MiB
+// L2) owns the x-th eighth of that list and its workgroups take consecutive tiles, so the tiles in flight on one XCD form
+// an R x (32 / R) patch that shares A panels and W tiles through that L2 while the panels of a strip stay resident.
+//
+// Launcher conditions: K % 128 == 0 (an even number of K-tiles: tile boundaries fall on buffer 0), N % 256 == 0, M >= 256.
+// Rows beyond M are clamped to the last valid row for the loads and never stored.
+#include "common.h"
+
+namespace sampt {
+
+typedef __attribute__((address_space(3))) void lds_void_p8;
+typedef const __attribute__((address_space(1))) void glb_void_p8;
+
+namespace {
+constexpr int P8_HALF = 128 * 64 * 2;      // bytes of a half tile
+constexpr int P8_BUF = 4 * P8_HALF;        // bytes of a K-tile buffer: A0 | A1 | B0 | B1
+constexpr int P8_SLOT_A0 = 0, P8_SLOT_A1 = 1, P8_SLOT_B0 = 2, P8_SLOT_B1 = 3;
+template <int V> struct IC { static constexpr int value = V; };
+#ifndef P8_EPI_ROWS
+#define P8_EPI_ROWS 2     // fragment rows (16 matrix rows each) whose residual is loaded in one batch: 2 x 4 x 16 B per lane
+#endif
+}  // namespace
+
+// erf-GELU with the complementary error function of Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 absolute, no
+// cancellation on the negative side): 0.5 x erfc(-x / sqrt 2).  The epilogue of a one-workgroup-per-CU kernel is not
+// hidden behind another workgroup's MFMAs, so its VALU cost is on the critical path: 2 transcendentals + ~11 plain
+// operations per element instead of the ~35 of the library erff.
+__device__ __forceinline__ float gelu_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float pl = fmaf(1.061405429f, t, -1.453152027f);
+  pl = fmaf(pl, t, 1.421413741f);
+  pl = fmaf(pl, t, -0.284496736f);
+  pl = fmaf(pl, t, 0.254829592f);
+  const float e = pl * t * __builtin_amdgcn_exp2f(z * z * -1.44269504088896340736f);   // erfc(|z|)
+  const float phi = x < 0.f ? 0.5f * e : 1.0f - 0.5f * e;
+  return x * phi;
+}
+
+// ACT: ACT_NONE or ACT_GELU (compile time; other activations are left to the generic kernels).  GELU_FAST: see gelu_fast.
+template <bool STAGGER, int ACT, bool OUTF16, bool GELU_FAST>
+__global__ __launch_bounds__(512, 2) void gemm_f16_p8(GemmP p) {
+  __shared__ __attribute__((aligned(1024))) char lds[2 * P8_BUF];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  // ---- this workgroup's tile list: global order = strips of R row panels, column-major inside a strip
+  const int nt_m = (p.M + 255) >> 8, nt_n = p.N >> 8, R = p.xcd_swizzle;
+  const int ntiles = nt_m * nt_n;
+  const int xcd = blockIdx.x & 7, nwg = gridDim.x >> 3;
+  const int g_end = (int)(((long)ntiles * (xcd + 1)) >> 3);
+  int g_cmp = (int)(((long)ntiles * xcd) >> 3) + (int)(blockIdx.x >> 3);
+  if (g_cmp >= g_end) return;
+  const int per_strip = R * nt_n, nfull = nt_m / R;
+  auto decode = [&](int g, int& tm, int& tn) {
+    int strip = g / per_strip, t, rows;
+    if (strip < nfull) t = g - strip * per_strip, rows = R;
+    else strip = nfull, t = g - nfull * per_strip, rows = nt_m - nfull * R;
+    tn = t / rows;
+    tm = strip * R + (t - tn * rows);
+  };
+
+  const char* __restrict__ A = (const char*)p.A;
+  const char* __restrict__ W = (const char*)p.W;
+  const int nk = p.K >> 6;
+
+  // ---- stage cursor (runs 7 half tiles ahead of the multiply, across output tiles)
+  const int sub = lane >> 3, chunk = (lane & 7) ^ sub;
+  unsigned a_so[2][2];                    // [half][instruction]: byte offset of this lane's A row + swizzled chunk
+  const unsigned b_so = (unsigned)(((wave >> 2) * 64 + (wave & 3) * 8 + sub) * p.ldw * 2 + chunk * 16);
+  long b_tile = 0;                        // uniform: byte offset of the staged tile's first W row
+  int s_kt = 0, g_stg = g_cmp;
+  auto stage_tile = [&](int g) {
+    int tm, tn;
+    decode(g, tm, tn);
+    b_tile = (long)(tn << 8) * p.ldw * 2;
+#pragma unroll
+    for (int ha = 0; ha < 2; ++ha)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        int row = (tm << 8) + i * 128 + ha * 64 + wave * 8 + sub;
+        if (row > p.M - 1) row = p.M - 1;
+        if (p.a_rowmap) row = p.a_rowmap[row];
+        a_so[ha][i] = (unsigned)row * (unsigned)p.lda * 2u + (unsigned)(chunk * 16);
+      }
+  };
+  auto stage_advance = [&]() {            // next K-tile; past the last tile of the list the cursor stays (dummy re-loads)
+    if (s_kt + 1 < nk) ++s_kt;
+    else if (g_stg + nwg < g_end) g_stg += nwg, s_kt = 0, stage_tile(g_stg);
+  };
+  auto stage = [&](int buf, int slot) {   // two LDS-DMA instructions: rows (i*8 + wave)*8 .. +8 of the half tile
+    char* dst = lds + buf * P8_BUF + slot * P8_HALF + wave * 1024;
+    const long kb = (long)s_kt * 128;
+    if (slot < 2) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        __builtin_amdgcn_global_load_lds((glb_void_p8*)(A + kb + a_so[slot][i]), (lds_void_p8*)(dst + i * 8192), 16, 0, 0);
+    } else {
+      const char* wk = W + kb + b_tile + (long)((slot - 2) * 32) * p.ldw * 2;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        __builtin_amdgcn_global_load_lds((glb_void_p8*)(wk + (long)(i * 128) * p.ldw * 2 + b_so), (lds_void_p8*)(dst + i * 8192), 16,
+                                         0, 0);
+    }
+  };
+
+  // ---- fragment read offsets (bytes inside a half tile): row (w*? + f*16 + lr), chunk (kk*4 + lq) ^ (lr & 7)
+  const int lr = lane & 15, lq = lane >> 4;
+  const int a_rd = (wm * 64 + lr) * 128 + ((lq ^ (lr & 7)) << 4);
+  const int b_rd = (wn * 32 + lr) * 128 + ((lq ^ (lr & 7)) << 4);
+  const int a_rd1 = a_rd ^ 64, b_rd1 = b_rd ^ 64;    // kk = 1: chunk bit 2 flipped
+
+  f32x4 acc[8][4];
+  h8 af[4][2], bf[2][2];
+
+  // ---- prologue: 7 half tiles in flight, the first K-tile landed
+  stage_tile(g_stg);
+  stage(0, P8_SLOT_A0), stage(0, P8_SLOT_B1), stage(0, P8_SLOT_A1), stage(0, P8_SLOT_B0);
+  stage_advance();
+  stage(1, P8_SLOT_A0), stage(1, P8_SLOT_B1), stage(1, P8_SLOT_A1);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (STAGGER && wm == 1) __builtin_amdgcn_s_barrier();
+
+  auto read_a = [&](const char* base, int slot) {
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      af[f][0] = *(const h8*)(base + slot * P8_HALF + f * 2048 + a_rd);
+      af[f][1] = *(const h8*)(base + slot * P8_HALF + f * 2048 + a_rd1);
+    }
+  };
+  auto read_b = [&](const char* base, int slot) {
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      bf[f][0] = *(const h8*)(base + slot * P8_HALF + f * 2048 + b_rd);
+      bf[f][1] = *(const h8*)(base + slot * P8_HALF + f * 2048 + b_rd1);
+    }
+  };
+  // one phase: quadrant (HA, HB) of the wave's patch out of K-tile buffer BUF
+  auto phase = [&](auto bufc, auto phc) {
+    constexpr int BUF = decltype(bufc)::value, PH = decltype(phc)::value;
+    constexpr int HA = PH >> 1, HB = (PH == 1 || PH == 2) ? 1 : 0;
+    const char* base = lds + BUF * P8_BUF;
+    if (PH == 0) read_b(base, P8_SLOT_B0), read_a(base, P8_SLOT_A0);
+    if (PH == 1) read_b(base, P8_SLOT_B1);
+    if (PH == 2) read_a(base, P8_SLOT_A1);
+    if (PH == 3) {
+      read_b(base, P8_SLOT_B0);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // K-tile +1 has landed (this wave's part)
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+        for (int fj = 0; fj < 2; ++fj) {   // swapped operands -> the accumulator fragment is C^T (see the epilogue)
+          acc[HA * 4 + fi][HB * 2 + fj] =
+              __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[fj][kk], af[fi][kk], acc[HA * 4 + fi][HB * 2 + fj], 0, 0, 0);
+          if (kk == 0 && fi == 0 && fj == 1) {
+            // the stage of this phase, behind the first MFMAs (the matrix pipe is busy while the DMA is issued)
+            if (PH == 0) stage(BUF ^ 1, P8_SLOT_B0), stage_advance();
+            if (PH == 1) stage(BUF, P8_SLOT_A0);
+            if (PH == 2) stage(BUF, P8_SLOT_B1);
+            if (PH == 3) stage(BUF, P8_SLOT_A1);
+          }
+        }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
+  };
+
+  for (;;) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nk; kt += 2) {
+      phase(IC<0>{}, IC<0>{}), phase(IC<0>{}, IC<1>{}), phase(IC<0>{}, IC<2>{}), phase(IC<0>{}, IC<3>{});
+      phase(IC<1>{}, IC<0>{}), phase(IC<1>{}, IC<1>{}), phase(IC<1>{}, IC<2>{}), phase(IC<1>{}, IC<3>{});
+    }
+
+    // ---- epilogue.  Swapped MFMA operands: lane (lr, lq) of fragment (i, j) owns row i*16 + lr and the 4 CONSECUTIVE
+    // columns j*16 + lq*4 .. +3 -> one 16-byte (f32) or 8-byte (f16) store per fragment.  bias, activation, residual at the
+    // (row-mapped) destination row, as gemm_kernel does.
+    int tm, tn;
+    decode(g_cmp, tm, tn);
+    const int m0 = tm << 8, n0 = tn << 8;
+    const int colbase = n0 + wn * 64 + lq * 4;
+    float4 bv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      bv[j] = p.bias ? *(const float4*)(p.bias + colbase + (j >> 1) * 32 + (j & 1) * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+    // The residual of RB fragment rows (RB x 4 fragments x 16 B per lane) is loaded in ONE batch into the registers the
+    // operand fragments no longer need: the epilogue waits for 8 / RB memory round trips per tile instead of 32.
+    constexpr int RB = P8_EPI_ROWS;
+#pragma unroll
+    for (int hb = 0; hb < 8 / RB; ++hb) {
+      int drow[RB];
+      float4 rv[RB][4];
+#pragma unroll
+      for (int ii = 0; ii < RB; ++ii) {
+        const int row = m0 + wm * 128 + ((hb * RB + ii) >> 2) * 64 + ((hb * RB + ii) & 3) * 16 + lr;
+        int d = row < p.M ? row : -1;
+        if (p.rowmap && d >= 0) d = p.rowmap[row];
+        drow[ii] = d;
+      }
+      if (p.res) {
+#pragma unroll
+        for (int ii = 0; ii < RB; ++ii) {
+          const int dr = drow[ii] < 0 ? 0 : drow[ii];
+          const float* rp = p.res + (long)(p.res_mod > 0 ? dr % p.res_mod : dr) * p.ldr + colbase;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) rv[ii][j] = *(const float4*)(rp + (j >> 1) * 32 + (j & 1) * 16);
+        }
+      }
+#pragma unroll
+      for (int ii = 0; ii < RB; ++ii) {
+        const int i = hb * RB + ii;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int cj = (j >> 1) * 32 + (j & 1) * 16;
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * p.alpha;
+          v[0] += bv[j].x, v[1] += bv[j].y, v[2] += bv[j].z, v[3] += bv[j].w;
+          if (ACT == ACT_GELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = GELU_FAST ? gelu_fast(v[r]) : gelu_erf(v[r]);
+          }
+          if (p.res) v[0] += rv[ii][j].x, v[1] += rv[ii][j].y, v[2] += rv[ii][j].z, v[3] += rv[ii][j].w;
+          if (drow[ii] >= 0) {
+            if (OUTF16) {
+              *(h4*)((half_t*)p.C + (long)drow[ii] * p.ldc + colbase + cj) =
+                  (h4){(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+            } else {
+              f32x4 o = (f32x4){v[0], v[1], v[2], v[3]};
+              __builtin_nontemporal_store(o, (f32x4*)((float*)p.C + (long)drow[ii] * p.ldc + colbase + cj));
+            }
+          }
+        }
+      }
+    }
+    g_cmp += nwg;
+    if (g_cmp >= g_end) break;
+  }
+  if (STAGGER && wm == 0) __builtin_amdgcn_s_barrier();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dummy tail stages must land before the LDS is handed on
+}
+
+// returns SAMPT_ERR_UNSUPPORTED when the shape does not fit this kernel
+int gemm_f16_p8_launch(const GemmP& p, hipStream_t s) {
+  if (p.conv || p.w_kn || p.nb1 * p.nb2 != 1 || (p.K % 128) || p.M < 256 || (p.N % 256)) return SAMPT_ERR_UNSUPPORTED;
+  if ((p.lda % 8) || (p.ldw % 8) || (((uintptr_t)p.A | (uintptr_t)p.W) & 15)) return SAMPT_ERR_UNSUPPORTED;
+  if ((p.ldc % 4) || (p.res && (p.ldr % 4))) return SAMPT_ERR_UNSUPPORTED;
+  // 32-bit byte offsets inside the operands (with a_rowmap the caller guarantees the gathered matrix is < 4 GiB as well)
+  if ((double)p.M * p.lda * 2.0 >= 4294967296.0 || (double)p.N * p.ldw * 2.0 >= 4294967296.0) return SAMPT_ERR_UNSUPPORTED;
+  GemmP q = p;
+  const int nt_m = cdiv(p.M, 256), nt_n = p.N / 256;
+  static const int r_env = getenv("SAMPT_GEMM_R") ? atoi(getenv("SAMPT_GEMM_R")) : 4;
+  int R = r_env;
+  if (R > nt_m) R = nt_m;
+  q.xcd_swizzle = R;
+  const long ntiles = (long)nt_m * nt_n;
+  // workgroups per XCD: one per CU (32) by default; fewer leaves whole CUs to kernels of other streams (a 512-thread,
+  // 128-KiB workgroup owns its CU: nothing else becomes resident beside it)
+  static const int wgs_env = getenv("SAMPT_GEMM_WGS") ? atoi(getenv("SAMPT_GEMM_WGS")) : 32;
+  const int wgs = wgs_env >= 1 && wgs_env <= 32 ? wgs_env : 32;
+  int per_xcd = (int)((ntiles + 7) / 8);
+  if (per_xcd > wgs) per_xcd = wgs;
+  static const int stagger = getenv("SAMPT_GEMM_STAGGER") ? atoi(getenv("SAMPT_GEMM_STAGGER")) : 1;
+  static const int fast = getenv("SAMPT_GEMM_GELU_FAST") ? atoi(getenv("SAMPT_GEMM_GELU_FAST")) : 1;
+  if (p.act != ACT_NONE && p.act != ACT_GELU) return SAMPT_ERR_UNSUPPORTED;
+  const dim3 grid(8 * per_xcd), block(512);
+#define P8_LAUNCH(ST, AC, OF, GF) hipLaunchKernelGGL((gemm_f16_p8<ST, AC, OF, GF>), grid, block, 0, s, q)
+#define P8_LAUNCH_ST(AC, OF, GF) do { if (stagger) P8_LAUNCH(true, AC, OF, GF); else P8_LAUNCH(false, AC, OF, GF); } while (0)
+  if (p.act == ACT_GELU) {
+    if (p.out_f16) { if (fast) P8_LAUNCH_ST(ACT_GELU, true, true); else P8_LAUNCH_ST(ACT_GELU, true, false); }
+    else { if (fast) P8_LAUNCH_ST(ACT_GELU, false, true); else P8_LAUNCH_ST(ACT_GELU, false, false); }
+  } else {
+    if (p.out_f16) P8_LAUNCH_ST(ACT_NONE, true, false);
+    else P8_LAUNCH_ST(ACT_NONE, false, false);
+  }
+#undef P8_LAUNCH_ST
+#undef P8_LAUNCH
+  SAMPT_CHECK_LAUNCH("gemm_f16_p8");
+  return SAMPT_OK;
+}
+
+}  // namespace sampt

@@ -456,6 +456,23 @@ class PipsPlusPlusPointTracker(PointTracker):
         return traj.unsqueeze(0), vis
 
 
+_COTRACKER_MODELS = {"cotracker_stride_4_wind_8": (8, 4), "cotracker_stride_4_wind_12": (12, 4),
+                     "cotracker_stride_8_wind_16": (16, 8)}
+
+
+def cotracker_model_from_checkpoint_name(checkpoint_path: str) -> Tuple[int, int]:
+    """(window length S, stride) of a CoTracker checkpoint, chosen from the FILE NAME as upstream's ``build_cotracker`` does
+    (co-tracker @ 4f297a9, cotracker/models/build_cotracker.py: ``model_name = checkpoint.split("/")[-1].split(".")[0]``,
+    unknown names raise ValueError).  The three checkpoints of configs/model/point_tracker/cotracker.yaml:2-4 share every
+    weight SHAPE (UpdateFormer and fnet do not depend on S or the stride), so loading one into the wrong model would run
+    silently with the wrong window — the name is the only thing that tells them apart."""
+    import os
+    name = os.path.basename(str(checkpoint_path)).split(".")[0]
+    if name not in _COTRACKER_MODELS:
+        raise ValueError(f"Unknown model name {name}")
+    return _COTRACKER_MODELS[name]
+
+
 def load_cotracker_checkpoint(checkpoint_path: Optional[str]):
     """``build_cotracker`` convention (co-tracker @ 4f297a9): a ``.pth`` state dict, optionally under the key 'model'."""
     if checkpoint_path is None:
@@ -508,10 +525,16 @@ class CoTrackerPointTracker(PointTracker):
         if add_debug_visualisations:
             raise NotImplementedError("add_debug_visualisations (cv2 / imageio gif dump, tracker.py:107-142) is not built")
         from .weights import init_cotracker_state_dict
+        self.s, self.stride = 8, 4            # the HIP engine is built for cotracker_stride_4_wind_8 (the YAML's default)
+        if state_dict is None and checkpoint_path is not None:
+            s_ckpt, stride_ckpt = cotracker_model_from_checkpoint_name(checkpoint_path)
+            if (s_ckpt, stride_ckpt) != (self.s, self.stride):
+                raise NotImplementedError(
+                    f"{checkpoint_path}: CoTracker with window {s_ckpt} / stride {stride_ckpt} is not built; the HIP engine "
+                    f"implements cotracker_stride_4_wind_8 (window {self.s}, stride {self.stride}) only")
         sd = state_dict if state_dict is not None else load_cotracker_checkpoint(checkpoint_path)
         self._sd = sd if sd is not None else init_cotracker_state_dict(seed)
         self.fnet_chunk, self.iters = fnet_chunk, iters
-        self.s, self.stride = 8, 4
         self._h = None
         self._device = None
         self._pos: Dict[Tuple[int, int], Tuple[torch.Tensor, torch.Tensor]] = {}

@@ -275,6 +275,16 @@ class SamPredictor:
             return
         _lib.require_hip(dev, "SamPredictor")
         lib = _lib.load()
+        if self._vit is not None:      # the model moved to another device: engines, scratch and caches of the old one go
+            with _lib.device_guard(self._dev):
+                torch.cuda.synchronize(self._dev)
+                lib.sampt_vit_destroy(self._vit)
+                lib.sampt_dec_destroy(self._dec)
+            self._vit = self._dec = None
+            self._ws_vit, self._ws_dec, self._ws_hq = {}, {}, None
+            self._stage.clear()
+            self._dead_cache.clear()
+            self.reset_image()
         cfg, m = self.model.cfg, self.model
         f16 = m.precision == "f16"
         self._wv = pack_vit(m.sd, cfg, dev, f16, m.max_batch)
@@ -349,7 +359,7 @@ class SamPredictor:
         shipped SAM-PT configuration; larger prompts — many objects feeding each other negatives, the VIS adapter's
         mask batches — grow it, the reference accepts any k)."""
         key = (oh, ow)
-        k = 120 if k <= 120 else -(-k // 256) * 256
+        k = 120 if k <= 120 else min(-(-k // 256) * 256, self.max_prompt_points)   # never past SAMPT_DEC_MAX_POINTS
         have = self._ws_dec.get(key)
         if have is None or have[0] < frames or have[1] < k:
             if have is not None:

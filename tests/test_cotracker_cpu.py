@@ -105,3 +105,25 @@ def test_product_tracker_constructor_matches_reference_yaml():
     assert isinstance(trk, PointTracker) and trk.interp_shape == (384, 512) and trk.visibility_threshold == 0.7
     with pytest.raises(Exception):                              # no CPU fallback: fails loudly without a HIP device
         trk(torch.zeros(1, 8, 3, 64, 64, dtype=torch.uint8), torch.zeros(1, 1, 3))
+
+
+def test_checkpoint_name_selects_the_model_like_build_cotracker(tmp_path):
+    """ADVICE r2: upstream's build_cotracker picks (window, stride) from the checkpoint's FILE NAME and raises on unknown names;
+    the three released checkpoints share all weight shapes, so anything else would run silently with the wrong window."""
+    from sam_pt_amd.point_tracker import CoTrackerPointTracker, cotracker_model_from_checkpoint_name
+    from sam_pt_amd.weights import init_cotracker_state_dict
+    assert cotracker_model_from_checkpoint_name("/a/b/cotracker_stride_4_wind_8.pth") == (8, 4)
+    assert cotracker_model_from_checkpoint_name("cotracker_stride_4_wind_12.pth") == (12, 4)
+    assert cotracker_model_from_checkpoint_name("models/cotracker_ckpts/cotracker_stride_8_wind_16.pth") == (16, 8)
+    with pytest.raises(ValueError, match="Unknown model name"):
+        cotracker_model_from_checkpoint_name("/x/my_finetune.pth")
+    sd = init_cotracker_state_dict(72)
+    for name in ("cotracker_stride_4_wind_12.pth", "cotracker_stride_8_wind_16.pth"):
+        torch.save({"model": sd}, tmp_path / name)          # loads without a shape error upstream too: same shapes
+        with pytest.raises(NotImplementedError, match="window"):
+            CoTrackerPointTracker(checkpoint_path=str(tmp_path / name))
+    torch.save(sd, tmp_path / "renamed.pth")
+    with pytest.raises(ValueError):
+        CoTrackerPointTracker(checkpoint_path=str(tmp_path / "renamed.pth"))
+    torch.save(sd, tmp_path / "cotracker_stride_4_wind_8.pth")
+    assert CoTrackerPointTracker(checkpoint_path=str(tmp_path / "cotracker_stride_4_wind_8.pth")).s == 8
