@@ -106,52 +106,62 @@ def one_step(model, video, max_frames, shard="sequences"):
         return full, full
     out = model(video)
     logits = torch.stack(out["logits"], dim=0)          # (M,T,H,W) on device
+    if not logits.is_cuda:                               # the reference protocol returns host tensors (sam_pt.py:862-864)
+        logits = logits.to(model.device)
     masks = index_masks(logits)                          # bg stack + softmax + argmax (eval.py:304-326)
     gathered = gather_masks(masks, max_frames)           # RCCL gather of uint8 masks (no-op for 1 GPU)
     return masks, gathered
 
 
-def gemm_roofline(args, dev, insitu=None):
-    """Dominant kernel = the fp16 MFMA GEMM of the ViT encoder (gemm_f16_glds<128,160,1> for ViT-H, <128,128,1> otherwise).
-    ``achieved`` / ``avg_launch_us`` are IN SITU: one extra (untimed) step of the very same workload runs with every GEMM
-    launch of the encoder bracketed by HIP events on its launching stream (sampt_vit_profile_begin/end), so the figure is
-    the real launches' algorithmic FLOP / their summed duration, tracker overlap included, and matches the rocprofv3
-    average of profiles/.  ``isolated_*`` repeats each distinct launch shape alone on an idle GPU."""
+def gemm_roofline(args, dev, insitu=None, frame_hw=(576, 1024)):
+    """Dominant kernel = the fp16 MFMA GEMM of the ViT encoder (gemm_f16_p8: 256 x 256 x 64 tiles, 8-phase LDS-DMA pipeline,
+    persistent workgroups; csrc/gemm_f16_p8.hip).  ``achieved`` / ``avg_launch_us`` are IN SITU: one extra (untimed) step
+    of the very same workload runs with every GEMM launch of the encoder bracketed by HIP events on its launching stream
+    (sampt_vit_profile_begin/end), so the figure is the real launches' algorithmic FLOP / their summed duration, tracker
+    overlap included, and matches the rocprofv3 average of profiles/.  ``isolated_*`` repeats each distinct launch (shape
+    AND epilogue: bias, GELU, in-place residual) alone on an idle GPU, weighted by its count per encode call."""
     from sam_pt_amd import _lib
     from sam_pt_amd.weights import SAM_CONFIGS
     lib = _lib.load()
     cfg = SAM_CONFIGS[args.model]
     B, D = args.encode_batch, cfg.embed_dim
-    Mg = B * 4096        # windowed blocks also run their GEMMs on the real tokens only (padding rows are never multiplied)
-    shapes = [  # (M, N, K, dtype(2 = f16 out, 1 = f32 out), count per encode call)
-        (Mg, 3 * D, D, 2, cfg.depth), (Mg, D, D, 1, cfg.depth),
-        (Mg, 4 * D, D, 2, cfg.depth), (Mg, D, 4 * D, 1, cfg.depth)]   # (patch embedding and neck run in exact fp32)
+    Mg = B * cfg.grid * cfg.grid
+    # blocks before the first global one run on the rows that hold pixels (VitEngine::live_rows), the others on the full grid;
+    # windowed blocks multiply the real tokens only (padding rows are never multiplied)
+    g0 = min(cfg.global_attn_indexes) if cfg.global_attn_indexes else cfg.depth
+    h_tok = -(-frame_hw[0] // cfg.patch_size)
+    lh = min(cfg.grid, -(-h_tok // cfg.window_size) * cfg.window_size) if frame_hw[1] == cfg.img_size else cfg.grid
+    Ml = B * lh * cfg.grid
+    n_live = g0 if lh < cfg.grid else 0
+    shapes = []   # (M, N, K, dtype(2 = f16 out, 1 = f32 out), act, in-place residual, count per encode call)
+    for M, cnt in ((Ml, n_live), (Mg, cfg.depth - n_live)):
+        if cnt:
+            shapes += [(M, 3 * D, D, 2, 0, 0, cnt), (M, D, D, 1, 0, 1, cnt), (M, 4 * D, D, 2, 2, 0, cnt), (M, D, 4 * D, 1, 0, 1, cnt)]
     tot_flop = tot_t = 0.0
     launches = 0
     # L2-miss (HBM + Infinity Cache) bytes per launch from the committed --pmc passes (tools/gemm_traffic.py); bench.py
     # cannot run rocprofv3 on itself, so the figure is looked up per shape and is null for shapes that were not profiled
     traffic_tab, tot_traffic, tot_alg_bytes = {}, 0.0, 0.0
     pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    tpath = os.path.join(pdir, "r2_gemm_hbm_traffic.json")        # PMC passes of the shipped kernel (tools/gemm_traffic.py)
-    if not os.path.exists(tpath):
-        tpath = os.path.join(pdir, "r1_gemm_hbm_traffic.json")
+    tpath = os.path.join(pdir, "r3_gemm_hbm_traffic.json")        # PMC passes of the shipped kernel (tools/gemm_traffic.py)
     if os.path.exists(tpath):
         with open(tpath) as fh:
             traffic_tab = json.load(fh)["per_launch"]
     g = torch.Generator(device="cpu").manual_seed(0)
-    for (M, N, K, dt, cnt) in shapes:
+    for (M, N, K, dt, act, res, cnt) in shapes:
         A = (torch.randn(M, K, generator=g) * 0.5).half().to(dev)
         W = (torch.randn(N, K, generator=g) / K ** 0.5).half().to(dev)
         bias = torch.zeros(N, device=dev)
-        Cc = torch.empty(M, N, device=dev, dtype=torch.float16 if dt == 2 else torch.float32)
+        Cc = torch.zeros(M, N, device=dev, dtype=torch.float16 if dt == 2 else torch.float32)
+        call = lambda: lib.sampt_gemm_ex(dt, _lib.ptr(A), _lib.ptr(W), _lib.ptr(bias), _lib.ptr(Cc) if res else None, _lib.ptr(Cc),
+                                         M, N, K, act, 1.0, None, None, 0, 0, _lib.stream_ptr())
         for _ in range(2):
-            _lib.check(lib.sampt_gemm(dt, _lib.ptr(A), _lib.ptr(W), _lib.ptr(bias), None, _lib.ptr(Cc), M, N, K, 0, 1.0,
-                                      _lib.stream_ptr()), "gemm")
+            _lib.check(call(), "gemm")
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = 8
         e0.record()
         for _ in range(reps):
-            lib.sampt_gemm(dt, _lib.ptr(A), _lib.ptr(W), _lib.ptr(bias), None, _lib.ptr(Cc), M, N, K, 0, 1.0, _lib.stream_ptr())
+            call()
         e1.record()
         torch.cuda.synchronize()
         t = e0.elapsed_time(e1) / reps * 1e-3
@@ -169,7 +179,8 @@ def gemm_roofline(args, dev, insitu=None):
     ach, avg_us, n_launch = iso, tot_t / launches * 1e6, launches
     if insitu is not None and insitu[2] > 0:
         ach, avg_us, n_launch = insitu[0] / (insitu[1] * 1e-3) / 1e12, insitu[1] * 1e3 / insitu[2], insitu[2]
-    return {"bound": "mfma", "kernel": "gemm_f16_glds<128,160,1> / <128,128,1> (ViT qkv / proj / MLP GEMMs, LDS-DMA fp16 MFMA; 160-wide tiles when N % 160 == 0)",
+    return {"bound": "mfma", "kernel": "gemm_f16_p8 (ViT qkv / proj / MLP GEMMs: 256x256x64 tiles, 8 waves, 8-phase LDS-DMA fp16 "
+                                       "MFMA pipeline, persistent workgroups)",
             "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
             "measured": "in situ: HIP events around every GEMM launch of one extra step" if insitu else "isolated shapes",
             "launches_timed": n_launch, "isolated_achieved": round(iso, 1),
@@ -333,9 +344,43 @@ def quick_fps(model, video, frames_n, steps=2):
     return round(frames_n * steps / (time.perf_counter() - t0), 2)
 
 
+class ReferenceApiPredictor:
+    """Hides everything the upstream ``segment_anything.SamPredictor`` does not have: ``SamPt`` then runs the REFERENCE
+    protocol over the two HIP seams — tracker first, then per frame ``set_image(numpy frame)`` and 1-2 + R sequential
+    ``predict_torch`` calls with a host round trip each (sam_pt/modeling/sam_pt.py:760-837, 848-858) — which is what the
+    unchanged reference ``SamPt`` does with ``model.sam_predictor._target_=sam_pt_amd.sam_predictor.SamPredictor``."""
+    _HIDDEN = ("encode_frames", "track_decode", "decode_staging", "set_features")
+
+    def __init__(self, pred):
+        object.__setattr__(self, "_p", pred)
+
+    def __getattr__(self, name):
+        if name in ReferenceApiPredictor._HIDDEN:
+            raise AttributeError(name)
+        return getattr(self._p, name)
+
+    def __setattr__(self, name, value):
+        setattr(self._p, name, value)
+
+
+def reference_protocol_lines(args, model, video):
+    """fps of the reference's own loop over the HIP seams, with and without the clip-embedding prefetch (prefetch.py)."""
+    from sam_pt_amd.sam_pt import SamPt
+    ref_model = SamPt(model.point_tracker, ReferenceApiPredictor(model.sam_predictor), **sampt_kwargs(args)).eval()
+    res = {"reference_sampt_over_hip_seams": quick_fps(ref_model, video, args.frames, steps=1)}
+    os.environ["SAMPT_PREFETCH"] = "0"
+    try:
+        res["reference_sampt_over_hip_seams_no_prefetch"] = quick_fps(ref_model, video, args.frames, steps=1)
+    finally:
+        del os.environ["SAMPT_PREFETCH"]
+    return res
+
+
 def secondary_lines(args, model, video, dev):
     """Variants of the headline workload the judge asked to see beside it (2 timed steps each, same clip): the exact-fp32
-    ViT, the reference's dead query-mask SAM pass switched back on (sam_pt.py:181), and the shipped IoU threshold 0.7."""
+    ViT, the reference's dead query-mask SAM pass switched back on (sam_pt.py:181), the shipped IoU threshold 0.7, and the
+    REFERENCE protocol (tracker, then set_image + sequential predict_torch per frame) over the two HIP seams — the speed a
+    user of the unchanged reference ``SamPt`` gets from the two ``_target_`` overrides alone (1 timed step each)."""
     res = {}
     model.compute_unused_query_masks = True
     res["with_reference_query_mask_pass"] = quick_fps(model, video, args.frames)
@@ -343,6 +388,7 @@ def secondary_lines(args, model, video, dev):
     model.sam_iou_threshold = 0.7
     res["sam_iou_threshold_0.7"] = quick_fps(model, video, args.frames)
     model.sam_iou_threshold = -1e9
+    res.update(reference_protocol_lines(args, model, video))
     if args.precision == "f16":
         import copy
         a32 = copy.copy(args)
@@ -483,7 +529,7 @@ def main():
         if lpt_info:
             res["lpt"] = lpt_info
         if not args.no_roofline and args.precision == "f16":
-            res["roofline"] = gemm_roofline(args, dev, insitu)
+            res["roofline"] = gemm_roofline(args, dev, insitu, (H, W))
             res["roofline"]["secondary"] = secondary_rooflines(args, dev)
         if world == 1 and not args.no_secondary:
             res["secondary"] = secondary_lines(args, model, video, dev)

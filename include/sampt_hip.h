@@ -61,6 +61,20 @@ int sampt_pips_fnet_f32(sampt_pips_t h, const uint8_t* frames_dev, int nf, int H
 int sampt_pips_sample_feat_f32(const float* fmap_dev, int H0, int W0, const int32_t* frame_idx_dev, const float* xy_dev,
                                int n, float* out_dev, sampt_stream_t stream);
 
+/* All chained 8-frame windows of PipsPointTracker._forward (sam_pt/point_tracker/pips/tracker.py:42-153) for n point CHAINS
+ * (one point in one temporal direction) over a T-frame pyramid, with the per-window bookkeeping — window frames, write-back
+ * of frames 1..7, visibility-threshold linking (tracker.py:111-148) — on the device.  q_* [n][3] = (t, x, y) of each chain's
+ * query in ITS OWN time axis (the same values on the device and on the host), flip_* [n] bytes: chain frame d reads pyramid
+ * frame T-1-d (tracker.py:162-167).  vis_threshold = initial_next_frame_visibility_threshold (pips.yaml:5).  chunk_events
+ * (hipEvent_t[nchunks], may be NULL with nchunks = 0): pyramid frames [chunk_lo[c], chunk_hi[c]) are valid once event c has
+ * fired; each round waits only for the chunks it can reach.  traj_dev [T][n][2] px and vis_dev [T][n] (sigmoid; 0 where
+ * never written) are complete when the call returns: the number of rounds is data dependent, so this entry point
+ * SYNCHRONISES with `stream` (rounds are enqueued one ahead of the device; at most one idle round is spent). */
+int sampt_pips_track_workspace_bytes(sampt_pips_t h, int n, size_t* bytes);
+int sampt_pips_track_f32(sampt_pips_t h, const float* const pyr_dev[4], int H0, int W0, int T, int n, const float* q_dev,
+                         const uint8_t* flip_dev, const float* q_host, const uint8_t* flip_host, float vis_threshold, int iters,
+                         void* const* chunk_events, const int32_t* chunk_lo, const int32_t* chunk_hi, int nchunks,
+                         float* traj_dev, float* vis_dev, void* ws, size_t ws_bytes, sampt_stream_t stream, int32_t* rounds);
 /* One 8-frame window of Pips.forward's iterative update (pips.py:458-476, 507-568) + sigmoid (pips/tracker.py:102).
  * frame_idx_dev: int32 [n][S] — per POINT, the indices of its window frames in the pyramid (tail repeated as
  * tracker.py:73-78).  Points are independent in PIPS, so points anchored at different frames share one call;
@@ -149,6 +163,10 @@ int sampt_vit_create(const sampt_vit_config* cfg, const char* const* names, cons
                      int win_batches, sampt_vit_t* out);
 void sampt_vit_destroy(sampt_vit_t h);
 int sampt_vit_encode_workspace_bytes(sampt_vit_t h, int B, size_t* bytes);
+/* Persistent workgroups per XCD (of 32 CUs) for the encoder's fp16 GEMMs from now on; 0 = one per CU (the default).  A
+ * GEMM workgroup (512 threads, 128 KiB of LDS, 256 VGPRs) owns its CU: a caller that runs latency-bound kernels on another
+ * stream beside the encoder (the point tracker's window rounds) leaves them a few CUs per XCD this way. */
+int sampt_vit_set_gemm_workgroups(sampt_vit_t h, int per_xcd);
 /* Measurement hook: between begin and end every fp16 GEMM launch of sampt_vit_encode is bracketed by HIP events on the
  * launching stream; end waits for them and returns the summed algorithmic FLOP (2*M*N*K), the summed kernel time and the
  * number of launches — the in-situ figures behind bench.py's `roofline`. */

@@ -88,6 +88,10 @@ _SIGS = {
     "sampt_vos_index_masks": (c_int, [_P, c_int, c_int, C.c_long, _P, _P, _P, _P]),
     "sampt_vos_index_masks_resized": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, c_int, c_int, _P, _P]),
     "sampt_gemm": (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
+    "sampt_pips_track_workspace_bytes": (c_int, [_P, c_int, C.POINTER(c_size_t)]),
+    "sampt_pips_track_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_float, c_int, _P, _P, _P, c_int,
+                                     _P, _P, _P, c_size_t, _P, C.POINTER(c_int)]),
+    "sampt_vit_set_gemm_workgroups": (c_int, [_P, c_int]),
     "sampt_gemm_ex": (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, c_int, c_int, _P]),
     "sampt_conv2d_nhwc": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "sampt_instance_norm_nhwc": (c_int, [_P, c_int, c_int, c_int, c_float, c_int, _P, _P, c_size_t, _P]),

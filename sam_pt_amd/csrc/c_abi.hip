@@ -43,7 +43,16 @@ static int create_handle(const char* what, H** out, Init init) {
 
 using namespace sampt;
 
-struct sampt_pips { PipsEngine e; };
+struct sampt_pips {
+  PipsEngine e;
+  int* flag = nullptr;                       // pinned host int32[2]: active chains after the last two rounds (sampt_pips_track_f32)
+  hipEvent_t flag_ev[2] = {nullptr, nullptr};
+  ~sampt_pips() {
+    if (flag) (void)hipHostFree(flag);
+    for (auto& ev : flag_ev)
+      if (ev) (void)hipEventDestroy(ev);
+  }
+};
 struct sampt_pips2 { Pips2Engine e; };
 struct sampt_cotracker { CotEngine e; };
 struct sampt_vit { VitEngine e; };
@@ -118,15 +127,6 @@ int sampt_pips_sample_feat_f32(const float* fmap, int H0, int W0, const int32_t*
   return pips_sample_feat(fmap, H0, W0, 128, (const int*)frame_idx, xy, n, out, (hipStream_t)stream);
 }
 
-int sampt_pips_update_workspace_bytes(sampt_pips_t h, int n, size_t* bytes) {
-  if (!h || !bytes || n <= 0) return SAMPT_ERR_ARG;
-  Arena a(nullptr, 0);
-  PyramidLevels p = {};
-  int rc = h->e.update(p, nullptr, n, nullptr, nullptr, 6, nullptr, nullptr, a, nullptr);
-  *bytes = a.peak + 256;
-  return rc;
-}
-
 static PyramidLevels make_pyr(const float* const pyr[4], int H0, int W0) {
   PyramidLevels p;
   int h = H0, w = W0;
@@ -135,6 +135,54 @@ static PyramidLevels make_pyr(const float* const pyr[4], int H0, int W0) {
     h /= 2, w /= 2;
   }
   return p;
+}
+
+int sampt_pips_track_workspace_bytes(sampt_pips_t h, int n, size_t* bytes) {
+  if (!h || !bytes || n <= 0) return fail(SAMPT_ERR_ARG, "sampt_pips_track_workspace_bytes: bad arguments");
+  Arena a(nullptr, 0);
+  PyramidLevels p = {};
+  int rounds = 0;
+  int rc = h->e.track(p, 2, n, nullptr, nullptr, nullptr, nullptr, 0.9f, 6, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr,
+                      nullptr, a, nullptr, &rounds);
+  *bytes = a.peak + 256;
+  return rc;
+}
+
+int sampt_pips_track_f32(sampt_pips_t h, const float* const pyr[4], int H0, int W0, int T, int n, const float* q_dev,
+                         const uint8_t* flip_dev, const float* q_host, const uint8_t* flip_host, float vis_threshold, int iters,
+                         void* const* chunk_events, const int32_t* chunk_lo, const int32_t* chunk_hi, int nchunks,
+                         float* traj_dev, float* vis_dev, void* ws, size_t ws_bytes, sampt_stream_t stream, int32_t* rounds) {
+  if (!h || !pyr || !q_dev || !flip_dev || !q_host || !flip_host || !traj_dev || !vis_dev || !ws || !rounds || n <= 0 || T < 1 ||
+      (nchunks > 0 && (!chunk_events || !chunk_lo || !chunk_hi)))
+    return fail(SAMPT_ERR_ARG, "sampt_pips_track_f32: bad arguments");
+  for (int i = 0; i < n; ++i)
+    if (!(q_host[i * 3] >= 0.f && q_host[i * 3] <= (float)(T - 1)))
+      return fail(SAMPT_ERR_ARG, "sampt_pips_track_f32: query frame outside the clip");
+  if (!h->flag) {
+    if (hipHostMalloc((void**)&h->flag, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess)
+      return fail(SAMPT_ERR_HIP, "sampt_pips_track_f32: hipHostMalloc failed");
+    for (auto& ev : h->flag_ev)
+      if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess)
+        return fail(SAMPT_ERR_HIP, "sampt_pips_track_f32: hipEventCreate failed");
+  }
+  h->flag[0] = h->flag[1] = -1;
+  Arena a(ws, ws_bytes);
+  int r = 0;
+  int rc = h->e.track(make_pyr(pyr, H0, W0), T, n, q_dev, flip_dev, q_host, flip_host, vis_threshold, iters, chunk_events,
+                      (const int*)chunk_lo, (const int*)chunk_hi, nchunks, h->flag, h->flag_ev, traj_dev, vis_dev, a,
+                      (hipStream_t)stream, &r);
+  *rounds = r;
+  if (rc != SAMPT_OK && !h->e.error.empty()) return fail(rc, h->e.error);
+  return rc;
+}
+
+int sampt_pips_update_workspace_bytes(sampt_pips_t h, int n, size_t* bytes) {
+  if (!h || !bytes || n <= 0) return SAMPT_ERR_ARG;
+  Arena a(nullptr, 0);
+  PyramidLevels p = {};
+  int rc = h->e.update(p, nullptr, n, nullptr, nullptr, 6, nullptr, nullptr, a, nullptr);
+  *bytes = a.peak + 256;
+  return rc;
 }
 
 int sampt_pips_update_f32(sampt_pips_t h, const float* const pyr[4], int H0, int W0, const int32_t* frame_idx, int n,
@@ -219,6 +267,12 @@ int sampt_vit_create(const sampt_vit_config* cfg, const char* const* names, cons
                                   [&](sampt_vit& h) { return h.e.init(make_map(names, ptrs, n), c, win_batches); });
 }
 void sampt_vit_destroy(sampt_vit_t h) { delete h; }
+
+int sampt_vit_set_gemm_workgroups(sampt_vit_t h, int per_xcd) {
+  if (!h || per_xcd < 0 || per_xcd > 32) return fail(SAMPT_ERR_ARG, "sampt_vit_set_gemm_workgroups: per_xcd must be 0 .. 32");
+  h->e.gemm_wgs = per_xcd;
+  return SAMPT_OK;
+}
 
 int sampt_vit_profile_begin(sampt_vit_t h) {
   if (!h) return SAMPT_ERR_ARG;

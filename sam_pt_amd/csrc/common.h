@@ -82,6 +82,7 @@ struct GemmP {
   const void* A = nullptr;
   const void* W = nullptr;
   const void* W_lo = nullptr;    // conv_f16x3 only: the lo plane of the split weights (W = hi plane)
+  const void* A_lo = nullptr;    // conv_f16x3 only: activations PRE-SPLIT into fp16 planes (A = hi plane, A_lo = lo plane, NHWC)
   const float* bias = nullptr;   // [N] or null
   const float* res = nullptr;    // residual, f32, row stride ldr, or null
   void* C = nullptr;
@@ -105,7 +106,7 @@ struct GemmP {
   // implicit-GEMM convolution over an NHWC input: A is [Nimg][H][W][Cin], W is [Cout][KH*KW*Cin]
   // split-K (set by the dispatcher; callers only provide the workspace): partial tiles [splitk][M][N] f32
   int xcd_swizzle = 0;           // set by the LDS-DMA fp16 launcher
-  int persist = 0;               // set by the LDS-DMA fp16 launcher: tiles per XCD when workgroups are persistent
+  int p8_wgs = 0;                // gemm_f16_p8: persistent workgroups per XCD (0: one per CU = 32); fewer leaves whole CUs free
   int force_generic = 0;         // tests: bypass the specialised LDS-DMA fp16 kernel
   int splitk = 1;
   float* splitk_ws = nullptr;
@@ -113,17 +114,6 @@ struct GemmP {
   int conv = 0;
   int cH = 0, cW = 0, cC = 0, KH = 0, KW = 0, cstride = 1, cpad = 0, OH = 0, OW = 0;
   int cpadw = -1;                // >= 0: padding along W differs from cpad (1-D convolutions over time: KW = 1, cpadw = 0)
-  // launch fusion around split-K (plain f32 GEMMs only, opt-in by the PIPS engine):
-  //  * defer_reduce: when the dispatcher splits K, leave the raw partial tiles [splitk][M][N] in splitk_ws and do NOT
-  //    launch k_splitk_reduce; the consumer applies the reduction + epilogue while it loads (gemm_f32_plan_splitk tells
-  //    the caller the split beforehand; with no split the normal epilogue runs as usual);
-  //  * a_nsplit > 0: A[m][k] = a_act(sum_{s < a_nsplit} A[s * a_split_stride + m * lda + k] + a_bias[k]) — exactly what
-  //    k_splitk_reduce would have stored (same order of additions), computed on the fly by the A loads.
-  int defer_reduce = 0;
-  int a_nsplit = 0;
-  long a_split_stride = 0;
-  const float* a_bias = nullptr;
-  int a_act = ACT_NONE;
 };
 
 int gemm_f32(const GemmP& p, hipStream_t s);

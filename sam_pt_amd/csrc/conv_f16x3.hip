@@ -8,7 +8,10 @@
 // of the fp32 MFMA's issue cycles.
 //   * weights arrive pre-split from the host: half [2][Cout][K] (hi plane, lo plane), K = KH*KW*Cin, scaled by
 //     2^F16X3_WSHIFT so the lo plane stays in fp16's normal range; the epilogue multiplies by p.alpha = 2^-F16X3_WSHIFT;
-//   * activations are split on the fly while they are staged into LDS (post-InstanceNorm values are O(1), |x| < 65504);
+//   * activations are split on the fly while they are staged into LDS (post-InstanceNorm values are O(1), |x| < 65504) —
+//     or arrive PRE-SPLIT as two fp16 NHWC planes written by their producer (AHL: p.A = hi plane, p.A_lo = lo plane; the
+//     tracker encoder's InstanceNorm does that).  A 3 x 3 convolution stages every input element 9 times, so splitting it
+//     once where it is produced removes ~16 VALU operations per staged float4 from a loop that is bound by exactly those;
 //   * requires Cin % 32 == 0, so a 32-deep K slab never straddles a filter tap: no div/mod in the main loop.
 //
 // Tile: 128 x BN (BN = 64 / 96 / 128 = the encoder's channel counts) x 32, 4 waves (2 x 2), LDS double-buffered with one
@@ -20,11 +23,12 @@ namespace sampt {
 
 // PF = prefetch distance in K slabs: the global loads of slab kt + PF are issued while slab kt is multiplied (PF register
 // sets; the split into fp16 planes happens when a set is stored to LDS, one slab ahead of its use).
-template <int BM, int BN, int PF>
+template <int BM, int BN, int PF, bool AHL = false>
 __global__ __launch_bounds__(256) void k_conv_f16x3(GemmP p) {
   constexpr int BK = 32, LDH = BK + 8;
   constexpr int WTM = BM / 2, WTN = BN / 2, FM = WTM / 16, FN = WTN / 16;
-  constexpr int A_IT = BM * 8 / 256;                   // float4 (4 k) vectors per thread and slab
+  constexpr int VW = AHL ? 8 : 4, VPR = BK / VW;       // channels per staged vector (float4, or h8 + h8), vectors per row
+  constexpr int A_IT = BM * VPR / 256;                 // vectors per thread and slab
   constexpr int B_VEC = BN * 4, B_IT = (B_VEC + 255) / 256;   // h8 (8 k) vectors per plane
   static_assert(WTN % 16 == 0 && WTM % 16 == 0, "wave tile must be made of 16x16 fragments");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];   // 2 * (2 BM + 2 BN) * LDH halves (<= 80 KiB)
@@ -39,6 +43,8 @@ __global__ __launch_bounds__(256) void k_conv_f16x3(GemmP p) {
   const int ntn = (p.N + BN - 1) / BN;
   const int m0 = (int)(blockIdx.x / ntn) * BM, n0 = (int)(blockIdx.x % ntn) * BN;
   const float* __restrict__ A = (const float*)p.A;
+  const half_t* __restrict__ Ahp = (const half_t*)p.A;       // AHL: the two planes
+  const half_t* __restrict__ Alp = (const half_t*)p.A_lo;
   const half_t* __restrict__ Wh = (const half_t*)p.W;
   const half_t* __restrict__ Wl = (const half_t*)p.W_lo;
 
@@ -48,7 +54,7 @@ __global__ __launch_bounds__(256) void k_conv_f16x3(GemmP p) {
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
     const int v = tid + i * 256;
-    a_row[i] = v >> 3, a_kv[i] = (v & 7) * 4;
+    a_row[i] = v / VPR, a_kv[i] = (v % VPR) * VW;
     const int m = m0 + a_row[i];
     a_ok[i] = m < p.M;
     const int ohw = p.OH * p.OW;
@@ -61,17 +67,28 @@ __global__ __launch_bounds__(256) void k_conv_f16x3(GemmP p) {
   // filter tap / channel offset of the slab being LOADED (uniform over the workgroup)
   int l_ky = 0, l_kx = 0, l_ci = 0, l_k = 0;
 
-  float4 ra0[A_IT], ra1[PF > 1 ? A_IT : 1];
+  struct AReg {             // one staged vector: a float4 to split (f32 activations) or its two fp16 halves (AHL)
+    float4 f;
+    h8 hi, lo;
+  };
+  AReg ra0[A_IT], ra1[PF > 1 ? A_IT : 1];
   h8 rbh0[B_IT], rbl0[B_IT], rbh1[PF > 1 ? B_IT : 1], rbl1[PF > 1 ? B_IT : 1];
-  auto load_slab = [&](float4* ra, h8* rbh, h8* rbl) {
+  auto load_slab = [&](AReg* ra, h8* rbh, h8* rbl) {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       const int iy = a_iy0[i] + l_ky, ix = a_ix0[i] + l_kx;
       const bool ok = a_ok[i] && iy >= 0 && iy < p.cH && ix >= 0 && ix < p.cW;
       // branch-free: out-of-image taps read the tensor's first pixel and are zeroed afterwards (a branch per vector
       // makes hipcc fence every load)
-      const float4 v = *(const float4*)(A + (ok ? a_off[i] + ((long)iy * p.cW + ix) * p.cC + l_ci + a_kv[i] : 0));
-      ra[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      const long off = ok ? a_off[i] + ((long)iy * p.cW + ix) * p.cC + l_ci + a_kv[i] : 0;
+      if constexpr (AHL) {
+        const h8 vh = *(const h8*)(Ahp + off), vl = *(const h8*)(Alp + off);
+        ra[i].hi = ok ? vh : (h8){0, 0, 0, 0, 0, 0, 0, 0};
+        ra[i].lo = ok ? vl : (h8){0, 0, 0, 0, 0, 0, 0, 0};
+      } else {
+        const float4 v = *(const float4*)(A + off);
+        ra[i].f = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
@@ -89,15 +106,20 @@ __global__ __launch_bounds__(256) void k_conv_f16x3(GemmP p) {
       if (++l_kx == p.KW) l_kx = 0, ++l_ky;
     }
   };
-  auto store_slab = [&](int buf, const float4* ra, const h8* rbh, const h8* rbl) {
+  auto store_slab = [&](int buf, const AReg* ra, const h8* rbh, const h8* rbl) {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-      const float4 v = ra[i];
-      const h4 hi = {(half_t)v.x, (half_t)v.y, (half_t)v.z, (half_t)v.w};
-      const h4 lo = {(half_t)(v.x - (float)hi[0]), (half_t)(v.y - (float)hi[1]), (half_t)(v.z - (float)hi[2]),
-                     (half_t)(v.w - (float)hi[3])};
-      *(h4*)&Ah[buf][a_row[i]][a_kv[i]] = hi;
-      *(h4*)&Al[buf][a_row[i]][a_kv[i]] = lo;
+      if constexpr (AHL) {
+        *(h8*)&Ah[buf][a_row[i]][a_kv[i]] = ra[i].hi;
+        *(h8*)&Al[buf][a_row[i]][a_kv[i]] = ra[i].lo;
+      } else {
+        const float4 v = ra[i].f;
+        const h4 hi = {(half_t)v.x, (half_t)v.y, (half_t)v.z, (half_t)v.w};
+        const h4 lo = {(half_t)(v.x - (float)hi[0]), (half_t)(v.y - (float)hi[1]), (half_t)(v.z - (float)hi[2]),
+                       (half_t)(v.w - (float)hi[3])};
+        *(h4*)&Ah[buf][a_row[i]][a_kv[i]] = hi;
+        *(h4*)&Al[buf][a_row[i]][a_kv[i]] = lo;
+      }
     }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
@@ -202,7 +224,8 @@ int conv_f16x3(const GemmP& p_in, hipStream_t s) {
   if (!p.conv || p.cC % 32 || p.K != p.KH * p.KW * p.cC || p.ldw % 8 || p.N % 4 || p.ldc % 4) return SAMPT_ERR_UNSUPPORTED;
   if (p.shuf_g && (p.shuf_n <= 0 || p.shuf_n % 4 || p.N != 4 * p.shuf_n || p.M % (p.shuf_g * p.shuf_g))) return SAMPT_ERR_ARG;
   if (p.cpadw >= 0 || p.rowmap || p.a_rowmap || p.nb1 * p.nb2 != 1 || (p.res && p.ldr % 4)) return SAMPT_ERR_UNSUPPORTED;
-  if (((uintptr_t)p.A | (uintptr_t)p.W | (uintptr_t)p.W_lo | (uintptr_t)p.C | (uintptr_t)p.bias | (uintptr_t)p.res) & 15)
+  if (((uintptr_t)p.A | (uintptr_t)p.A_lo | (uintptr_t)p.W | (uintptr_t)p.W_lo | (uintptr_t)p.C | (uintptr_t)p.bias |
+       (uintptr_t)p.res) & 15)
     return SAMPT_ERR_ARG;
   const int BN = p.N <= 32 ? 32 : (p.N <= 64 ? 64 : (p.N <= 96 ? 96 : 128));
   const size_t lds = (size_t)2 * (2 * 128 + 2 * BN) * (32 + 8) * sizeof(half_t);
@@ -214,7 +237,9 @@ int conv_f16x3(const GemmP& p_in, hipStream_t s) {
   if (!raised) {  // 128 x 128 tiles need 80 KiB, above the default 64 KiB dynamic-LDS limit (gfx950: 160 KiB per CU)
     const void* fns[] = {(const void*)k_conv_f16x3<128, 64, 1>,  (const void*)k_conv_f16x3<128, 96, 1>,
                          (const void*)k_conv_f16x3<128, 128, 1>, (const void*)k_conv_f16x3<128, 64, 2>,
-                         (const void*)k_conv_f16x3<128, 96, 2>,  (const void*)k_conv_f16x3<128, 128, 2>};
+                         (const void*)k_conv_f16x3<128, 96, 2>,  (const void*)k_conv_f16x3<128, 128, 2>,
+                         (const void*)k_conv_f16x3<128, 64, 1, true>, (const void*)k_conv_f16x3<128, 96, 1, true>,
+                         (const void*)k_conv_f16x3<128, 128, 1, true>};
     for (const void* f : fns)
       if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) return SAMPT_ERR_HIP;
     raised = true;
@@ -222,7 +247,8 @@ int conv_f16x3(const GemmP& p_in, hipStream_t s) {
   dim3 grid((unsigned)((long)cdiv(p.N, BN) * cdiv(p.M, 128))), block(256);
 #define CONV_LAUNCH(BNv)                                                                              \
   do {                                                                                                \
-    if (pf >= 2) hipLaunchKernelGGL((k_conv_f16x3<128, BNv, 2>), grid, block, lds, s, p);            \
+    if (p.A_lo) hipLaunchKernelGGL((k_conv_f16x3<128, BNv, 1, true>), grid, block, lds, s, p);       \
+    else if (pf >= 2) hipLaunchKernelGGL((k_conv_f16x3<128, BNv, 2>), grid, block, lds, s, p);       \
     else hipLaunchKernelGGL((k_conv_f16x3<128, BNv, 1>), grid, block, lds, s, p);                    \
   } while (0)
   if (BN == 32) CONV_LAUNCH(32);   // (51 KiB: under the default limit)

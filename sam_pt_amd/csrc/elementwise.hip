@@ -70,17 +70,23 @@ __global__ void k_instnorm_partial(const float* __restrict__ x, long hw, int C, 
   }
 }
 
+// second stage: the chunk partials of one image, summed in fp64 in a fixed order (thread (c, ty) takes chunks ty, ty + NY, ...;
+// the NY partial sums are then added in ty order), 1 workgroup per image
 __global__ void k_instnorm_final(const double* __restrict__ part, int nchunks, long hw, int C, float eps,
                                  float* __restrict__ mean_rstd) {
-  int c = threadIdx.x;
-  long img = blockIdx.x;
-  if (c >= C) return;
+  extern __shared__ double shf[];   // [NY][C][2]
+  const int c = threadIdx.x, ty = threadIdx.y, NY = blockDim.y;
+  const long img = blockIdx.x;
   double s1 = 0.0, s2 = 0.0;
-  for (int j = 0; j < nchunks; ++j) {
+  for (int j = ty; j < nchunks; j += NY) {
     const double* o = part + ((img * nchunks + j) * C + c) * 2;
     s1 += o[0];
     s2 += o[1];
   }
+  shf[(ty * C + c) * 2] = s1, shf[(ty * C + c) * 2 + 1] = s2;
+  __syncthreads();
+  if (ty != 0) return;
+  for (int t = 1; t < NY; ++t) s1 += shf[(t * C + c) * 2], s2 += shf[(t * C + c) * 2 + 1];
   double mean = s1 / (double)hw;
   double var = s2 / (double)hw - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -149,7 +155,11 @@ int instnorm_stats(const float* x, int nimg, long hw, int C, float eps, double* 
     hipLaunchKernelGGL(k_instnorm_partial_v4, dim3(nch, nimg), dim3(256), (size_t)nyv * C * 2 * sizeof(double), s, x, hw, C,
                        nyv, partials);
     SAMPT_CHECK_LAUNCH("instnorm_partial_v4");
-    hipLaunchKernelGGL(k_instnorm_final, dim3(nimg), dim3(C), 0, s, partials, nch, hw, C, eps, mean_rstd);
+    {
+      const int nyf = 1024 / C > 16 ? 16 : (1024 / C < 1 ? 1 : 1024 / C);
+      hipLaunchKernelGGL(k_instnorm_final, dim3(nimg), dim3(C, nyf), (size_t)nyf * C * 2 * sizeof(double), s, partials, nch, hw, C,
+                         eps, mean_rstd);
+    }
     SAMPT_CHECK_LAUNCH("instnorm_final");
     return SAMPT_OK;
   }
@@ -159,14 +169,21 @@ int instnorm_stats(const float* x, int nimg, long hw, int C, float eps, double* 
   hipLaunchKernelGGL(k_instnorm_partial, dim3(nchunks, nimg), dim3(C, ny), (size_t)ny * C * 2 * sizeof(double), s, x,
                      hw, C, partials);
   SAMPT_CHECK_LAUNCH("instnorm_partial");
-  hipLaunchKernelGGL(k_instnorm_final, dim3(nimg), dim3(C), 0, s, partials, nchunks, hw, C, eps, mean_rstd);
+  {
+    const int nyf = 1024 / C > 16 ? 16 : (1024 / C < 1 ? 1 : 1024 / C);
+    hipLaunchKernelGGL(k_instnorm_final, dim3(nimg), dim3(C, nyf), (size_t)nyf * C * 2 * sizeof(double), s, partials, nchunks, hw,
+                       C, eps, mean_rstd);
+  }
   SAMPT_CHECK_LAUNCH("instnorm_final");
   return SAMPT_OK;
 }
 
+// HL: additionally write y split into two fp16 planes (hi = fp16(y), lo = fp16(y - hi)) for the split-fp16 convolution that
+// consumes it (conv_f16x3.hip, AHL): the split is done once here instead of once per filter tap there
+template <bool HL>
 __global__ void k_instnorm_apply(const float4* __restrict__ x, const float* __restrict__ mr,
                                  const float4* __restrict__ skip, float4* __restrict__ y, long n4, long hwc4, int c4n,
-                                 int relu1) {
+                                 int relu1, h4* __restrict__ y_hi, h4* __restrict__ y_lo) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4) return;
   long img = i / hwc4;
@@ -187,14 +204,24 @@ __global__ void k_instnorm_apply(const float4* __restrict__ x, const float* __re
     o[3] = fmaxf(o[3] + k.w, 0.f);
   }
   y[i] = make_float4(o[0], o[1], o[2], o[3]);
+  if (HL) {
+    const h4 hi = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
+    const h4 lo = {(half_t)(o[0] - (float)hi[0]), (half_t)(o[1] - (float)hi[1]), (half_t)(o[2] - (float)hi[2]),
+                   (half_t)(o[3] - (float)hi[3])};
+    y_hi[i] = hi, y_lo[i] = lo;
+  }
 }
 
 int instnorm_apply(const float* x, const float* mean_rstd, const float* skip, float* y, int nimg, long hw, int C,
-                   int relu1, hipStream_t s) {
+                   int relu1, hipStream_t s, half_t* y_hi, half_t* y_lo) {
   if (C % 4) return SAMPT_ERR_ARG;
   long n4 = (long)nimg * hw * C / 4;
-  hipLaunchKernelGGL(k_instnorm_apply, dim3(cdiv(n4, 256)), dim3(256), 0, s, (const float4*)x, mean_rstd,
-                     (const float4*)skip, (float4*)y, n4, hw * C / 4, C / 4, relu1);
+  if (y_hi && y_lo)
+    hipLaunchKernelGGL(k_instnorm_apply<true>, dim3(cdiv(n4, 256)), dim3(256), 0, s, (const float4*)x, mean_rstd,
+                       (const float4*)skip, (float4*)y, n4, hw * C / 4, C / 4, relu1, (h4*)y_hi, (h4*)y_lo);
+  else
+    hipLaunchKernelGGL(k_instnorm_apply<false>, dim3(cdiv(n4, 256)), dim3(256), 0, s, (const float4*)x, mean_rstd,
+                       (const float4*)skip, (float4*)y, n4, hw * C / 4, C / 4, relu1, (h4*)nullptr, (h4*)nullptr);
   SAMPT_CHECK_LAUNCH("instnorm_apply");
   return SAMPT_OK;
 }

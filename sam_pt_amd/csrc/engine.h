@@ -74,6 +74,17 @@ struct PipsEngine {
   // feat_init (device [n][128]).  traj_out [S][n][2] px, vis_out [S][n] = sigmoid(logit).
   int update(const PyramidLevels& pyr, const int* frame_idx, int n, const float* xys, const float* feat_init, int iters,
              float* traj_out, float* vis_out, Arena& ws, hipStream_t s);
+  // All chained windows of n point chains over a T-frame pyramid (pips/tracker.py:42-153), bookkeeping on the device.
+  // q (device [n][3]): query (t, x, y) of each chain in ITS OWN time axis; flip (device [n] bytes): chain d-axis frame d
+  // reads pyramid frame T-1-d.  q_host / flip_host: the same values on the host (which pyramid chunks a round may touch).
+  // chunk_*: events recorded (on another stream) when pyramid frames [chunk_lo, chunk_hi) became valid; every round waits
+  // for the chunks it can reach.  Rounds are enqueued one ahead of the device: the host learns through `flag` (pinned
+  // host int32[2]) + `flag_ev[2]` that no chain is left, so this call synchronises with the stream and spends at most one
+  // idle round.  traj [T][n][2] px, vis [T][n] sigmoid (device); *rounds = window rounds run.
+  int track(const PyramidLevels& pyr, int T, int n, const float* q, const unsigned char* flip, const float* q_host,
+            const unsigned char* flip_host, float thr0, int iters, void* const* chunk_ev, const int* chunk_lo,
+            const int* chunk_hi, int nchunks, int* flag, hipEvent_t flag_ev[2], float* traj, float* vis, Arena& ws,
+            hipStream_t s, int* rounds);
 };
 
 // PIPS++ (pips_plus_plus.py): the PIPS encoder at stride 8 + a 1-D ResNet over time instead of the MLP-Mixer; one call
@@ -156,6 +167,9 @@ struct VitEngine {
   };
   mutable std::vector<GemmEv> prof;
   bool profiling = false;
+  // persistent workgroups per XCD of the fp16 GEMMs (0 = one per CU).  A 512-thread, 128-KiB GEMM workgroup owns its CU, so
+  // a caller that runs latency-bound kernels on another stream beside the encoder (the point tracker) asks for fewer.
+  int gemm_wgs = 0;
   int profile_end(double* flop, double* ms, int* launches);
 
   int init(const WeightMap& w, const VitConfig& cfg, int win_rows_batches);

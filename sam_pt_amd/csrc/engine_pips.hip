@@ -1,17 +1,9 @@
 // PIPS engine: fnet (BasicEncoder, pips.py:191-287) and the iterative point-update window (pips.py:439-620).
 #include <stdlib.h>
-#include <string.h>
 
 #include "engine.h"
 
 namespace sampt {
-
-// Opt-in launch fusion of the mixer's split-K reductions: SAMPT_PIPS_FUSE_REDUCE=1.  Off by default —
-// the default launch sequence is the one every parity test ran on.
-static bool fuse_reduce_enabled() {   // read per call (a getenv per window round), so one process can compare both modes
-  const char* v = getenv("SAMPT_PIPS_FUSE_REDUCE");
-  return v && *v && strcmp(v, "0") != 0;
-}
 
 static int load_conv(const WeightMap& w, const std::string& name, int cin, int cout, int k, int stride, int pad,
                      ConvW& c) {
@@ -78,8 +70,12 @@ int PipsEngine::init(const WeightMap& w) {
 }
 
 // conv (implicit GEMM, bias fused) -> raw output; returns output dims
+struct Planes {          // an activation map pre-split into fp16 planes (written by run_inorm), or {null, null}
+  half_t *hi = nullptr, *lo = nullptr;
+};
+
 static int run_conv(const ConvW& c, const float* x, int n, int H, int W, float* y, int& OH, int& OW, bool dry,
-                    hipStream_t s) {
+                    hipStream_t s, Planes xp = Planes()) {
   OH = (H + 2 * c.pad - c.k) / c.stride + 1;
   OW = (W + 2 * c.pad - c.k) / c.stride + 1;
   if (dry) return SAMPT_OK;
@@ -92,6 +88,7 @@ static int run_conv(const ConvW& c, const float* x, int n, int H, int W, float* 
   if (c.w_hl) {  // split-fp16 weights packed by the host: fp32-grade result on the fp16 matrix pipe
     p.W = c.w_hl, p.W_lo = c.w_hl + (size_t)c.cout * p.K;
     p.alpha = 1.0f / (float)(1 << F16X3_WSHIFT);
+    if (xp.hi) p.A = xp.hi, p.A_lo = xp.lo;     // activations already split by the producing InstanceNorm
     return conv_f16x3(p, s);
   }
   return gemm_f32(p, s);
@@ -104,10 +101,10 @@ struct NormCtx {
 
 // InstanceNorm (+ReLU) (+skip add + ReLU), in place on y
 static int run_inorm(const NormCtx& nc, float* y, int n, long hw, int C, int relu1, const float* skip, bool dry,
-                     hipStream_t s) {
+                     hipStream_t s, Planes out = Planes()) {
   if (dry) return SAMPT_OK;
   SAMPT_TRY(instnorm_stats(y, n, hw, C, 1e-5f, nc.partials, nc.mean_rstd, s));
-  return instnorm_apply(y, nc.mean_rstd, skip, y, n, hw, C, relu1, s);
+  return instnorm_apply(y, nc.mean_rstd, skip, y, n, hw, C, relu1, s, out.hi, out.lo);
 }
 
 int PipsEngine::fnet(const uint8_t* frames, int nf, int H, int W, float* const out[4], Arena& ws, hipStream_t s) {
@@ -119,9 +116,18 @@ int PipsEngine::fnet(const uint8_t* frames, int nf, int H, int W, float* const o
   float* x0 = ws.f32((size_t)nf * H * W * 4);
   if (!dry) SAMPT_TRY(rgb_u8chw_to_nhwc4(frames, frames_f32, x0, nf, H, W, s));
   int h, w;
+  // Every InstanceNorm output that feeds a split-fp16 convolution is also written as two fp16 planes (same bytes as the
+  // f32 map): the convolution then stages ready-made halves instead of splitting each element once per filter tap.
+  static const bool use_planes = !(getenv("SAMPT_FNET_PLANES") && atoi(getenv("SAMPT_FNET_PLANES")) == 0);
+  auto planes = [&](size_t elems, const ConvW& consumer) {
+    Planes pl;
+    if (use_planes && consumer.w_hl) pl.hi = ws.f16(elems), pl.lo = ws.f16(elems);
+    return pl;
+  };
   float* cur = ws.f32((size_t)nf * H2 * W2 * 64);
+  Planes cur_p = planes((size_t)nf * H2 * W2 * 64, blk[0][0][0]);
   SAMPT_TRY(run_conv(stem, x0, nf, H, W, cur, h, w, dry, s));
-  SAMPT_TRY(run_inorm(nc, cur, nf, (long)h * w, 64, 1, nullptr, dry, s));
+  SAMPT_TRY(run_inorm(nc, cur, nf, (long)h * w, 64, 1, nullptr, dry, s, cur_p));
   const int dims[4] = {64, 96, 128, 128};
   float* scale_out[4];
   int sh[4], sw[4];
@@ -131,21 +137,26 @@ int PipsEngine::fnet(const uint8_t* frames, int nf, int H, int W, float* const o
       const ConvW& c2 = blk[li][bi][1];
       int oh, ow, oh2, ow2;
       int ohh = (h + 2 - 3) / c1.stride + 1, oww = (w + 2 - 3) / c1.stride + 1;
-      float* y1 = ws.f32((size_t)nf * ohh * oww * dims[li]);
-      float* y2 = ws.f32((size_t)nf * ohh * oww * dims[li]);
-      SAMPT_TRY(run_conv(c1, cur, nf, h, w, y1, oh, ow, dry, s));
-      SAMPT_TRY(run_inorm(nc, y1, nf, (long)oh * ow, dims[li], 1, nullptr, dry, s));
-      SAMPT_TRY(run_conv(c2, y1, nf, oh, ow, y2, oh2, ow2, dry, s));
+      const size_t oel = (size_t)nf * ohh * oww * dims[li];
+      float* y1 = ws.f32(oel);
+      float* y2 = ws.f32(oel);
+      Planes y1_p = planes(oel, c2);
+      // the block's output feeds the next block's conv1 (and its 1x1 downsample); the last block's only the resize
+      const bool last = li == 3 && bi == 1;
+      Planes y2_p = last ? Planes() : planes(oel, bi == 0 ? blk[li][1][0] : blk[li + 1][0][0]);
+      SAMPT_TRY(run_conv(c1, cur, nf, h, w, y1, oh, ow, dry, s, cur_p));
+      SAMPT_TRY(run_inorm(nc, y1, nf, (long)oh * ow, dims[li], 1, nullptr, dry, s, y1_p));
+      SAMPT_TRY(run_conv(c2, y1, nf, oh, ow, y2, oh2, ow2, dry, s, y1_p));
       const float* skip = cur;
       if (has_down[li][bi]) {
         float* dn = y1;  // y1 is dead after conv2 has consumed it (stream order)
         int dh, dw;
-        SAMPT_TRY(run_conv(blk[li][bi][2], cur, nf, h, w, dn, dh, dw, dry, s));
+        SAMPT_TRY(run_conv(blk[li][bi][2], cur, nf, h, w, dn, dh, dw, dry, s, cur_p));
         SAMPT_TRY(run_inorm(nc, dn, nf, (long)dh * dw, dims[li], 0, nullptr, dry, s));
         skip = dn;
       }
-      SAMPT_TRY(run_inorm(nc, y2, nf, (long)oh2 * ow2, dims[li], 1, skip, dry, s));
-      cur = y2, h = oh2, w = ow2;
+      SAMPT_TRY(run_inorm(nc, y2, nf, (long)oh2 * ow2, dims[li], 1, skip, dry, s, y2_p));
+      cur = y2, cur_p = y2_p, h = oh2, w = ow2;
     }
     scale_out[li] = cur, sh[li] = h, sw[li] = w;
   }
@@ -157,9 +168,10 @@ int PipsEngine::fnet(const uint8_t* frames, int nf, int H, int W, float* const o
       SAMPT_TRY(resize_bilinear_nhwc(scale_out[li], nf, sh[li], sw[li], dims[li], cat, H4, W4, 416, coff[li], 1, s));
   float* y = ws.f32((size_t)nf * H4 * W4 * 256);
   int oh, ow;
+  Planes y_p = planes((size_t)nf * H4 * W4 * 256, conv3);
   SAMPT_TRY(run_conv(conv2, cat, nf, H4, W4, y, oh, ow, dry, s));
-  SAMPT_TRY(run_inorm(nc, y, nf, (long)oh * ow, 256, 1, nullptr, dry, s));
-  SAMPT_TRY(run_conv(conv3, y, nf, oh, ow, out[0], oh, ow, dry, s));
+  SAMPT_TRY(run_inorm(nc, y, nf, (long)oh * ow, 256, 1, nullptr, dry, s, y_p));
+  SAMPT_TRY(run_conv(conv3, y, nf, oh, ow, out[0], oh, ow, dry, s, y_p));
   if (!dry) {
     int ph = H4, pw = W4;
     for (int l = 1; l < 4; ++l) {
@@ -193,71 +205,102 @@ int PipsEngine::update(const PyramidLevels& pyr, const int* frame_idx, int n, co
   float* hid = ws.f32((size_t)R * 4 * D);
   float* mean = ws.f32((size_t)n * D);
   float* delta = ws.f32((size_t)n * S * 130);
-  const size_t skn = (size_t)8 * R * 4 * D;  // split-K partials of the weight-bandwidth-bound mixer GEMMs
-  float* skws = ws.f32(skn);
-  const bool fuse = fuse_reduce_enabled();
-  float* skws_b = fuse ? ws.f32(skn) : nullptr;  // second partial buffer: producer and consumer partials are live together
   if (!ws.ok()) return SAMPT_ERR_WORKSPACE;
   if (dry) return SAMPT_OK;
   SAMPT_TRY(pips_init_state(xys, feat_init, (float)stride, S, n, coords, coords0, ffeats, s));
   for (int it = 0; it < iters; ++it) {
     SAMPT_TRY(pips_corr_sample(pyr, frame_idx, S, n, 128, ffeats, coords, x, LDX, 128, s));
     SAMPT_TRY(pips_build_input(ffeats, coords, times, S, n, x, LDX, s));
-    SAMPT_TRY(lin(x, R, LDX, LDX, in_w, in_b, hbuf, D, ACT_NONE, nullptr, s, skws, skn));
-    const float* mixed = hbuf;   // output of the 12 mixer blocks
-    if (!fuse) {
-      for (int i = 0; i < 12; ++i) {
-        const MixBlk& m = mix[i];
-        SAMPT_TRY(pips_token_mix(hbuf, hbuf2, m.ln1w, m.ln1b, m.tw1, m.tb1, m.tw2, m.tb2, n, S, D, s));
-        SAMPT_TRY(layernorm_rows(hbuf2, m.ln2w, m.ln2b, lnb, R, D, 1e-5f, nullptr, 0, ACT_NONE, s));
-        SAMPT_TRY(lin(lnb, R, D, D, m.cw1, m.cb1, hid, 4 * D, ACT_GELU, nullptr, s, skws, skn));
-        SAMPT_TRY(lin(hid, R, 4 * D, 4 * D, m.cw2, m.cb2, hbuf, D, ACT_NONE, hbuf2, s, skws, skn));
-      }
-    } else {
-      // Same arithmetic, fewer launches: a split-K GEMM leaves its raw partials and the consumer (the next GEMM's A
-      // loads / the next block's token mixing) applies sum + bias (+ GELU / + residual) while it reads them.
-      float* cur = hbuf;                 // materialised block input (null while it only exists as pending partials)
-      int pend_ns = 0;                   // > 0: block input = sum(skws_b partials) + pend_bias + pend_res
-      const float *pend_bias = nullptr, *pend_res = nullptr;
-      for (int i = 0; i < 12; ++i) {
-        const MixBlk& m = mix[i];
-        float* tm;                       // token-mixing output = residual of this block's channel mixing
-        if (pend_ns) {
-          tm = pend_res == hbuf2 ? hbuf : hbuf2;
-          SAMPT_TRY(pips_token_mix_fused_in(skws_b, pend_ns, (long)R * D, pend_bias, pend_res, tm, m.ln1w, m.ln1b, m.tw1,
-                                            m.tb1, m.tw2, m.tb2, n, S, D, s));
-        } else {
-          tm = cur == hbuf ? hbuf2 : hbuf;
-          SAMPT_TRY(pips_token_mix(cur, tm, m.ln1w, m.ln1b, m.tw1, m.tb1, m.tw2, m.tb2, n, S, D, s));
-        }
-        float* dst = tm == hbuf2 ? hbuf : hbuf2;   // where a materialised block output goes
-        SAMPT_TRY(layernorm_rows(tm, m.ln2w, m.ln2b, lnb, R, D, 1e-5f, nullptr, 0, ACT_NONE, s));
-        GemmP p1;
-        p1.A = lnb, p1.W = m.cw1, p1.bias = m.cb1, p1.C = hid, p1.act = ACT_GELU;
-        p1.M = R, p1.N = 4 * D, p1.K = D, p1.lda = D, p1.ldw = D, p1.ldc = 4 * D, p1.ldr = 4 * D;
-        p1.splitk_ws = skws, p1.splitk_ws_floats = skn;
-        const int sk1 = gemm_f32_plan_splitk(p1);
-        p1.defer_reduce = sk1 > 1;
-        SAMPT_TRY(gemm_f32(p1, s));
-        GemmP p2;
-        p2.W = m.cw2, p2.bias = m.cb2, p2.C = dst, p2.res = tm;
-        p2.M = R, p2.N = D, p2.K = 4 * D, p2.lda = 4 * D, p2.ldw = 4 * D, p2.ldc = D, p2.ldr = D;
-        p2.splitk_ws = skws_b, p2.splitk_ws_floats = skn;
-        if (sk1 > 1) p2.A = skws, p2.a_nsplit = sk1, p2.a_split_stride = (long)R * 4 * D, p2.a_bias = m.cb1, p2.a_act = ACT_GELU;
-        else p2.A = hid;
-        const int sk2 = gemm_f32_plan_splitk(p2);
-        p2.defer_reduce = sk2 > 1 && i < 11;       // the last block's output is materialised for the final LayerNorm
-        SAMPT_TRY(gemm_f32(p2, s));
-        if (p2.defer_reduce) pend_ns = sk2, pend_bias = m.cb2, pend_res = tm, cur = nullptr;
-        else pend_ns = 0, cur = dst;
-      }
-      mixed = cur;
+    SAMPT_TRY(lin(x, R, LDX, LDX, in_w, in_b, hbuf, D, ACT_NONE, nullptr, s));
+    // 12 mixer blocks, 4 launches each: token mixing, LayerNorm, fc1 + GELU, fc2 + residual (thin GEMMs: K split inside the
+    // workgroup, no split-K grid + reduction pass).  Measured alternatives (profiles/r3_v5_tracker_kernel_stats.txt): token
+    // mixing fused with the LayerNorm in one workgroup per sequence — 30.6 us, all of a sequence's VALU work on one CU.
+    for (int i = 0; i < 12; ++i) {
+      const MixBlk& m = mix[i];
+      SAMPT_TRY(pips_token_mix(hbuf, hbuf2, m.ln1w, m.ln1b, m.tw1, m.tb1, m.tw2, m.tb2, n, S, D, s));
+      SAMPT_TRY(layernorm_rows(hbuf2, m.ln2w, m.ln2b, lnb, R, D, 1e-5f, nullptr, 0, ACT_NONE, s));
+      SAMPT_TRY(lin(lnb, R, D, D, m.cw1, m.cb1, hid, 4 * D, ACT_GELU, nullptr, s));
+      SAMPT_TRY(lin(hid, R, 4 * D, 4 * D, m.cw2, m.cb2, hbuf, D, ACT_NONE, hbuf2, s));
     }
+    const float* mixed = hbuf;
     SAMPT_TRY(pips_ln_mean(mixed, oln_w, oln_b, mean, n, S, D, s));
-    SAMPT_TRY(lin(mean, n, D, D, head_w, head_b, delta, S * 130, ACT_NONE, nullptr, s, skws, skn));
+    SAMPT_TRY(lin(mean, n, D, D, head_w, head_b, delta, S * 130, ACT_NONE, nullptr, s));
     SAMPT_TRY(pips_update(delta, gn_w, gn_b, up_wT, up_b, ffeats, coords, coords0, S, n, s));
   }
   SAMPT_TRY(pips_finalize(ffeats, vis_w, vis_b, coords, (float)stride, S, n, traj_out, vis_out, s));
+  return SAMPT_OK;
+}
+
+int PipsEngine::track(const PyramidLevels& pyr, int T, int n, const float* q, const unsigned char* flip, const float* q_host,
+                      const unsigned char* flip_host, float thr0, int iters, void* const* chunk_ev, const int* chunk_lo,
+                      const int* chunk_hi, int nchunks, int* flag, hipEvent_t flag_ev[2], float* traj, float* vis, Arena& ws,
+                      hipStream_t s, int* rounds) {
+  const bool dry = ws.dry();
+  int* cur = (int*)ws.get((size_t)n * sizeof(int));
+  int* fidx = (int*)ws.get((size_t)n * S * sizeof(int));
+  int* f0 = (int*)ws.get((size_t)n * sizeof(int));
+  int* n_active = (int*)ws.get(256);
+  float* xys = ws.f32((size_t)n * 2);
+  float* xy_feat = ws.f32((size_t)n * 2);
+  float* feat_init = ws.f32((size_t)n * 128);
+  float* tr = ws.f32((size_t)S * n * 2);
+  float* vi = ws.f32((size_t)S * n);
+  if (dry) {   // the window's own scratch, measured
+    SAMPT_TRY(update(pyr, nullptr, n, nullptr, nullptr, iters, nullptr, nullptr, ws, s));
+    return ws.ok() ? SAMPT_OK : SAMPT_ERR_WORKSPACE;
+  }
+  if (!ws.ok()) return SAMPT_ERR_WORKSPACE;
+  const size_t ws_mark = ws.off;
+  // host view: the frames a round can reach.  A chain anchored at frame a reads [a, a + S - 1] and its next anchor is at
+  // most a + S - 1, so after r rounds every anchor is <= start + r (S - 1).
+  int smin[2] = {T, T}, smax[2] = {-1, -1};
+  for (int i = 0; i < n; ++i) {
+    const int t0 = (int)q_host[i * 3], d = flip_host[i] ? 1 : 0;
+    if (t0 >= T - 1) continue;                 // never active (tracker.py:67)
+    smin[d] = t0 < smin[d] ? t0 : smin[d];
+    smax[d] = t0 > smax[d] ? t0 : smax[d];
+  }
+  std::vector<char> waited(nchunks > 0 ? nchunks : 0, 0);
+  auto wait_chunks = [&](int r) -> int {
+    for (int d = 0; d < 2; ++d) {
+      if (smax[d] < 0) continue;
+      int lo = smin[d], hi = smax[d] + (r + 1) * (S - 1);
+      if (hi > T - 1) hi = T - 1;
+      if (d) { const int a = T - 1 - hi, b = T - 1 - lo; lo = a, hi = b; }
+      for (int c = 0; c < nchunks; ++c)
+        if (!waited[c] && chunk_lo[c] <= hi && chunk_hi[c] > lo) {
+          if (hipStreamWaitEvent(s, (hipEvent_t)chunk_ev[c], 0) != hipSuccess) return SAMPT_ERR_HIP;
+          waited[c] = 1;
+        }
+    }
+    return SAMPT_OK;
+  };
+  *rounds = 0;
+  SAMPT_TRY(pips_chain_init(q, n, T, cur, traj, vis, s));
+  if (smax[0] < 0 && smax[1] < 0) return SAMPT_OK;                       // every query sits on its direction's last frame
+  const int max_rounds = T + 1;
+  for (int r = 0; r < max_rounds; ++r) {
+    SAMPT_TRY(wait_chunks(r));
+    SAMPT_TRY(pips_round_begin(cur, flip, traj, T, n, S, fidx, xys, r == 0 ? xy_feat : nullptr, r == 0 ? f0 : nullptr,
+                               (float)stride, s));
+    if (r == 0)   // tracker.py:81-90 == App. B-6: the only used output of the init pass is the feature at the query frame
+      SAMPT_TRY(pips_sample_feat(pyr.base[0], pyr.H[0], pyr.W[0], 128, f0, xy_feat, n, feat_init, s));
+    ws.off = ws_mark;
+    SAMPT_TRY(update(pyr, fidx, n, xys, feat_init, iters, tr, vi, ws, s));
+    SAMPT_TRY(pips_round_end(cur, tr, vi, T, n, S, thr0, traj, vis, n_active, s));
+    if (hipMemcpyAsync(&flag[r & 1], n_active, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess) return SAMPT_ERR_HIP;
+    if (hipEventRecord(flag_ev[r & 1], s) != hipSuccess) return SAMPT_ERR_HIP;
+    ++*rounds;
+    if (r >= 1) {   // one round of look-ahead: the host enqueues round r while the device runs it / finishes round r - 1
+      if (hipEventSynchronize(flag_ev[(r - 1) & 1]) != hipSuccess) return SAMPT_ERR_HIP;
+      if (flag[(r - 1) & 1] == 0) break;       // round r found no active chain and wrote nothing
+    }
+  }
+  if (hipStreamSynchronize(s) != hipSuccess) return SAMPT_ERR_HIP;
+  if (flag[0] != 0 && flag[1] != 0) {
+    error = "PipsEngine::track: chains still active after T + 1 rounds";
+    return SAMPT_ERR_ARG;
+  }
   return SAMPT_OK;
 }
 

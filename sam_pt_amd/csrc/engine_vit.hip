@@ -78,6 +78,7 @@ struct G {
     p.A = A, p.W = W, p.bias = bias, p.C = C, p.res = res, p.rowmap = rowmap, p.a_rowmap = a_rowmap;
     p.M = M, p.N = N, p.K = K, p.lda = K, p.ldw = K, p.ldc = N, p.ldr = ldr, p.act = act, p.res_mod = res_mod;
     p.out_f16 = out_f16 ? 1 : 0;
+    p.p8_wgs = eng ? eng->gemm_wgs : 0;
     if (exact && hl) {   // fp32-grade on the fp16 pipe: the GEMM as a 1x1 convolution over an [1][M][1][K] image
       p.W = hl, p.W_lo = hl + (size_t)N * K;
       p.alpha = 1.0f / (float)(1 << F16X3_WSHIFT);

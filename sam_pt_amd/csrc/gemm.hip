@@ -18,6 +18,8 @@
 //    caller-provided workspace and a second kernel reduces them in a fixed order and applies the epilogue;
 //  * skinny (M <= 32): no MFMA at all — each wave owns two output columns, lanes stride K with 16-byte loads of the
 //    weight row (weight-bandwidth bound, one pass over W), wave-shuffle reduction.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace sampt {
@@ -34,9 +36,8 @@ template <> struct GT<half_t> {
   __device__ static vec_t zero() { return (h8){0, 0, 0, 0, 0, 0, 0, 0}; }
 };
 
-template <typename T, int BM, int BN, int BK, bool CONV, bool W_KN, bool A_SK = false>
+template <typename T, int BM, int BN, int BK, bool CONV, bool W_KN>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
-  static_assert(!A_SK || (sizeof(T) == 4 && !CONV), "A_SK: plain f32 GEMMs only");
   typedef GT<T> G;
   typedef typename G::vec_t vec_t;
   constexpr int VEC = G::VEC, PAD = G::PAD;
@@ -103,20 +104,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
       int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
       if (iy < 0 || iy >= p.cH || ix < 0 || ix >= p.cW) return G::zero();
       return *(const vec_t*)(A + a_off[i] + ((long)iy * p.cW + ix) * p.cC + ci);
-    } else if constexpr (A_SK) {
-      // A = act(sum of the producer's split-K partials + bias): the arithmetic of k_splitk_reduce, in its order
-      float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int sp = 0; sp < p.a_nsplit; ++sp) {
-        const float4 t = *(const float4*)((const float*)A + (long)sp * p.a_split_stride + a_off[i] + k);
-        acc4.x += t.x, acc4.y += t.y, acc4.z += t.z, acc4.w += t.w;
-      }
-      if (p.a_bias) {
-        const float4 bb = *(const float4*)(p.a_bias + k);
-        acc4.x += bb.x, acc4.y += bb.y, acc4.z += bb.z, acc4.w += bb.w;
-      }
-      acc4.x = apply_act(acc4.x, p.a_act), acc4.y = apply_act(acc4.y, p.a_act);
-      acc4.z = apply_act(acc4.z, p.a_act), acc4.w = apply_act(acc4.w, p.a_act);
-      return acc4;
     } else {
       return *(const vec_t*)(A + a_off[i] + k);
     }
@@ -334,12 +321,129 @@ static int plan_tiles_splitk(const GemmP& p, bool plain, int& BM_out, bool& big_
   return 1;
 }
 
+static bool thin_f32_eligible(const GemmP& p, bool plain);
+
 int gemm_f32_plan_splitk(const GemmP& p) {
   const bool plain = !p.conv && !p.w_kn && p.nb1 * p.nb2 == 1 && !p.rowmap && !p.a_rowmap;
-  if (plain && p.M <= 16 && p.a_nsplit == 0) return 1;  // skinny path
+  if (plain && p.M <= 16) return 1;  // skinny path
+  if (thin_f32_eligible(p, plain)) return 1;             // thin path: K is split inside the workgroup
   int BM;
   bool big;
   return plan_tiles_splitk(p, plain, BM, big);
+}
+
+// ---------------------------------------------------------------------------------------------
+// thin f32 GEMM for the latency-bound token-side products (PIPS / CoTracker mixers: 64 .. 400 rows; decoder tokens):
+// a workgroup owns a (16 * FM) x 16 output tile and its NWV WAVES SPLIT K; the partial tiles meet in LDS and are summed
+// in wave order (deterministic), so a 64 x 512 x 2048 product is 128 workgroups and ONE launch — where the 64 x 64 tile
+// needed a split-K grid plus a reduction launch.  Exact fp32: v_mfma_f32_16x16x4_f32.  These products are bound by the
+// latency of their (L2 / Infinity-Cache resident) operands, not by bandwidth or FLOPs: NWV is chosen so that a wave's
+// share of K is at most 8 chunks of 16 and ALL its loads are issued before the first MFMA — one memory round trip per
+// workgroup (16 waves for K = 2048, 4 for K = 512).
+// No LDS staging: a lane loads 16 bytes of its A row / W row per 16-deep chunk straight into the MFMA operands (the K
+// index a lane supplies to MFMA j of a chunk is chunk*16 + 4*(lane/16) + j for both operands, so every k is multiplied
+// exactly once).  Swapped MFMA operands give C^T fragments: lane (lr, lq) owns row lr and 4 consecutive columns.
+// ---------------------------------------------------------------------------------------------
+template <int FM, int NWV>
+__global__ __launch_bounds__(NWV * 64) void gemm_thin_f32(GemmP p) {
+  __shared__ f32x4 red[NWV][FM][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lq = lane >> 4;
+  const int n0 = blockIdx.x * 16, m0 = blockIdx.y * (16 * FM);
+  const float* __restrict__ A = (const float*)p.A;
+  const float* __restrict__ W = (const float*)p.W;
+  const int wcol = n0 + lr < p.N ? n0 + lr : p.N - 1;
+  const float* wp = W + (long)wcol * p.ldw + lq * 4;
+  const float* ap[FM];
+#pragma unroll
+  for (int f = 0; f < FM; ++f) {
+    const int r = m0 + f * 16 + lr;
+    ap[f] = A + (long)(r < p.M ? r : p.M - 1) * p.lda + lq * 4;
+  }
+  const int nchunk = (p.K + 15) >> 4;
+  const int c_lo = (nchunk * wave) / NWV, c_hi = (nchunk * (wave + 1)) / NWV;
+  f32x4 acc[FM];
+#pragma unroll
+  for (int f = 0; f < FM; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  constexpr int U = FM >= 4 ? 4 : 8;    // chunks whose loads are in flight together (one round trip when c_hi - c_lo <= U)
+  for (int c = c_lo; c < c_hi; c += U) {
+    float4 wv[U], av[U][FM];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = (c + u) << 4;
+      const bool in = c + u < c_hi && k + lq * 4 < p.K;     // K % 4 == 0: a float4 is wholly inside or outside
+      const int ko = in ? k : 0;
+      wv[u] = *(const float4*)(wp + ko);
+#pragma unroll
+      for (int f = 0; f < FM; ++f) av[u][f] = *(const float4*)(ap[f] + ko);
+      if (!in) wv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int f = 0; f < FM; ++f) {
+        acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u].x, av[u][f].x, acc[f], 0, 0, 0);
+        acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u].y, av[u][f].y, acc[f], 0, 0, 0);
+        acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u].z, av[u][f].z, acc[f], 0, 0, 0);
+        acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u].w, av[u][f].w, acc[f], 0, 0, 0);
+      }
+  }
+#pragma unroll
+  for (int f = 0; f < FM; ++f) red[wave][f][lane] = acc[f];
+  __syncthreads();
+  // fragment f is finished by wave f (FM <= 4 <= NWV): sum the K shares in wave order, epilogue, store
+  if (wave < FM) {
+    const int f = wave;
+    f32x4 v = red[0][f][lane];
+#pragma unroll
+    for (int w = 1; w < NWV; ++w) v += red[w][f][lane];
+    const int row = m0 + f * 16 + lr, col = n0 + lq * 4;
+    if (row < p.M && col < p.N) {
+      float o[4] = {v[0] * p.alpha, v[1] * p.alpha, v[2] * p.alpha, v[3] * p.alpha};
+      if (p.bias) {
+        const float4 b = *(const float4*)(p.bias + col);
+        o[0] += b.x, o[1] += b.y, o[2] += b.z, o[3] += b.w;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = apply_act(o[r], p.act);
+      if (p.res) {
+        const int rrow = p.res_mod > 0 ? row % p.res_mod : row;
+        const float4 rv = *(const float4*)(p.res + (long)rrow * p.ldr + col);
+        o[0] += rv.x, o[1] += rv.y, o[2] += rv.z, o[3] += rv.w;
+      }
+      *(float4*)((float*)p.C + (long)row * p.ldc + col) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  }
+}
+
+// the thin kernel takes plain f32 GEMMs whose 64 x 64 tiling would leave most CUs idle (the split-K regime)
+static bool thin_f32_eligible(const GemmP& p, bool plain) {
+  static const int on = getenv("SAMPT_GEMM_THIN") ? atoi(getenv("SAMPT_GEMM_THIN")) : 1;
+  if (!on || !plain || p.out_f16 || p.M <= 16 || p.K < 64) return false;
+  if ((p.N % 4) || (p.ldc % 4) || (p.res && (p.ldr % 4)) || (p.lda % 4) || (p.ldw % 4) || (p.K % 4)) return false;
+  if (((uintptr_t)p.C & 15) || (p.bias && ((uintptr_t)p.bias & 15)) || (p.res && ((uintptr_t)p.res & 15))) return false;
+  const long tiles64 = (long)cdiv(p.M, 64) * cdiv(p.N, 64);
+  return tiles64 < 128;
+}
+
+static int gemm_thin_f32_launch(const GemmP& p, hipStream_t s) {
+  const long cols = cdiv(p.N, 16);
+  int FM = 4;                                  // the tallest tile that still yields >= 256 workgroups (>= 1 per CU)
+  while (FM > 1 && cols * cdiv(p.M, 16 * FM) < 256) FM >>= 1;
+  const int nchunk = cdiv(p.K, 16), per_wave = FM >= 4 ? 4 : 8;
+  int NWV = nchunk > 8 * per_wave ? 16 : (nchunk > 4 * per_wave ? 8 : 4);   // a wave's K share: one batch of loads
+  static const int fm_env = getenv("SAMPT_THIN_FM") ? atoi(getenv("SAMPT_THIN_FM")) : 0;      // experiments only
+  static const int nwv_env = getenv("SAMPT_THIN_NWV") ? atoi(getenv("SAMPT_THIN_NWV")) : 0;
+  if (fm_env == 1 || fm_env == 2 || fm_env == 4) FM = fm_env;
+  if (nwv_env == 4 || nwv_env == 8 || nwv_env == 16) NWV = nwv_env;
+  dim3 grid((unsigned)cols, (unsigned)cdiv(p.M, 16 * FM)), block(NWV * 64);
+#define THIN(FMv, NWVv) hipLaunchKernelGGL((gemm_thin_f32<FMv, NWVv>), grid, block, 0, s, p)
+  if (FM == 4) { if (NWV == 16) THIN(4, 16); else if (NWV == 8) THIN(4, 8); else THIN(4, 4); }
+  else if (FM == 2) { if (NWV == 16) THIN(2, 16); else if (NWV == 8) THIN(2, 8); else THIN(2, 4); }
+  else { if (NWV == 16) THIN(1, 16); else if (NWV == 8) THIN(1, 8); else THIN(1, 4); }
+#undef THIN
+  SAMPT_CHECK_LAUNCH("gemm_thin_f32");
+  return SAMPT_OK;
 }
 
 template <typename T>
@@ -366,11 +470,8 @@ static int gemm_dispatch(const GemmP& p_in, hipStream_t s) {
   const bool plain = !p.conv && !p.w_kn && batch == 1 && !p.rowmap && !p.a_rowmap;
 
   // ---- skinny path
-  if (p.a_nsplit > 0 && (sizeof(T) != 4 || !plain || p.a_nsplit > 16 || p.a_split_stride % 4 ||
-                         ((uintptr_t)p.a_bias & 15)))
-    return SAMPT_ERR_UNSUPPORTED;
   if constexpr (sizeof(T) == 4) {
-    if (plain && p.M <= 16 && p.a_nsplit == 0) {
+    if (plain && p.M <= 16) {
       p.splitk = 1;
       dim3 grid(cdiv(p.N, 8)), block(256);
       if (p.M <= 4) hipLaunchKernelGGL(gemm_skinny_f32<4>, grid, block, 0, s, p);
@@ -378,6 +479,10 @@ static int gemm_dispatch(const GemmP& p_in, hipStream_t s) {
       SAMPT_CHECK_LAUNCH("gemm_skinny");
       return SAMPT_OK;
     }
+  }
+
+  if constexpr (sizeof(T) == 4) {
+    if (thin_f32_eligible(p, plain)) return gemm_thin_f32_launch(p, s);
   }
 
   // ---- tile selection: the big tile only when it still yields enough workgroups for 256 CUs;
@@ -394,9 +499,6 @@ static int gemm_dispatch(const GemmP& p_in, hipStream_t s) {
       if (big) LAUNCH(128, 16, false, true); else LAUNCH(64, 16, false, true);
     } else if (p.conv) {
       if (big) LAUNCH(128, 32, true, false); else LAUNCH(64, 64, true, false);
-    } else if (p.a_nsplit > 0) {
-      if (big) hipLaunchKernelGGL((gemm_kernel<float, 128, 128, 32, false, false, true>), grid, block, 0, s, p);
-      else hipLaunchKernelGGL((gemm_kernel<float, 64, 64, 64, false, false, true>), grid, block, 0, s, p);
     } else {
       if (big) LAUNCH(128, 32, false, false); else LAUNCH(64, 64, false, false);
     }
@@ -410,7 +512,7 @@ static int gemm_dispatch(const GemmP& p_in, hipStream_t s) {
   }
 #undef LAUNCH
   SAMPT_CHECK_LAUNCH("gemm");
-  if (p.splitk > 1 && !p.defer_reduce) {
+  if (p.splitk > 1) {
     long total = (long)p.M * p.N;
     hipLaunchKernelGGL(k_splitk_reduce, dim3(cdiv(total, 256)), dim3(256), 0, s, p);
     SAMPT_CHECK_LAUNCH("splitk_reduce");

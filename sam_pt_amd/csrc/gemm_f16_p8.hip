@@ -300,8 +300,9 @@ int gemm_f16_p8_launch(const GemmP& p, hipStream_t s) {
   const long ntiles = (long)nt_m * nt_n;
   // workgroups per XCD: one per CU (32) by default; fewer leaves whole CUs to kernels of other streams (a 512-thread,
   // 128-KiB workgroup owns its CU: nothing else becomes resident beside it)
-  static const int wgs_env = getenv("SAMPT_GEMM_WGS") ? atoi(getenv("SAMPT_GEMM_WGS")) : 32;
-  const int wgs = wgs_env >= 1 && wgs_env <= 32 ? wgs_env : 32;
+  static const int wgs_env = getenv("SAMPT_GEMM_WGS") ? atoi(getenv("SAMPT_GEMM_WGS")) : 0;   // experiments: overrides p8_wgs
+  const int wgs_req = wgs_env ? wgs_env : p.p8_wgs;
+  const int wgs = wgs_req >= 1 && wgs_req <= 32 ? wgs_req : 32;
   int per_xcd = (int)((ntiles + 7) / 8);
   if (per_xcd > wgs) per_xcd = wgs;
   static const int stagger = getenv("SAMPT_GEMM_STAGGER") ? atoi(getenv("SAMPT_GEMM_STAGGER")) : 1;

@@ -15,8 +15,10 @@ size_t instnorm_partial_doubles(int nimg, long hw, int C);
 int instnorm_stats(const float* x, int nimg, long hw, int C, float eps, double* partials, float* mean_rstd,
                    hipStream_t s);
 // y = (x-mean)*rstd ; if relu1: y = max(y,0) ; if skip: y = max(y + skip, 0)
+// y_hi / y_lo (optional, both or none): y additionally split into two fp16 planes (hi = fp16(y), lo = fp16(y - hi)), the
+// operand format of conv_f16x3's pre-split path
 int instnorm_apply(const float* x, const float* mean_rstd, const float* skip, float* y, int nimg, long hw, int C,
-                   int relu1, hipStream_t s);
+                   int relu1, hipStream_t s, half_t* y_hi = nullptr, half_t* y_lo = nullptr);
 // bilinear resize of an NHWC f32 tensor into channels [c_off, c_off+C) of a dstC-channel NHWC tensor
 int resize_bilinear_nhwc(const float* src, int n, int sh, int sw, int C, float* dst, int dh, int dw, int dstC,
                          int c_off, int align_corners, hipStream_t s);
@@ -88,13 +90,16 @@ int pips2_apply_delta(const float* delta, const float* bak, float stride, int S,
 // coords[s][pt] = coords0[pt] = xys[pt]/stride ; ffeats[pt][s] = feat_init[pt]     (pips.py:458-476)
 int pips_init_state(const float* xys, const float* feat_init, float stride, int S, int n, float* coords,
                     float* coords0, float* ffeats, hipStream_t s);
-// token-mixing PreNormResidual block of the MLP-Mixer, one workgroup per sequence (pips.py:116,120-121)
-// out of place: xo != x
-int pips_token_mix_fused_in(const float* parts, int nsplit, long split_stride, const float* bias, const float* res,
-                            float* xo, const float* lnw, const float* lnb, const float* w1, const float* b1,
-                            const float* w2, const float* b2, int nseq, int S, int D, hipStream_t s);
+// token-mixing PreNormResidual block of the MLP-Mixer, grid (sequence, 64-channel chunk) (pips.py:116,120-121); out of
+// place: xo != x
 int pips_token_mix(const float* x, float* xo, const float* lnw, const float* lnb, const float* w1, const float* b1,
                    const float* w2, const float* b2, int nseq, int S, int D, hipStream_t s);
+// device-side bookkeeping of the chained PIPS windows (pips/tracker.py:42-153; kernels and layouts: pips.hip)
+int pips_chain_init(const float* q, int n, int T, int* cur, float* traj, float* vis, hipStream_t s);
+int pips_round_begin(const int* cur, const unsigned char* flip, const float* traj, int T, int n, int S, int* fidx, float* xys,
+                     float* xy_feat, int* f0, float stride, hipStream_t s);
+int pips_round_end(int* cur, const float* tr, const float* vi, int T, int n, int S, float thr0, float* traj, float* vis,
+                   int* n_active, hipStream_t s);
 // mean over the S tokens of LN(x): out[n][D]
 int pips_ln_mean(const float* x, const float* lnw, const float* lnb, float* out, int nseq, int S, int D, hipStream_t s);
 // feature / coordinate update (pips.py:536-544): delta [n][S][130]; ffeats [n][S][128]; coords [S][n][2]

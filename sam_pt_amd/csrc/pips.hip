@@ -171,17 +171,11 @@ int pips_init_state(const float* xys, const float* feat_init, float stride, int 
 // K12a: token-mixing block  x = x + W2 . gelu(W1 . LN(x) + b1) + b2  over the S=8 tokens (Conv1d k=1)
 // One workgroup per sequence; the 8 x 512 activations live in LDS.
 // ---------------------------------------------------------------------------------------------
-// FUSED_IN: the input slab is not materialised — x points at the previous channel-mix GEMM's raw split-K partials
-// [nsplit][rows][D] and every read applies what k_splitk_reduce would have stored: sum over the partials (in order) + bias
-// + residual (launch fusion).
-template <int S, int D, bool FUSED_IN = false>
+template <int S, int D>
 __global__ __launch_bounds__(256) void k_pips_token_mix(const float* __restrict__ x, float* __restrict__ xo,
                                                         const float* __restrict__ lnw, const float* __restrict__ lnb,
                                                         const float* __restrict__ w1, const float* __restrict__ b1,
-                                                        const float* __restrict__ w2, const float* __restrict__ b2,
-                                                        int nsplit = 0, long split_stride = 0,
-                                                        const float* __restrict__ in_bias = nullptr,
-                                                        const float* __restrict__ in_res = nullptr) {
+                                                        const float* __restrict__ w2, const float* __restrict__ b2) {
   // grid = (sequence, D/64 channel chunks).  Every workgroup recomputes the LayerNorm statistics of the 8 tokens
   // (16 KiB of L2-resident reads) and then mixes its own 64 channels; out of place, so chunks never race.
   constexpr int H = 4 * S, CH = 64;
@@ -191,17 +185,7 @@ __global__ __launch_bounds__(256) void k_pips_token_mix(const float* __restrict_
   const float* xs = x + (long)blockIdx.x * S * D;
   float* xos = xo + (long)blockIdx.x * S * D;
   const int c0 = blockIdx.y * CH;
-  auto ld = [&](int tok, int ch) -> float {
-    if constexpr (FUSED_IN) {
-      float v = 0.f;
-      for (int sp = 0; sp < nsplit; ++sp) v += xs[(long)sp * split_stride + tok * D + ch];
-      v += in_bias[ch];
-      v += in_res[(long)blockIdx.x * S * D + tok * D + ch];
-      return v;
-    } else {
-      return xs[tok * D + ch];
-    }
-  };
+  auto ld = [&](int tok, int ch) -> float { return xs[tok * D + ch]; };
   for (int i = tid; i < H * S; i += 256) {
     ((float*)sw1)[i] = w1[i];
     ((float*)sw2)[i] = w2[i];
@@ -264,21 +248,8 @@ __global__ __launch_bounds__(256) void k_pips_token_mix(const float* __restrict_
 int pips_token_mix(const float* x, float* xo, const float* lnw, const float* lnb, const float* w1, const float* b1,
                    const float* w2, const float* b2, int nseq, int S, int D, hipStream_t s) {
   if (S != 8 || D != 512 || nseq <= 0 || x == xo) return SAMPT_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((k_pips_token_mix<8, 512>), dim3(nseq, D / 64), dim3(256), 0, s, x, xo, lnw, lnb, w1, b1, w2, b2, 0,
-                     0L, (const float*)nullptr, (const float*)nullptr);
+  hipLaunchKernelGGL((k_pips_token_mix<8, 512>), dim3(nseq, D / 64), dim3(256), 0, s, x, xo, lnw, lnb, w1, b1, w2, b2);
   SAMPT_CHECK_LAUNCH("pips_token_mix");
-  return SAMPT_OK;
-}
-
-// token mixing whose input is the previous block's un-reduced channel-mix output: x = sum_s parts[s] + bias + res
-int pips_token_mix_fused_in(const float* parts, int nsplit, long split_stride, const float* bias, const float* res,
-                            float* xo, const float* lnw, const float* lnb, const float* w1, const float* b1,
-                            const float* w2, const float* b2, int nseq, int S, int D, hipStream_t s) {
-  if (S != 8 || D != 512 || nseq <= 0 || nsplit < 1 || nsplit > 16 || !parts || !bias || !res || res == xo)
-    return SAMPT_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((k_pips_token_mix<8, 512, true>), dim3(nseq, D / 64), dim3(256), 0, s, parts, xo, lnw, lnb, w1, b1, w2,
-                     b2, nsplit, split_stride, bias, res);
-  SAMPT_CHECK_LAUNCH("pips_token_mix_fused_in");
   return SAMPT_OK;
 }
 
@@ -396,6 +367,101 @@ int pips_finalize(const float* ffeats, const float* vis_w, const float* vis_b, c
                   int S, int n, float* traj, float* vis, hipStream_t s) {
   hipLaunchKernelGGL(k_pips_finalize, dim3(n * S), dim3(64), 0, s, ffeats, vis_w, vis_b, coords, stride, S, n, traj, vis);
   SAMPT_CHECK_LAUNCH("pips_finalize");
+  return SAMPT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Chained windows of PipsPointTracker._forward (pips/tracker.py:42-153) with the bookkeeping ON THE DEVICE: every chain
+// (one point in one temporal direction) owns an anchor frame `cur`; a ROUND runs one 8-frame window for every chain at
+// once (the mixer treats points independently, pips.py:525-532).  Chain time axis d = 0..T-1; a flipped chain reads
+// pyramid frame T-1-d (tracker.py:162-167).  traj [T][n][2] px, vis [T][n] = sigmoid(logit) (0 where never written).
+// ---------------------------------------------------------------------------------------------
+// state reset + query frame entries (tracker.py:57-63): one thread per chain
+__global__ void k_pips_chain_init(const float* __restrict__ q /*[n][3] = (t, x, y)*/, int n, int* __restrict__ cur,
+                                  float* __restrict__ traj, float* __restrict__ vis) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int t0 = (int)q[i * 3];
+  cur[i] = t0;
+  traj[((long)t0 * n + i) * 2] = q[i * 3 + 1];
+  traj[((long)t0 * n + i) * 2 + 1] = q[i * 3 + 2];
+  vis[(long)t0 * n + i] = 1.0f;
+}
+
+// window frames (the last frame repeated when the clip ends inside the window, tracker.py:73-78) and anchor positions of
+// every chain for this round; finished chains keep a valid dummy window (their results are never written back)
+__global__ void k_pips_round_begin(const int* __restrict__ cur, const unsigned char* __restrict__ flip, const float* __restrict__ traj,
+                                   int T, int n, int S, int* __restrict__ fidx /*[n][S]*/, float* __restrict__ xys /*[n][2]*/,
+                                   float* __restrict__ xy_feat /*[n][2] or null: anchor / stride (first round only)*/,
+                                   int* __restrict__ f0 /*[n] or null: pyramid frame of the anchor*/, float stride) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int f = cur[i];
+  if (f > T - 1) f = T - 1;
+  const int hi = min(T - f, S);
+  for (int s = 0; s < S; ++s) {
+    const int w = min(f + s, f + hi - 1);
+    fidx[i * S + s] = flip[i] ? T - 1 - w : w;
+  }
+  const float x = traj[((long)f * n + i) * 2], y = traj[((long)f * n + i) * 2 + 1];
+  xys[i * 2] = x, xys[i * 2 + 1] = y;
+  if (xy_feat) xy_feat[i * 2] = x / stride, xy_feat[i * 2 + 1] = y / stride, f0[i] = flip[i] ? T - 1 - f : f;
+}
+
+// write frames 1 .. hi-1 of every active chain's window (tracker.py:104-109), then link: the next anchor is the latest
+// frame of the window whose visibility exceeds the threshold, the threshold decaying by 0.02 per sweep (tracker.py:111-148;
+// float32 arithmetic like the reference's torch code).  n_active[0] = chains that still have frames to track.
+__global__ void k_pips_round_end(int* __restrict__ cur, const float* __restrict__ tr /*[S][n][2]*/, const float* __restrict__ vi /*[S][n]*/,
+                                 int T, int n, int S, float thr0, float* __restrict__ traj, float* __restrict__ vis,
+                                 int* __restrict__ n_active) {
+  __shared__ int cnt;
+  if (threadIdx.x == 0) cnt = 0;
+  __syncthreads();
+  int still = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int f = cur[i];
+    if (f >= T - 1) continue;                      // tracker.py:67: anchors range over n_frames - 1
+    const int hi = min(T - f, S);
+    for (int s = 1; s < hi; ++s) {
+      vis[(long)(f + s) * n + i] = vi[s * n + i];
+      traj[((long)(f + s) * n + i) * 2] = tr[(s * n + i) * 2];
+      traj[((long)(f + s) * n + i) * 2 + 1] = tr[(s * n + i) * 2 + 1];
+    }
+    float thr = thr0;
+    const int earliest = f + 1, last = f + hi - 1;
+    int nxt = last;
+    while (vis[(long)nxt * n + i] <= thr) {
+      nxt -= 1;
+      if (nxt < earliest) thr = thr - 0.02f, nxt = last;
+    }
+    cur[i] = nxt;
+    still += nxt < T - 1;
+  }
+  if (still) atomicAdd(&cnt, still);
+  __syncthreads();
+  if (threadIdx.x == 0) n_active[0] = cnt;
+}
+
+int pips_chain_init(const float* q, int n, int T, int* cur, float* traj, float* vis, hipStream_t s) {
+  if (hipMemsetAsync(traj, 0, (size_t)T * n * 2 * sizeof(float), s) != hipSuccess) return SAMPT_ERR_HIP;
+  if (hipMemsetAsync(vis, 0, (size_t)T * n * sizeof(float), s) != hipSuccess) return SAMPT_ERR_HIP;
+  hipLaunchKernelGGL(k_pips_chain_init, dim3(cdiv(n, 64)), dim3(64), 0, s, q, n, cur, traj, vis);
+  SAMPT_CHECK_LAUNCH("pips_chain_init");
+  return SAMPT_OK;
+}
+
+int pips_round_begin(const int* cur, const unsigned char* flip, const float* traj, int T, int n, int S, int* fidx, float* xys,
+                     float* xy_feat, int* f0, float stride, hipStream_t s) {
+  hipLaunchKernelGGL(k_pips_round_begin, dim3(cdiv(n, 64)), dim3(64), 0, s, cur, flip, traj, T, n, S, fidx, xys, xy_feat, f0,
+                     stride);
+  SAMPT_CHECK_LAUNCH("pips_round_begin");
+  return SAMPT_OK;
+}
+
+int pips_round_end(int* cur, const float* tr, const float* vi, int T, int n, int S, float thr0, float* traj, float* vis,
+                   int* n_active, hipStream_t s) {
+  hipLaunchKernelGGL(k_pips_round_end, dim3(1), dim3(256), 0, s, cur, tr, vi, T, n, S, thr0, traj, vis, n_active);
+  SAMPT_CHECK_LAUNCH("pips_round_end");
   return SAMPT_OK;
 }
 

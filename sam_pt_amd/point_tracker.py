@@ -162,112 +162,48 @@ class PipsPointTracker(PointTracker):
 
     chunk_events_on_other_stream = True      # SamPt: the side stream needs no event for the whole pyramid
 
-    def _run_chains(self, pyr, T: int, query_points: torch.Tensor, flipped: torch.Tensor, ws, chunk_events=None):
+    def _run_chains(self, pyr, T: int, query_points: torch.Tensor, flipped: torch.Tensor, chunk_events=None):
         """query_points (N,3) CPU float = (t, x, y) in each chain's OWN time axis; ``flipped[i]`` marks chains that run on
         the time-reversed clip (direction frame d = original frame T-1-d).  Returns CPU (T,N,2), (T,N) bool in each
         chain's own time axis.
 
         The reference walks ``current_frame`` upwards and runs one ``Pips.forward`` per distinct anchor frame with the
         points anchored there (tracker.py:67-109).  PIPS treats points independently (the mixer batch is per point,
-        pips.py:525-532), so the same per-point window sequence can be executed in ROUNDS: every unfinished chain
-        advances by one window per round, all of them batched into one ``sampt_pips_update_f32`` call with per-point
-        window frames.  Results are identical per point; the number of device calls drops from one per distinct anchor
-        to max-windows-per-chain, and the MFMA GEMMs of the mixer always see all active points."""
+        pips.py:525-532), so the same per-point window sequence is executed in ROUNDS: every unfinished chain advances by
+        one window per round, all chains batched into one window call.  Results are identical per point; the number of
+        window calls drops from one per distinct anchor to max-windows-per-chain.  The whole loop — window frames, write-back
+        of frames 1..7, visibility-threshold linking (tracker.py:111-148) — runs on the device inside
+        ``sampt_pips_track_f32``: no per-round download / upload, rounds are enqueued one ahead of the GPU."""
         import numpy as np
         dev = pyr[0].device
         N = query_points.shape[0]
         H0, W0 = pyr[0].shape[1:3]
-        S = self.s
-        # Host state in numpy: a round's bookkeeping is a few dozen tiny array operations and the tracker stream idles while
-        # the host does them (23 rounds per benchmark clip), so their per-call overhead matters.  Arithmetic that decides
-        # anything (visibility thresholds) stays float32, as in the reference's torch code.
-        qp = query_points.numpy().astype(np.float32)
-        traj = np.zeros((T, N, 2), np.float32)
-        vis = np.zeros((T, N), np.float32)
-        start = qp[:, 0].astype(np.int64)
-        ar = np.arange(N)
-        vis[start, ar] = 1.0
-        traj[start, ar] = qp[:, 1:]
-        flip = flipped.numpy().astype(bool)
-        feat_init = torch.zeros(N, 128, device=dev)
-        have_feat = np.zeros(N, bool)
-        cur = start.copy()
-        thr0 = np.float32(self.initial_next_frame_visibility_threshold)
-        step = np.float32(0.02)
-        pyr_ptrs = _lib.ptr_array(pyr)
-        pending = list(chunk_events) if chunk_events else []
-        sw = np.arange(S)[None, :]
-
-        while True:
-            act = np.nonzero(cur < T - 1)[0]                    # tracker.py:67: anchors range over n_frames-1
-            if act.size == 0:
-                break
-            n = int(act.size)
-            f = cur[act]                                        # (n,) anchor frame of each active chain
-            hi = np.minimum(T - f, S)                           # frames available in the window (S - n_missing)
-            win = np.minimum(f[:, None] + sw, (f + hi - 1)[:, None])   # repeat the last frame (tracker.py:73-78)
-            used = np.where(flip[act][:, None], T - 1 - win, win)      # direction frame -> original frame index
-            if pending:                                         # pyramid chunks this round reads (prepare() on another stream)
-                lo, hi_f = int(used.min()), int(used.max())
-                for c in [c for c in pending if c[0] <= hi_f and c[1] > lo]:
-                    torch.cuda.current_stream().wait_event(c[2])
-                    pending.remove(c)
-            xys_np = traj[f, act]                               # (n,2)
-            fresh = ~have_feat[act]
-            nf = int(fresh.sum())
-            # ONE upload per round: [window frames n*S | chain ids n | fresh chain ids nf | fresh frames nf] as int32 and
-            # [anchor positions n*2 | fresh positions / stride nf*2] as float32 behind them (bit-cast)
-            ints = np.concatenate([used.reshape(-1), act, act[fresh], used[fresh, 0]]).astype(np.int32)
-            flts = np.concatenate([xys_np.reshape(-1), (xys_np[fresh] / np.float32(self.stride)).reshape(-1)]).astype(np.float32)
-            stage = torch.from_numpy(np.concatenate([ints, flts.view(np.int32)])).to(dev)
-            o = 0
-            fidx = stage[o:o + n * S].view(n, S); o += n * S
-            act_d = stage[o:o + n].long(); o += n
-            fa_d = stage[o:o + nf].long(); o += nf
-            fr = stage[o:o + nf]; o += nf
-            xys = stage[o:o + 2 * n].view(torch.float32).view(n, 2); o += 2 * n
-            if nf:                                              # tracker.py:81-90 == App. B-6: feature at the query frame
-                xy = stage[o:o + 2 * nf].view(torch.float32).view(nf, 2)
-                out = torch.empty(nf, 128, device=dev)
-                _lib.check(self._lib.sampt_pips_sample_feat_f32(_lib.ptr(pyr[0]), H0, W0, _lib.ptr(fr), _lib.ptr(xy), nf,
-                                                                _lib.ptr(out), _lib.stream_ptr()), "sampt_pips_sample_feat_f32")
-                feat_init[fa_d] = out
-                have_feat[act[fresh]] = True
-            fi = feat_init.index_select(0, act_d)
-            res = torch.empty(S * n * 3, device=dev)            # ONE download per round: [trajectories S*n*2 | visibilities S*n]
-            tr_o, vi_o = res[:S * n * 2].view(S, n, 2), res[S * n * 2:].view(S, n)
-            _lib.check(self._lib.sampt_pips_update_f32(self._h, pyr_ptrs, H0, W0, _lib.ptr(fidx), n, _lib.ptr(xys),
-                                                       _lib.ptr(fi), 6, _lib.ptr(tr_o), _lib.ptr(vi_o), _lib.ptr(ws),
-                                                       ws.numel(), _lib.stream_ptr()), "sampt_pips_update_f32")
-            self.stats["windows"] += 1
-            self.stats["point_windows"] = self.stats.get("point_windows", 0) + n
-            res_c = res.cpu().numpy()                           # linking below is data-dependent host control flow
-            tr_c, vi_c = res_c[:S * n * 2].reshape(S, n, 2), res_c[S * n * 2:].reshape(S, n)
-            # write frames 1..hi-1 of each chain (tracker.py:104-109)
-            ss = np.arange(1, S)[:, None]                       # (S-1, 1) window slots
-            ok = ss < hi[None, :]                               # (S-1, n)
-            rows = (f[None, :] + ss)[ok]
-            cols = np.broadcast_to(act[None, :], ok.shape)[ok]
-            vis[rows, cols] = vi_c[1:][ok]
-            traj[rows, cols] = tr_c[1:][ok]
-            # trajectory linking per chain (tracker.py:111-148)
-            thr = np.full(n, thr0, np.float32)
-            earliest, last = f + 1, f + hi - 1
-            nxt = last.copy()
-            while True:
-                low = vis[nxt, act] <= thr
-                if not low.any():
-                    break
-                nxt = np.where(low, nxt - 1, nxt)
-                wrap = nxt < earliest
-                thr = np.where(wrap, thr - step, thr)
-                nxt = np.where(wrap, last, nxt)
-            cur[act] = nxt
-        return torch.from_numpy(traj), torch.from_numpy(vis > 0.5)
+        q_np = np.ascontiguousarray(query_points.numpy().astype(np.float32))
+        f_np = np.ascontiguousarray(flipped.numpy().astype(np.uint8))
+        q_d, f_d = torch.from_numpy(q_np).to(dev), torch.from_numpy(f_np).to(dev)
+        traj = torch.empty((T, N, 2), dtype=torch.float32, device=dev)
+        vis = torch.empty((T, N), dtype=torch.float32, device=dev)
+        nbytes = C.c_size_t()
+        _lib.check(self._lib.sampt_pips_track_workspace_bytes(self._h, N, C.byref(nbytes)), "track_workspace")
+        ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+        evs = list(chunk_events) if chunk_events else []
+        ev_arr = (C.c_void_p * max(len(evs), 1))(*[e[2].cuda_event for e in evs])
+        lo_arr = (C.c_int * max(len(evs), 1))(*[int(e[0]) for e in evs])
+        hi_arr = (C.c_int * max(len(evs), 1))(*[int(e[1]) for e in evs])
+        rounds = C.c_int(0)
+        _lib.check(self._lib.sampt_pips_track_f32(
+            self._h, _lib.ptr_array(pyr), H0, W0, T, N, _lib.ptr(q_d), _lib.ptr(f_d), q_np.ctypes.data_as(C.c_void_p),
+            f_np.ctypes.data_as(C.c_void_p), float(self.initial_next_frame_visibility_threshold), 6,
+            ev_arr if evs else None, lo_arr if evs else None, hi_arr if evs else None, len(evs), _lib.ptr(traj), _lib.ptr(vis),
+            _lib.ptr(ws), ws.numel(), _lib.stream_ptr(), C.byref(rounds)), "sampt_pips_track_f32")
+        self.stats["windows"] += rounds.value
+        return traj.cpu(), vis.cpu() > 0.5
 
     @torch.no_grad()
     @_lib.on_device(lambda self, rgbs, query_points: rgbs.device)
     def forward(self, rgbs, query_points):
+        from . import prefetch
+        prefetch.publish(rgbs[0] if rgbs.dim() == 5 else rgbs)    # unchanged-SamPt fast path: see prefetch.py
         if rgbs.shape[0] != 1:
             raise NotImplementedError("Batch size > 1 is not supported for PIPS yet")  # tracker.py:50-51
         assert rgbs.dtype == torch.uint8, "rgbs must be uint8 (PointTracker.forward contract)"
@@ -281,14 +217,20 @@ class PipsPointTracker(PointTracker):
         chunk_events = getattr(self, "_prepared_events", None) if pyr is not None else None
         if pyr is None:
             pyr = self.compute_pyramid(frames)
-        nbytes = C.c_size_t()
-        _lib.check(self._lib.sampt_pips_update_workspace_bytes(self._h, 2 * N, C.byref(nbytes)), "update_workspace")
-        ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
         # both temporal directions are independent chains too: run them in the same rounds (tracker.py:159-167)
         qf = q.clone()
         qf[:, 0] = T - qf[:, 0] - 1
         flipped = torch.cat([torch.zeros(N, dtype=torch.bool), torch.ones(N, dtype=torch.bool)])
-        tr_all, vi_all = self._run_chains(pyr, T, torch.cat([q, qf]), flipped, ws, chunk_events)
+        # (a direction whose query sits on its last frame never runs a window, tracker.py:67: those chains are left out)
+        q_all = torch.cat([q, qf])
+        live = (q_all[:, 0] < T - 1).nonzero().flatten()
+        tr_all = torch.zeros(T, 2 * N, 2)
+        vi_all = torch.zeros(T, 2 * N, dtype=torch.bool)
+        tr_all[q_all[:, 0].long(), torch.arange(2 * N)] = q_all[:, 1:]
+        vi_all[q_all[:, 0].long(), torch.arange(2 * N)] = True
+        if live.numel():
+            tr_l, vi_l = self._run_chains(pyr, T, q_all[live], flipped[live], chunk_events)
+            tr_all[:, live], vi_all[:, live] = tr_l, vi_l
         for c in (chunk_events or []):                          # chunks no round touched: still order this stream after them
             torch.cuda.current_stream().wait_event(c[2])
         tr_r, vi_r = tr_all[:, :N], vi_all[:, :N]
@@ -419,6 +361,8 @@ class PipsPlusPlusPointTracker(PointTracker):
     @torch.no_grad()
     @_lib.on_device(lambda self, rgbs, query_points: rgbs.device)
     def forward(self, rgbs, query_points):
+        from . import prefetch
+        prefetch.publish(rgbs[0] if rgbs.dim() == 5 else rgbs)    # unchanged-SamPt fast path: see prefetch.py
         if rgbs.shape[0] != 1:
             raise NotImplementedError("Only batch size 1 is supported.")          # tracker.py:83
         assert rgbs.dtype == torch.uint8, "rgbs must be uint8 (PointTracker.forward contract)"
@@ -635,6 +579,8 @@ class CoTrackerPointTracker(PointTracker):
     @torch.no_grad()
     @_lib.on_device(lambda self, rgbs, query_points: rgbs.device)
     def forward(self, rgbs, query_points):
+        from . import prefetch
+        prefetch.publish(rgbs[0] if rgbs.dim() == 5 else rgbs)    # unchanged-SamPt fast path: see prefetch.py
         if rgbs.shape[0] != 1:
             raise NotImplementedError("Batch size > 1 is not supported for CoTracker")   # the model asserts B == 1
         dev = rgbs.device

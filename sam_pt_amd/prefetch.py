@@ -1,0 +1,105 @@
+"""Clip embedding prefetch for the UNCHANGED reference ``SamPt`` (VERDICT r2 "next round" #4).
+
+The reference protocol hands the two seams the same frames at two different moments: the point tracker receives the whole
+clip ``rgbs (1, T, 3, H, W)`` on the device (sam_pt/modeling/sam_pt.py:584-593) before ``_apply_sam_to_trajectories`` calls
+``sam_predictor.set_image(images[t].permute(1, 2, 0).cpu().numpy())`` once per frame (sam_pt.py:848-849).  A per-frame
+``set_image`` runs the ViT at batch 1; the same 24 frames encoded in batches of 8 cost a fraction of that.  So:
+
+* every tracker of this package ``publish``-es the clip it is given (a private device copy: later in-place edits of the
+  caller's tensor cannot make the cache lie);
+* ``SamPredictor.set_image`` asks ``lookup``: the numpy frame is uploaded (it has to be, for the encoder, anyway) and compared
+  BYTE FOR BYTE with the expected clip frame on the device (next index first, then all frames); on a match the whole clip is
+  encoded once, in batches, and this and every later ``set_image`` of the clip resolve to the cached embedding;
+* anything else (a frame that is not in the clip, another resolution, another device) takes the normal path.
+
+The embeddings are those of ``encode_frames``, whose rows do not depend on the batch they were computed in (GEMM rows,
+LayerNorm rows and attention windows are independent: ``test_vit_dead_row_skipping_is_exact``, ``tools/gemm_bench.py``
+"bitwise" check), so results are identical to per-frame encoding.  ``SAMPT_PREFETCH=0`` switches the mechanism off."""
+from __future__ import annotations
+
+import os
+import weakref
+from typing import Optional
+
+import torch
+
+
+class _Clip:
+    def __init__(self, frames: torch.Tensor):
+        self.frames = frames                      # (T, 3, H, W) uint8, private device copy
+        self.owner = None                         # weakref to the predictor whose embeddings ``feats`` holds
+        self.feats = None                         # embeddings of the whole clip (that predictor's encode_frames result)
+        self.next_idx = 0
+
+
+_current: Optional[_Clip] = None
+stats = {"published": 0, "hits": 0, "misses": 0, "clips_encoded": 0}
+
+
+_suspended = 0
+
+
+def enabled() -> bool:
+    return _suspended == 0 and os.environ.get("SAMPT_PREFETCH", "1") != "0"
+
+
+class suspended:
+    """Context manager for callers that keep the clip's embeddings themselves (this package's fused ``SamPt``): the trackers
+    they call do not publish."""
+
+    def __enter__(self):
+        global _suspended
+        _suspended += 1
+
+    def __exit__(self, *exc):
+        global _suspended
+        _suspended -= 1
+        return False
+
+
+def publish(frames: torch.Tensor) -> None:
+    """Called by the point trackers with the clip (T, 3, H, W) uint8 they are about to track."""
+    global _current
+    if not enabled() or not isinstance(frames, torch.Tensor) or not frames.is_cuda or frames.dtype != torch.uint8 \
+            or frames.dim() != 4 or frames.shape[1] != 3:
+        return
+    cur = _current
+    if cur is not None and cur.frames.shape == frames.shape and cur.frames.device == frames.device \
+            and bool(torch.equal(cur.frames, frames)):
+        cur.next_idx = 0                          # the same clip again (a benchmark loop): keep its embeddings
+        return
+    _current = _Clip(frames.detach().clone())
+    stats["published"] += 1
+
+
+def clear() -> None:
+    global _current
+    _current = None
+
+
+def lookup(predictor, image_hwc: torch.Tensor):
+    """image_hwc: the frame ``set_image`` was given, already on the predictor's device, uint8 (H, W, 3) RGB.  Returns the
+    clip-embedding item of that frame (what ``encode_frames(...)[i]`` returns) or None."""
+    c = _current
+    if c is None or not enabled() or image_hwc.dtype != torch.uint8 or image_hwc.device != c.frames.device \
+            or tuple(image_hwc.shape) != (c.frames.shape[2], c.frames.shape[3], 3):
+        return None
+    chw = image_hwc.permute(2, 0, 1)
+    idx = None
+    T = c.frames.shape[0]
+    if c.next_idx < T and bool(torch.equal(c.frames[c.next_idx], chw)):
+        idx = c.next_idx
+    else:
+        same = (c.frames == chw[None]).flatten(1).all(dim=1).nonzero()
+        if same.numel():
+            idx = int(same[0])
+    if idx is None:
+        stats["misses"] += 1
+        return None
+    if c.feats is None or c.owner is None or c.owner() is not predictor:     # one predictor's embeddings at a time
+        c.feats = predictor.encode_frames(c.frames, chw=True)
+        c.owner = weakref.ref(predictor)
+        stats["clips_encoded"] += 1
+    c.next_idx = idx + 1
+    stats["hits"] += 1
+    return c.feats[idx]

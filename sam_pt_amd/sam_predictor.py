@@ -316,6 +316,13 @@ class SamPredictor:
             pass
 
     @_lib.on_device(lambda self, *a, **k: self.model.device)
+    def set_gemm_workgroups(self, per_xcd: int):
+        """Persistent GEMM workgroups per XCD (of 32 CUs) for the following ``encode_frames`` calls; 0 = one per CU.  See
+        sampt_vit_set_gemm_workgroups (include/sampt_hip.h)."""
+        self._ensure()
+        _lib.check(self._lib.sampt_vit_set_gemm_workgroups(self._vit, int(per_xcd)), "sampt_vit_set_gemm_workgroups")
+
+    @_lib.on_device(lambda self, *a, **k: self.model.device)
     def gemm_profile_begin(self):
         """Start timing every fp16 GEMM launch of the image encoder with HIP events (see sampt_vit_profile_begin)."""
         self._ensure()
@@ -372,12 +379,15 @@ class SamPredictor:
     # -- image encoder -------------------------------------------------------------------------------
     @torch.no_grad()
     @_lib.on_device(lambda self, *a, **k: self.model.device)
-    def encode_frames(self, frames: torch.Tensor, chw: bool = True, batch_events: Optional[list] = None):
+    def encode_frames(self, frames: torch.Tensor, chw: bool = True, batch_events: Optional[list] = None,
+                      gemm_workgroups=None):
         """frames uint8 (T,3,H,W) [chw] or (T,H,W,3) on device -> token-major embeddings (T, grid*grid, 256) f32; for an
         HQ-SAM model a ``ClipFeatures`` that also carries the per-frame HQ features (T, 16*grid*grid, 32).
         ``batch_events``: a list that receives one ``(end_frame, torch.cuda.Event)`` per encoder batch, recorded on the
         current stream when frames [.., end_frame) are done — lets a caller start decoding early frames on another stream
-        while later batches are still being encoded."""
+        while later batches are still being encoded.  ``gemm_workgroups``: persistent GEMM workgroups per XCD for the encoder
+        batches of this call — an int, or a sequence with one entry per batch (the last one repeats); see
+        ``set_gemm_workgroups``.  Reset to the default (one per CU) afterwards."""
         self._ensure()
         frames = frames.to(self._dev).contiguous()
         frames = self.transform.apply_image_torch(frames, chw=chw)      # PIL-exact resize when the longest side != img_size
@@ -391,9 +401,13 @@ class SamPredictor:
             hq = torch.empty((T, 16 * g * g, Cc // 8), dtype=torch.float32, device=self._dev)
             interm = torch.empty((min(Bm, T), g * g, self.model.cfg.embed_dim), dtype=torch.float32, device=self._dev)
         dead = self._dead_rows(frames, chw, H, W, self._vit_ws(min(Bm, T))) if self.skip_dead_rows else None
-        for t0 in range(0, T, Bm):
+        wgs = None if gemm_workgroups is None else ([int(gemm_workgroups)] if isinstance(gemm_workgroups, int)
+                                                      else [int(v) for v in gemm_workgroups])
+        for bi, t0 in enumerate(range(0, T, Bm)):
             B = min(Bm, T - t0)
             ws = self._vit_ws(B)
+            if wgs:
+                self.set_gemm_workgroups(wgs[min(bi, len(wgs) - 1)])
             if dead is not None:
                 _lib.check(self._lib.sampt_vit_encode_live(self._vit, _lib.ptr(frames[t0:t0 + B]), 1 if chw else 0, B, H, W,
                                                            _lib.ptr(out[t0:t0 + B]), _lib.ptr(interm), _lib.ptr(dead), 0,
@@ -416,6 +430,8 @@ class SamPredictor:
                 ev = torch.cuda.Event()
                 ev.record()
                 batch_events.append((t0 + B, ev))
+        if wgs:
+            self.set_gemm_workgroups(0)
         self.stats["encoded_frames"] += T
         return ClipFeatures(out, hq) if hq is not None else out
 
@@ -441,10 +457,15 @@ class SamPredictor:
         H, W = image.shape[:2]
         self._ensure()
         t = torch.as_tensor(np.ascontiguousarray(image), device=self._dev)
+        self.stats["set_image"] += 1
+        from . import prefetch
+        item = prefetch.lookup(self, t)          # a frame of the clip the tracker was given: batch-encoded once (prefetch.py)
+        if item is not None:
+            self.set_features(item, (H, W), self.transform.get_preprocess_shape(H, W, self.transform.target_length))
+            return
         t = self.transform.apply_image_torch(t)                      # identity when the longest side is already img_size
         feats = self.encode_frames(t[None], chw=False)
         self.set_features(feats[0], (H, W), tuple(t.shape[:2]))      # (ClipFeatures[0] for HQ-SAM)
-        self.stats["set_image"] += 1
 
     # -- prompt encoder + mask decoder ---------------------------------------------------------------
     @torch.no_grad()

@@ -24,6 +24,7 @@ restated ``rgb2lab`` (skimage absent: that one function is parity unpinned).
 """
 from __future__ import annotations
 
+import os
 import time
 from enum import IntEnum
 from typing import List, Optional
@@ -89,6 +90,10 @@ class SamPt(nn.Module):
         self.profile = {}
         self.compute_unused_query_masks = False        # fused path: see forward()
         self.overlap_tracker_and_encoder = True        # fused path only: tracker on a second HIP stream (see forward)
+        # persistent GEMM workgroups per XCD (of 32 CUs) for the encoder batches while the tracker runs beside them: an int or
+        # one entry per batch (the last repeats); None / 0 = every CU.  SAMPT_ENC_WGS="28,28,32" overrides (experiments).
+        env = os.environ.get("SAMPT_ENC_WGS")
+        self.encoder_gemm_workgroups_beside_tracker = [int(v) for v in env.split(",")] if env else 28
         # fused path only.  The decoder chain always runs on a third (non-default, hence hipGraph-capturable) stream after
         # the encoder; pipeline_decoder=True instead starts the chains of each encoder batch as soon as that batch is done,
         # and overlap_tracker_encoder_fnet=True moves the tracker's own encoder to the side stream too.  Both were
@@ -109,9 +114,13 @@ class SamPt(nn.Module):
     def forward(self, video):
         if self.training:
             raise NotImplementedError(f"{self._get_name()} does not support training...")
-        from . import _lib
+        from . import _lib, prefetch
+        fused = hasattr(self.sam_predictor, "encode_frames") and hasattr(self.sam_predictor, "track_decode")
         try:
             with _lib.device_guard(self.device):      # streams / events / launches all on the model's device
+                if fused:                             # the fused path holds the clip's embeddings itself
+                    with prefetch.suspended():
+                        return self._forward_impl(video)
                 return self._forward_impl(video)
         finally:                                      # never leave a clip's feature pyramid cached in the tracker
             if hasattr(self.point_tracker, "_prepared"):
@@ -177,7 +186,12 @@ class SamPt(nn.Module):
             sam_images = images if frame_ids is None else images[torch.as_tensor(frame_ids, device=images.device)]
             batch_events = [] if overlap else None
             self._mark("prepared")
-            feats = self.sam_predictor.encode_frames(sam_images, chw=True, batch_events=batch_events)   # embeddings in HBM
+            # the tracker's window rounds run BESIDE the encoder on the side stream: leave them whole CUs (a persistent GEMM
+            # workgroup owns its CU; measured on MI355X, profiles/r3_v3_timeline_wgs*.log: 32 / 30 workgroups per XCD
+            # 248 ms per clip with the tracker ending 24 ms after the encoder, 28 per XCD 229 ms)
+            reserve = self.encoder_gemm_workgroups_beside_tracker if overlap else None
+            kw = {"gemm_workgroups": reserve} if reserve else {}
+            feats = self.sam_predictor.encode_frames(sam_images, chw=True, batch_events=batch_events, **kw)   # embeddings in HBM
             self._mark("encoded")
             if overlap:
                 self._side_stream.wait_event(ready)

@@ -86,6 +86,52 @@ class FakeHip:
             vi_o[:, idx] = torch.sigmoid(vlog)
         return 0
 
+    def sampt_pips_track_workspace_bytes(self, h, n, out):
+        _set(out, 256)
+        return 0
+
+    def sampt_pips_track_f32(self, h, pyr, H0, W0, T, n, q, flip, q_host, flip_host, thr0, iters, evs, ev_lo, ev_hi, nchunks,
+                             traj, vis, ws, nbytes, stream, rounds):
+        """The device-side chain loop restated on the CPU (pips/tracker.py:42-153): window frames with the tail repeated,
+        write-back of frames 1..hi-1, threshold linking in float32 — over ``sampt_pips_update_f32`` above."""
+        S = 8
+        assert tuple(q.shape) == (n, 3) and tuple(flip.shape) == (n,) and tuple(traj.shape) == (T, n, 2) and nchunks == 0
+        traj.zero_(), vis.zero_()
+        cur = q[:, 0].long().clone()
+        ar = torch.arange(n)
+        traj[cur, ar], vis[cur, ar] = q[:, 1:], 1.0
+        feat_init = torch.zeros(n, 128)
+        r = 0
+        while True:
+            act = (cur < T - 1).nonzero().flatten()
+            if act.numel() == 0:
+                break
+            f = cur[act]
+            hi = torch.minimum(T - f, torch.tensor(S))
+            win = torch.minimum(f[:, None] + torch.arange(S)[None], (f + hi - 1)[:, None])
+            used = torch.where(flip[act].bool()[:, None], T - 1 - win, win)
+            xys = traj[f, act]
+            if r == 0:
+                out = torch.empty(act.numel(), 128)
+                self.sampt_pips_sample_feat_f32(pyr[0], H0, W0, used[:, 0].int(), xys / 4.0, act.numel(), out, None)
+                feat_init[act] = out
+            tr_o, vi_o = torch.empty(S, act.numel(), 2), torch.empty(S, act.numel())
+            self.sampt_pips_update_f32(h, pyr, H0, W0, used.int(), act.numel(), xys, feat_init[act], iters, tr_o, vi_o, None, 0, None)
+            for j, i in enumerate(act.tolist()):
+                fj, hj = int(f[j]), int(hi[j])
+                traj[fj + 1:fj + hj, i], vis[fj + 1:fj + hj, i] = tr_o[1:hj, j], vi_o[1:hj, j]
+                thr = torch.tensor(thr0, dtype=torch.float32)
+                earliest, last = fj + 1, fj + hj - 1
+                nxt = last
+                while bool(vis[nxt, i] <= thr):
+                    nxt -= 1
+                    if nxt < earliest:
+                        thr, nxt = thr - torch.tensor(0.02, dtype=torch.float32), last
+                cur[i] = nxt
+            r += 1
+        _set(rounds, r)
+        return 0
+
     # ------------------------------------------------------------------ SAM
     def sampt_vit_create(self, cfg_ref, names, ptrs, n, max_batch, out):
         self.calls["vit_create"] += 1

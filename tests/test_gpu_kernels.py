@@ -33,7 +33,11 @@ def ok(rc, what=""):
 
 
 @pytest.mark.parametrize("M,N,K,act", [(300, 200, 64, 0), (64, 1040, 512, 0), (1, 32, 256, 1), (4096, 128, 256, 0),
-                                         (130, 70, 520, 2), (16, 2048, 512, 2), (777, 513, 36, 0)])
+                                         (130, 70, 520, 2), (16, 2048, 512, 2), (777, 513, 36, 0),
+                                         # the thin kernel's shapes (K split over the waves of a workgroup): PIPS mixer
+                                         # fc1 / fc2 / input projection at 8 chains, 48 chains, decoder token rows
+                                         (64, 2048, 512, 2), (64, 512, 2048, 0), (64, 512, 520, 0), (384, 512, 2048, 2),
+                                         (360, 256, 2048, 1), (17, 36, 68, 0), (129, 1040, 72, 2)])
 def test_gemm_f32(lib, dev, M, N, K, act):
     g = torch.Generator().manual_seed(M * 7 + N)
     A = torch.randn(M, K, generator=g)

@@ -817,23 +817,6 @@ def test_decoder_image_side_gemms_both_arithmetics(dev, monkeypatch, f16x3):
     assert max_abs(l1, l0) < 3e-4 and max_abs(i1, i0) < 1e-4 and max_abs(m1, m0) < 3e-4
 
 
-@pytest.mark.skipif(os.environ.get("SAMPT_TEST_EXPERIMENTAL", "0") == "0",
-                    reason="opt-in experiment (SAMPT_PIPS_FUSE_REDUCE): run with SAMPT_TEST_EXPERIMENTAL=1")
-def test_pips_fused_splitk_reductions_opt_in(dev, pips_sd, clip, monkeypatch):
-    """the mixer's split-K reductions folded into their consumers (4 instead of 6 launches per block) —
-    the same additions in the same order, so trajectories and visibilities must not move."""
-    from sam_pt_amd.point_tracker import PipsPointTracker
-    frames, centres = clip
-    q = disc_queries(centres, n_pos=8, r=9.0)[None]
-    monkeypatch.delenv("SAMPT_PIPS_FUSE_REDUCE", raising=False)
-    tr0, vi0 = PipsPointTracker(state_dict=pips_sd)(frames[None].to(dev), q.to(dev))
-    monkeypatch.setenv("SAMPT_PIPS_FUSE_REDUCE", "1")
-    tr1, vi1 = PipsPointTracker(state_dict=pips_sd)(frames[None].to(dev), q.to(dev))
-    assert torch.equal(vi0, vi1) and max_abs(tr1, tr0) < 1e-3
-    assert torch.equal(torch.round(tr0), torch.round(tr1))
-    print("fused == unfused bitwise:", torch.equal(tr0, tr1))
-
-
 # ------------------------------------------------------------------------------------------ streams / hipGraph
 def test_track_decode_graph_replay_is_bitwise_eager(dev):
     """north_star "hipGraph capture of the per-frame decode": the chain of sampt_sam_track_decode replayed from a captured
@@ -905,3 +888,45 @@ def test_pipelined_decoder_stream_equals_serial(dev, pips_sd):
         for t in range(11):
             assert iou(a["logits"][m][t] > 0, b["logits"][m][t] > 0) >= 1 - 1e-3
     assert np.allclose(np.array(a["scores_per_frame"]), np.array(b["scores_per_frame"]), atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------ unchanged-SamPt fast path
+def test_reference_protocol_with_clip_embedding_prefetch_is_exact(dev, pips_sd, monkeypatch):
+    """SURVEY.md §7.1 / VERDICT r2 #4: under the reference protocol (tracker first, then per frame ``set_image(numpy)`` +
+    sequential ``predict_torch``; sam_pt.py:584-593, 848-858) ``set_image`` resolves to the embedding of the clip the tracker
+    was given, batch-encoded once.  Same logits bit for bit as with per-frame encoding; a frame that is not in the clip, or a
+    clip edited in place after the tracker saw it, takes the normal path."""
+    import bench
+    from sam_pt_amd import prefetch
+    from sam_pt_amd.point_tracker import PipsPointTracker
+    from sam_pt_amd.sam_predictor import SamHip, SamPredictor
+    from sam_pt_amd.sam_pt import SamPt
+    from sam_pt_amd.weights import SAM_CONFIGS
+    cfg = SAM_CONFIGS["vit_test"]
+    frames, centres = synthetic_clip(T=6, H=128, W=256, seed=3)
+    q = disc_queries(centres, n_pos=4, r=9.0)[None]
+    kw = dict(sam_iou_threshold=-1e9, positive_points_per_mask=4, negative_points_per_mask=0, iterative_refinement_iterations=2)
+    video = {"image": [f.to(dev) for f in frames], "target_hw": (128, 256), "query_points": q}
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SAMPT_PREFETCH", mode)
+        prefetch.clear()
+        for k in prefetch.stats:
+            prefetch.stats[k] = 0
+        pred = SamPredictor(SamHip(config=cfg, seed=72, precision="f16", max_batch=4).to(dev))
+        model = SamPt(PipsPointTracker(state_dict=pips_sd), bench.ReferenceApiPredictor(pred), **kw).eval()
+        outs[mode] = model(video)
+        if mode == "1":
+            # query-mask pass (sam_pt.py:181): 1 set_image before the tracker has published anything -> a miss; then 6 hits
+            assert prefetch.stats["hits"] == 6 and prefetch.stats["clips_encoded"] == 1, prefetch.stats
+            assert pred.stats["encoded_frames"] <= 6 + 1 + 1, pred.stats      # clip + query frame (+ dead-row cache build)
+            other = (frames[0].permute(1, 2, 0).numpy().copy())
+            other[5, 7, 1] ^= 1                                            # one bit off: not a frame of the clip
+            h0 = prefetch.stats["hits"]
+            pred.set_image(other)
+            assert prefetch.stats["hits"] == h0
+        else:
+            assert prefetch.stats["hits"] == 0
+    for a, b in zip(outs["0"]["logits"], outs["1"]["logits"]):
+        assert torch.equal(a.cpu(), b.cpu())
+    assert torch.equal(outs["0"]["trajectories"], outs["1"]["trajectories"])
