@@ -311,7 +311,9 @@ int sampt_gemm_ex(int dtype, const void* A_dev, const void* W_dev, const float* 
                   const int32_t* a_rowmap_dev, int res_mod, int ldr, sampt_stream_t stream);
 /* NHWC convolution as implicit GEMM: x [n][H][W][Cin], w [Cout][KH][KW][Cin], y [n][OH][OW][Cout] (f32 out).
  * dtype 3 = fp32-grade result on the fp16 matrix pipe: x is f32, w_dev is half [2][Cout][KH*KW*Cin] = the weights times
- * 2^8 split as hi = fp16(w), lo = fp16(w - hi) (sam_pt_amd/pack.py:split_f16x3); Cin % 32 == 0, Cout % 4 == 0. */
+ * 2^8 split as hi = fp16(w), lo = fp16(w - hi) (sam_pt_amd/pack.py:split_f16x3); Cin % 32 == 0, Cout % 4 == 0.
+ * dtype 4 = the same with PRE-SPLIT activations: x_dev is half [2][n][H][W][Cin] = hi plane fp16(x), lo plane fp16(x - hi)
+ * (what the tracker encoder's InstanceNorm writes); all four operand planes then reach LDS by LDS-DMA. */
 int sampt_conv2d_nhwc(int dtype, const void* x_dev, const void* w_dev, const float* bias_dev, float* y_dev, int n,
                       int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, sampt_stream_t stream);
 int sampt_instance_norm_nhwc(float* x_dev, int n, int hw, int C, float eps, int relu, const float* skip_dev,

@@ -129,6 +129,49 @@ __global__ __launch_bounds__(NW * 64, 2) void k_flash_f16(const half_t* __restri
   const int qblk = blockIdx.x * QT;
   const int ql = wave * 32 + li;
   const int q = qblk + ql;
+  // ---- key tiles.  A tile has 64 slots holding KTV = RPT*SG keys = RPT whole rows of the SG x SG token grid (global
+  //      blocks: 1 row of 64; 14x14 windows: 4 rows = 56 keys + 8 pad slots), so that the rel_w bias of a lane's 32
+  //      score slots is the same for every tile (registers) and rel_h is RPT values per tile.  Pad slots and rows
+  //      beyond the grid get a -inf bias (their K/V rows are clamped copies of valid keys: finite, weight 0).
+  //      Everything is kept in the log2 domain: s2 = s*scale*log2e + bias*log2e, p = exp2(s2 - m2) (one v_exp_f32).
+  constexpr int RPT = SG >= 64 ? 1 : 64 / SG, KTV = SG >= 64 ? 64 : RPT * SG;
+  constexpr float LOG2E = 1.4426950408889634f;
+  const float c2 = scale * LOG2E;
+  constexpr int TV = 64 * (HD / 8);                 // 16-byte vectors per K (or V) tile
+  constexpr int LI = (TV + NT - 1) / NT;            // vectors per thread
+  h8 kreg[LI], vreg[LI];
+  // register-staged K/V pipeline: the global loads of tile t+1 are issued before tile t is multiplied and written
+  // to LDS (K row-major, V transposed) only after the barrier that retires tile t
+  auto load_tile = [&](int kt0) {
+#pragma unroll
+    for (int i = 0; i < LI; ++i) {
+      const int v = tid + i * NT;
+      if (v < TV) {
+        const int kr = v / (HD / 8), kv = v - kr * (HD / 8);
+        const int krow = min(kt0 + min(kr, KTV - 1), N - 1);
+        kreg[i] = *(const h8*)(qkv + (tok0 + krow) * 3 * D + D + h * HD + kv * 8);
+        const int vr = v & 63, dv = v >> 6;
+        const int vrow = min(kt0 + min(vr, KTV - 1), N - 1);
+        vreg[i] = *(const h8*)(qkv + (tok0 + vrow) * 3 * D + 2 * D + h * HD + dv * 8);
+      }
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < LI; ++i) {
+      const int v = tid + i * NT;
+      if (v < TV) {
+        const int kr = v / (HD / 8), kv = v - kr * (HD / 8);
+        *(h8*)&Ks[kr][kv * 8] = kreg[i];
+        const int vr = v & 63, dv = v >> 6;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) Vt[dv * 8 + e][vr] = vreg[i][e];
+      }
+    }
+  };
+  // the first K / V tile is requested before anything else: its latency overlaps the Q loads and the rel-pos prologue
+  load_tile(0);
+
   // ---- prologue: zero the unused V^T rows, Q fragments, then the decomposed rel-pos tables of THIS wave's 32 queries
   //      computed with MFMA straight into LDS (fp16): G[rho][q] = <rel_pos[rho], q_vec> for all 2*SG-1 table rows, and
   //      rel_h[q][kh] = G_h[qh - kh + SG-1][q], rel_w[q][kw] = G_w[qw - kw + SG-1][q]   (App. A-3) — no HBM round trip.
@@ -195,47 +238,6 @@ __global__ __launch_bounds__(NW * 64, 2) void k_flash_f16(const half_t* __restri
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  // ---- key tiles.  A tile has 64 slots holding KTV = RPT*SG keys = RPT whole rows of the SG x SG token grid (global
-  //      blocks: 1 row of 64; 14x14 windows: 4 rows = 56 keys + 8 pad slots), so that the rel_w bias of a lane's 32
-  //      score slots is the same for every tile (registers) and rel_h is RPT values per tile.  Pad slots and rows
-  //      beyond the grid get a -inf bias (their K/V rows are clamped copies of valid keys: finite, weight 0).
-  //      Everything is kept in the log2 domain: s2 = s*scale*log2e + bias*log2e, p = exp2(s2 - m2) (one v_exp_f32).
-  constexpr int RPT = SG >= 64 ? 1 : 64 / SG, KTV = SG >= 64 ? 64 : RPT * SG;
-  constexpr float LOG2E = 1.4426950408889634f;
-  const float c2 = scale * LOG2E;
-  constexpr int TV = 64 * (HD / 8);                 // 16-byte vectors per K (or V) tile
-  constexpr int LI = (TV + NT - 1) / NT;            // vectors per thread
-  h8 kreg[LI], vreg[LI];
-  // register-staged K/V pipeline: the global loads of tile t+1 are issued before tile t is multiplied and written
-  // to LDS (K row-major, V transposed) only after the barrier that retires tile t
-  auto load_tile = [&](int kt0) {
-#pragma unroll
-    for (int i = 0; i < LI; ++i) {
-      const int v = tid + i * NT;
-      if (v < TV) {
-        const int kr = v / (HD / 8), kv = v - kr * (HD / 8);
-        const int krow = min(kt0 + min(kr, KTV - 1), N - 1);
-        kreg[i] = *(const h8*)(qkv + (tok0 + krow) * 3 * D + D + h * HD + kv * 8);
-        const int vr = v & 63, dv = v >> 6;
-        const int vrow = min(kt0 + min(vr, KTV - 1), N - 1);
-        vreg[i] = *(const h8*)(qkv + (tok0 + vrow) * 3 * D + 2 * D + h * HD + dv * 8);
-      }
-    }
-  };
-  auto store_tile = [&]() {
-#pragma unroll
-    for (int i = 0; i < LI; ++i) {
-      const int v = tid + i * NT;
-      if (v < TV) {
-        const int kr = v / (HD / 8), kv = v - kr * (HD / 8);
-        *(h8*)&Ks[kr][kv * 8] = kreg[i];
-        const int vr = v & 63, dv = v >> 6;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) Vt[dv * 8 + e][vr] = vreg[i][e];
-      }
-    }
-  };
-  load_tile(0);
   __syncthreads();                                   // rel tables of all waves are in LDS
   float relw2[32];                                   // log2e * rel_w bias of this lane's 32 slots (tile-invariant)
 #pragma unroll
@@ -376,6 +378,10 @@ int vit_flash_attention_f16(const half_t* qkv, const float* relh, const float* r
   else if (S == 64 && hd == 64) FL(64, 4, 64);
   // (a 7-wave workgroup per (window, head) — 224 query slots for the 196 tokens instead of 2 x 128 — measured 4 % slower,
   //  profiles/r2_v7_attn_nw7.log: the K/V staging is the same and 188 VGPRs leave one workgroup per SIMD set)
+  // (a 7-wave workgroup per (window, head) — 224 query slots for the 196 tokens instead of 2 x 128 — measured 4 % slower,
+  //  profiles/r2_v7_attn_nw7.log; an 8-wave one whose two query-less waves only help staging the K / V tiles, staged once per
+  //  window instead of twice: neutral, 261.2 vs 261.0 us, profiles/r3_v15_bench_attn_nw8.log — the kernel is bound by the
+  //  latency of its register-staged tiles at two waves per SIMD, not by the staging work)
   else if (S == 14 && hd == 80) FL(80, 4, 14);
   else if (S == 14 && hd == 64) FL(64, 4, 14);
   else if (S == 16 && hd == 32) FL(32, 4, 16);   // reduced test geometry (vit_test)

@@ -580,9 +580,10 @@ int sampt_conv2d_nhwc(int dtype, const void* x, const void* w, const float* bias
   p.A = x, p.W = w, p.bias = bias, p.C = y;
   p.M = n * p.OH * p.OW, p.N = Cout, p.K = KH * KW * Cin, p.ldw = p.K, p.ldc = Cout;
   p.conv = 1, p.cH = H, p.cW = W, p.cC = Cin, p.KH = KH, p.KW = KW, p.cstride = stride, p.cpad = pad;
-  if (dtype == 3) {
+  if (dtype == 3 || dtype == 4) {
     p.W_lo = (const half_t*)w + (size_t)Cout * p.K;
     p.alpha = 1.0f / (float)(1 << F16X3_WSHIFT);
+    if (dtype == 4) p.A_lo = (const half_t*)x + (size_t)n * H * W * Cin;   // activations pre-split: [2][n][H][W][Cin] halves
     return conv_f16x3(p, (hipStream_t)stream);
   }
   return dtype == 0 ? gemm_f32(p, (hipStream_t)stream) : gemm_f16(p, (hipStream_t)stream);

@@ -23,12 +23,11 @@ namespace sampt {
 
 // PF = prefetch distance in K slabs: the global loads of slab kt + PF are issued while slab kt is multiplied (PF register
 // sets; the split into fp16 planes happens when a set is stored to LDS, one slab ahead of its use).
-template <int BM, int BN, int PF, bool AHL = false>
+template <int BM, int BN, int PF>
 __global__ __launch_bounds__(256) void k_conv_f16x3(GemmP p) {
   constexpr int BK = 32, LDH = BK + 8;
   constexpr int WTM = BM / 2, WTN = BN / 2, FM = WTM / 16, FN = WTN / 16;
-  constexpr int VW = AHL ? 8 : 4, VPR = BK / VW;       // channels per staged vector (float4, or h8 + h8), vectors per row
-  constexpr int A_IT = BM * VPR / 256;                 // vectors per thread and slab
+  constexpr int A_IT = BM * 8 / 256;                   // float4 (4 k) vectors per thread and slab
   constexpr int B_VEC = BN * 4, B_IT = (B_VEC + 255) / 256;   // h8 (8 k) vectors per plane
   static_assert(WTN % 16 == 0 && WTM % 16 == 0, "wave tile must be made of 16x16 fragments");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];   // 2 * (2 BM + 2 BN) * LDH halves (<= 80 KiB)
@@ -43,8 +42,6 @@ __global__ __launch_bounds__(256) void k_conv_f16x3(GemmP p) {
   const int ntn = (p.N + BN - 1) / BN;
   const int m0 = (int)(blockIdx.x / ntn) * BM, n0 = (int)(blockIdx.x % ntn) * BN;
   const float* __restrict__ A = (const float*)p.A;
-  const half_t* __restrict__ Ahp = (const half_t*)p.A;       // AHL: the two planes
-  const half_t* __restrict__ Alp = (const half_t*)p.A_lo;
   const half_t* __restrict__ Wh = (const half_t*)p.W;
   const half_t* __restrict__ Wl = (const half_t*)p.W_lo;
 
@@ -54,7 +51,7 @@ __global__ __launch_bounds__(256) void k_conv_f16x3(GemmP p) {
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
     const int v = tid + i * 256;
-    a_row[i] = v / VPR, a_kv[i] = (v % VPR) * VW;
+    a_row[i] = v >> 3, a_kv[i] = (v & 7) * 4;
     const int m = m0 + a_row[i];
     a_ok[i] = m < p.M;
     const int ohw = p.OH * p.OW;
@@ -67,28 +64,17 @@ __global__ __launch_bounds__(256) void k_conv_f16x3(GemmP p) {
   // filter tap / channel offset of the slab being LOADED (uniform over the workgroup)
   int l_ky = 0, l_kx = 0, l_ci = 0, l_k = 0;
 
-  struct AReg {             // one staged vector: a float4 to split (f32 activations) or its two fp16 halves (AHL)
-    float4 f;
-    h8 hi, lo;
-  };
-  AReg ra0[A_IT], ra1[PF > 1 ? A_IT : 1];
+  float4 ra0[A_IT], ra1[PF > 1 ? A_IT : 1];
   h8 rbh0[B_IT], rbl0[B_IT], rbh1[PF > 1 ? B_IT : 1], rbl1[PF > 1 ? B_IT : 1];
-  auto load_slab = [&](AReg* ra, h8* rbh, h8* rbl) {
+  auto load_slab = [&](float4* ra, h8* rbh, h8* rbl) {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       const int iy = a_iy0[i] + l_ky, ix = a_ix0[i] + l_kx;
       const bool ok = a_ok[i] && iy >= 0 && iy < p.cH && ix >= 0 && ix < p.cW;
       // branch-free: out-of-image taps read the tensor's first pixel and are zeroed afterwards (a branch per vector
       // makes hipcc fence every load)
-      const long off = ok ? a_off[i] + ((long)iy * p.cW + ix) * p.cC + l_ci + a_kv[i] : 0;
-      if constexpr (AHL) {
-        const h8 vh = *(const h8*)(Ahp + off), vl = *(const h8*)(Alp + off);
-        ra[i].hi = ok ? vh : (h8){0, 0, 0, 0, 0, 0, 0, 0};
-        ra[i].lo = ok ? vl : (h8){0, 0, 0, 0, 0, 0, 0, 0};
-      } else {
-        const float4 v = *(const float4*)(A + off);
-        ra[i].f = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
+      const float4 v = *(const float4*)(A + (ok ? a_off[i] + ((long)iy * p.cW + ix) * p.cC + l_ci + a_kv[i] : 0));
+      ra[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
@@ -106,20 +92,15 @@ __global__ __launch_bounds__(256) void k_conv_f16x3(GemmP p) {
       if (++l_kx == p.KW) l_kx = 0, ++l_ky;
     }
   };
-  auto store_slab = [&](int buf, const AReg* ra, const h8* rbh, const h8* rbl) {
+  auto store_slab = [&](int buf, const float4* ra, const h8* rbh, const h8* rbl) {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-      if constexpr (AHL) {
-        *(h8*)&Ah[buf][a_row[i]][a_kv[i]] = ra[i].hi;
-        *(h8*)&Al[buf][a_row[i]][a_kv[i]] = ra[i].lo;
-      } else {
-        const float4 v = ra[i].f;
-        const h4 hi = {(half_t)v.x, (half_t)v.y, (half_t)v.z, (half_t)v.w};
-        const h4 lo = {(half_t)(v.x - (float)hi[0]), (half_t)(v.y - (float)hi[1]), (half_t)(v.z - (float)hi[2]),
-                       (half_t)(v.w - (float)hi[3])};
-        *(h4*)&Ah[buf][a_row[i]][a_kv[i]] = hi;
-        *(h4*)&Al[buf][a_row[i]][a_kv[i]] = lo;
-      }
+      const float4 v = ra[i];
+      const h4 hi = {(half_t)v.x, (half_t)v.y, (half_t)v.z, (half_t)v.w};
+      const h4 lo = {(half_t)(v.x - (float)hi[0]), (half_t)(v.y - (float)hi[1]), (half_t)(v.z - (float)hi[2]),
+                     (half_t)(v.w - (float)hi[3])};
+      *(h4*)&Ah[buf][a_row[i]][a_kv[i]] = hi;
+      *(h4*)&Al[buf][a_row[i]][a_kv[i]] = lo;
     }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
@@ -218,6 +199,152 @@ __global__ __launch_bounds__(256) void k_conv_f16x3(GemmP p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same convolution for PRE-SPLIT activations (p.A = hi plane, p.A_lo = lo plane: fp16 NHWC, written by the producing
+// InstanceNorm): with ready-made halves in memory all four operand planes go HBM -> LDS by LDS-DMA
+// (`global_load_lds_dwordx4`, no VGPR staging, no ds_write pass, no split arithmetic), the slab loop is the single-buffer
+// "issue, wait, barrier, multiply" of gemm_f16.hip and the kernel is light enough (24 - 32 KiB of LDS, <= 128 VGPRs) for four
+// workgroups per CU to hide each other's DMA latency.  128 x BN x 32 tile, 4 waves (2 x 2), K slab = 32 channels of one
+// filter tap (Cin % 32 == 0).  LDS rows are 64 B (one slab row of one plane); a DMA instruction lands 16 rows; the image of
+// an instruction is linear (M0 base + lane * 16), so the bank swizzle sits on the SOURCE side: the lane that fills LDS chunk
+// position q of row r fetches source chunk q ^ F[(r >> 2) & 3], F = {0, 3, 2, 1}, and fragment reads apply the same XOR
+// (every ds_read_b128 lane group then touches 16 distinct 16-byte slots).  Taps outside the image read a page of zeros.
+// ---------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(64))) half_t g_conv_zero_page[64];
+
+template <int BN>
+__global__ __launch_bounds__(256, BN >= 128 ? 3 : 4) void k_conv_f16x3_dma(GemmP p) {
+  constexpr int BM = 128, BK = 32, ROWB = BK * 2;            // bytes per LDS row
+  constexpr int WTM = 64, WTN = BN / 2, FM = WTM / 16, FN = WTN / 16;
+  constexpr int NBP = 2 * BN / 16;                           // B pieces (16 rows each) over both planes
+  static_assert(NBP % 4 == 0, "B pieces must divide over the 4 waves");
+  __shared__ __attribute__((aligned(1024))) char lds[(2 * BM + 2 * BN) * ROWB];   // [A hi | A lo | B hi | B lo]
+  constexpr int OFF_AL = BM * ROWB, OFF_BH = 2 * BM * ROWB, OFF_BL = OFF_BH + BN * ROWB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntn = (p.N + BN - 1) / BN;
+  const int m0 = (int)(blockIdx.x / ntn) * BM, n0 = (int)(blockIdx.x % ntn) * BN;
+  const char* __restrict__ Ah = (const char*)p.A;
+  const char* __restrict__ Al = (const char*)p.A_lo;
+  const char* __restrict__ Wh = (const char*)p.W;
+  const char* __restrict__ Wl = (const char*)p.W_lo;
+  const char* zero = (const char*)g_conv_zero_page;
+
+  // DMA roles: lane l of an instruction fills row (l >> 2), chunk position (l & 3) of its 16-row piece
+  const int prow = lane >> 2;
+  const int fsw = (4 - (lane >> 4)) & 3;                     // F[(row >> 2) & 3] with (row >> 2) & 3 == lane >> 4
+  const int csrc = ((lane & 3) ^ fsw) * 16;                  // byte offset of the source chunk inside the 64-byte slab row
+  // A: this wave fills pieces 2*wave, 2*wave + 1 of both planes -> two tile rows per lane
+  long a_base[2];
+  int a_iy0[2], a_ix0[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + (2 * wave + i) * 16 + prow;
+    const int ohw = p.OH * p.OW;
+    const int mm = m < p.M ? m : p.M - 1;
+    const int img = mm / ohw, rem = mm - img * ohw;
+    const int oy = rem / p.OW, ox = rem - oy * p.OW;
+    a_base[i] = (long)img * p.cH * p.cW * p.cC;
+    a_iy0[i] = m < p.M ? oy * p.cstride - p.cpad : -(1 << 28);     // rows beyond M: never inside the image
+    a_ix0[i] = ox * p.cstride - p.cpad;
+  }
+  // B: pieces q = wave + 4 j over [hi plane pieces | lo plane pieces]
+  long b_off[NBP / 4];
+#pragma unroll
+  for (int j = 0; j < NBP / 4; ++j) {
+    const int q = wave + 4 * j, piece = q % (BN / 16);
+    int n = n0 + piece * 16 + prow;
+    if (n > p.N - 1) n = p.N - 1;
+    b_off[j] = ((long)n * p.ldw) * 2 + csrc;
+  }
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int lr = lane & 15, lq = lane >> 4;
+  const int rsw = ((lq ^ ((4 - ((lr >> 2) & 3)) & 3)) * 16);  // swizzled chunk of this lane's fragment rows
+  const int a_rd = (wm * WTM + lr) * ROWB + rsw, b_rd = OFF_BH + (wn * WTN + lr) * ROWB + rsw;
+
+  const int nk = p.K / BK;
+  int l_ky = 0, l_kx = 0, l_ci = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt > 0) __syncthreads();                               // everyone done reading the previous slab
+    // ---- issue the slab: A rows (tap l_ky, l_kx; channels l_ci .. +31), W rows (k = kt * 32 .. +31)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int iy = a_iy0[i] + l_ky, ix = a_ix0[i] + l_kx;
+      const bool ok = iy >= 0 && iy < p.cH && ix >= 0 && ix < p.cW;
+      const long off = (a_base[i] + ((long)iy * p.cW + ix) * p.cC + l_ci) * 2 + csrc;
+      const char* sh = ok ? Ah + off : zero + csrc;
+      const char* sl = ok ? Al + off : zero + csrc;
+      char* dst = lds + (2 * wave + i) * 16 * ROWB;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sh, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sl, (__attribute__((address_space(3))) void*)(dst + OFF_AL), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < NBP / 4; ++j) {
+      const int q = wave + 4 * j;                                // uniform
+      const bool lo = q >= BN / 16;
+      const int piece = lo ? q - BN / 16 : q;
+      const char* src = (lo ? Wl : Wh) + b_off[j] + (long)kt * (BK * 2);
+      char* dst = lds + (lo ? OFF_BL : OFF_BH) + piece * 16 * ROWB;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+    l_ci += BK;
+    if (l_ci == p.cC) {
+      l_ci = 0;
+      if (++l_kx == p.KW) l_kx = 0, ++l_ky;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // ---- multiply: hi*lo + lo*hi + hi*hi per fragment (operands swapped: the fragment is C^T, see the epilogue)
+    h8 ah[FM], al[FM];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      ah[i] = *(const h8*)(lds + a_rd + i * 16 * ROWB);
+      al[i] = *(const h8*)(lds + OFF_AL + a_rd + i * 16 * ROWB);
+    }
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const h8 bh = *(const h8*)(lds + b_rd + j * 16 * ROWB);
+      const h8 bl = *(const h8*)(lds + (OFF_BL - OFF_BH) + b_rd + j * 16 * ROWB);
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, al[i], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ah[i], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, ah[i], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: lane (lr, lq) holds channels lq*4 .. lq*4+3 of output pixel lr of each fragment
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int row = m0 + wm * WTM + i * 16 + lr;
+    if (row >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int col = n0 + wn * WTN + j * 16 + lq * 4;
+      if (col >= p.N) continue;
+      float4 v = make_float4(acc[i][j][0] * p.alpha, acc[i][j][1] * p.alpha, acc[i][j][2] * p.alpha, acc[i][j][3] * p.alpha);
+      if (p.bias) {
+        const float4 b = *(const float4*)(p.bias + col);
+        v.x += b.x, v.y += b.y, v.z += b.z, v.w += b.w;
+      }
+      v.x = apply_act(v.x, p.act), v.y = apply_act(v.y, p.act), v.z = apply_act(v.z, p.act), v.w = apply_act(v.w, p.act);
+      if (p.res) {
+        const long rrow = p.res_mod > 0 ? row % p.res_mod : row;
+        const float4 r = *(const float4*)(p.res + rrow * p.ldr + col);
+        v.x += r.x, v.y += r.y, v.z += r.z, v.w += r.w;
+      }
+      *(float4*)((float*)p.C + (long)row * p.ldc + col) = v;
+    }
+  }
+}
+
 int conv_f16x3(const GemmP& p_in, hipStream_t s) {
   GemmP p = p_in;
   if (!p.A || !p.W || !p.W_lo || !p.C || p.M <= 0 || p.N <= 0) return SAMPT_ERR_ARG;
@@ -227,6 +354,16 @@ int conv_f16x3(const GemmP& p_in, hipStream_t s) {
   if (((uintptr_t)p.A | (uintptr_t)p.A_lo | (uintptr_t)p.W | (uintptr_t)p.W_lo | (uintptr_t)p.C | (uintptr_t)p.bias |
        (uintptr_t)p.res) & 15)
     return SAMPT_ERR_ARG;
+  if (p.A_lo) {   // pre-split activations: the LDS-DMA kernel
+    if (p.shuf_g) return SAMPT_ERR_UNSUPPORTED;
+    const int BNd = p.N <= 64 ? 64 : (p.N <= 96 ? 96 : 128);
+    dim3 gridd((unsigned)((long)cdiv(p.N, BNd) * cdiv(p.M, 128))), blockd(256);
+    if (BNd == 64) hipLaunchKernelGGL(k_conv_f16x3_dma<64>, gridd, blockd, 0, s, p);
+    else if (BNd == 96) hipLaunchKernelGGL(k_conv_f16x3_dma<96>, gridd, blockd, 0, s, p);
+    else hipLaunchKernelGGL(k_conv_f16x3_dma<128>, gridd, blockd, 0, s, p);
+    SAMPT_CHECK_LAUNCH("conv_f16x3_dma");
+    return SAMPT_OK;
+  }
   const int BN = p.N <= 32 ? 32 : (p.N <= 64 ? 64 : (p.N <= 96 ? 96 : 128));
   const size_t lds = (size_t)2 * (2 * 128 + 2 * BN) * (32 + 8) * sizeof(half_t);
   // SAMPT_CONV_PF=2: two slabs in flight (two register sets).  Measured slower everywhere — decode chain 24.70 vs 24.34 ms,
@@ -237,9 +374,7 @@ int conv_f16x3(const GemmP& p_in, hipStream_t s) {
   if (!raised) {  // 128 x 128 tiles need 80 KiB, above the default 64 KiB dynamic-LDS limit (gfx950: 160 KiB per CU)
     const void* fns[] = {(const void*)k_conv_f16x3<128, 64, 1>,  (const void*)k_conv_f16x3<128, 96, 1>,
                          (const void*)k_conv_f16x3<128, 128, 1>, (const void*)k_conv_f16x3<128, 64, 2>,
-                         (const void*)k_conv_f16x3<128, 96, 2>,  (const void*)k_conv_f16x3<128, 128, 2>,
-                         (const void*)k_conv_f16x3<128, 64, 1, true>, (const void*)k_conv_f16x3<128, 96, 1, true>,
-                         (const void*)k_conv_f16x3<128, 128, 1, true>};
+                         (const void*)k_conv_f16x3<128, 96, 2>,  (const void*)k_conv_f16x3<128, 128, 2>};
     for (const void* f : fns)
       if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) return SAMPT_ERR_HIP;
     raised = true;
@@ -247,8 +382,7 @@ int conv_f16x3(const GemmP& p_in, hipStream_t s) {
   dim3 grid((unsigned)((long)cdiv(p.N, BN) * cdiv(p.M, 128))), block(256);
 #define CONV_LAUNCH(BNv)                                                                              \
   do {                                                                                                \
-    if (p.A_lo) hipLaunchKernelGGL((k_conv_f16x3<128, BNv, 1, true>), grid, block, lds, s, p);       \
-    else if (pf >= 2) hipLaunchKernelGGL((k_conv_f16x3<128, BNv, 2>), grid, block, lds, s, p);       \
+    if (pf >= 2) hipLaunchKernelGGL((k_conv_f16x3<128, BNv, 2>), grid, block, lds, s, p);       \
     else hipLaunchKernelGGL((k_conv_f16x3<128, BNv, 1>), grid, block, lds, s, p);                    \
   } while (0)
   if (BN == 32) CONV_LAUNCH(32);   // (51 KiB: under the default limit)

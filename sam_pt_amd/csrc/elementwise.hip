@@ -245,8 +245,12 @@ __device__ __forceinline__ void bilinear_src(int d, int in, int out, int align, 
   l1 = fminf(fmaxf(src - (float)i0, 0.f), 1.f);
 }
 
+// HL: the result goes out as two fp16 planes (hi = fp16(v), lo = fp16(v - hi); same [n][dh][dw][dstC] layout) instead of f32 —
+// the operand format of the split-fp16 convolution that consumes the concatenated map (conv_f16x3.hip, LDS-DMA kernel)
+template <bool HL>
 __global__ void k_resize_bilinear_nhwc(const float4* __restrict__ src, int sh, int sw, int c4n, float4* __restrict__ dst,
-                                       int dh, int dw, int dst_c4n, int c_off4, int align, long total) {
+                                       int dh, int dw, int dst_c4n, int c_off4, int align, long total,
+                                       h4* __restrict__ dst_hi, h4* __restrict__ dst_lo) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   int c = (int)(i % c4n);
@@ -268,15 +272,27 @@ __global__ void k_resize_bilinear_nhwc(const float4* __restrict__ src, int sh, i
   o.y = hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
   o.z = hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z);
   o.w = hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
-  dst[((n * dh + y) * dw + x) * dst_c4n + c_off4 + c] = o;
+  const long di = ((n * dh + y) * dw + x) * dst_c4n + c_off4 + c;
+  if (HL) {
+    const h4 hi = {(half_t)o.x, (half_t)o.y, (half_t)o.z, (half_t)o.w};
+    const h4 lo = {(half_t)(o.x - (float)hi[0]), (half_t)(o.y - (float)hi[1]), (half_t)(o.z - (float)hi[2]),
+                   (half_t)(o.w - (float)hi[3])};
+    dst_hi[di] = hi, dst_lo[di] = lo;
+  } else {
+    dst[di] = o;
+  }
 }
 
 int resize_bilinear_nhwc(const float* src, int n, int sh, int sw, int C, float* dst, int dh, int dw, int dstC,
-                         int c_off, int align_corners, hipStream_t s) {
+                         int c_off, int align_corners, hipStream_t s, half_t* dst_hi, half_t* dst_lo) {
   if (C % 4 || dstC % 4 || c_off % 4) return SAMPT_ERR_ARG;
   long total = (long)n * dh * dw * (C / 4);
-  hipLaunchKernelGGL(k_resize_bilinear_nhwc, dim3(cdiv(total, 256)), dim3(256), 0, s, (const float4*)src, sh, sw, C / 4,
-                     (float4*)dst, dh, dw, dstC / 4, c_off / 4, align_corners, total);
+  if (dst_hi && dst_lo)
+    hipLaunchKernelGGL(k_resize_bilinear_nhwc<true>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const float4*)src, sh, sw, C / 4,
+                       (float4*)nullptr, dh, dw, dstC / 4, c_off / 4, align_corners, total, (h4*)dst_hi, (h4*)dst_lo);
+  else
+    hipLaunchKernelGGL(k_resize_bilinear_nhwc<false>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const float4*)src, sh, sw, C / 4,
+                       (float4*)dst, dh, dw, dstC / 4, c_off / 4, align_corners, total, (h4*)nullptr, (h4*)nullptr);
   SAMPT_CHECK_LAUNCH("resize_bilinear_nhwc");
   return SAMPT_OK;
 }

@@ -161,15 +161,19 @@ int PipsEngine::fnet(const uint8_t* frames, int nf, int H, int W, float* const o
     scale_out[li] = cur, sh[li] = h, sw[li] = w;
   }
   const int H4 = H / stride, W4 = W / stride;
-  float* cat = ws.f32((size_t)nf * H4 * W4 * 416);
+  // the 4 scales resized to H/4 x W/4 and concatenated (pips.py:266-281): written straight as split fp16 planes when the
+  // 416 -> 256 convolution takes them (same bytes as the f32 map, which is then never materialised)
+  Planes cat_p = planes((size_t)nf * H4 * W4 * 416, conv2);
+  float* cat = cat_p.hi ? nullptr : ws.f32((size_t)nf * H4 * W4 * 416);
   const int coff[4] = {0, 64, 160, 288};
   if (!dry)
     for (int li = 0; li < 4; ++li)
-      SAMPT_TRY(resize_bilinear_nhwc(scale_out[li], nf, sh[li], sw[li], dims[li], cat, H4, W4, 416, coff[li], 1, s));
+      SAMPT_TRY(resize_bilinear_nhwc(scale_out[li], nf, sh[li], sw[li], dims[li], cat, H4, W4, 416, coff[li], 1, s, cat_p.hi,
+                                     cat_p.lo));
   float* y = ws.f32((size_t)nf * H4 * W4 * 256);
   int oh, ow;
   Planes y_p = planes((size_t)nf * H4 * W4 * 256, conv3);
-  SAMPT_TRY(run_conv(conv2, cat, nf, H4, W4, y, oh, ow, dry, s));
+  SAMPT_TRY(run_conv(conv2, cat, nf, H4, W4, y, oh, ow, dry, s, cat_p));
   SAMPT_TRY(run_inorm(nc, y, nf, (long)oh * ow, 256, 1, nullptr, dry, s, y_p));
   SAMPT_TRY(run_conv(conv3, y, nf, oh, ow, out[0], oh, ow, dry, s, y_p));
   if (!dry) {

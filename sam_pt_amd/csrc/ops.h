@@ -20,8 +20,10 @@ int instnorm_stats(const float* x, int nimg, long hw, int C, float eps, double* 
 int instnorm_apply(const float* x, const float* mean_rstd, const float* skip, float* y, int nimg, long hw, int C,
                    int relu1, hipStream_t s, half_t* y_hi = nullptr, half_t* y_lo = nullptr);
 // bilinear resize of an NHWC f32 tensor into channels [c_off, c_off+C) of a dstC-channel NHWC tensor
+// dst_hi / dst_lo (optional, both or none): write the result as two fp16 planes (hi, lo = the split-fp16 convolution's
+// operand format) INSTEAD of the f32 dst
 int resize_bilinear_nhwc(const float* src, int n, int sh, int sw, int C, float* dst, int dh, int dw, int dstC,
-                         int c_off, int align_corners, hipStream_t s);
+                         int c_off, int align_corners, hipStream_t s, half_t* dst_hi = nullptr, half_t* dst_lo = nullptr);
 int avgpool2x2_nhwc(const float* src, int n, int h, int w, int C, float* dst, hipStream_t s);
 // LayerNorm over the last dim of rows. src_rows: optional gather (row index into x, or -1 -> output row = 0).
 // out_f16: y is half. act: applied after the affine transform (ACT_GELU for LayerNorm2d+GELU).

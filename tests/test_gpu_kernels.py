@@ -105,6 +105,13 @@ def test_conv_f16x3(lib, dev, n, H, W, Cin, Cout, k, s, p):
     ok(lib.sampt_conv2d_nhwc(0, P(xd), P(wd), P(bd), P(y32), n, H, W, Cin, Cout, k, k, s, p, S()), "conv f32")
     e3, e32 = rel_err(y, ref), rel_err(y32, ref)
     assert e3 < max(2e-6, 1.5 * e32), (e3, e32)
+    # pre-split activations (dtype 4: the LDS-DMA kernel the tracker encoder runs): same products, same bar
+    xh = xd.half()
+    xhl = torch.stack([xh, (xd - xh.float()).half()]).contiguous()
+    y4 = torch.full(ref.shape, 7.0, device=dev)
+    ok(lib.sampt_conv2d_nhwc(4, P(xhl), P(whl), P(bd), P(y4), n, H, W, Cin, Cout, k, k, s, p, S()), "conv f16x3 planes")
+    e4 = rel_err(y4, ref)
+    assert e4 < max(2e-6, 1.5 * e32), (e4, e32)
     # unsupported shapes are refused, never silently computed another way
     assert lib.sampt_conv2d_nhwc(3, P(xd), P(whl), P(bd), P(y), n, H, W, Cin - 4, Cout, k, k, s, p, S()) == -3
 
