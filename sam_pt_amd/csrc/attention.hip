@@ -105,8 +105,23 @@ int softmax_rel_rows(float* scores, const float* relh, const float* relw, long B
 // lane holds 16 keys x ONE query column per 32x32 tile: softmax row statistics are per-lane (+1 exchange with
 // lane^32) and the per-query rescale factors line up with O^T = V^T.P^T, whose columns are the same queries.
 // P^T is fed to the second MFMA straight from the score registers (any k-slot permutation is legal as long as
-// the A operand uses the same one, and V^T is read from LDS with exactly that permutation).
+// the A operand uses the same one, and V^T is gathered from LDS with exactly that permutation).
+//
+// K and V tiles go HBM -> LDS by LDS-DMA straight from the packed qkv rows into TWO buffers: no staging registers,
+// no transposing stores, one barrier per tile, the next tile's DMA in flight while this one is multiplied.  V stays ROW-major
+// ([key slot][channel], as it lies in HBM); the A operand of O^T = V^T.P^T is gathered with ds_read_b64_tr_b16, gfx950's
+// transposing LDS read: within a 16-lane group, lane s passes the address of 4 consecutive channels of key (s >> 2), channel
+// chunk (s & 3), and lane c receives channel c of the 4 keys (tools/probes/tr_probe.hip) — exactly the 4 consecutive key
+// slots a lane's P fragment holds, twice per k-step.  An LDS image written by DMA is linear, so bank conflicts are handled
+// on the source side: K rows (HD * 2 bytes) XOR their 16-byte chunk index with row bits (for HD = 80, 10 chunks: bit 0 with
+// row bit 3); V rows are 192 B for HD = 80 (conflict-free for the 4-row x 64-byte footprint of a transposing read; the 32
+// pad bytes come from a constant page whose first half is 1.0: channel HD of "V" is all ones, see LROW below) and for
+// HD = 64 swap their 64-byte halves on rows with bit 1 set.
 // ---------------------------------------------------------------------------------------------
+__device__ half_t g_flash_pad[16] = {(half_t)1.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f,
+                                     (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f,
+                                     (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+
 template <int HD, int NW, int SG>
 __global__ __launch_bounds__(NW * 64, 2) void k_flash_f16(const half_t* __restrict__ qkv, const float* __restrict__ rel_h,
                                                        const float* __restrict__ rel_w, half_t* __restrict__ out, int N,
@@ -115,13 +130,18 @@ __global__ __launch_bounds__(NW * 64, 2) void k_flash_f16(const half_t* __restri
   constexpr int DT = (HD + 31) / 32;     // 32-row tiles of O^T
   constexpr int QT = NW * 32;
   constexpr int NT = NW * 64;
-  constexpr int KLD = HD + 8, VLD = 64 + 8, RLD = QT + 2;
-  __shared__ __attribute__((aligned(16))) half_t Ks[64][KLD];
-  __shared__ __attribute__((aligned(16))) half_t Vt[DT * 32][VLD];
+  constexpr bool LROW = DT * 32 > HD;
+  constexpr int VP = LROW ? DT * 32 : HD;   // halves per (row-major) V row in LDS
+  constexpr int RLD = QT + 2;
+  constexpr int CPR = HD / 8, CPV = VP / 8;   // 16-byte chunks per K row / per LDS V row
+  // K chunk ^= (row >> KSH) & KSWZ
+  constexpr int KSWZ = CPR == 8 ? 7 : (CPR == 4 ? 3 : (CPR == 10 ? 1 : 0)), KSH = CPR == 4 ? 2 : (CPR == 10 ? 3 : 1);
+  __shared__ __attribute__((aligned(1024))) half_t Ks[2][64][HD];
+  __shared__ __attribute__((aligned(1024))) half_t Vs[2][64][VP];
   __shared__ half_t relh_s[SG][RLD];
   __shared__ half_t relw_s[SG][RLD];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, hi = lane >> 5;
   const int h = blockIdx.y, b = blockIdx.z;
   const int D = heads * HD;
@@ -137,50 +157,35 @@ __global__ __launch_bounds__(NW * 64, 2) void k_flash_f16(const half_t* __restri
   constexpr int RPT = SG >= 64 ? 1 : 64 / SG, KTV = SG >= 64 ? 64 : RPT * SG;
   constexpr float LOG2E = 1.4426950408889634f;
   const float c2 = scale * LOG2E;
-  constexpr int TV = 64 * (HD / 8);                 // 16-byte vectors per K (or V) tile
-  constexpr int LI = (TV + NT - 1) / NT;            // vectors per thread
-  h8 kreg[LI], vreg[LI];
-  // register-staged K/V pipeline: the global loads of tile t+1 are issued before tile t is multiplied and written
-  // to LDS (K row-major, V transposed) only after the barrier that retires tile t
-  auto load_tile = [&](int kt0) {
-#pragma unroll
-    for (int i = 0; i < LI; ++i) {
-      const int v = tid + i * NT;
-      if (v < TV) {
-        const int kr = v / (HD / 8), kv = v - kr * (HD / 8);
-        const int krow = min(kt0 + min(kr, KTV - 1), N - 1);
-        kreg[i] = *(const h8*)(qkv + (tok0 + krow) * 3 * D + D + h * HD + kv * 8);
-        const int vr = v & 63, dv = v >> 6;
-        const int vrow = min(kt0 + min(vr, KTV - 1), N - 1);
-        vreg[i] = *(const h8*)(qkv + (tok0 + vrow) * 3 * D + 2 * D + h * HD + dv * 8);
-      }
+  // DMA staging: wave w issues the K instructions i = w, w + NW, ... (CPR of them, 64 lanes x 16 B each: LDS bytes
+  // [i * 1024, +1024) of the K buffer = slots (i*64 + lane) / CPR) and likewise the CPV V instructions
+  auto dma_tile = [&](int kt0, int buf) {
+    const half_t* kbase = qkv + tok0 * 3 * D + D + h * HD;
+    for (int i = wave; i < CPR; i += NW) {
+      const int e = i * 64 + lane, slot = e / CPR, c = e - slot * CPR;
+      const int krow = min(kt0 + min(slot, KTV - 1), N - 1);
+      const half_t* src = kbase + (long)krow * 3 * D + ((c ^ ((slot >> KSH) & KSWZ)) * 8);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)((char*)&Ks[buf][0][0] + i * 1024), 16, 0, 0);
     }
-  };
-  auto store_tile = [&]() {
-#pragma unroll
-    for (int i = 0; i < LI; ++i) {
-      const int v = tid + i * NT;
-      if (v < TV) {
-        const int kr = v / (HD / 8), kv = v - kr * (HD / 8);
-        *(h8*)&Ks[kr][kv * 8] = kreg[i];
-        const int vr = v & 63, dv = v >> 6;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) Vt[dv * 8 + e][vr] = vreg[i][e];
-      }
+    for (int i = wave; i < CPV; i += NW) {
+      const int e = i * 64 + lane, slot = e / CPV, c = e - slot * CPV;
+      const int vrow = min(kt0 + min(slot, KTV - 1), N - 1);
+      const int cs = HD == 64 ? c ^ (((slot >> 1) & 1) << 2) : c;
+      const half_t* src = c < CPR ? kbase + D + (long)vrow * 3 * D + cs * 8 : g_flash_pad + (c - CPR) * 8;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)((char*)&Vs[buf][0][0] + i * 1024), 16, 0, 0);
     }
   };
   // the first K / V tile is requested before anything else: its latency overlaps the Q loads and the rel-pos prologue
-  load_tile(0);
+  dma_tile(0, 0);
 
-  // ---- prologue: zero the unused V^T rows, Q fragments, then the decomposed rel-pos tables of THIS wave's 32 queries
+  // ---- prologue: Q fragments, then the decomposed rel-pos tables of THIS wave's 32 queries
   //      computed with MFMA straight into LDS (fp16): G[rho][q] = <rel_pos[rho], q_vec> for all 2*SG-1 table rows, and
   //      rel_h[q][kh] = G_h[qh - kh + SG-1][q], rel_w[q][kw] = G_w[qw - kw + SG-1][q]   (App. A-3) — no HBM round trip.
-  // With HD % 32 != 0 the padded V^T rows are free MFMA work: row HD is all ones, so O^T[HD][q] accumulates the
-  // softmax denominator sum_k P[k][q] (of the SAME fp16-rounded P the numerator uses) with no VALU adds.
-  constexpr bool LROW = DT * 32 > HD;
-  if (LROW) {
-    for (int i = tid; i < (DT * 32 - HD) * VLD; i += NT) Vt[HD + i / VLD][i % VLD] = (half_t)(i < VLD ? 1.f : 0.f);
-  }
+  // With HD % 32 != 0 (LROW) the padded V channels are free MFMA work: channel HD is all ones (the DMA pad page), so
+  // O^T[HD][q] accumulates the softmax denominator sum_k P[k][q] (of the SAME fp16-rounded P the numerator uses) with no
+  // VALU adds.
   for (int i = tid; i < SG * RLD; i += NT) {
     (&relh_s[0][0])[i] = (half_t)0.f;
     (&relw_s[0][0])[i] = (half_t)0.f;
@@ -250,11 +255,20 @@ __global__ __launch_bounds__(NW * 64, 2) void k_flash_f16(const half_t* __restri
     }
   (void)dbg;
 
-  for (int kt0 = 0, kh0 = 0; kt0 < N; kt0 += KTV, kh0 += RPT) {
-    __syncthreads();  // previous tile fully consumed
-    store_tile();
-    __syncthreads();
-    if (kt0 + KTV < N) load_tile(kt0 + KTV);
+  // transposing V reads: byte offset inside a V buffer of this lane's source chunk for k-step 0, first key quad
+  int vl[DT];
+  {
+    const int s16 = li & 15, r4 = s16 >> 2, cc = s16 & 3, g16 = li >> 4;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+      vl[dt] = (4 * hi + r4) * VP * 2 + ((dt * 64 + g16 * 32 + cc * 8) ^ (HD == 64 ? ((r4 >> 1) & 1) << 6 : 0));
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile 0 has landed: this wave's part; the barrier publishes all parts
+  __syncthreads();
+  for (int kt0 = 0, kh0 = 0, it = 0; kt0 < N; kt0 += KTV, kh0 += RPT, ++it) {
+    const int buf = it & 1;
+    // the other buffer was last read before the barrier that ended the previous iteration: refill it now, wait at the end
+    if (kt0 + KTV < N) dma_tile(kt0 + KTV, buf ^ 1);
 
     // ---- S^T = K . Q^T  (two 32-slot tiles)
     f32x16 st[2];
@@ -264,7 +278,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_flash_f16(const half_t* __restri
       for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        h8 kf = *(const h8*)&Ks[kt * 32 + li][ks * 16 + hi * 8];
+        const int krow = kt * 32 + li;
+        h8 kf = *(const h8*)&Ks[buf][krow][((ks * 2 + hi) ^ ((krow >> KSH) & KSWZ)) * 8];
         st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], st[kt], 0, 0, 0);
       }
     }
@@ -334,12 +349,21 @@ __global__ __launch_bounds__(NW * 64, 2) void k_flash_f16(const half_t* __restri
     for (int t = 0; t < 4; ++t) {
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
-        const half_t* vp = &Vt[dt * 32 + li][16 * t + 4 * hi];
-        h4 v0 = *(const h4*)vp, v1 = *(const h4*)(vp + 8);
-        h8 vf = (h8){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        // channel dt*32 + li of key slots 16t + 4hi + {0..3} and 16t + 8 + 4hi + {0..3}
+        typedef short s4 __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) s4 lds_s4;
+        const __attribute__((address_space(3))) char* vb =
+            (const __attribute__((address_space(3))) char*)&Vs[buf][0][0] + vl[dt] + 16 * t * VP * 2;
+        const s4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)vb);
+        const s4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(vb + 8 * VP * 2));
+        const h8 vf = __builtin_bit_cast(h8, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
         o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pb[t], o[dt], 0, 0, 0);
       }
     }
+    // the next tile has landed (every wave waits for its own DMA, the barrier publishes all of it) and everyone is done
+    // reading this buffer
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
   }
 
   // ---- epilogue: out[q][h*HD + d] = O^T[d][q] / l
@@ -371,17 +395,15 @@ int vit_flash_attention_f16(const half_t* qkv, const float* relh, const float* r
   const int N = S * S;
   const float scale = 1.0f / sqrtf((float)hd);
   static const int dbg = getenv("SAMPT_FLASH_DBG") ? atoi(getenv("SAMPT_FLASH_DBG")) : 0;
-#define FL(HDv, NWv, SGv)                                                                                        \
-  hipLaunchKernelGGL((k_flash_f16<HDv, NWv, SGv>), dim3(cdiv(N, NWv * 32), heads, B), dim3(NWv * 64), 0, s, qkv, \
-                     relh, relw, out, N, heads, scale, dbg)
+#define FL(HDv, NWv, SGv)                                                                                     \
+  hipLaunchKernelGGL((k_flash_f16<HDv, NWv, SGv>), dim3(cdiv(N, NWv * 32), heads, B), dim3(NWv * 64), 0, s, qkv, relh, \
+                     relw, out, N, heads, scale, dbg)
   if (S == 64 && hd == 80) FL(80, 4, 64);
   else if (S == 64 && hd == 64) FL(64, 4, 64);
   // (a 7-wave workgroup per (window, head) — 224 query slots for the 196 tokens instead of 2 x 128 — measured 4 % slower,
-  //  profiles/r2_v7_attn_nw7.log: the K/V staging is the same and 188 VGPRs leave one workgroup per SIMD set)
-  // (a 7-wave workgroup per (window, head) — 224 query slots for the 196 tokens instead of 2 x 128 — measured 4 % slower,
   //  profiles/r2_v7_attn_nw7.log; an 8-wave one whose two query-less waves only help staging the K / V tiles, staged once per
-  //  window instead of twice: neutral, 261.2 vs 261.0 us, profiles/r3_v15_bench_attn_nw8.log — the kernel is bound by the
-  //  latency of its register-staged tiles at two waves per SIMD, not by the staging work)
+  //  window instead of twice: neutral, 261.2 vs 261.0 us, profiles/r3_v15_bench_attn_nw8.log — both with the register-staged
+  //  tiles this kernel had before the LDS-DMA staging)
   else if (S == 14 && hd == 80) FL(80, 4, 14);
   else if (S == 14 && hd == 64) FL(64, 4, 14);
   else if (S == 16 && hd == 32) FL(32, 4, 16);   // reduced test geometry (vit_test)

@@ -68,8 +68,8 @@ def test_bench_clip_masks_vs_oracle(dev, variant, T, precision, emb_tol):
 
 # name: (tracker, objects, positives, negatives, square, hq, T, SAM-stage frames)
 CONFIGS = {
-    "cfg4_pips_3obj": ("pips", 3, 8, 0, 0, False, 8, (0, 7)),
-    "cfg3_cotracker_8p8": ("cotracker", 1, 8, 8, 0, False, 13, (0, 12)),
+    "cfg4_pips_3obj": ("pips", 3, 8, 0, 0, False, 8, (0, 4, 7)),
+    "cfg3_cotracker_8p8": ("cotracker", 1, 8, 8, 0, False, 13, (0, 6, 12)),
     "cfg5_hq_cotracker_1024_5obj_16pts": ("cotracker", 5, 16, 0, 1024, True, 3, (0, 2)),
 }
 

@@ -110,7 +110,7 @@ def test_vit_test_encoder_vs_oracle(dev, precision, tol):
     assert rel_err(got, ref) < tol
 
 
-@pytest.mark.parametrize("precision,tol", [("f32", 1e-4), ("f16", 3e-2)])
+@pytest.mark.parametrize("precision,tol", [("f32", 2e-5), ("f16", 2e-3)])     # measured 2.6e-6 / 7.4e-4
 def test_vit_b_encoder_vs_oracle(dev, precision, tol):
     from oracle import sam_ref as R
     from sam_pt_amd.weights import SAM_CONFIGS, init_sam_state_dict

@@ -12,7 +12,7 @@ timeout 420 python -m pytest tests -q -m gpu -s > "$OUT/pytest_gpu.log" 2>&1; ec
 timeout 300 python bench.py > "$OUT/bench_vith.log" 2>&1
 Q="--no-cpu-baseline --no-roofline --no-secondary"
 SAMPT_DEC_F16X3=1 timeout 90 python bench.py $Q > "$OUT/bench_vith_dec_f16x3.log" 2>&1
-SAMPT_GEMM_LDS_PAD=9728 timeout 90 python bench.py $Q > "$OUT/bench_vith_gemm_3wg.log" 2>&1
+# (round-2 experiment SAMPT_GEMM_LDS_PAD removed with the experimental GEMM variants)
 SAMPT_PIPS_FUSE_REDUCE=1 timeout 90 python bench.py $Q > "$OUT/bench_vith_fuse_reduce.log" 2>&1
 SAMPT_TEST_EXPERIMENTAL=1 timeout 120 python -m pytest tests/test_gpu_modules.py -q -m gpu -s -k "opt_in" > "$OUT/pytest_experimental.log" 2>&1
 timeout 90 python tools/stage_times.py > "$OUT/stage_times.log" 2>&1
