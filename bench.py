@@ -70,6 +70,11 @@ def parse():
                          "24-frame clip, ~10 s of host time per ViT-H frame)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary lines (fp32 ViT, query-mask pass, IoU 0.7)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--submit", default="pipelined", choices=["pipelined", "sequential"],
+                    help="pipelined (default): the step loop keeps ONE clip in flight ahead of the one it collects "
+                         "(SamPt.forward_begin / forward_end: the decoder chain of clip i overlaps the tracker encoder of clip "
+                         "i + 1; exactly --steps clips are submitted AND collected inside the timed region); sequential: one "
+                         "blocking SamPt.forward per step")
     return ap.parse_args()
 
 
@@ -99,18 +104,43 @@ def build_model(args, dev):
     return model
 
 
-def one_step(model, video, max_frames, shard="sequences"):
-    from sam_pt_amd.dist import gather_masks, index_masks, sharded_forward
-    if shard == "frames":
-        full, _ = sharded_forward(model, video, batch=8)     # rank 0: the assembled (T,H,W) index masks; others: None
-        return full, full
-    out = model(video)
+def consume(model, out, max_frames):
+    """What the reference's timed window does with a clip's result (eval.py:304-326) + the mask gather of a multi-GPU job."""
+    from sam_pt_amd.dist import gather_masks, index_masks
     logits = torch.stack(out["logits"], dim=0)          # (M,T,H,W) on device
     if not logits.is_cuda:                               # the reference protocol returns host tensors (sam_pt.py:862-864)
         logits = logits.to(model.device)
     masks = index_masks(logits)                          # bg stack + softmax + argmax (eval.py:304-326)
     gathered = gather_masks(masks, max_frames)           # RCCL gather of uint8 masks (no-op for 1 GPU)
     return masks, gathered
+
+
+def one_step(model, video, max_frames, shard="sequences"):
+    from sam_pt_amd.dist import sharded_forward
+    if shard == "frames":
+        full, _ = sharded_forward(model, video, batch=8)     # rank 0: the assembled (T,H,W) index masks; others: None
+        return full, full
+    return consume(model, model(video), max_frames)
+
+
+class ClipsInFlight:
+    """The pipelined step loop: ``submit`` enqueues a clip (SamPt.forward_begin) and THEN collects the previous one
+    (forward_end + consume); ``flush`` collects the last.  K submits + one flush = K clips submitted and collected."""
+
+    def __init__(self, model, max_frames):
+        self.model, self.max_frames, self.pending, self.last = model, max_frames, None, None
+
+    def submit(self, video):
+        h = self.model.forward_begin(video)
+        self.flush()
+        self.pending = h
+        return self.last
+
+    def flush(self):
+        if self.pending is not None:
+            out, self.pending = self.model.forward_end(self.pending), None
+            self.last = consume(self.model, out, self.max_frames)[0]
+        return self.last
 
 
 def gemm_roofline(args, dev, insitu=None, frame_hw=(576, 1024)):
@@ -382,11 +412,12 @@ def reference_protocol_lines(args, model, video):
 
 
 def secondary_lines(args, model, video, dev):
-    """Variants of the headline workload the judge asked to see beside it (2 timed steps each, same clip): the exact-fp32
+    """Variants of the headline workload the judge asked to see beside it (2 timed steps each, same clip, every one with a
+    blocking ``SamPt.forward`` per step — ``sequential_forward`` is the headline workload itself run that way): the exact-fp32
     ViT, the reference's dead query-mask SAM pass switched back on (sam_pt.py:181), the shipped IoU threshold 0.7, and the
     REFERENCE protocol (tracker, then set_image + sequential predict_torch per frame) over the two HIP seams — the speed a
     user of the unchanged reference ``SamPt`` gets from the two ``_target_`` overrides alone (1 timed step each)."""
-    res = {}
+    res = {"sequential_forward": quick_fps(model, video, args.frames, steps=4)}   # one blocking SamPt.forward per step
     model.compute_unused_query_masks = True
     res["with_reference_query_mask_pass"] = quick_fps(model, video, args.frames)
     model.compute_unused_query_masks = False
@@ -458,13 +489,14 @@ def main():
         torch.cuda.synchronize()
 
     shard = "frames" if frames_sharded else "sequences"
+    pipelined = args.submit == "pipelined" and not frames_sharded and not (lpt and world > 1)
+    flight = ClipsInFlight(model, args.frames) if pipelined else None
 
     def step():
-        if not lpt:
-            return one_step(model, video, args.frames, shard)[0]
+        clips = [video] if not lpt else [{**video, "image": video["image"][:L]} for L in mine]   # this rank's sequences
         m = None
-        for L in mine:                                  # this rank's sequences, one SamPt.forward each (+ mask gather)
-            m = one_step(model, {**video, "image": video["image"][:L]}, args.frames, "sequences")[0]
+        for v in clips:                                 # one SamPt.forward each (+ mask gather)
+            m = flight.submit(v) if pipelined else one_step(model, v, args.frames, shard)[0]
         return m
 
     if lpt and world > 1:                               # ranks hold different numbers of sequences: gather per step instead
@@ -483,10 +515,14 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if pipelined:
+        flight.flush()                                  # nothing of the warm-up is left in flight
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         masks = step()
+    if pipelined:
+        masks = flight.flush()                          # the last clip is collected INSIDE the timed region
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -525,7 +561,11 @@ def main():
                                       f"{'+' + str(args.neg_points) if args.neg_points else ''} query points, {args.objects} object(s), "
                                       f"{args.frames}x 480p synthetic frames " + ("at native " if args.native_480p else "upscaled to ") + f"{H}x{W}, "
                                       f"{args.refine} refinement iterations, random-init weights (seed 72)",
-                          "frames_per_step": lpt_info["frames_total"] if lpt else args.frames, "parallelism": f"{'frame-batch' if frames_sharded else 'sequence'}-sharded x{world}",
+                          "frames_per_step": lpt_info["frames_total"] if lpt else args.frames,
+                          "submit": ("pipelined: one clip in flight ahead of the one being collected (SamPt.forward_begin / "
+                                     "forward_end), all submitted and collected inside the timed region" if pipelined
+                                     else "sequential: one blocking SamPt.forward per step"),
+                          "parallelism": f"{'frame-batch' if frames_sharded else 'sequence'}-sharded x{world}",
                           "vit_precision": args.precision + " MFMA inputs, fp32 accumulate/LN/softmax/residual"
                                            + ("; patch embedding and neck fp32-grade (3-term split-fp16 MFMA)" if args.precision == "f16" else ""),
                           "tracker_precision": tracker_precision, "decoder_precision": "fp32"},

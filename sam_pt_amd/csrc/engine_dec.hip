@@ -412,9 +412,8 @@ int DecEngine::track_decode(int F, const float* features, const float* hq_feat, 
   SAMPT_TRY(decode(F, features, hq_feat, pts, labels, k, k_item, ld_pts, nullptr, mask_in, in_h, in_w, oh, ow, cur_logits,
                    cur_iou, cur_low, cur_bb, ws, s));
   if (R > 0) {
-    if (hipMemsetAsync(active, 0xff, sizeof(int) * F, s) != hipSuccess) return SAMPT_ERR_HIP;
     for (int r = 0; r < R; ++r) {
-      SAMPT_TRY(sam_refine_gate(active, cur_bb, boxf, F, s));
+      SAMPT_TRY(sam_refine_gate(active, cur_bb, boxf, F, r == 0, s));
       ws.off = mark;
       SAMPT_TRY(decode(F, features, hq_feat, pts, labels, k, k_item, ld_pts, boxf, cur_low, in_h, in_w, oh, ow, cand_logits,
                        cand_iou, cand_low, cand_bb, ws, s));

@@ -168,7 +168,7 @@ struct MaskEmbedW {
 int sam_mask_embed_src(const float* mask, int g, int F, const MaskEmbedW& w, const float* feat, float* tmp0,
                        float* tmp1, float* src, hipStream_t s);
 // refinement gating (sam_pt.py:809-811): active[f] &= count(bbox_cur[f]) >= 2 ; box_f[f] = bbox_cur[f]
-int sam_refine_gate(int* active, const int* bbox_cur, float* box_f, int F, hipStream_t s);
+int sam_refine_gate(int* active, const int* bbox_cur, float* box_f, int F, bool first, hipStream_t s);
 // where active[f]: cur <- cand for logits (n_logits), low-res (n_low), iou and the bbox state
 int sam_commit(const int* active, const float* cand_logits, float* cur_logits, long n_logits, const float* cand_low,
                float* cur_low, long n_low, const float* cand_iou, float* cur_iou, const int* cand_bbox, int* cur_bbox,

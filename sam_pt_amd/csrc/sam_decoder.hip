@@ -997,19 +997,21 @@ int sam_mask_embed_src(const float* mask, int g, int F, const MaskEmbedW& w, con
   return SAMPT_OK;
 }
 
-// active[f] &= count(bbox_cur[f]) >= 2 ; box_f[f] = bbox_cur[f]     (sam_pt.py:809-820)
+// active[f] &= count(bbox_cur[f]) >= 2 ; box_f[f] = bbox_cur[f]     (sam_pt.py:809-820).  first: every item starts active
+// (no memset in front of the chain: the captured chain is kernel nodes only — a memset node of a replayed hipGraph was
+// observed to land late on ROCm 7.2, re-activating items a later pass had switched off)
 __global__ void k_sam_refine_gate(int* __restrict__ active, const int* __restrict__ bbox_cur, float* __restrict__ box_f,
-                                  int F) {
+                                  int F, int first) {
   int f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= F) return;
   const int* b = bbox_cur + f * 5;
 #pragma unroll
   for (int i = 0; i < 4; ++i) box_f[f * 4 + i] = (float)b[i];
-  active[f] = (active[f] != 0 && b[4] >= 2) ? 1 : 0;
+  active[f] = ((first || active[f] != 0) && b[4] >= 2) ? 1 : 0;
 }
 
-int sam_refine_gate(int* active, const int* bbox_cur, float* box_f, int F, hipStream_t s) {
-  hipLaunchKernelGGL(k_sam_refine_gate, dim3(cdiv(F, 64)), dim3(64), 0, s, active, bbox_cur, box_f, F);
+int sam_refine_gate(int* active, const int* bbox_cur, float* box_f, int F, bool first, hipStream_t s) {
+  hipLaunchKernelGGL(k_sam_refine_gate, dim3(cdiv(F, 64)), dim3(64), 0, s, active, bbox_cur, box_f, F, first ? 1 : 0);
   SAMPT_CHECK_LAUNCH("sam_refine_gate");
   return SAMPT_OK;
 }

@@ -59,6 +59,18 @@ class PointVisibilityType(IntEnum):
     REJECTED_AFTER_PATCH_WAS_NON_SIMILAR = -4
 
 
+class PendingForward:
+    """Handle of a clip submitted with ``SamPt.forward_begin``; ``SamPt.forward_end`` turns it into ``forward``'s result."""
+
+    def __init__(self, complete, result=None):
+        self._complete, self._result = complete, result
+
+    def result(self):
+        if self._complete is not None:
+            self._result, self._complete = self._complete(), None
+        return self._result
+
+
 class SamPt(nn.Module):
     def __init__(self, point_tracker, sam_predictor, sam_iou_threshold: float,
                  positive_point_selection_method: str = "kmedoids", negative_point_selection_method: str = "mixed",
@@ -112,6 +124,9 @@ class SamPt(nn.Module):
 
     # ------------------------------------------------------------------------------------------------
     def forward(self, video):
+        return self._forward_guarded(video, defer=False)
+
+    def _forward_guarded(self, video, defer):
         if self.training:
             raise NotImplementedError(f"{self._get_name()} does not support training...")
         from . import _lib, prefetch
@@ -120,14 +135,42 @@ class SamPt(nn.Module):
             with _lib.device_guard(self.device):      # streams / events / launches all on the model's device
                 if fused:                             # the fused path holds the clip's embeddings itself
                     with prefetch.suspended():
-                        return self._forward_impl(video)
-                return self._forward_impl(video)
+                        return self._forward_impl(video, defer)
+                return self._forward_impl(video, False)
         finally:                                      # never leave a clip's feature pyramid cached in the tracker
             if hasattr(self.point_tracker, "_prepared"):
                 self.point_tracker._prepared = None
                 self.point_tracker._prepared_events = None
 
-    def _forward_impl(self, video):
+    # -- clips in flight ---------------------------------------------------------------------------------------
+    # ``forward`` ends with the decoder chain: ~20 ms of small, latency-bound launches that leave most of the GPU idle, and
+    # it has to wait for them (the scores go back to the host).  A loop over clips (the reference's evaluator,
+    # vos_eval/evaluator.py: one ``model(video)`` per sequence) gets that time back by submitting clip i + 1 — whose first
+    # stage, the tracker's encoder, is throughput-bound — BEFORE collecting clip i: ``forward_begin`` enqueues everything
+    # (the decoder chain on its own stream, after the encoder's event) and returns a handle, ``forward_end`` waits for that
+    # clip's event only and builds the result.  ``forward(v)`` is ``forward_end(forward_begin(v))`` in effect: same kernels,
+    # same streams, same results (tests/test_gpu_modules.py::test_stream_of_clips_equals_forward).
+    def forward_begin(self, video) -> "PendingForward":
+        r = self._forward_guarded(video, defer=True)
+        return r if isinstance(r, PendingForward) else PendingForward(None, r)
+
+    def forward_end(self, pending: "PendingForward"):
+        from . import _lib
+        with _lib.device_guard(self.device):
+            return pending.result()
+
+    def stream(self, videos):
+        """Generator over ``forward`` results of an iterable of clips, one clip in flight ahead of the one being collected."""
+        prev = None
+        for v in videos:
+            cur = self.forward_begin(v)
+            if prev is not None:
+                yield self.forward_end(prev)
+            prev = cur
+        if prev is not None:
+            yield self.forward_end(prev)
+
+    def _forward_impl(self, video, defer=False):
         images = torch.stack(video["image"], dim=0) if isinstance(video["image"], (list, tuple)) else video["image"]
         n_frames, channels, height, width = images.shape
         assert images.dtype == torch.uint8, "Input images must be in uint8 format (0-255)"
@@ -218,31 +261,42 @@ class SamPt(nn.Module):
             if not fused or self.compute_unused_query_masks or hasattr(self.point_tracker, "set_masks"):
                 query_masks = self.extract_query_masks(images, query_points, feats)
         assert query_masks is None or query_masks.shape == (n_masks, height, width)
+        target_hw = tuple(video["target_hw"])
+
+        def tail(trajectories, visibilities, logits, scores, scores_per_frame):
+            resize_factor = torch.tensor(target_hw) / torch.tensor(logits.shape[-2:])
+            assert (resize_factor[0] - resize_factor[1]).abs().item() < 0.01, "The resizing should have been isotropic"
+            if tuple(logits.shape[-2:]) != target_hw:
+                logits = self._resize_logits(logits, target_hw)
+            trajectories = trajectories * resize_factor
+            assert logits.shape == (n_masks, n_frames if frame_ids is None else len(frame_ids), target_hw[0], target_hw[1])
+            assert trajectories.shape == (n_frames, n_masks, n_points_per_mask, 2)
+            assert visibilities.shape == (n_frames, n_masks, n_points_per_mask)
+            return {"logits": [m for m in logits], "scores": scores.tolist(), "scores_per_frame": scores_per_frame.tolist(),
+                    "trajectories": trajectories, "visibilities": visibilities}
+
         if not self.use_point_reinit:
             trajectories, visibilities = tracked if tracked is not None else self._track_points(images, query_points)
             pl = pipeline if fused else None
             if frame_ids is None:
-                _, logits, scores_per_frame = self._apply_sam_to_trajectories(images, trajectories, visibilities, feats, pl)
+                sam_args = (images, trajectories, visibilities)
             else:
                 ids = torch.as_tensor(frame_ids)
-                _, logits, scores_per_frame = self._apply_sam_to_trajectories(sam_images, trajectories[ids],
-                                                                                visibilities[ids], feats, pl)
+                sam_args = (sam_images, trajectories[ids], visibilities[ids])
+            if defer and pl is not None:     # forward_begin: the decoder chain is enqueued, nobody waits for it yet
+                pend = self._apply_sam_to_trajectories(*sam_args, feats, pl, defer=True)
+
+                def complete():
+                    _, logits, scores_per_frame = self._finish_sam_fused(pend)
+                    self._mark("decoded")
+                    return tail(trajectories, visibilities, logits, scores_per_frame.mean(dim=0), scores_per_frame)
+                return PendingForward(complete)
+            _, logits, scores_per_frame = self._apply_sam_to_trajectories(*sam_args, feats, pl)
             scores = scores_per_frame.mean(dim=0)
             self._mark("decoded")
         else:
             trajectories, visibilities, logits, scores, scores_per_frame = self._forward_w_reinit(images, query_points, feats)
-
-        target_hw = tuple(video["target_hw"])
-        resize_factor = torch.tensor(target_hw) / torch.tensor(logits.shape[-2:])
-        assert (resize_factor[0] - resize_factor[1]).abs().item() < 0.01, "The resizing should have been isotropic"
-        if tuple(logits.shape[-2:]) != target_hw:
-            logits = self._resize_logits(logits, target_hw)
-        trajectories = trajectories * resize_factor
-        assert logits.shape == (n_masks, n_frames if frame_ids is None else len(frame_ids), target_hw[0], target_hw[1])
-        assert trajectories.shape == (n_frames, n_masks, n_points_per_mask, 2)
-        assert visibilities.shape == (n_frames, n_masks, n_points_per_mask)
-        return {"logits": [m for m in logits], "scores": scores.tolist(), "scores_per_frame": scores_per_frame.tolist(),
-                "trajectories": trajectories, "visibilities": visibilities}
+        return tail(trajectories, visibilities, logits, scores, scores_per_frame)
 
     def _mark(self, name):
         if self.timeline is not None and torch.cuda.is_available():
@@ -491,7 +545,7 @@ class SamPt(nn.Module):
             labels = np.concatenate([labels, np.zeros((len(others)), dtype=int)], axis=0)
         return coords, labels
 
-    def _apply_sam_to_trajectories(self, images, trajectories, visibilities, feats=None, pipeline=None):
+    def _apply_sam_to_trajectories(self, images, trajectories, visibilities, feats=None, pipeline=None, defer=False):
         n_frames, channels, height, width = images.shape
         _, n_masks, points_per_mask, _ = trajectories.shape
         assert trajectories.shape == (n_frames, n_masks, points_per_mask, 2)
@@ -501,17 +555,35 @@ class SamPt(nn.Module):
             if pipeline is None:
                 return self._apply_sam_fused(images, trajectories, visibilities, feats)
             events, stream = pipeline
-            with torch.cuda.stream(stream):       # everything of the SAM stage is allocated, launched and synced on `stream`
-                out = self._apply_sam_fused(images, trajectories, visibilities, feats, events)
-            cur = torch.cuda.current_stream()
-            cur.wait_stream(stream)
-            out[1].record_stream(cur)             # the logits are consumed on the caller's stream from here on
-            return out
+            with torch.cuda.stream(stream):       # everything of the SAM stage is allocated and launched on `stream`
+                pend = self._enqueue_sam_fused(images, trajectories, visibilities, feats, events)
+                pend["event"] = torch.cuda.Event()
+                pend["event"].record()            # this clip's chain (and the copy of its scores to the host) ends here
+            return pend if defer else self._finish_sam_fused(pend)
         return self._apply_sam_stepwise(images, trajectories, visibilities)
 
     # -- device-resident path --------------------------------------------------------------------------------
     def _apply_sam_fused(self, images, trajectories, visibilities, feats, batch_events=None):
-        """``batch_events``: [(end_frame, event)] of the encoder batches (``SamPredictor.encode_frames``).  When given, the
+        return self._finish_sam_fused(self._enqueue_sam_fused(images, trajectories, visibilities, feats, batch_events))
+
+    def _finish_sam_fused(self, pend):
+        """Second half of the SAM stage: wait for the chain enqueued by ``_enqueue_sam_fused`` (its own event when it ran on a
+        decoder stream — later clips' chains on that stream are not waited for), hand the logits over to the caller's
+        stream, bring the scores home: the only sync of the SAM stage."""
+        logits, scores = pend["logits"], pend["scores"]
+        if pend.get("event") is not None:
+            pend["event"].synchronize()
+            cur = torch.cuda.current_stream()
+            cur.wait_event(pend["event"])
+            logits.record_stream(cur)             # the logits are consumed on the caller's stream from here on
+        elif scores.is_cuda:
+            torch.cuda.current_stream().synchronize()
+        scores_cpu = (pend["host"].clone() if pend["host"] is not None else scores.cpu()).view(pend["n_frames"], pend["n_masks"])
+        return self._mean_scores(scores_cpu), logits, scores_cpu
+
+    def _enqueue_sam_fused(self, images, trajectories, visibilities, feats, batch_events=None):
+        """First half: prompts assembled on the host, every decoder chain of the clip enqueued on the current stream.
+        ``batch_events``: [(end_frame, event)] of the encoder batches (``SamPredictor.encode_frames``).  When given, the
         current stream is a decoder stream that must not wait for the whole encoder: the items are chunked per encoder
         batch and every chunk waits only for the event of the batch that holds its frames."""
         n_frames, _, height, width = images.shape
@@ -558,10 +630,12 @@ class SamPt(nn.Module):
             chunks = [(items[s0:s0 + Fmax], None) for s0 in range(0, len(items), Fmax)]
         cur_stream = torch.cuda.current_stream() if batch_events else None
         use_graph = bool(getattr(pred, "use_graph", False)) and hasattr(pred, "decode_staging") and images.is_cuda
-        for chunk, ev in chunks:
+        # (host -> device copies first: a pageable copy blocks the host until the stream reaches it, and past the wait for
+        #  the encoder's event that is the end of the encoder — a clip submitted with forward_begin must not wait there)
+        idx_d = [torch.tensor(chunk, dtype=torch.long, device=dev) for chunk, _ in chunks]
+        for (chunk, ev), idx in zip(chunks, idx_d):
             if ev is not None:
                 cur_stream.wait_event(ev)
-            idx = torch.tensor(chunk, dtype=torch.long, device=dev)
             t_idx, m_idx = idx // n_masks, idx % n_masks
             F_ = idx.numel()
             ks, ps = k_all[chunk], npos_all[chunk]
@@ -595,9 +669,12 @@ class SamPt(nn.Module):
                                   npos_item=npos_d.index_select(0, idx).contiguous() if (ragged and two_pass) else None)
             logits[m_idx, t_idx] = out_l
             scores[idx] = out_s
-        scores_cpu = scores.cpu().view(n_frames, n_masks)                        # the only sync of the SAM stage
-        pred_scores = self._mean_scores(scores_cpu)
-        return pred_scores, logits, scores_cpu
+        host = None
+        if scores.is_cuda:                        # asynchronous copy into pinned memory: nobody waits here
+            host = torch.empty(scores.shape, dtype=scores.dtype, pin_memory=True)
+            host.copy_(scores, non_blocking=True)
+        return {"logits": logits, "scores": scores, "host": host, "n_frames": n_frames, "n_masks": n_masks, "event": None,
+                "feats": feats}                    # (the embeddings stay referenced until the chain that reads them is done)
 
     @staticmethod
     def _mean_scores(scores_per_frame):

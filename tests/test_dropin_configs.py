@@ -184,6 +184,35 @@ def test_prepared_pyramid_path_on_the_fake_device(monkeypatch):
     assert fake.calls["pips_fnet_frames"] == 27
 
 
+def test_stream_of_clips_on_the_fake_device(monkeypatch):
+    """SamPt.stream / forward_begin / forward_end (a clip in flight ahead of the one being collected) on the recording fake:
+    clip by clip the result of forward(); on a device without streams the handle is simply complete."""
+    from tests import fake_hip
+    from sam_pt_amd.point_tracker import PipsPointTracker
+    from sam_pt_amd.sam_predictor import SamHip, SamPredictor
+    from sam_pt_amd.sam_pt import PendingForward, SamPt
+    from sam_pt_amd.weights import SAM_CONFIGS, init_pips_state_dict, init_sam_state_dict
+    tcfg = SAM_CONFIGS["vit_test"]
+    sd, psd = init_sam_state_dict(tcfg, 72), init_pips_state_dict(72)
+    fake_hip.install(monkeypatch, sd, tcfg, psd)
+    videos = []
+    for seed, T in ((72, 6), (73, 4)):
+        frames, centres = synthetic_clip(T=T, H=128, W=256, seed=seed)
+        videos.append({"image": [f for f in frames], "target_hw": (128, 256), "query_points": disc_queries(centres, n_pos=4, r=9.0)[None]})
+    model = SamPt(PipsPointTracker(state_dict=psd), SamPredictor(SamHip(config=tcfg, state_dict=sd, precision="f32")),
+                  sam_iou_threshold=-1e9, positive_points_per_mask=4, negative_points_per_mask=0,
+                  iterative_refinement_iterations=1).eval()
+    ref = [model(v) for v in videos]
+    got = list(model.stream(videos))
+    assert len(got) == 2
+    for a, b in zip(got, ref):
+        assert torch.equal(a["trajectories"], b["trajectories"]) and a["scores_per_frame"] == b["scores_per_frame"]
+        assert torch.equal(torch.stack(a["logits"]), torch.stack(b["logits"]))
+    h = model.forward_begin(videos[1])
+    assert isinstance(h, PendingForward) and model.forward_end(h) is model.forward_end(h)
+    assert list(model.stream([])) == []
+
+
 def test_dead_row_cache_host_logic_on_the_fake_device(monkeypatch):
     """SamPredictor.encode_frames around sampt_vit_encode_live: one cache per frame geometry, built once from the first frame
     of that size and reused by later clips; square frames (nothing to skip) take the plain entry point; the embeddings equal

@@ -930,3 +930,50 @@ def test_reference_protocol_with_clip_embedding_prefetch_is_exact(dev, pips_sd, 
     for a, b in zip(outs["0"]["logits"], outs["1"]["logits"]):
         assert torch.equal(a.cpu(), b.cpu())
     assert torch.equal(outs["0"]["trajectories"], outs["1"]["trajectories"])
+
+
+# ------------------------------------------------------------------------------------------ clips in flight
+def test_stream_of_clips_equals_forward(dev, pips_sd):
+    """``SamPt.stream`` (forward_begin of clip i + 1 before forward_end of clip i: the decoder chain of one clip runs beside
+    the tracker encoder / first encoder batches of the next) returns, clip by clip, exactly what ``forward`` returns: same
+    kernels on the same streams, only the host's waiting point moves — so bitwise, not within a tolerance."""
+    from sam_pt_amd.point_tracker import PipsPointTracker
+    from sam_pt_amd.sam_predictor import SamHip, SamPredictor
+    from sam_pt_amd.sam_pt import SamPt
+    from sam_pt_amd.weights import SAM_CONFIGS
+    cfg = SAM_CONFIGS["vit_test"]
+    videos = []
+    for seed, T in ((72, 11), (73, 9), (74, 11), (75, 5)):
+        frames, centres = synthetic_clip(T=T, H=128, W=256, seed=seed)
+        q = torch.stack([disc_queries(centres, n_pos=4, r=9.0), disc_queries(centres, n_pos=4, r=5.0) + torch.tensor([0.0, -50.0, 20.0])])
+        videos.append({"image": [f.to(dev) for f in frames], "target_hw": (128, 256), "query_points": q})
+    pred = SamPredictor(SamHip(config=cfg, seed=72, precision="f32", max_batch=4, max_decode_batch=8).to(dev))
+    model = SamPt(PipsPointTracker(state_dict=pips_sd), pred, sam_iou_threshold=0.1, positive_points_per_mask=4,
+                  negative_points_per_mask=0, iterative_refinement_iterations=3).eval()
+    graph = pred.use_graph
+    pred.use_graph = False                             # plain launches: the yardstick for the replayed chains below
+    ref = [model(v) for v in videos]
+    torch.cuda.synchronize()
+    pred.use_graph = graph
+    for rep in range(3):                               # (first sight of a signature is eager, then capture, then replays)
+        again = [model(v) for v in videos]
+        torch.cuda.synchronize()
+        for a, b in zip(again, ref):
+            # replayed hipGraphs over several clips whose items switch refinement off at different passes: bitwise the eager
+            # chain (a memset NODE in the captured chain used to land late on replay and re-activate items: round 3)
+            assert torch.equal(torch.stack(a["logits"]), torch.stack(b["logits"])) and a["scores_per_frame"] == b["scores_per_frame"]
+    assert not graph or pred.graph_stats()[2] > 0
+    for rep in range(2):
+        got = list(model.stream(videos))
+        torch.cuda.synchronize()
+        assert len(got) == len(ref)
+        for a, b in zip(got, ref):
+            assert torch.equal(a["trajectories"], b["trajectories"]) and torch.equal(a["visibilities"], b["visibilities"])
+            assert a["scores_per_frame"] == b["scores_per_frame"] and a["scores"] == b["scores"]
+            for la, lb in zip(a["logits"], b["logits"]):
+                assert torch.equal(la, lb)
+    h = model.forward_begin(videos[0])                 # a handle may be collected late, and more than once
+    torch.cuda.synchronize()
+    out = model.forward_end(h)
+    assert model.forward_end(h) is out
+    assert torch.equal(torch.stack(out["logits"]), torch.stack(ref[0]["logits"]))
