@@ -29,15 +29,27 @@ def _khwc(w: torch.Tensor, pad_cin_to: int = 0) -> torch.Tensor:
 F16X3_WSHIFT = 8          # csrc/common.h
 
 
-def split_f16x3(w: torch.Tensor) -> torch.Tensor:
+def split_f16x3(w: torch.Tensor, strict: bool = True):
     """fp32 weights [Cout][K] -> half [2][Cout][K]: w * 2^8 = hi + lo with hi = fp16(.), lo = fp16(. - hi), the operand
-    format of csrc/conv_f16x3.hip (three fp16 MFMAs reproduce the fp32 product to 2^-22)."""
+    format of csrc/conv_f16x3.hip (three fp16 MFMAs reproduce the fp32 product to 2^-22).  A weight with |w| * 2^8 outside
+    the fp16 range cannot be split: ``strict`` raises, otherwise None is returned and the caller leaves the planes out
+    (every decoder / tracker-encoder consumer then runs that one layer on the exact f32 MFMA path)."""
     ws = w.float() * float(1 << F16X3_WSHIFT)
     if not bool(torch.isfinite(ws).all()) or float(ws.abs().max()) >= 65504.0:
-        raise ValueError("split_f16x3: weight magnitude outside the fp16 range")
+        if strict:
+            raise ValueError(f"split_f16x3: weight magnitude {float(w.abs().max()):.3g} * 2^{F16X3_WSHIFT} outside the fp16 "
+                             "range (this layer has no f32 fallback in the fp16-ViT mode: use precision='f32')")
+        return None
     hi = ws.half()
     lo = (ws - hi.float()).half()
     return torch.stack([hi, lo]).contiguous()
+
+
+def _put_split(out: Dict[str, torch.Tensor], key: str, w: torch.Tensor) -> None:
+    """out[key] = split planes of w — or nothing when w cannot be split (the consumer falls back to f32 for that layer)."""
+    hl = split_f16x3(w, strict=False)
+    if hl is not None:
+        out[key] = hl
 
 
 def fnet_f16x3_enabled(default: bool) -> bool:
@@ -53,7 +65,7 @@ def _add_fnet_split(out: Dict[str, torch.Tensor], sd: Dict[str, torch.Tensor], d
         return
     for k, v in sd.items():
         if k.startswith("fnet.") and k.endswith(".weight") and v.dim() == 4 and v.shape[1] % 32 == 0:
-            out[k + "_hl"] = split_f16x3(out[k])
+            _put_split(out, k + "_hl", out[k])
 
 
 def pack_pips(sd: Dict[str, torch.Tensor], device, S: int = 8) -> Dict[str, torch.Tensor]:
@@ -259,8 +271,8 @@ def pack_decoder(sd: Dict[str, torch.Tensor], cfg: SamConfig, device, max_frames
             out[f"mask_decoder.embedding_maskfeature.{i}.weight_packed"] = \
                 w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
             if os.environ.get("SAMPT_DEC_F16X3", "1") != "0":                  # fp32-grade on the fp16 pipe (Cin 32 / 64)
-                out[f"mask_decoder.embedding_maskfeature.{i}.weight_packed_hl"] = \
-                    split_f16x3(out[f"mask_decoder.embedding_maskfeature.{i}.weight_packed"])
+                _put_split(out, f"mask_decoder.embedding_maskfeature.{i}.weight_packed_hl",
+                           out[f"mask_decoder.embedding_maskfeature.{i}.weight_packed"])
     out["mask_decoder.__out_tokens"] = torch.cat(toks, dim=0).float().contiguous()
     out["prompt_encoder.__point_embeddings"] = torch.cat(
         [sd[f"prompt_encoder.point_embeddings.{i}.weight"] for i in range(4)], dim=0).float().contiguous()
@@ -275,7 +287,7 @@ def pack_decoder(sd: Dict[str, torch.Tensor], cfg: SamConfig, device, max_frames
             for i in (0, 3):
                 wp = out[f"mask_decoder.{nme}.{i}.weight_packed"]
                 if wp.shape[2] % 32 == 0 and wp.shape[1] % 4 == 0:
-                    out[f"mask_decoder.{nme}.{i}.weight_packed_hl"] = split_f16x3(wp.reshape(-1, wp.shape[2]))
+                    _put_split(out, f"mask_decoder.{nme}.{i}.weight_packed_hl", wp.reshape(-1, wp.shape[2]))
     # Fused image-side projections of the two-way transformer (csrc/engine.h DecEngine::FusedProj): the token -> image keys
     # (keys + pe) Wk, values keys Wv and the image -> token queries (keys + pe) Wq' of a layer read the same image tokens, so
     # they run as one GEMM with W = [Wk; Wv; Wq'] and the constant pe [Wk; 0; Wq']^T added in its epilogue.
@@ -289,7 +301,7 @@ def pack_decoder(sd: Dict[str, torch.Tensor], cfg: SamConfig, device, max_frames
         Wpe = torch.cat([out[m + ".weight"] if u else torch.zeros_like(out[m + ".weight"]) for m, u in zip(mats, with_pe)], dim=0)
         out[key + "_pe"] = (pe64 @ Wpe.double().t()).float().contiguous()
         if os.environ.get("SAMPT_DEC_F16X3", "1") != "0" and W.shape[1] % 32 == 0:
-            out[key + "_w_hl"] = split_f16x3(W)
+            _put_split(out, key + "_w_hl", W)
 
     for i in range(cfg.dec_depth):
         lp = f"{tr}layers.{i}."
@@ -304,5 +316,5 @@ def pack_decoder(sd: Dict[str, torch.Tensor], cfg: SamConfig, device, max_frames
         # (measured +1.4 % end to end, profiles/r2_v0_bench_vith_dec_f16x3.log; SAMPT_DEC_F16X3=0 restores the f32 MFMAs)
         for k in [k for k in out if k.startswith("mask_decoder.transformer.") and k.endswith("_proj.weight")]:
             if out[k].shape[1] % 32 == 0 and out[k].shape[0] % 4 == 0:
-                out[k + "_hl"] = split_f16x3(out[k])
+                _put_split(out, k + "_hl", out[k])
     return {k: v.to(device) for k, v in out.items()}

@@ -538,7 +538,7 @@ class SamPredictor:
         hipGraph replays fixed pointers, so the decode chain of a bucket always reads and writes these tensors."""
         self._ensure()
         key = (F, ld_pts, tuple(size_hw))
-        st = self._stage.get(key)
+        st = self._stage.pop(key, None)                    # (re-inserted below: dict order = least recently used first)
         if st is None:
             g, Cc, dev = self.model.cfg.grid, self.model.cfg.out_chans, self._dev
             st = {"feats": torch.empty((F, g * g, Cc), dtype=torch.float32, device=dev),
@@ -550,10 +550,17 @@ class SamPredictor:
                   "score": torch.empty((F,), dtype=torch.float32, device=dev)}
             if self.model.hq:
                 st["hq"] = torch.empty((F, 16 * g * g, Cc // 8), dtype=torch.float32, device=dev)
-            if len(self._stage) >= 8:                       # a handful of buckets is all a clip needs
-                self._stage.pop(next(iter(self._stage)))
-            self._stage[key] = st
+        self._stage[key] = st
+        # a handful of buckets is all a clip needs; beyond 8 buckets or SAMPT_STAGE_MAX_BYTES (default 4 GiB: one F = 128
+        # bucket of HQ-SAM at 480p is 1.7 GB) the least recently used ones go (a bucket still being read by an enqueued chain
+        # is safe to drop: its memory returns to the allocator of the stream that chain runs on)
+        cap = int(os.environ.get("SAMPT_STAGE_MAX_BYTES", str(4 << 30)))
+        while len(self._stage) > 1 and (len(self._stage) > 8 or self._stage_bytes() > cap):
+            self._stage.pop(next(iter(self._stage)))
         return st
+
+    def _stage_bytes(self) -> int:
+        return sum(t.numel() * t.element_size() for st in self._stage.values() for t in st.values())
 
     def graph_stats(self):
         """(cached graphs, captures, replays) of the decoder handle."""

@@ -601,6 +601,9 @@ class SamPt(nn.Module):
                     c = pred.transform.apply_coords(c, size)
                 prompts.append((c, l))
                 kmax = max(kmax, len(c))
+        use_graph = bool(getattr(pred, "use_graph", False)) and hasattr(pred, "decode_staging") and images.is_cuda
+        if use_graph:        # point slots in steps of 8: clips whose longest prompts differ by a point share their staging
+            kmax = -(-kmax // 8) * 8     # buckets and captured graphs (the slots past an item's count are never read)
         xy = np.zeros((len(prompts), kmax, 2), dtype=np.float32)
         lab = np.zeros((len(prompts), kmax), dtype=np.int32)
         for i, (c, l) in enumerate(prompts):
@@ -629,7 +632,6 @@ class SamPt(nn.Module):
         else:
             chunks = [(items[s0:s0 + Fmax], None) for s0 in range(0, len(items), Fmax)]
         cur_stream = torch.cuda.current_stream() if batch_events else None
-        use_graph = bool(getattr(pred, "use_graph", False)) and hasattr(pred, "decode_staging") and images.is_cuda
         # (host -> device copies first: a pageable copy blocks the host until the stream reaches it, and past the wait for
         #  the encoder's event that is the end of the encoder — a clip submitted with forward_begin must not wait there)
         idx_d = [torch.tensor(chunk, dtype=torch.long, device=dev) for chunk, _ in chunks]

@@ -120,6 +120,43 @@ def _unsplit(hl):
     return (hl[0].double() + hl[1].double()).float() / float(1 << F16X3_WSHIFT)
 
 
+def test_unsplittable_weights_fall_back_per_layer():
+    """a weight whose magnitude * 2^8 leaves the fp16 range cannot be split into hi + lo planes.  The decoder and
+    the tracker encoder keep their f32 weights beside the planes, so packing leaves out the planes of that ONE layer (the
+    engines then run it on the exact f32 MFMA path) instead of refusing the checkpoint; the fp16-ViT ends have no f32 twin
+    and still raise, with a message that says what to do."""
+    import pytest
+    from sam_pt_amd.pack import pack_decoder, pack_pips, pack_vit, split_f16x3
+    from sam_pt_amd.weights import SAM_CONFIGS, init_pips_state_dict, init_sam_state_dict
+    cfg = SAM_CONFIGS["vit_test"]
+    sd = init_sam_state_dict(cfg, 3)
+    big = "mask_decoder.transformer.layers.0.cross_attn_token_to_image.k_proj.weight"
+    ref = pack_decoder(sd, cfg, "cpu", 2)
+    sd2 = dict(sd)
+    sd2[big] = sd[big].clone()
+    sd2[big][0, 0] = 300.0                                       # 300 * 2^8 > 65504
+    p = pack_decoder(sd2, cfg, "cpu", 2)
+    gone = {k for k in ref if k not in p}
+    assert gone == {big + "_hl", "mask_decoder.transformer.layers.0.__kvq_w_hl"}, gone      # the layer itself + its fused form
+    assert torch.equal(p[big], sd2[big].float())                 # the f32 weight the fallback multiplies with
+    assert split_f16x3(sd2[big], strict=False) is None
+    with pytest.raises(ValueError, match="precision='f32'"):
+        split_f16x3(sd2[big])
+    psd = init_pips_state_dict(72)
+    name = "fnet.layer1.0.conv1.weight"
+    psd2 = dict(psd)
+    psd2[name] = psd[name].clone()
+    psd2[name][0, 0, 0, 0] = 1e3
+    pp, pr = pack_pips(psd2, "cpu"), pack_pips(psd, "cpu")
+    assert {k for k in pr if k not in pp} == {name + "_hl"}
+    vsd = dict(sd)
+    vsd["image_encoder.neck.2.weight"] = sd["image_encoder.neck.2.weight"].clone()
+    vsd["image_encoder.neck.2.weight"][0, 0, 0, 0] = 300.0
+    with pytest.raises(ValueError, match="fp16 range"):
+        pack_vit(vsd, cfg, "cpu", True, 1)
+    pack_vit(vsd, cfg, "cpu", False, 1)                          # the exact mode takes it
+
+
 def test_decoder_fused_projection_packing():
     """pack_decoder's fused image-side projections: keys @ W^T + b + pe-term must equal the three separate projections of
     the two-way transformer — (keys + pe) Wk, keys Wv, (keys + pe) Wq' (SAM TwoWayAttentionBlock) — and the final
