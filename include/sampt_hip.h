@@ -350,6 +350,12 @@ int sampt_attention_t2i_f32(const float* q_dev, const float* k_dev, const float*
  * is row b*batch_stride_rows + t*token_stride_rows (time attention: S, 1; space attention: 1, S); out [rows][heads*hd]. */
 int sampt_cotracker_attention_f32(const float* qkv_dev, float* out_dev, int nbatch, int L, int batch_stride_rows,
                                   int token_stride_rows, int heads, int hd, sampt_stream_t stream);
+/* SAM's ViT attention (sam/modeling/image_encoder.py Attention.forward with use_rel_pos: third-party segment-anything, absent
+ * from /root/reference; restated in oracle/sam_ref.py) for B windows (or whole frames) of S x S tokens straight from the
+ * packed fp16 qkv rows [B*S*S][3*heads*hd]; rel_h / rel_w: the block's rel_pos tables f32 [2S-1][hd] (the decomposed bias
+ * is computed inside the kernel); out fp16 [B*S*S][heads*hd].  Supported geometries: (S, hd) = (64, 80), (64, 64),
+ * (14, 80), (14, 64), (16, 32), (6, 32); anything else returns SAMPT_ERR_UNSUPPORTED.  workspace_dev / workspace_bytes
+ * are unused (kept for ABI stability: K / V tiles are staged by LDS-DMA, nothing goes through HBM scratch). */
 int sampt_vit_attention_f16(const void* qkv_dev, const float* rel_h_dev, const float* rel_w_dev, void* out_dev, int B,
                             int S, int heads, int hd, void* workspace_dev, size_t workspace_bytes, sampt_stream_t stream);
 

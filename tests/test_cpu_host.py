@@ -297,6 +297,68 @@ dist.barrier(); dist.destroy_process_group()
     assert "GATHER_OK" in r.stdout
 
 
+def test_pipelined_step_loop_two_ranks_gloo():
+    """bench.py's pipelined step loop (ClipsInFlight: submit clip i + 1, then collect clip i with the VOS tail and the mask
+    gather) with 2 gloo processes: every rank issues its gathers in the same order, rank 0 receives each step's masks of
+    both ranks, nothing is left in flight at the closing barrier."""
+    code = r"""
+import os, sys, torch
+sys.path.insert(0, %r)
+import torch.distributed as dist
+import bench
+from sam_pt_amd.dist import init_from_env
+rank, world, local = init_from_env("gloo")
+assert world == 2
+
+class FakeModel:
+    device = torch.device("cpu")
+    def forward_begin(self, step):
+        return step
+    def forward_end(self, step):     # one object, 2 frames; rank r, step s marks pixel (r, s) as foreground
+        logits = torch.full((1, 2, 3, 5), -4.0)
+        logits[0, :, rank, step] = 4.0
+        return {"logits": [logits[0]]}
+
+seen = []
+orig = bench.consume
+def spy(model, out, max_frames):
+    masks, gathered = orig(model, out, max_frames)
+    seen.append(None if gathered is None else gathered.clone())
+    return masks, gathered
+bench.consume = spy
+flight = bench.ClipsInFlight(FakeModel(), 2)
+for s in range(4):
+    flight.submit(s)
+last = flight.flush()
+dist.barrier()
+assert flight.pending is None and len(seen) == 4 and int(last[0, rank, 3]) == 1
+if rank == 0:
+    for s, g in enumerate(seen):
+        assert g.shape == (2, 2, 3, 5)
+        for r in range(2):
+            want = torch.zeros(2, 3, 5, dtype=torch.uint8); want[:, r, s] = 1
+            assert torch.equal(g[r], want), (s, r)
+    print("PIPELINED_GATHER_OK")
+else:
+    assert all(g is None for g in seen)
+dist.destroy_process_group()
+""" % ROOT
+    port = str(_free_port())
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:
+        f.write(code)
+        path = f.name
+    try:
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                            "--master-addr", "127.0.0.1", "--master-port", port, path], env=env, capture_output=True,
+                           text=True, timeout=240)
+    finally:
+        os.unlink(path)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "PIPELINED_GATHER_OK" in r.stdout
+
+
 def test_vos_index_masks_formula_matches_the_evaluator():
     """dist.index_masks with query-frame overrides == the reference evaluator's sequence (vos_eval/eval.py:304-326)."""
     from sam_pt_amd.dist import index_masks
@@ -622,3 +684,32 @@ def test_f16x3_scheme_is_fp32_grade():
         y3 = (conv(xl, whl[0]) + conv(xh, whl[1]) + conv(xh, whl[0])) / 2 ** F16X3_WSHIFT
         err = lambda a: float((a - ref).abs().max() / ref.abs().max())
         assert err(y3) < 2e-7 and err(y3) < err(f32), (cin, err(y3), err(f32))
+
+
+def test_bench_clips_in_flight_accounting(monkeypatch):
+    """bench.py's pipelined step loop: K ``submit`` calls + one ``flush`` begin K clips and collect K clips, each clip is
+    collected only after the NEXT one was submitted, and nothing stays in flight after the flush (the contract's "exactly K
+    steps inside the timed region")."""
+    import importlib
+    import sys
+    sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parents[1]))
+    bench = importlib.import_module("bench")
+    log = []
+
+    class FakeModel:
+        def forward_begin(self, video):
+            log.append(("begin", video))
+            return video
+
+        def forward_end(self, handle):
+            log.append(("end", handle))
+            return {"id": handle}
+
+    monkeypatch.setattr(bench, "consume", lambda model, out, max_frames: (out["id"], None))
+    flight = bench.ClipsInFlight(FakeModel(), 24)
+    assert flight.flush() is None and log == []                 # nothing in flight: a no-op
+    got = [flight.submit(i) for i in range(4)]
+    assert got == [None, 0, 1, 2]                                # submit(i) returns the masks of clip i - 1
+    assert flight.flush() == 3 and flight.pending is None
+    assert log == [("begin", 0), ("begin", 1), ("end", 0), ("begin", 2), ("end", 1), ("begin", 3), ("end", 2), ("end", 3)]
+    assert flight.flush() == 3 and len(log) == 8                 # idempotent
