@@ -3,8 +3,9 @@
 //
 //  * vit_rel_bias            — the two small bias tables per query (shared by both modes)
 //  * softmax_rel_rows        — exact-fp32 mode: bias + softmax over a materialised score matrix
-//  * vit_flash_attention_f16 — fused flash-style kernel: fp16 MFMA (32x32x16), fp32 online softmax, K / V^T tiles
-//                              and the bias tables staged in LDS, scores never leave registers.
+//  * vit_flash_attention_f16 — fused flash-style kernel: fp16 MFMA (32x32x16), fp32 online softmax; K / V tiles by LDS-DMA
+//                              (double-buffered), V consumed through transposing LDS reads, bias tables built by MFMA in the
+//                              prologue and kept in LDS, scores never leave registers.
 #include "ops.h"
 
 namespace sampt {
