@@ -713,3 +713,22 @@ def test_bench_clips_in_flight_accounting(monkeypatch):
     assert flight.flush() == 3 and flight.pending is None
     assert log == [("begin", 0), ("begin", 1), ("end", 0), ("begin", 2), ("end", 1), ("begin", 3), ("end", 2), ("end", 3)]
     assert flight.flush() == 3 and len(log) == 8                 # idempotent
+
+
+def test_captured_decode_chain_is_kernel_nodes_only():
+    """Source-level guard for the round-3 finding: a memset / memcpy NODE of a replayed hipGraph is not
+    ordered with the kernel nodes around it on ROCm 7.2, so nothing that sampt_sam_track_decode_graph captures may issue
+    one.  DecEngine::track_decode must not call hipMemset* / hipMemcpy* at all; DecEngine::decode only inside its
+    multimask branch (never active on the captured path: the flag is set and cleared inside sampt_sam_decode_multimask)."""
+    import re
+    src = open(os.path.join(ROOT, "sam_pt_amd", "csrc", "engine_dec.hip")).read()
+    body = src[src.index("int DecEngine::track_decode("):]
+    assert not re.search(r"hipMem(set|cpy)\w*\(", body), "track_decode issues a memset / memcpy: it would become a graph node"
+    dec = src[src.index("int DecEngine::decode("):src.index("int DecEngine::track_decode(")]
+    calls = [m.start() for m in re.finditer(r"hipMem(set|cpy)\w*\(", dec)]
+    assert len(calls) <= 1
+    if calls:                                                     # the one copy sits inside `if (multimask) { ... }`
+        lo = dec.index("if (multimask) {")
+        assert lo < calls[0] < dec.index("hypernetwork MLP of mask token 0", lo)
+    cabi = open(os.path.join(ROOT, "sam_pt_amd", "csrc", "c_abi.hip")).read()
+    assert cabi.count("h->e.multimask = true") == 1 and cabi.count("h->e.multimask = false") == 1
