@@ -11,8 +11,8 @@ RCCL inside the timed region; value = all frames of all ranks / max-over-ranks t
 Submission (``--submit``, default ``pipelined``): the step loop keeps one clip in flight ahead of the one it collects
 (``SamPt.forward_begin`` / ``forward_end``, the loop a sequence-by-sequence evaluator would run): the decoder chain of clip i
 overlaps the tracker encoder of clip i + 1.  Exactly ``--steps`` clips are submitted AND collected between the two barriers
-(the pipeline is empty at both); ``secondary.sequential_forward`` is the same workload with one blocking ``SamPt.forward`` per
-step, and ``--submit sequential`` times the whole run that way.
+(the pipeline is empty at both); the line's ``value_per_forward`` is the same workload over the same K steps with one blocking
+``SamPt.forward`` per step (what the reference evaluator's loop does), and ``--submit sequential`` makes that the ``value``.
 
 Launch: ``python bench.py --gpus 1`` or ``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N``.
 """
@@ -40,7 +40,9 @@ def parse():
     ap.add_argument("--points", type=int, default=8)
     ap.add_argument("--objects", type=int, default=1, help="number of tracked objects (BASELINE config #4 uses 3)")
     ap.add_argument("--refine", type=int, default=12)
-    ap.add_argument("--precision", default="f16", choices=["f16", "f32"])
+    ap.add_argument("--precision", default="f16", choices=["f16", "f16x3", "f32"],
+                    help="ViT block arithmetic: f16 = fp16 MFMA inputs (the headline mode); f16x3 = every product from split-fp16 "
+                         "pieces (3 fp16 MFMAs, fp32 accumulate): the reference's fp32 arithmetic at fp32 grade; f32 = exact f32 MFMA")
     ap.add_argument("--encode-batch", type=int, default=8)
     ap.add_argument("--decode-batch", type=int, default=128, help="max (frame, object) items per batched decoder chain")
     ap.add_argument("--tracker", default="pips", choices=["pips", "pips_plus_plus", "cotracker"],
@@ -223,6 +225,8 @@ def gemm_roofline(args, dev, insitu=None, frame_hw=(576, 1024)):
             "isolated_avg_launch_us": round(tot_t / launches * 1e6, 1),
             "traffic": None if tot_traffic is None else round(tot_traffic / launches),
             "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE; counts Infinity-Cache hits)",
+            "traffic_source": "committed --pmc passes of the shipped kernel (" + os.path.basename(tpath) + "), looked up per shape — "
+                              "not measured by this run (bench.py cannot run rocprofv3 on itself)",
             "algorithmic_bytes_per_launch": None if tot_traffic is None else round(tot_alg_bytes / launches),
             "launches_per_encode_call": launches,
             "avg_launch_us": round(avg_us, 1), "encode_batch": B}
@@ -407,8 +411,12 @@ class ReferenceApiPredictor:
 def reference_protocol_lines(args, model, video):
     """fps of the reference's own loop over the HIP seams, with and without the clip-embedding prefetch (prefetch.py)."""
     from sam_pt_amd.sam_pt import SamPt
+    from sam_pt_amd import prefetch
     ref_model = SamPt(model.point_tracker, ReferenceApiPredictor(model.sam_predictor), **sampt_kwargs(args)).eval()
+    n0 = prefetch.stats["clips_encoded"]
     res = {"reference_sampt_over_hip_seams": quick_fps(ref_model, video, args.frames, steps=1)}
+    # every pass (warm-up and timed) encoded its clip: the timed step includes the ViT (a cache across passes would skip it)
+    assert prefetch.stats["clips_encoded"] - n0 == 2, prefetch.stats
     os.environ["SAMPT_PREFETCH"] = "0"
     try:
         res["reference_sampt_over_hip_seams_no_prefetch"] = quick_fps(ref_model, video, args.frames, steps=1)
@@ -419,11 +427,11 @@ def reference_protocol_lines(args, model, video):
 
 def secondary_lines(args, model, video, dev):
     """Variants of the headline workload the judge asked to see beside it (2 timed steps each, same clip, every one with a
-    blocking ``SamPt.forward`` per step — ``sequential_forward`` is the headline workload itself run that way): the exact-fp32
+    blocking ``SamPt.forward`` per step — compare with the line's ``value_per_forward``): the split-fp16 and the exact-fp32
     ViT, the reference's dead query-mask SAM pass switched back on (sam_pt.py:181), the shipped IoU threshold 0.7, and the
     REFERENCE protocol (tracker, then set_image + sequential predict_torch per frame) over the two HIP seams — the speed a
     user of the unchanged reference ``SamPt`` gets from the two ``_target_`` overrides alone (1 timed step each)."""
-    res = {"sequential_forward": quick_fps(model, video, args.frames, steps=4)}   # one blocking SamPt.forward per step
+    res = {}
     model.compute_unused_query_masks = True
     res["with_reference_query_mask_pass"] = quick_fps(model, video, args.frames)
     model.compute_unused_query_masks = False
@@ -433,12 +441,13 @@ def secondary_lines(args, model, video, dev):
     res.update(reference_protocol_lines(args, model, video))
     if args.precision == "f16":
         import copy
-        a32 = copy.copy(args)
-        a32.precision = "f32"
-        m32 = build_model(a32, dev)
-        res["vit_precision_f32"] = quick_fps(m32, video, args.frames)
-        del m32
-        torch.cuda.empty_cache()
+        for prec in ("f16x3", "f32"):     # the reference's fp32 arithmetic: on the fp16 pipe at fp32 grade / on the f32 MFMA
+            a2 = copy.copy(args)
+            a2.precision = prec
+            m2 = build_model(a2, dev)
+            res["vit_precision_" + prec] = quick_fps(m2, video, args.frames)
+            del m2
+            torch.cuda.empty_cache()
     return {"unit": "frames/s", "steps": 2, **res}
 
 
@@ -537,6 +546,21 @@ def main():
         dt = float(tmax.item())
     total_frames = (lpt_info["frames_total"] if lpt else (1 if frames_sharded else world) * args.frames) * args.steps
     fps = total_frames / dt
+    # The same K steps once more with ONE BLOCKING SamPt.forward per step — what the reference's evaluator loop does with the
+    # drop-in (`value` above keeps one clip in flight through forward_begin / forward_end); same barriers, same max over ranks.
+    fps_seq = dt_seq = None
+    if pipelined:
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            one_step(model, video, args.frames, shard)
+        barrier()
+        dt_seq = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt_seq], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt_seq = float(tmax.item())
+        fps_seq = total_frames / dt_seq
     insitu = None
     if rank == 0 and not args.no_roofline and args.precision == "f16":   # one more step, GEMM launches event-timed
         model.sam_predictor.gemm_profile_begin()
@@ -562,18 +586,25 @@ def main():
                "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "strong" if (frames_sharded or lpt) else "weak",
                "vs_baseline": None,
-               "dtype": "f16" if args.precision == "f16" else "f32", "data": "synthetic",
+               # the metric as SURVEY.md §8(d) defines it — T / wall time of one blocking SamPt.forward — over the same K steps
+               "value_per_forward": round(fps_seq, 3) if fps_seq else round(fps, 3),
+               "ms_per_forward": round((dt_seq if dt_seq else dt) / args.steps * 1e3, 2),
+               "dtype": args.precision, "data": "synthetic",
                "config": {"workload": f"{'HQ-SAM' if args.hq else 'SAM'} {args.model} + { {'pips': 'PIPS', 'cotracker': 'CoTracker', 'pips_plus_plus': 'PIPS++'}[args.tracker]}, {args.points}"
                                       f"{'+' + str(args.neg_points) if args.neg_points else ''} query points, {args.objects} object(s), "
-                                      f"{args.frames}x 480p synthetic frames " + ("at native " if args.native_480p else "upscaled to ") + f"{H}x{W}, "
+                                      + (f"{args.frames}x {H}x{W} synthetic frames, " if args.square else
+                                         f"{args.frames}x 480p synthetic frames " + ("at native " if args.native_480p else "upscaled to ") + f"{H}x{W}, ") +
                                       f"{args.refine} refinement iterations, random-init weights (seed 72)",
                           "frames_per_step": lpt_info["frames_total"] if lpt else args.frames,
                           "submit": ("pipelined: one clip in flight ahead of the one being collected (SamPt.forward_begin / "
                                      "forward_end), all submitted and collected inside the timed region" if pipelined
                                      else "sequential: one blocking SamPt.forward per step"),
                           "parallelism": f"{'frame-batch' if frames_sharded else 'sequence'}-sharded x{world}",
-                          "vit_precision": args.precision + " MFMA inputs, fp32 accumulate/LN/softmax/residual"
-                                           + ("; patch embedding and neck fp32-grade (3-term split-fp16 MFMA)" if args.precision == "f16" else ""),
+                          "vit_precision": {"f16": "fp16 MFMA inputs, fp32 accumulate/LN/softmax/residual; patch embedding and neck "
+                                                   "fp32-grade (3-term split-fp16 MFMA)",
+                                            "f16x3": "fp32-grade on the fp16 matrix pipe: every GEMM / attention product as hi.hi + "
+                                                     "hi.lo + lo.hi of split-fp16 operands, fp32 accumulate/LN/softmax/residual",
+                                            "f32": "exact f32 MFMA, materialised attention scores"}[args.precision],
                           "tracker_precision": tracker_precision, "decoder_precision": "fp32"},
                "mask_foreground_fraction": round(float((masks > 0).float().mean()), 4),
                "published_reference_fps_unstated_hw": {"vit_h": 1.4, "vit_l": 1.8, "vit_b": 2.6}[args.model]}

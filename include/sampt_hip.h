@@ -150,12 +150,15 @@ int sampt_cotracker_track_f32(sampt_cotracker_t h, const float* const pyr_dev[4]
 /* ---------------------------------------------------------------------------------------------------------
  * seam 2a — SAM image encoder = SamPredictor.set_image (Sam.preprocess + ImageEncoderViT, Appendix A-1..A-3).
  * cfg: see sampt_vit_config.  Weight names: upstream sam_vit_*.pth keys; GEMM weights as ".f16" copies when
- * cfg.f16 != 0; "image_encoder.neck.2.weight_khwc"; "__win_rows" (window-partition row map for win_batches frames).
+ * cfg.f16 == 1, as ".x3" copies (x3 rows of w * 2^8, see sampt_gemm_ex) when cfg.f16 == 2;
+ * "image_encoder.neck.2.weight_khwc"; "__win_rows" (window-partition row map for win_batches frames).
  * --------------------------------------------------------------------------------------------------------- */
 typedef struct sampt_vit_config {
   int embed_dim, depth, num_heads, grid, window, patch, out_chans, mlp_ratio, img_size;
   int global_mask; /* bit i: block i uses global attention (configs/model/sam/image_encoder/vit_*.yaml) */
-  int f16;         /* 1: fp16 MFMA + flash attention (fp32 accumulate/softmax/LN/residual); 0: exact fp32 */
+  int f16;         /* 1: fp16 MFMA + flash attention (fp32 accumulate/softmax/LN/residual); 0: exact fp32 (f32 MFMA,
+                      materialised scores); 2: "f16x3" — the fp16 graph with every product rebuilt from split-fp16 pieces
+                      (hi.hi + hi.lo + lo.hi, fp32 accumulate): fp32-grade results on the fp16 matrix pipe */
   float pixel_mean[3], pixel_std[3];
 } sampt_vit_config;
 
@@ -309,6 +312,11 @@ int sampt_gemm(int dtype, const void* A_dev, const void* W_dev, const float* bia
 int sampt_gemm_ex(int dtype, const void* A_dev, const void* W_dev, const float* bias_dev, const float* res_dev,
                   void* C_dev, int M, int N, int K, int act, float alpha, const int32_t* rowmap_dev,
                   const int32_t* a_rowmap_dev, int res_mod, int ldr, sampt_stream_t stream);
+/* dtype 3 / 4 of sampt_gemm_ex: fp32-grade product on the fp16 matrix pipe.  A [M][2K] and W [N][2K] are "x3 rows": every
+ * block of 32 consecutive k of a logical row is stored as 64 halves hi(32) | lo(32), v = hi + lo with hi = fp16(v),
+ * lo = fp16(v - hi) (sampt_split_rows_x3; weights are split after scaling by 2^8 — sam_pt_amd/pack.py:x3_rows — and the
+ * caller passes alpha = 2^-8).  K is the LOGICAL K (K % 64 == 0).  dtype 3: C f32 [M][N]; dtype 4: C x3 rows [M][2N]. */
+int sampt_split_rows_x3(const float* x_dev, void* y_dev, int M, int K, sampt_stream_t stream);
 /* NHWC convolution as implicit GEMM: x [n][H][W][Cin], w [Cout][KH][KW][Cin], y [n][OH][OW][Cout] (f32 out).
  * dtype 3 = fp32-grade result on the fp16 matrix pipe: x is f32, w_dev is half [2][Cout][KH*KW*Cin] = the weights times
  * 2^8 split as hi = fp16(w), lo = fp16(w - hi) (sam_pt_amd/pack.py:split_f16x3); Cin % 32 == 0, Cout % 4 == 0.
@@ -319,6 +327,7 @@ int sampt_conv2d_nhwc(int dtype, const void* x_dev, const void* w_dev, const flo
 int sampt_instance_norm_nhwc(float* x_dev, int n, int hw, int C, float eps, int relu, const float* skip_dev,
                              void* workspace_dev, size_t workspace_bytes, sampt_stream_t stream);
 size_t sampt_instance_norm_workspace_bytes(int n, int hw, int C);
+/* out_f16: 0 = f32 rows, 1 = fp16 rows, 2 = x3 rows [M][2D] (see sampt_split_rows_x3; D % 32 == 0) */
 int sampt_layernorm(const float* x_dev, const float* w_dev, const float* b_dev, void* y_dev, int M, int D, float eps,
                     int out_f16, int act, sampt_stream_t stream);
 int sampt_resize_bilinear_nhwc(const float* src_dev, int n, int sh, int sw, int C, float* dst_dev, int dh, int dw,
@@ -358,6 +367,11 @@ int sampt_cotracker_attention_f32(const float* qkv_dev, float* out_dev, int nbat
  * are unused (kept for ABI stability: K / V tiles are staged by LDS-DMA, nothing goes through HBM scratch). */
 int sampt_vit_attention_f16(const void* qkv_dev, const float* rel_h_dev, const float* rel_w_dev, void* out_dev, int B,
                             int S, int heads, int hd, void* workspace_dev, size_t workspace_bytes, sampt_stream_t stream);
+/* The same attention at fp32 grade (precision "f16x3": three split-fp16 MFMAs per product in Q.K^T, the bias tables and
+ * P.V; fp32 softmax).  qkv_dev: x3 rows [B*S*S][2*3*heads*hd] halves (what the dtype-4 qkv GEMM writes), out_dev: x3 rows
+ * [B*S*S][2*heads*hd].  Same geometries as sampt_vit_attention_f16; heads*hd % 32 == 0. */
+int sampt_vit_attention_x3(const void* qkv_dev, const float* rel_h_dev, const float* rel_w_dev, void* out_dev, int B, int S,
+                           int heads, int hd, sampt_stream_t stream);
 
 #ifdef __cplusplus
 }

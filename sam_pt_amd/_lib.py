@@ -103,6 +103,8 @@ _SIGS = {
     "sampt_attention_f32": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "sampt_cotracker_attention_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "sampt_vit_attention_f16": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
+    "sampt_vit_attention_x3": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "sampt_split_rows_x3": (c_int, [_P, _P, c_int, c_int, _P]),
 }
 
 _lib = None

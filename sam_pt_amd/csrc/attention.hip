@@ -126,7 +126,7 @@ __device__ half_t g_flash_pad[16] = {(half_t)1.f, (half_t)0.f, (half_t)0.f, (hal
 template <int HD, int NW, int SG>
 __global__ __launch_bounds__(NW * 64, 2) void k_flash_f16(const half_t* __restrict__ qkv, const float* __restrict__ rel_h,
                                                        const float* __restrict__ rel_w, half_t* __restrict__ out, int N,
-                                                       int heads, float scale, int dbg) {
+                                                       int heads, float scale) {
   constexpr int KS = HD / 16;            // k-steps of QK^T
   constexpr int DT = (HD + 31) / 32;     // 32-row tiles of O^T
   constexpr int QT = NW * 32;
@@ -254,7 +254,6 @@ __global__ __launch_bounds__(NW * 64, 2) void k_flash_f16(const half_t* __restri
       const int kw = SG >= 64 ? j : j % SG;
       relw2[kt * 16 + r] = j < KTV ? LOG2E * (float)relw_s[kw][ql] : -INFINITY;
     }
-  (void)dbg;
 
   // transposing V reads: byte offset inside a V buffer of this lane's source chunk for k-step 0, first key quad
   int vl[DT];
@@ -395,10 +394,9 @@ int vit_flash_attention_f16(const half_t* qkv, const float* relh, const float* r
                             int heads, int hd, hipStream_t s) {
   const int N = S * S;
   const float scale = 1.0f / sqrtf((float)hd);
-  static const int dbg = getenv("SAMPT_FLASH_DBG") ? atoi(getenv("SAMPT_FLASH_DBG")) : 0;
 #define FL(HDv, NWv, SGv)                                                                                     \
   hipLaunchKernelGGL((k_flash_f16<HDv, NWv, SGv>), dim3(cdiv(N, NWv * 32), heads, B), dim3(NWv * 64), 0, s, qkv, relh, \
-                     relw, out, N, heads, scale, dbg)
+                     relw, out, N, heads, scale)
   if (S == 64 && hd == 80) FL(80, 4, 64);
   else if (S == 64 && hd == 64) FL(64, 4, 64);
   // (a 7-wave workgroup per (window, head) — 224 query slots for the 196 tokens instead of 2 x 128 — measured 4 % slower,

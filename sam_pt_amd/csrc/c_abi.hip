@@ -570,7 +570,16 @@ int sampt_gemm_ex(int dtype, const void* A, const void* W, const float* bias, co
   p.M = M, p.N = N, p.K = K, p.lda = K, p.ldw = K, p.ldc = N, p.ldr = ldr > 0 ? ldr : N, p.act = act, p.alpha = alpha;
   p.res_mod = res_mod;
   p.out_f16 = dtype == 2;
+  if (dtype == 3 || dtype == 4) {   // x3 rows in (A, W: 2K halves per row), f32 or x3 rows out
+    p.x3 = 1, p.K = 2 * K, p.lda = 2 * K, p.ldw = 2 * K;
+    if (dtype == 4) p.out_f16 = 2, p.ldc = 2 * N;
+  }
   return dtype == 0 ? gemm_f32(p, (hipStream_t)stream) : gemm_f16(p, (hipStream_t)stream);
+}
+
+int sampt_split_rows_x3(const float* x, void* y, int M, int K, sampt_stream_t stream) {
+  if (!x || !y) return fail(SAMPT_ERR_ARG, "sampt_split_rows_x3: bad arguments");
+  return split_rows_x3(x, (half_t*)y, M, K, (hipStream_t)stream);
 }
 
 int sampt_conv2d_nhwc(int dtype, const void* x, const void* w, const float* bias, float* y, int n, int H, int W, int Cin,
@@ -656,6 +665,12 @@ int sampt_vit_attention_f16(const void* qkv, const float* rel_h, const float* re
                             int hd, void* ws, size_t ws_bytes, sampt_stream_t stream) {
   (void)ws, (void)ws_bytes;  // the decomposed rel-pos bias is computed inside the kernel: no scratch needed any more
   return vit_flash_attention_f16((const half_t*)qkv, rel_h, rel_w, (half_t*)out, B, S, heads, hd, (hipStream_t)stream);
+}
+
+int sampt_vit_attention_x3(const void* qkv, const float* rel_h, const float* rel_w, void* out, int B, int S, int heads,
+                           int hd, sampt_stream_t stream) {
+  if (!qkv || !rel_h || !rel_w || !out) return fail(SAMPT_ERR_ARG, "sampt_vit_attention_x3: bad arguments");
+  return vit_flash_attention_x3((const half_t*)qkv, rel_h, rel_w, (half_t*)out, B, S, heads, hd, (hipStream_t)stream);
 }
 
 int sampt_attention_f32(int kind, const float* q, const float* k, const float* v, float* out, int F, int Nq, int Nk,

@@ -70,6 +70,15 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
+// v = hi + lo in fp16 pieces, the operand format of the 3-term split-fp16 products (conv_f16x3.hip, GemmP::x3).  Saturating:
+// hi is clamped to the fp16 range and lo carries the rest, so |v| up to 2 x 65504 stays finite (beyond that lo overflows).
+__device__ __forceinline__ void split_f16(float v, half_t& hi, half_t& lo) {
+  hi = (half_t)__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
+  lo = (half_t)(v - (float)hi);
+}
+// column c of a logical row -> its position in an x3 row (the hi half; lo is 32 halves further)
+__device__ __forceinline__ long x3_col(int c) { return ((long)(c >> 5) << 6) + (c & 31); }
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---------------------------------------------------------------------------------------------
@@ -100,7 +109,13 @@ struct GemmP {
   // shuf_n columns, bias has shuf_n entries).  shuf_g = g (0: off)
   int shuf_g = 0, shuf_n = 0;
   int act = ACT_NONE;
-  int out_f16 = 0;               // C is half (only when the input type is half)
+  int out_f16 = 0;               // half inputs only: 1 = C is half; 2 = C is half in the split "x3 row" format (see x3), ldc = 2N
+  // x3 (half inputs only): fp32-grade products on the fp16 matrix pipe.  Both operands are "x3 rows": every block of 32
+  // consecutive k of a row is stored as 64 halves [hi(32) | lo(32)] with v = hi + lo (hi = fp16(v), lo = fp16(v - hi);
+  // weights pre-scaled by 2^F16X3_WSHIFT, the caller passes alpha = 2^-F16X3_WSHIFT).  K / lda / ldw count STORED halves
+  // (2 x the real K, a multiple of 64); per 64-half K-slab the kernels issue hi.hi + hi.lo + lo.hi (the dropped lo.lo
+  // term is < 2^-22 relative) instead of the two half-slab products of a plain fp16 GEMM.
+  int x3 = 0;
   int w_kn = 0;                  // W stored [K][N]
   float alpha = 1.0f;
   // implicit-GEMM convolution over an NHWC input: A is [Nimg][H][W][Cin], W is [Cout][KH*KW*Cin]

@@ -96,9 +96,16 @@ __global__ __launch_bounds__(256) void k_conv_f16x3(GemmP p) {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       const float4 v = ra[i];
-      const h4 hi = {(half_t)v.x, (half_t)v.y, (half_t)v.z, (half_t)v.w};
-      const h4 lo = {(half_t)(v.x - (float)hi[0]), (half_t)(v.y - (float)hi[1]), (half_t)(v.z - (float)hi[2]),
-                     (half_t)(v.w - (float)hi[3])};
+      // saturating split (common.h): an activation beyond the fp16 range keeps hi finite and lo carries the rest (the ViT
+      // neck reads the raw residual stream, which trained checkpoints push to O(10^2 - 10^3) in a few channels)
+      const float vv[4] = {v.x, v.y, v.z, v.w};
+      h4 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        half_t a, b;
+        split_f16(vv[e], a, b);
+        hi[e] = a, lo[e] = b;
+      }
       *(h4*)&Ah[buf][a_row[i]][a_kv[i]] = hi;
       *(h4*)&Al[buf][a_row[i]][a_kv[i]] = lo;
     }
@@ -366,25 +373,19 @@ int conv_f16x3(const GemmP& p_in, hipStream_t s) {
   }
   const int BN = p.N <= 32 ? 32 : (p.N <= 64 ? 64 : (p.N <= 96 ? 96 : 128));
   const size_t lds = (size_t)2 * (2 * 128 + 2 * BN) * (32 + 8) * sizeof(half_t);
-  // SAMPT_CONV_PF=2: two slabs in flight (two register sets).  Measured slower everywhere — decode chain 24.70 vs 24.34 ms,
-  // tracker-encoder pass 6.54 vs 6.08 ms, 93.9 vs 95.0 fps end to end (profiles/r2_v16_*): these kernels are not bound by
-  // the latency of their global loads, and the extra 30 registers cost the 64- and 96-column tiles a resident wave.
-  static const int pf = getenv("SAMPT_CONV_PF") ? atoi(getenv("SAMPT_CONV_PF")) : 1;
+  // One K slab of register prefetch.  Two slabs in flight (a second register set) measured slower everywhere — decode chain
+  // 24.70 vs 24.34 ms, tracker-encoder pass 6.54 vs 6.08 ms (profiles/r2_v16_*): these kernels are not bound by the latency of
+  // their global loads, and the extra 30 registers cost the 64- and 96-column tiles a resident wave.
   static bool raised = false;
   if (!raised) {  // 128 x 128 tiles need 80 KiB, above the default 64 KiB dynamic-LDS limit (gfx950: 160 KiB per CU)
-    const void* fns[] = {(const void*)k_conv_f16x3<128, 64, 1>,  (const void*)k_conv_f16x3<128, 96, 1>,
-                         (const void*)k_conv_f16x3<128, 128, 1>, (const void*)k_conv_f16x3<128, 64, 2>,
-                         (const void*)k_conv_f16x3<128, 96, 2>,  (const void*)k_conv_f16x3<128, 128, 2>};
+    const void* fns[] = {(const void*)k_conv_f16x3<128, 64, 1>, (const void*)k_conv_f16x3<128, 96, 1>,
+                         (const void*)k_conv_f16x3<128, 128, 1>};
     for (const void* f : fns)
       if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) return SAMPT_ERR_HIP;
     raised = true;
   }
   dim3 grid((unsigned)((long)cdiv(p.N, BN) * cdiv(p.M, 128))), block(256);
-#define CONV_LAUNCH(BNv)                                                                              \
-  do {                                                                                                \
-    if (pf >= 2) hipLaunchKernelGGL((k_conv_f16x3<128, BNv, 2>), grid, block, lds, s, p);       \
-    else hipLaunchKernelGGL((k_conv_f16x3<128, BNv, 1>), grid, block, lds, s, p);                    \
-  } while (0)
+#define CONV_LAUNCH(BNv) hipLaunchKernelGGL((k_conv_f16x3<128, BNv, 1>), grid, block, lds, s, p)
   if (BN == 32) CONV_LAUNCH(32);   // (51 KiB: under the default limit)
   else if (BN == 64) CONV_LAUNCH(64);
   else if (BN == 96) CONV_LAUNCH(96);

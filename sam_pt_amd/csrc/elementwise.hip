@@ -342,7 +342,8 @@ __global__ __launch_bounds__(256) void k_layernorm_rows(const float* __restrict_
     for (int i = 0; i < NI; ++i) {
       int idx = lane + 64 * i;
       if (idx < D) {
-        if (out_f16) ((half_t*)y)[row * D + idx] = (half_t)0.f;
+        if (out_f16 == 2) ((half_t*)y)[row * 2 * D + x3_col(idx)] = ((half_t*)y)[row * 2 * D + x3_col(idx) + 32] = (half_t)0.f;
+        else if (out_f16) ((half_t*)y)[row * D + idx] = (half_t)0.f;
         else ((float*)y)[row * D + idx] = 0.f;
       }
     }
@@ -373,7 +374,12 @@ __global__ __launch_bounds__(256) void k_layernorm_rows(const float* __restrict_
     if (idx < D) {
       float o = (v[i] - mean) * rstd * w[idx] + b[idx];
       o = apply_act(o, act);
-      if (out_f16) ((half_t*)y)[row * D + idx] = (half_t)o;
+      if (out_f16 == 2) {
+        half_t hi, lo;
+        split_f16(o, hi, lo);
+        half_t* yp = (half_t*)y + row * 2 * D + x3_col(idx);
+        yp[0] = hi, yp[32] = lo;
+      } else if (out_f16) ((half_t*)y)[row * D + idx] = (half_t)o;
       else ((float*)y)[row * D + idx] = o;
     }
   }
@@ -393,7 +399,10 @@ __global__ __launch_bounds__(256) void k_layernorm_rows_v4(const float* __restri
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       int c = (lane + 64 * i) * 4;
-      if (out_f16) *(h4*)((half_t*)y + row * D + c) = (h4){0, 0, 0, 0};
+      if (out_f16 == 2) {
+        *(h4*)((half_t*)y + row * 2 * D + x3_col(c)) = (h4){0, 0, 0, 0};
+        *(h4*)((half_t*)y + row * 2 * D + x3_col(c) + 32) = (h4){0, 0, 0, 0};
+      } else if (out_f16) *(h4*)((half_t*)y + row * D + c) = (h4){0, 0, 0, 0};
       else *(float4*)((float*)y + row * D + c) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     return;
@@ -422,7 +431,17 @@ __global__ __launch_bounds__(256) void k_layernorm_rows_v4(const float* __restri
     float o1 = apply_act((v[i].y - mean) * rstd * wv.y + bv.y, act);
     float o2 = apply_act((v[i].z - mean) * rstd * wv.z + bv.z, act);
     float o3 = apply_act((v[i].w - mean) * rstd * wv.w + bv.w, act);
-    if (out_f16) *(h4*)((half_t*)y + row * D + c) = (h4){(half_t)o0, (half_t)o1, (half_t)o2, (half_t)o3};
+    if (out_f16 == 2) {
+      h4 hi, lo;
+      half_t a, bb;
+      split_f16(o0, a, bb), hi[0] = a, lo[0] = bb;
+      split_f16(o1, a, bb), hi[1] = a, lo[1] = bb;
+      split_f16(o2, a, bb), hi[2] = a, lo[2] = bb;
+      split_f16(o3, a, bb), hi[3] = a, lo[3] = bb;
+      half_t* yp = (half_t*)y + row * 2 * D + x3_col(c);
+      *(h4*)yp = hi;
+      *(h4*)(yp + 32) = lo;
+    } else if (out_f16) *(h4*)((half_t*)y + row * D + c) = (h4){(half_t)o0, (half_t)o1, (half_t)o2, (half_t)o3};
     else *(float4*)((float*)y + row * D + c) = make_float4(o0, o1, o2, o3);
   }
 }
@@ -456,6 +475,7 @@ __global__ __launch_bounds__(256) void k_layernorm_rows_d64(const float* __restr
 int layernorm_rows(const float* x, const float* w, const float* b, void* y, long M, int D, float eps,
                    const int* src_rows, int out_f16, int act, hipStream_t s) {
   if (D <= 0 || D > 2048 || M <= 0) return SAMPT_ERR_ARG;
+  if (out_f16 == 2 && (D % 32)) return SAMPT_ERR_ARG;     // x3 rows are made of whole 32-blocks
   if (D == 64 && !src_rows && !out_f16 && ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)w | (uintptr_t)b) & 15) == 0)) {
     hipLaunchKernelGGL(k_layernorm_rows_d64, dim3((unsigned)cdiv(M, 16)), dim3(256), 0, s, x, w, b, (float*)y, M, eps, act);
     SAMPT_CHECK_LAUNCH("layernorm_rows_d64");
@@ -508,6 +528,32 @@ int add_bcast(const float* a, const float* b, float* out, long n, long bmod, hip
 __global__ void k_cast_f32_f16(const float* __restrict__ x, half_t* __restrict__ y, long n) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) y[i] = (half_t)x[i];
+}
+
+// f32 rows [M][K] -> x3 rows [M][2K] (common.h): one thread per 4 consecutive columns
+__global__ void k_split_rows_x3(const float4* __restrict__ x, half_t* __restrict__ y, long n4, int K4) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const long row = i / K4;
+  const int c = (int)(i - row * K4) * 4;
+  const float4 v = x[i];
+  h4 hi, lo;
+  half_t a, b;
+  split_f16(v.x, a, b), hi[0] = a, lo[0] = b;
+  split_f16(v.y, a, b), hi[1] = a, lo[1] = b;
+  split_f16(v.z, a, b), hi[2] = a, lo[2] = b;
+  split_f16(v.w, a, b), hi[3] = a, lo[3] = b;
+  half_t* yp = y + row * 8 * K4 + x3_col(c);
+  *(h4*)yp = hi;
+  *(h4*)(yp + 32) = lo;
+}
+
+int split_rows_x3(const float* x, half_t* y, long M, int K, hipStream_t s) {
+  if (M <= 0 || K <= 0 || (K % 32) || (((uintptr_t)x | (uintptr_t)y) & 15)) return SAMPT_ERR_ARG;
+  const long n4 = M * (K / 4);
+  hipLaunchKernelGGL(k_split_rows_x3, dim3(cdiv(n4, 256)), dim3(256), 0, s, (const float4*)x, y, n4, K / 4);
+  SAMPT_CHECK_LAUNCH("split_rows_x3");
+  return SAMPT_OK;
 }
 
 int cast_f32_f16(const float* x, half_t* y, long n, hipStream_t s) {
@@ -757,10 +803,23 @@ __global__ void k_fill_rows_bias(T* __restrict__ out, const int* __restrict__ ro
   if (c < N) out[(long)rows[blockIdx.y] * N + c] = (T)bias[c];
 }
 
+// the same for a matrix of x3 rows (common.h): [*][2N] halves
+__global__ void k_fill_rows_bias_x3(half_t* __restrict__ out, const int* __restrict__ rows, const float* __restrict__ bias,
+                                    int N) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= N) return;
+  half_t hi, lo;
+  split_f16(bias[c], hi, lo);
+  half_t* op = out + (long)rows[blockIdx.y] * 2 * N + x3_col(c);
+  op[0] = hi, op[32] = lo;
+}
+
+// f16: 0 = f32 rows, 1 = fp16 rows, 2 = x3 rows
 int fill_rows_bias(void* out, int f16, const int* rows, int nrows, const float* bias, int N, hipStream_t s) {
   if (nrows <= 0) return SAMPT_OK;
   dim3 grid(cdiv(N, 256), nrows);
-  if (f16) hipLaunchKernelGGL(k_fill_rows_bias<half_t>, grid, dim3(256), 0, s, (half_t*)out, rows, bias, N);
+  if (f16 == 2) hipLaunchKernelGGL(k_fill_rows_bias_x3, grid, dim3(256), 0, s, (half_t*)out, rows, bias, N);
+  else if (f16) hipLaunchKernelGGL(k_fill_rows_bias<half_t>, grid, dim3(256), 0, s, (half_t*)out, rows, bias, N);
   else hipLaunchKernelGGL(k_fill_rows_bias<float>, grid, dim3(256), 0, s, (float*)out, rows, bias, N);
   SAMPT_CHECK_LAUNCH("fill_rows_bias");
   return SAMPT_OK;

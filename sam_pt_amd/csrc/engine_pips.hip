@@ -118,10 +118,9 @@ int PipsEngine::fnet(const uint8_t* frames, int nf, int H, int W, float* const o
   int h, w;
   // Every InstanceNorm output that feeds a split-fp16 convolution is also written as two fp16 planes (same bytes as the
   // f32 map): the convolution then stages ready-made halves instead of splitting each element once per filter tap.
-  static const bool use_planes = !(getenv("SAMPT_FNET_PLANES") && atoi(getenv("SAMPT_FNET_PLANES")) == 0);
   auto planes = [&](size_t elems, const ConvW& consumer) {
     Planes pl;
-    if (use_planes && consumer.w_hl) pl.hi = ws.f16(elems), pl.lo = ws.f16(elems);
+    if (consumer.w_hl) pl.hi = ws.f16(elems), pl.lo = ws.f16(elems);
     return pl;
   };
   float* cur = ws.f32((size_t)nf * H2 * W2 * 64);

@@ -2,6 +2,10 @@
 //   fast mode (c.f16 = 1): fp16 MFMA GEMMs with fused bias / GELU / residual epilogues, fused flash attention with
 //                          on-the-fly decomposed rel-pos bias, fp32 residual stream / LayerNorm / softmax.
 //   exact mode (c.f16 = 0): the same graph in fp32 (f32 MFMA GEMMs, materialised scores) — parity reference.
+//   f16x3 mode (c.f16 = 2): the fast mode's graph with every product rebuilt from split-fp16 pieces (3 fp16 MFMAs per
+//                          product, fp32 accumulate): fp32-grade results at a third of the fp16 MFMA rate instead of the f32
+//                          MFMA's 1/16.  Activations travel between kernels as "x3 rows" (common.h GemmP::x3): LayerNorm,
+//                          the qkv / fc1 GEMM epilogues and the attention kernel emit them, the next GEMM consumes them.
 // Activations are token-major [rows][channels] throughout (NHWC): the neck's output is directly the decoder's
 // image-token matrix.
 #include "engine.h"
@@ -11,7 +15,7 @@ namespace sampt {
 int VitEngine::init(const WeightMap& w, const VitConfig& cfg, int wrb) {
   c = cfg;
   win_rows_batches = wrb;
-  const std::string sfx = c.f16 ? ".f16" : "";
+  const std::string sfx = c.f16 == 2 ? ".x3" : (c.f16 ? ".f16" : "");
   const std::string e = "image_encoder.";
   // the encoder's two ends are fp32-grade in both modes (see encode): exact f32 weights, or their split-fp16 planes
   patch_hl = c.f16 ? w.h(e + "patch_embed.proj.weight_hl") : nullptr;
@@ -67,17 +71,18 @@ int VitEngine::profile_end(double* flop, double* ms, int* launches) {
 
 namespace {
 struct G {
-  bool f16;
+  int mode;            // VitConfig::f16: 0 exact f32, 1 fp16, 2 split-fp16 (x3 rows)
   hipStream_t s;
   const VitEngine* eng = nullptr;
-  // C = act(A.W^T + bias) (+ residual at the (row-mapped) destination row)
-  int run(const void* A, int M, int K, const void* W, const float* bias, void* C, int N, int act, bool out_f16,
+  // C = act(A.W^T + bias) (+ residual at the (row-mapped) destination row).  out: 0 = f32, 1 = fp16, 2 = x3 rows.
+  // M, N, K are the logical sizes; in mode 2 A and W are x3 rows (2K halves per row).
+  int run(const void* A, int M, int K, const void* W, const float* bias, void* C, int N, int act, int out,
           const float* res, int ldr, const int* rowmap, int res_mod, const int* a_rowmap = nullptr,
           bool exact = false, const half_t* hl = nullptr) const {
     GemmP p;
     p.A = A, p.W = W, p.bias = bias, p.C = C, p.res = res, p.rowmap = rowmap, p.a_rowmap = a_rowmap;
     p.M = M, p.N = N, p.K = K, p.lda = K, p.ldw = K, p.ldc = N, p.ldr = ldr, p.act = act, p.res_mod = res_mod;
-    p.out_f16 = out_f16 ? 1 : 0;
+    p.out_f16 = out;
     p.p8_wgs = eng ? eng->gemm_wgs : 0;
     if (exact && hl) {   // fp32-grade on the fp16 pipe: the GEMM as a 1x1 convolution over an [1][M][1][K] image
       p.W = hl, p.W_lo = hl + (size_t)N * K;
@@ -85,7 +90,12 @@ struct G {
       p.conv = 1, p.cH = M, p.cW = 1, p.cC = K, p.KH = 1, p.KW = 1, p.cstride = 1, p.cpad = 0, p.OH = M, p.OW = 1;
       return conv_f16x3(p, s);
     }
-    if (!f16 || exact) return gemm_f32(p, s);
+    if (mode == 0 || exact) return gemm_f32(p, s);
+    if (mode == 2) {
+      p.x3 = 1, p.K = 2 * K, p.lda = 2 * K, p.ldw = 2 * K;
+      p.alpha = 1.0f / (float)(1 << F16X3_WSHIFT);
+      if (out == 2) p.ldc = 2 * N;
+    }
     if (!eng || !eng->profiling) return gemm_f16(p, s);
     VitEngine::GemmEv ev;
     ev.flop = 2.0 * M * N * K;
@@ -117,7 +127,7 @@ int VitEngine::encode(const uint8_t* frames, int chw, int B, int H, int W, float
   const int g = c.grid, T = g * g, D = c.D, ws_ = c.window, hd = D / c.heads;
   const int gp = ((g + ws_ - 1) / ws_) * ws_, nw1 = gp / ws_, nwin = nw1 * nw1, wt = ws_ * ws_;
   const long Mg = (long)B * T, Mw = (long)B * nwin * wt, Mmax = Mw > Mg ? Mw : Mg;
-  const size_t esz = c.f16 ? 2 : 4;
+  const size_t esz = c.f16 == 1 ? 2 : 4;                // fp16 rows; f32 rows and x3 rows (2 halves per element) alike
   const int Kp = 3 * c.patch * c.patch;
   if (B > win_rows_batches) return SAMPT_ERR_ARG;
 
@@ -161,11 +171,12 @@ int VitEngine::encode(const uint8_t* frames, int chw, int B, int H, int W, float
   if (dry) return SAMPT_OK;
   (void)Smax;
 
-  G gm{c.f16 != 0, s, this};
+  G gm{c.f16, s, this};
+  const int act_out = c.f16;                             // GEMM outputs that feed the next GEMM / attention: f32, fp16 or x3 rows
   // ---- patch embedding: preprocess + im2col, GEMM + bias + positional embedding (broadcast over the batch)
   //      (exact fp32 in both modes: first and last layers of the encoder, 0.3 % of its FLOPs)
   SAMPT_TRY(sam_patchify(frames, chw, B, H, W, c.img, c.patch, c.mean, c.stdv, xn, 0, s));
-  SAMPT_TRY(gm.run(xn, (int)Mg, Kp, patch_w, patch_b, x, D, ACT_NONE, false, pos, D, nullptr, T, nullptr, true, patch_hl));
+  SAMPT_TRY(gm.run(xn, (int)Mg, Kp, patch_w, patch_b, x, D, ACT_NONE, 0, pos, D, nullptr, T, nullptr, true, patch_hl));
 
   const float scale = 1.0f / sqrtf((float)hd);
   bool tapped = false;
@@ -205,10 +216,12 @@ int VitEngine::encode(const uint8_t* frames, int chw, int B, int H, int W, float
     // norm1; the window partition (zero padding AFTER the norm, App. A-3) is a row scatter of the qkv GEMM: only the
     // real tokens go through the GEMM, the padded rows' qkv is the bias alone
     SAMPT_TRY(layernorm_rows(x, b.ln1w, b.ln1b, xn, Mg, D, 1e-6f, nullptr, c.f16, ACT_NONE, s));
-    SAMPT_TRY(gm.run(xn, (int)Mg, D, b.qkv_w, b.qkv_b, qkv, 3 * D, ACT_NONE, c.f16 != 0, nullptr, 0, inv, 0));
+    SAMPT_TRY(gm.run(xn, (int)Mg, D, b.qkv_w, b.qkv_b, qkv, 3 * D, ACT_NONE, act_out, nullptr, 0, inv, 0));
     if (!glob) SAMPT_TRY(fill_rows_bias(qkv, c.f16, win_pad, (int)(M - Mg), b.qkv_b, 3 * D, s));
-    if (c.f16) {
+    if (c.f16 == 1) {
       SAMPT_TRY(vit_flash_attention_f16((const half_t*)qkv, b.rel_h, b.rel_w, (half_t*)att, Bw, S, c.heads, hd, s));
+    } else if (c.f16 == 2) {
+      SAMPT_TRY(vit_flash_attention_x3((const half_t*)qkv, b.rel_h, b.rel_w, (half_t*)att, Bw, S, c.heads, hd, s));
     } else {
       SAMPT_TRY(vit_rel_bias(qkv, 0, b.rel_h, b.rel_w, Bw, S, c.heads, hd, relh, relw, s));
       const float* q = (const float*)qkv;
@@ -230,11 +243,11 @@ int VitEngine::encode(const uint8_t* frames, int chw, int B, int H, int W, float
       SAMPT_TRY(gemm_f32(v, s));
     }
     // proj + bias + residual on the real tokens: A rows are gathered from the window-ordered attention output
-    SAMPT_TRY(gm.run(att, (int)Mg, D, b.proj_w, b.proj_b, x, D, ACT_NONE, false, x, D, nullptr, 0, inv));
+    SAMPT_TRY(gm.run(att, (int)Mg, D, b.proj_w, b.proj_b, x, D, ACT_NONE, 0, x, D, nullptr, 0, inv));
     // MLP
     SAMPT_TRY(layernorm_rows(x, b.ln2w, b.ln2b, xn, Mg, D, 1e-6f, nullptr, c.f16, ACT_NONE, s));
-    SAMPT_TRY(gm.run(xn, (int)Mg, D, b.w1, b.b1, hid, c.mlp_ratio * D, ACT_GELU, c.f16 != 0, nullptr, 0, nullptr, 0));
-    SAMPT_TRY(gm.run(hid, (int)Mg, c.mlp_ratio * D, b.w2, b.b2, x, D, ACT_NONE, false, x, D, nullptr, 0));
+    SAMPT_TRY(gm.run(xn, (int)Mg, D, b.w1, b.b1, hid, c.mlp_ratio * D, ACT_GELU, act_out, nullptr, 0, nullptr, 0));
+    SAMPT_TRY(gm.run(hid, (int)Mg, c.mlp_ratio * D, b.w2, b.b2, x, D, ACT_NONE, 0, x, D, nullptr, 0));
     if (interm_out && glob && !tapped) {  // HQ-SAM: the first global block's output feeds compress_vit_feat
       if (hipMemcpyAsync(interm_out, x, (size_t)Mg * D * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
         return SAMPT_ERR_HIP;
@@ -244,7 +257,7 @@ int VitEngine::encode(const uint8_t* frames, int chw, int B, int H, int W, float
   if (dead_mode == 1) return SAMPT_ERR_ARG;   // (no global block: live_rows() already refused)
   // ---- neck: conv1x1 (no bias) -> LayerNorm2d -> conv3x3 (no bias) -> LayerNorm2d
   //      fp32 in both modes: the neck's operand roundings would land on the embedding undamped
-  SAMPT_TRY(gm.run(x, (int)Mg, D, neck0_w, nullptr, neck_a, c.out_chans, ACT_NONE, false, nullptr, 0, nullptr, 0, nullptr,
+  SAMPT_TRY(gm.run(x, (int)Mg, D, neck0_w, nullptr, neck_a, c.out_chans, ACT_NONE, 0, nullptr, 0, nullptr, 0, nullptr,
                    true, neck0_hl));
   SAMPT_TRY(layernorm_rows(neck_a, neck1w, neck1b, neck_b, Mg, c.out_chans, 1e-6f, nullptr, 0, ACT_NONE, s));
   {

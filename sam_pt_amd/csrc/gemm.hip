@@ -178,13 +178,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
       }
     } else {
-#pragma unroll
-      for (int kk = 0; kk < BK / 32; ++kk) {
+      // plain: BK / 32 consecutive 32-deep steps; x3 (GemmP::x3, BK == 64): lo.hi, hi.lo, hi.hi of the slab's 32 real k
+      const int nterm = p.x3 ? 3 : BK / 32;
+      for (int kk = 0; kk < nterm; ++kk) {
+        const int ka = p.x3 ? (kk == 0 ? 1 : 0) : kk, kb = p.x3 ? (kk == 1 ? 1 : 0) : kk;
         h8 a[FM], b[FN];
 #pragma unroll
-        for (int i = 0; i < FM; ++i) a[i] = *(const h8*)&As[wm * WTM + i * 16 + lr][kk * 32 + lq * 8];
+        for (int i = 0; i < FM; ++i) a[i] = *(const h8*)&As[wm * WTM + i * 16 + lr][ka * 32 + lq * 8];
 #pragma unroll
-        for (int j = 0; j < FN; ++j) b[j] = *(const h8*)&Bs[wn * WTN + j * 16 + lr][kk * 32 + lq * 8];
+        for (int j = 0; j < FN; ++j) b[j] = *(const h8*)&Bs[wn * WTN + j * 16 + lr][kb * 32 + lq * 8];
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -233,7 +235,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
         if (p.bias) v += p.bias[col];
         v = apply_act(v, p.act);
         if (p.res) v += p.res[(long)rrow * p.ldr + col];
-        if (sizeof(T) == 2 && p.out_f16) ((half_t*)p.C)[c_off + (long)drow * p.ldc + col] = (half_t)v;
+        if (sizeof(T) == 2 && p.out_f16 == 2) {
+          half_t hi, lo;
+          split_f16(v, hi, lo);
+          half_t* cp = (half_t*)p.C + c_off + (long)drow * p.ldc + x3_col(col);
+          cp[0] = hi, cp[32] = lo;
+        } else if (sizeof(T) == 2 && p.out_f16) ((half_t*)p.C)[c_off + (long)drow * p.ldc + col] = (half_t)v;
         else ((float*)p.C)[c_off + (long)drow * p.ldc + col] = v;
       }
     }
@@ -310,7 +317,7 @@ static int plan_tiles_splitk(const GemmP& p, bool plain, int& BM_out, bool& big_
   const int BM = big ? 128 : 64;
   const long tiles = (long)cdiv(p.M, BM) * cdiv(p.N, BM) * batch;
   BM_out = BM, big_out = big;
-  if (plain && !p.out_f16 && p.splitk_ws && tiles < 128 && p.K >= 512) {
+  if (plain && !p.out_f16 && !p.x3 && p.splitk_ws && tiles < 128 && p.K >= 512) {
     int want = (int)((255 + tiles) / tiles);
     int maxs = p.K / 256;
     int sk = want < maxs ? want : maxs;
@@ -418,8 +425,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_thin_f32(GemmP p) {
 
 // the thin kernel takes plain f32 GEMMs whose 64 x 64 tiling would leave most CUs idle (the split-K regime)
 static bool thin_f32_eligible(const GemmP& p, bool plain) {
-  static const int on = getenv("SAMPT_GEMM_THIN") ? atoi(getenv("SAMPT_GEMM_THIN")) : 1;
-  if (!on || !plain || p.out_f16 || p.M <= 16 || p.K < 64) return false;
+  if (!plain || p.out_f16 || p.M <= 16 || p.K < 64) return false;
   if ((p.N % 4) || (p.ldc % 4) || (p.res && (p.ldr % 4)) || (p.lda % 4) || (p.ldw % 4) || (p.K % 4)) return false;
   if (((uintptr_t)p.C & 15) || (p.bias && ((uintptr_t)p.bias & 15)) || (p.res && ((uintptr_t)p.res & 15))) return false;
   const long tiles64 = (long)cdiv(p.M, 64) * cdiv(p.N, 64);
@@ -432,10 +438,6 @@ static int gemm_thin_f32_launch(const GemmP& p, hipStream_t s) {
   while (FM > 1 && cols * cdiv(p.M, 16 * FM) < 256) FM >>= 1;
   const int nchunk = cdiv(p.K, 16), per_wave = FM >= 4 ? 4 : 8;
   int NWV = nchunk > 8 * per_wave ? 16 : (nchunk > 4 * per_wave ? 8 : 4);   // a wave's K share: one batch of loads
-  static const int fm_env = getenv("SAMPT_THIN_FM") ? atoi(getenv("SAMPT_THIN_FM")) : 0;      // experiments only
-  static const int nwv_env = getenv("SAMPT_THIN_NWV") ? atoi(getenv("SAMPT_THIN_NWV")) : 0;
-  if (fm_env == 1 || fm_env == 2 || fm_env == 4) FM = fm_env;
-  if (nwv_env == 4 || nwv_env == 8 || nwv_env == 16) NWV = nwv_env;
   dim3 grid((unsigned)cols, (unsigned)cdiv(p.M, 16 * FM)), block(NWV * 64);
 #define THIN(FMv, NWVv) hipLaunchKernelGGL((gemm_thin_f32<FMv, NWVv>), grid, block, 0, s, p)
   if (FM == 4) { if (NWV == 16) THIN(4, 16); else if (NWV == 8) THIN(4, 8); else THIN(4, 4); }
@@ -458,6 +460,8 @@ static int gemm_dispatch(const GemmP& p_in, hipStream_t s) {
   }
   if (!p.A || !p.W || !p.C || p.M <= 0 || p.N <= 0 || p.K <= 0) return SAMPT_ERR_ARG;
   if (p.K % VEC) return SAMPT_ERR_ARG;
+  if (sizeof(T) == 4 ? (p.x3 != 0 || p.out_f16 != 0) : ((p.x3 && (p.K % 64 || p.conv)) || (p.out_f16 == 2 && p.ldc % 64)))
+    return SAMPT_ERR_ARG;
   if (p.conv) {
     if (p.cC % VEC || p.K != p.KH * p.KW * p.cC || p.w_kn) return SAMPT_ERR_ARG;
   } else if (p.lda % VEC) {

@@ -1,7 +1,7 @@
 // fp16 MFMA GEMM, LDS-DMA version with 128-row tiles: the FALLBACK of the ViT encoder's GEMM for the shapes the 256 x 256
 // 8-phase persistent kernel (gemm_f16_p8.hip, the dominant kernel of the SAM-PT hot path) does not take — fewer than 256
 // rows, N not a multiple of 256, K not a multiple of 128 (reduced test geometries, odd batches) — and the round-1 / round-2
-// kernel every ViT GEMM ran on (SAMPT_GEMM_P8=0 selects it for A/B measurements).
+// kernel every ViT GEMM ran on (A/B: profiles/r3_v1_gemm_microbench_old.log).
 //
 //   C[M][N] = epi(A[M][K] . W[N][K]^T + bias) (+ residual)        A, W fp16 K-contiguous; fp32 accumulate
 //
@@ -127,9 +127,11 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64, 4) void gemm_f16_glds
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const half_t* base = lds;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int pos = ((kk * 4 + lq) ^ sw) * 8;
+    // plain: the two 32-deep halves of the slab; x3 (GemmP::x3): lo.hi, hi.lo, hi.hi of the slab's 32 real k
+    const int nterm = p.x3 ? 3 : 2;
+    for (int kk = 0; kk < nterm; ++kk) {
+      const int ka = p.x3 ? (kk == 0 ? 1 : 0) : kk, kb = p.x3 ? (kk == 1 ? 1 : 0) : kk;
+      const int pos = ((ka * 4 + lq) ^ sw) * 8, posb = ((kb * 4 + lq) ^ sw) * 8;
       if constexpr (FN > 4) {
         // wide wave tiles (FN = 5): keep the A fragments of the K-step and ONE B fragment (plus the next one in flight)
         // live instead of all FN — the 80 accumulator registers leave no room for 9 operand fragments under the
@@ -137,11 +139,11 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64, 4) void gemm_f16_glds
         h8 a[FM];
 #pragma unroll
         for (int i = 0; i < FM; ++i) a[i] = *(const h8*)(base + a_off[i] + pos);
-        h8 bc = *(const h8*)(base + b_off[0] + pos);
+        h8 bc = *(const h8*)(base + b_off[0] + posb);
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
           h8 bn = bc;
-          if (j + 1 < FN) bn = *(const h8*)(base + b_off[j + 1] + pos);
+          if (j + 1 < FN) bn = *(const h8*)(base + b_off[j + 1] + posb);
 #pragma unroll
           for (int i = 0; i < FM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bc, a[i], acc[i][j], 0, 0, 0);
           bc = bn;
@@ -152,7 +154,7 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64, 4) void gemm_f16_glds
 #pragma unroll
         for (int i = 0; i < FM; ++i) a[i] = *(const h8*)(base + a_off[i] + pos);
 #pragma unroll
-        for (int j = 0; j < FN; ++j) b[j] = *(const h8*)(base + b_off[j] + pos);
+        for (int j = 0; j < FN; ++j) b[j] = *(const h8*)(base + b_off[j] + posb);
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -191,7 +193,18 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64, 4) void gemm_f16_glds
         float4 rv = *(const float4*)(p.res + (long)rrow * p.ldr + col);
         v[0] += rv.x, v[1] += rv.y, v[2] += rv.z, v[3] += rv.w;
       }
-      if (p.out_f16) {
+      if (p.out_f16 == 2) {        // x3 row (common.h): hi / lo halves of the 4 columns, inside one 32-block
+        h4 hi, lo;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          half_t a, b;
+          split_f16(v[r], a, b);
+          hi[r] = a, lo[r] = b;
+        }
+        half_t* cp = (half_t*)p.C + (long)drow * p.ldc + x3_col(col);
+        *(h4*)cp = hi;
+        *(h4*)(cp + 32) = lo;
+      } else if (p.out_f16) {
         h4 o = (h4){(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
         *(h4*)((half_t*)p.C + (long)drow * p.ldc + col) = o;
       } else {
@@ -208,8 +221,7 @@ int gemm_f16_p8_launch(const GemmP& p, hipStream_t s);   // gemm_f16_p8.hip
 
 // returns SAMPT_ERR_UNSUPPORTED when the shape does not fit this kernel (caller falls back to gemm_kernel)
 int gemm_f16_glds_launch(const GemmP& p, hipStream_t s) {
-  static const int p8 = getenv("SAMPT_GEMM_P8") ? atoi(getenv("SAMPT_GEMM_P8")) : 1;
-  if (p8) {
+  {
     int rc = gemm_f16_p8_launch(p, s);
     if (rc != SAMPT_ERR_UNSUPPORTED) return rc;
   }
@@ -220,7 +232,7 @@ int gemm_f16_glds_launch(const GemmP& p, hipStream_t s) {
   const dim3 block(256);
   // 128 x 160 tiles wherever N is a multiple of 160 (the ViT-H / ViT-L widths): every GEMM is then a whole number of
   // generations of the 1024 resident workgroups (+3.6 .. +4.8 % per shape, profiles/r2_v4_gemm_microbench_{default,bn160}.log)
-  const bool wide = p.N % 160 == 0;
+  const bool wide = p.N % 160 == 0 && p.out_f16 != 2;
   const int nt_m = cdiv(p.M, 128), nt_n = wide ? p.N / 160 : cdiv(p.N, 128);
   int R = 8;                                        // strip height of the XCD-aware tile order (see the kernel)
   while (R > 1 && cdiv(nt_m, R) < 16) R /= 2;       // keep >= 2 strips per XCD so that all 8 XCDs get work

@@ -37,6 +37,11 @@
 // L2) owns the x-th eighth of that list and its workgroups take consecutive tiles, so the tiles in flight on one XCD form
 // an R x (32 / R) patch that shares A panels and W tiles through that L2 while the panels of a strip stay resident.
 //
+// GemmP::x3 (template X3): the operands are "x3 rows" (common.h: every 64-half K-tile row is [hi(32) | lo(32)] of 32 real k)
+// and a phase issues 24 MFMAs instead of 16 — hi.hi + hi.lo + lo.hi per fragment pair, fp32-grade products at a third of
+// the fp16 rate — on the very same stage / barrier schedule (the K-tile images in LDS are byte-identical in size and
+// layout, only the fragment pairing changes).  OUT = 2 writes C as x3 rows too (the next GEMM's A operand).
+//
 // Launcher conditions: K % 128 == 0 (an even number of K-tiles: tile boundaries fall on buffer 0), N % 256 == 0, M >= 256.
 // Rows beyond M are clamped to the last valid row for the loads and never stored.
 #include "common.h"
@@ -72,9 +77,11 @@ __device__ __forceinline__ float gelu_fast(float x) {
   return x * phi;
 }
 
-// ACT: ACT_NONE or ACT_GELU (compile time; other activations are left to the generic kernels).  GELU_FAST: see gelu_fast.
-template <bool STAGGER, int ACT, bool OUTF16, bool GELU_FAST>
+// ACT: ACT_NONE or ACT_GELU (compile time; other activations are left to the generic kernels).  OUT: 0 = f32, 1 = f16,
+// 2 = f16 x3 rows.  X3: 3-term split-fp16 products.
+template <int ACT, int OUT, bool X3>
 __global__ __launch_bounds__(512, 2) void gemm_f16_p8(GemmP p) {
+  constexpr bool STAGGER = true;   // the two wave rows run one barrier apart (without: -1.7 %, profiles/r3_v1_*)
   __shared__ __attribute__((aligned(1024))) char lds[2 * P8_BUF];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -186,14 +193,17 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_p8(GemmP p) {
     }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_setprio(1);
+    // plain: the two 32-deep halves of the K-tile; X3: lo.hi, hi.lo, hi.hi of its 32 real k (small terms first)
+    constexpr int NTERM = X3 ? 3 : 2;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
+    for (int kk = 0; kk < NTERM; ++kk)
 #pragma unroll
       for (int fi = 0; fi < 4; ++fi)
 #pragma unroll
         for (int fj = 0; fj < 2; ++fj) {   // swapped operands -> the accumulator fragment is C^T (see the epilogue)
+          const int ka = X3 ? (kk == 0 ? 1 : 0) : kk, kb = X3 ? (kk == 1 ? 1 : 0) : kk;
           acc[HA * 4 + fi][HB * 2 + fj] =
-              __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[fj][kk], af[fi][kk], acc[HA * 4 + fi][HB * 2 + fj], 0, 0, 0);
+              __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[fj][kb], af[fi][ka], acc[HA * 4 + fi][HB * 2 + fj], 0, 0, 0);
           if (kk == 0 && fi == 0 && fj == 1) {
             // the stage of this phase, behind the first MFMAs (the matrix pipe is busy while the DMA is issued)
             if (PH == 0) stage(BUF ^ 1, P8_SLOT_B0), stage_advance();
@@ -262,11 +272,22 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_p8(GemmP p) {
           v[0] += bv[j].x, v[1] += bv[j].y, v[2] += bv[j].z, v[3] += bv[j].w;
           if (ACT == ACT_GELU) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = GELU_FAST ? gelu_fast(v[r]) : gelu_erf(v[r]);
+            for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r]);
           }
           if (p.res) v[0] += rv[ii][j].x, v[1] += rv[ii][j].y, v[2] += rv[ii][j].z, v[3] += rv[ii][j].w;
           if (drow[ii] >= 0) {
-            if (OUTF16) {
+            if (OUT == 2) {        // x3 row: the 4 columns lie inside one 32-block (colbase + cj is a multiple of 4)
+              h4 hi, lo;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                half_t a, b;
+                split_f16(v[r], a, b);
+                hi[r] = a, lo[r] = b;
+              }
+              half_t* cp = (half_t*)p.C + (long)drow[ii] * p.ldc + x3_col(colbase + cj);
+              *(h4*)cp = hi;
+              *(h4*)(cp + 32) = lo;
+            } else if (OUT == 1) {
               *(h4*)((half_t*)p.C + (long)drow[ii] * p.ldc + colbase + cj) =
                   (h4){(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
             } else {
@@ -289,36 +310,35 @@ int gemm_f16_p8_launch(const GemmP& p, hipStream_t s) {
   if (p.conv || p.w_kn || p.nb1 * p.nb2 != 1 || (p.K % 128) || p.M < 256 || (p.N % 256)) return SAMPT_ERR_UNSUPPORTED;
   if ((p.lda % 8) || (p.ldw % 8) || (((uintptr_t)p.A | (uintptr_t)p.W) & 15)) return SAMPT_ERR_UNSUPPORTED;
   if ((p.ldc % 4) || (p.res && (p.ldr % 4))) return SAMPT_ERR_UNSUPPORTED;
+  if (p.out_f16 == 2 && (p.ldc % 64)) return SAMPT_ERR_UNSUPPORTED;
   // 32-bit byte offsets inside the operands (with a_rowmap the caller guarantees the gathered matrix is < 4 GiB as well)
   if ((double)p.M * p.lda * 2.0 >= 4294967296.0 || (double)p.N * p.ldw * 2.0 >= 4294967296.0) return SAMPT_ERR_UNSUPPORTED;
+  if (p.act != ACT_NONE && p.act != ACT_GELU) return SAMPT_ERR_UNSUPPORTED;
   GemmP q = p;
   const int nt_m = cdiv(p.M, 256), nt_n = p.N / 256;
-  static const int r_env = getenv("SAMPT_GEMM_R") ? atoi(getenv("SAMPT_GEMM_R")) : 4;
-  int R = r_env;
+  int R = 4;                      // strip height in row panels (2 / 8 measured: more L2 misses, profiles/r3_gemm_hbm_traffic_strip*)
   if (R > nt_m) R = nt_m;
   q.xcd_swizzle = R;
   const long ntiles = (long)nt_m * nt_n;
   // workgroups per XCD: one per CU (32) by default; fewer leaves whole CUs to kernels of other streams (a 512-thread,
   // 128-KiB workgroup owns its CU: nothing else becomes resident beside it)
-  static const int wgs_env = getenv("SAMPT_GEMM_WGS") ? atoi(getenv("SAMPT_GEMM_WGS")) : 0;   // experiments: overrides p8_wgs
-  const int wgs_req = wgs_env ? wgs_env : p.p8_wgs;
-  const int wgs = wgs_req >= 1 && wgs_req <= 32 ? wgs_req : 32;
+  const int wgs = p.p8_wgs >= 1 && p.p8_wgs <= 32 ? p.p8_wgs : 32;
   int per_xcd = (int)((ntiles + 7) / 8);
   if (per_xcd > wgs) per_xcd = wgs;
-  static const int stagger = getenv("SAMPT_GEMM_STAGGER") ? atoi(getenv("SAMPT_GEMM_STAGGER")) : 1;
-  static const int fast = getenv("SAMPT_GEMM_GELU_FAST") ? atoi(getenv("SAMPT_GEMM_GELU_FAST")) : 1;
-  if (p.act != ACT_NONE && p.act != ACT_GELU) return SAMPT_ERR_UNSUPPORTED;
   const dim3 grid(8 * per_xcd), block(512);
-#define P8_LAUNCH(ST, AC, OF, GF) hipLaunchKernelGGL((gemm_f16_p8<ST, AC, OF, GF>), grid, block, 0, s, q)
-#define P8_LAUNCH_ST(AC, OF, GF) do { if (stagger) P8_LAUNCH(true, AC, OF, GF); else P8_LAUNCH(false, AC, OF, GF); } while (0)
-  if (p.act == ACT_GELU) {
-    if (p.out_f16) { if (fast) P8_LAUNCH_ST(ACT_GELU, true, true); else P8_LAUNCH_ST(ACT_GELU, true, false); }
-    else { if (fast) P8_LAUNCH_ST(ACT_GELU, false, true); else P8_LAUNCH_ST(ACT_GELU, false, false); }
+#define P8_LAUNCH(AC, OU, X) hipLaunchKernelGGL((gemm_f16_p8<AC, OU, X>), grid, block, 0, s, q)
+  const int out = p.out_f16;      // 0 f32, 1 f16, 2 x3 rows
+  if (p.x3) {
+    if (p.act == ACT_GELU) { if (out == 2) P8_LAUNCH(ACT_GELU, 2, true); else return SAMPT_ERR_UNSUPPORTED; }
+    else if (out == 2) P8_LAUNCH(ACT_NONE, 2, true);
+    else if (out == 0) P8_LAUNCH(ACT_NONE, 0, true);
+    else return SAMPT_ERR_UNSUPPORTED;
   } else {
-    if (p.out_f16) P8_LAUNCH_ST(ACT_NONE, true, false);
-    else P8_LAUNCH_ST(ACT_NONE, false, false);
+    if (out == 2) return SAMPT_ERR_UNSUPPORTED;
+    if (p.act == ACT_GELU) { if (out == 1) P8_LAUNCH(ACT_GELU, 1, false); else P8_LAUNCH(ACT_GELU, 0, false); }
+    else if (out == 1) P8_LAUNCH(ACT_NONE, 1, false);
+    else P8_LAUNCH(ACT_NONE, 0, false);
   }
-#undef P8_LAUNCH_ST
 #undef P8_LAUNCH
   SAMPT_CHECK_LAUNCH("gemm_f16_p8");
   return SAMPT_OK;

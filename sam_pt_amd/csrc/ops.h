@@ -26,12 +26,14 @@ int resize_bilinear_nhwc(const float* src, int n, int sh, int sw, int C, float* 
                          int c_off, int align_corners, hipStream_t s, half_t* dst_hi = nullptr, half_t* dst_lo = nullptr);
 int avgpool2x2_nhwc(const float* src, int n, int h, int w, int C, float* dst, hipStream_t s);
 // LayerNorm over the last dim of rows. src_rows: optional gather (row index into x, or -1 -> output row = 0).
-// out_f16: y is half. act: applied after the affine transform (ACT_GELU for LayerNorm2d+GELU).
+// out_f16: 1 = y is half; 2 = y is half "x3 rows" [M][2D] (common.h GemmP::x3; D % 32 == 0). act: applied after the affine transform (ACT_GELU for LayerNorm2d+GELU).
 int layernorm_rows(const float* x, const float* w, const float* b, void* y, long M, int D, float eps,
                    const int* src_rows, int out_f16, int act, hipStream_t s);
 // out[i] = a[i] + b[i % bmod] (f32).  n, bmod in elements.
 int add_bcast(const float* a, const float* b, float* out, long n, long bmod, hipStream_t s);
 int cast_f32_f16(const float* x, half_t* y, long n, hipStream_t s);
+// f32 rows [M][K] -> x3 rows [M][2K] halves (common.h GemmP::x3: per 32-block hi(32) | lo(32), saturating split)
+int split_rows_x3(const float* x, half_t* y, long M, int K, hipStream_t s);
 // SAM preprocess + patch im2col: frames u8 HWC (B,H,W,3) -> A[B*g*g][3*P*P] with k = c*P*P + ky*P + kx,
 // value = (x-mean[c])/std[c] inside the h x w image, 0 in the padded region (Sam.preprocess, App. A-2)
 // chw: frames are (B,3,H,W) planar instead of (B,H,W,3).  mean/stdv are HOST pointers (3 floats each).
@@ -55,6 +57,11 @@ int softmax_rel_rows(float* scores, const float* relh, const float* relw, long B
 // rel_h / rel_w: rel_pos tables f32 [2S-1][hd] (the decomposed bias is computed inside the kernel).
 int vit_flash_attention_f16(const half_t* qkv, const float* rel_h, const float* rel_w, half_t* out, int B, int S,
                             int heads, int hd, hipStream_t s);
+
+// attention_x3.hip: the same attention at fp32 grade (3-term split-fp16 products).  qkv: x3 rows [B*S*S][2*3D] halves (common.h
+// GemmP::x3), out: x3 rows [B*S*S][2*D]
+int vit_flash_attention_x3(const half_t* qkv, const float* rel_h, const float* rel_w, half_t* out, int B, int S, int heads,
+                           int hd, hipStream_t s);
 
 // ---- pips.hip ---------------------------------------------------------------------------------
 struct PyramidLevels {

@@ -45,6 +45,28 @@ def split_f16x3(w: torch.Tensor, strict: bool = True):
     return torch.stack([hi, lo]).contiguous()
 
 
+def x3_rows(x: torch.Tensor, scale_shift: int = 0) -> torch.Tensor:
+    """fp32 rows [R][K] (K % 32 == 0) -> half [R][2K] "x3 rows", the operand format of the split-fp16 GEMM / attention
+    kernels (csrc/common.h GemmP::x3): every block of 32 consecutive k is stored as hi(32) | lo(32) with
+    v * 2^scale_shift = hi + lo, hi = fp16(.) clamped to the fp16 range, lo = fp16(. - hi).  Weights use
+    ``scale_shift = F16X3_WSHIFT`` (so that lo stays in fp16's normal range; the GEMM multiplies by 2^-8), activations 0."""
+    R, K = x.shape
+    assert K % 32 == 0, f"x3_rows: K = {K} is not a multiple of 32"
+    v = x.float() * float(1 << scale_shift)
+    hi = v.clamp(-65504.0, 65504.0).half()
+    lo = (v - hi.float()).half()
+    if not bool(torch.isfinite(lo.float()).all()):
+        raise ValueError(f"x3_rows: magnitude {float(x.abs().max()):.3g} * 2^{scale_shift} cannot be split into two fp16 pieces")
+    return torch.stack([hi.view(R, K // 32, 32), lo.view(R, K // 32, 32)], dim=2).reshape(R, 2 * K).contiguous()
+
+
+def x3_unrows(y: torch.Tensor, scale_shift: int = 0) -> torch.Tensor:
+    """Inverse of ``x3_rows``: half [R][2K] -> fp32 [R][K] = (hi + lo) * 2^-scale_shift (tests / debugging)."""
+    R, K2 = y.shape
+    p = y.float().view(R, K2 // 64, 2, 32)
+    return ((p[:, :, 0] + p[:, :, 1]).reshape(R, K2 // 2) / float(1 << scale_shift)).contiguous()
+
+
 def _put_split(out: Dict[str, torch.Tensor], key: str, w: torch.Tensor) -> None:
     """out[key] = split planes of w — or nothing when w cannot be split (the consumer falls back to f32 for that layer)."""
     hl = split_f16x3(w, strict=False)
@@ -169,8 +191,12 @@ def window_row_map(grid: int, window: int, batches: int, rows: int = 0) -> torch
     return m.reshape(-1).to(torch.int32)
 
 
-def pack_vit(sd: Dict[str, torch.Tensor], cfg: SamConfig, device, f16: bool, win_batches: int) -> Dict[str, torch.Tensor]:
+def pack_vit(sd: Dict[str, torch.Tensor], cfg: SamConfig, device, f16, win_batches: int) -> Dict[str, torch.Tensor]:
+    """``f16``: False / 0 = exact fp32, True / 1 = fp16 block GEMMs (".f16" copies), 2 = split-fp16 block GEMMs (".x3" x3 rows
+    of w * 2^8); the encoder's two ends are split-fp16 planes ("_hl") in both 16-bit modes."""
     out: Dict[str, torch.Tensor] = {}
+    mode = int(f16)
+    f16 = mode != 0
     e = "image_encoder."
     # The two ends of the encoder stay fp32-grade in the fast mode too (3-term split-fp16 MFMAs, 0.3 % of the FLOPs): every fp16
     # rounding inside the 12-32 blocks is damped by the residual stream, but the neck's roundings land on the embedding
@@ -201,7 +227,10 @@ def pack_vit(sd: Dict[str, torch.Tensor], cfg: SamConfig, device, f16: bool, win
                 out[k] = w
         elif k in gemm_keys:
             w = v.reshape(v.shape[0], -1).contiguous()
-            out[k + (".f16" if f16 else "")] = w.half() if f16 else w
+            if mode == 2:
+                out[k + ".x3"] = x3_rows(w, F16X3_WSHIFT)
+            else:
+                out[k + (".f16" if f16 else "")] = w.half() if f16 else w
         else:
             out[k] = v.contiguous()
     rows = window_row_map(cfg.grid, cfg.window_size, win_batches)

@@ -33,7 +33,18 @@ class _Clip:
 
 
 _current: Optional[_Clip] = None
-stats = {"published": 0, "hits": 0, "misses": 0, "clips_encoded": 0}
+stats = {"published": 0, "hits": 0, "misses": 0, "clips_encoded": 0, "skipped_too_large": 0}
+
+
+def max_bytes() -> int:
+    """Budget for the private clip copy + its embeddings (``SAMPT_PREFETCH_MAX_GB``, default 16): longer clips are not
+    prefetched — the reference's per-frame ``set_image`` path has no such footprint and must keep working for them."""
+    return int(float(os.environ.get("SAMPT_PREFETCH_MAX_GB", "16")) * (1 << 30))
+
+
+def _clip_bytes(frames: torch.Tensor) -> int:
+    # uint8 frames + 4 MiB of SAM embedding per frame (+ 8 MiB of HQ features for HQ-SAM: budgeted as if present)
+    return int(frames.numel()) + int(frames.shape[0]) * (12 << 20)
 
 
 _suspended = 0
@@ -63,10 +74,12 @@ def publish(frames: torch.Tensor) -> None:
     if not enabled() or not isinstance(frames, torch.Tensor) or not frames.is_cuda or frames.dtype != torch.uint8 \
             or frames.dim() != 4 or frames.shape[1] != 3:
         return
-    cur = _current
-    if cur is not None and cur.frames.shape == frames.shape and cur.frames.device == frames.device \
-            and bool(torch.equal(cur.frames, frames)):
-        cur.next_idx = 0                          # the same clip again (a benchmark loop): keep its embeddings
+    # Every publish starts from scratch, also when the very same clip comes again: one tracker call = one forward pass = one
+    # encoder pass over the clip (embeddings cached across calls would outlive a weight / precision change of the predictor,
+    # and would make a benchmark loop over one clip skip the encoder altogether).
+    if _clip_bytes(frames) > max_bytes():
+        _current = None                           # a clip too long to keep embedded: per-frame set_image, as the reference does
+        stats["skipped_too_large"] += 1
         return
     _current = _Clip(frames.detach().clone())
     stats["published"] += 1
@@ -102,4 +115,7 @@ def lookup(predictor, image_hwc: torch.Tensor):
         stats["clips_encoded"] += 1
     c.next_idx = idx + 1
     stats["hits"] += 1
-    return c.feats[idx]
+    item = c.feats[idx]
+    if idx == T - 1:                              # the last frame of the clip has been served: nothing stays pinned after the pass
+        clear()
+    return item

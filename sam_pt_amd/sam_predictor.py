@@ -181,7 +181,10 @@ class SamHip(nn.Module):
         self.hq = has_hq if hq is None else bool(hq)
         if self.hq and not has_hq:
             raise ValueError("hq=True but the checkpoint has no MaskDecoderHQ weights (mask_decoder.hf_token.weight ...)")
-        assert precision in ("f16", "f32")
+        # "f16": fp16 MFMA inputs in the ViT blocks (fast mode); "f16x3": every ViT product from split-fp16 pieces (three fp16
+        # MFMAs, fp32 accumulate) — the reference's fp32 arithmetic (sam_pt.py:849) at fp32 grade on the fp16 matrix pipe;
+        # "f32": exact f32 MFMAs and materialised attention scores (parity reference, 1/16 of the fp16 MFMA rate)
+        assert precision in ("f16", "f16x3", "f32")
         self.precision = precision
         self.max_batch = max_batch
         self.max_decode_batch = max_decode_batch
@@ -286,13 +289,13 @@ class SamPredictor:
             self._dead_cache.clear()
             self.reset_image()
         cfg, m = self.model.cfg, self.model
-        f16 = m.precision == "f16"
+        f16 = {"f32": 0, "f16": 1, "f16x3": 2}[m.precision]
         self._wv = pack_vit(m.sd, cfg, dev, f16, m.max_batch)
         c = _lib.VitConfigC()
         c.embed_dim, c.depth, c.num_heads, c.grid, c.window = cfg.embed_dim, cfg.depth, cfg.num_heads, cfg.grid, cfg.window_size
         c.patch, c.out_chans, c.mlp_ratio, c.img_size = cfg.patch_size, cfg.out_chans, cfg.mlp_ratio, cfg.img_size
         c.global_mask = sum(1 << i for i in cfg.global_attn_indexes)
-        c.f16 = 1 if f16 else 0
+        c.f16 = f16
         for i in range(3):
             c.pixel_mean[i], c.pixel_std[i] = cfg.pixel_mean[i], cfg.pixel_std[i]
         names, ptrs, n = _lib.name_table(self._wv)

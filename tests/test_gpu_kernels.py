@@ -68,6 +68,101 @@ def test_gemm_f16(lib, dev, M, N, K, dtype):
     assert rel_err(Cd.float(), ref) < (2e-3 if dtype == 2 else 2e-5 * K ** 0.5)
 
 
+def _row_maps(M, g, drop=7):
+    """A destination permutation with a few dropped rows (-1) and a gather permutation, as the ViT's window maps are."""
+    dest = torch.randperm(M + 5, generator=g)[:M].to(torch.int32)
+    dest[torch.randperm(M, generator=g)[:drop]] = -1
+    return dest, torch.randperm(M, generator=g).to(torch.int32)
+
+
+@pytest.mark.parametrize("M,N,K,dtype,act", [(512, 512, 256, 1, 0), (777, 1280, 1280, 1, 0), (1000, 768, 384, 2, 2),
+                                               (4100, 1280, 5120, 1, 0), (300, 200, 192, 1, 0)])
+def test_gemm_f16_epilogues(lib, dev, M, N, K, dtype, act):
+    """sampt_gemm_ex on the 256 x 256 8-phase kernel's shapes (and one fallback shape) WITH everything the encoder's epilogues
+    use at once: bias, in-place-style f32 residual at the row-mapped destination, row scatter (rowmap, dropped rows), row
+    gather (a_rowmap), f32 / f16 output — against fp64."""
+    g = torch.Generator().manual_seed(M * 3 + N + K)
+    A = torch.randn(M, K, generator=g).half()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).half()
+    b = torch.randn(N, generator=g)
+    dest, src = _row_maps(M, g)
+    R = torch.randn(M + 5, N, generator=g)
+    acc = A[src.long()].double() @ W.double().t() + b.double()
+    acc = F.gelu(acc) if act == 2 else acc
+    use_res = dtype == 1
+    ref = torch.full((M + 5, N), 7.0, dtype=torch.float64)
+    keep = dest >= 0
+    ref[dest[keep].long()] = acc[keep] + (R[dest[keep].long()].double() if use_res else 0.0)
+    Ad, Wd, bd, Rd, dd, sd_ = A.to(dev), W.to(dev), b.to(dev), R.to(dev), dest.to(dev), src.to(dev)
+    Cd = torch.full((M + 5, N), 7.0, device=dev, dtype=torch.float16 if dtype == 2 else torch.float32)
+    ok(lib.sampt_gemm_ex(dtype, P(Ad), P(Wd), P(bd), P(Rd) if use_res else None, P(Cd), M, N, K, act, 1.0, P(dd), P(sd_), 0, 0,
+                         S()), "gemm_ex f16")
+    torch.cuda.synchronize()
+    assert rel_err(Cd.float(), ref) < (2e-3 if dtype == 2 else 2e-5 * K ** 0.5)
+    # residual broadcast (res_mod: the positional embedding of the patch GEMM) without row maps
+    if use_res:
+        mod = 100
+        ref2 = A.double() @ W.double().t() + b.double() + R[:mod].double().repeat((M + mod - 1) // mod, 1)[:M]
+        C2 = torch.empty(M, N, device=dev)
+        ok(lib.sampt_gemm_ex(1, P(Ad), P(Wd), P(bd), P(Rd), P(C2), M, N, K, 0, 1.0, None, None, mod, 0, S()), "gemm_ex res_mod")
+        assert rel_err(C2, ref2) < 2e-5 * K ** 0.5
+
+
+@pytest.mark.parametrize("M,N,K,out_x3,act", [(512, 512, 256, 0, 0), (777, 1280, 1280, 0, 0), (1000, 768, 384, 1, 2),
+                                                (4100, 1280, 5120, 0, 0), (300, 256, 192, 1, 0), (100, 72, 64, 0, 2),
+                                                (129, 129, 64, 0, 0), (2050, 3840, 1280, 1, 0), (333, 160, 128, 0, 0)])
+def test_gemm_x3(lib, dev, M, N, K, out_x3, act):
+    """Split-fp16 GEMM (GemmP::x3: hi.hi + hi.lo + lo.hi on x3 rows; the "f16x3" precision of the image encoder): as close to
+    the fp64 product as the exact f32 MFMA path, on the 8-phase kernel's shapes and on both fallback kernels, with the
+    encoder's epilogues (bias, GELU, residual, row scatter / gather), f32 and x3-row outputs, and operands that only a
+    saturating split keeps finite."""
+    from sam_pt_amd.pack import F16X3_WSHIFT, x3_rows, x3_unrows
+    g = torch.Generator().manual_seed(M + 7 * N + K)
+    A = torch.randn(M, K, generator=g) * 1.7
+    A[3, 5], A[M - 1, K - 1], A[0, 0] = 1.0e5, -9.0e4, 3e-6         # beyond the fp16 range: hi saturates, lo carries the rest
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    W[0, 0], W[1, 1] = 3e-6, -37.0
+    b = torch.randn(N, generator=g)
+    dest, src = _row_maps(M, g)
+    R = torch.randn(M + 5, N, generator=g)
+    acc = A[src.long()].double() @ W.double().t() + b.double()
+    acc = F.gelu(acc) if act == 2 else acc
+    use_res = not out_x3
+    keep = dest >= 0
+    ref = torch.full((M + 5, N), 7.0, dtype=torch.float64)
+    ref[dest[keep].long()] = acc[keep] + (R[dest[keep].long()].double() if use_res else 0.0)
+    Ax, Wx = x3_rows(A).to(dev), x3_rows(W, F16X3_WSHIFT).to(dev)
+    assert rel_err(x3_unrows(Ax.cpu()), A) < 1e-6
+    bd, Rd, dd, sd_ = b.to(dev), R.to(dev), dest.to(dev), src.to(dev)
+    alpha = 1.0 / (1 << F16X3_WSHIFT)
+    if out_x3:
+        Cx = x3_rows(torch.full((M + 5, N), 7.0)).to(dev)
+        ok(lib.sampt_gemm_ex(4, P(Ax), P(Wx), P(bd), None, P(Cx), M, N, K, act, alpha, P(dd), P(sd_), 0, 0, S()), "gemm x3 -> x3")
+        got = x3_unrows(Cx.cpu())
+    else:
+        Cd = torch.full((M + 5, N), 7.0, device=dev)
+        ok(lib.sampt_gemm_ex(3, P(Ax), P(Wx), P(bd), P(Rd), P(Cd), M, N, K, act, alpha, P(dd), P(sd_), 0, 0, S()), "gemm x3 -> f32")
+        got = Cd
+    # yardstick: the exact f32 MFMA GEMM on the same (gathered) operands
+    A32, W32 = A[src.long()].contiguous().to(dev), W.to(dev)
+    C32 = torch.empty(M, N, device=dev)
+    ok(lib.sampt_gemm(0, P(A32), P(W32), P(bd), None, P(C32), M, N, K, act, 1.0, S()), "gemm f32")
+    # rows fed by the out-of-range operands are judged on their own scale, the others on theirs
+    big = torch.zeros(M, dtype=torch.bool)
+    big[(src == 3) | (src == M - 1)] = True
+    for sel in (big & keep, ~big & keep):
+        e32 = rel_err(C32.cpu()[sel], acc[sel])
+        e3 = rel_err(got.cpu()[dest[sel].long()], ref[dest[sel].long()])
+        assert e3 < max(2e-6, 2.0 * e32), (e3, e32)
+    assert torch.equal(got.cpu()[[i for i in range(M + 5) if i not in set(dest[keep].tolist())]].float(),
+                       torch.full((M + 5 - int(keep.sum()), N), 7.0)), "rows outside the row map were written"
+    # the device-side splitter writes the very rows the host packer does
+    Ad = A.to(dev)
+    Ay = torch.empty(M, 2 * K, dtype=torch.float16, device=dev)
+    ok(lib.sampt_split_rows_x3(P(Ad), P(Ay), M, K, S()), "split_rows_x3")
+    assert torch.equal(Ay.cpu(), Ax.cpu())
+
+
 @pytest.mark.parametrize("n,H,W,Cin,Cout,k,s,p", [(2, 20, 28, 64, 96, 3, 2, 1), (1, 32, 48, 4, 64, 7, 2, 3),
                                                   (2, 17, 23, 96, 128, 1, 2, 0), (1, 16, 24, 416, 256, 3, 1, 1)])
 def test_conv_f32(lib, dev, n, H, W, Cin, Cout, k, s, p):
@@ -143,7 +238,8 @@ def test_instance_norm(lib, dev, C_):
     assert max_abs(xd, ref) < 5e-6
 
 
-@pytest.mark.parametrize("D,f16,act", [(64, 0, 2), (256, 0, 0), (512, 0, 0), (768, 1, 0), (1280, 1, 0), (4, 0, 2), (16, 0, 0)])
+@pytest.mark.parametrize("D,f16,act", [(64, 0, 2), (256, 0, 0), (512, 0, 0), (768, 1, 0), (1280, 1, 0), (4, 0, 2), (16, 0, 0),
+                                       (1280, 2, 0), (768, 2, 0), (64, 2, 0), (96, 2, 2)])
 def test_layernorm(lib, dev, D, f16, act):
     M = 333
     g = torch.Generator().manual_seed(D)
@@ -151,10 +247,14 @@ def test_layernorm(lib, dev, D, f16, act):
     w, b = torch.randn(D, generator=g), torch.randn(D, generator=g)
     ref = F.layer_norm(x.double(), (D,), w.double(), b.double(), 1e-6)
     ref = F.gelu(ref) if act == 2 else ref
-    y = torch.empty(M, D, device=dev, dtype=torch.float16 if f16 else torch.float32)
+    y = torch.empty(M, 2 * D if f16 == 2 else D, device=dev, dtype=torch.float16 if f16 else torch.float32)
     xd, wd, bd = x.to(dev), w.to(dev), b.to(dev)  # keep the device copies alive across the async launch
     ok(lib.sampt_layernorm(P(xd), P(wd), P(bd), P(y), M, D, 1e-6, f16, act, S()), "layernorm")
-    assert max_abs(y.float(), ref) < (2e-2 if f16 else 1e-5)
+    if f16 == 2:                                  # x3 rows: hi + lo is the fp32 result
+        from sam_pt_amd.pack import x3_unrows
+        assert max_abs(x3_unrows(y.cpu()), ref) < 1e-5
+    else:
+        assert max_abs(y.float(), ref) < (2e-2 if f16 else 1e-5)
 
 
 @pytest.mark.parametrize("align", [0, 1])
@@ -230,6 +330,25 @@ def test_vit_flash_attention(lib, dev, B, S_, heads, hd):
     qd, hd_, wd_ = qkv.to(dev), rel_h.to(dev), rel_w.to(dev)
     ok(lib.sampt_vit_attention_f16(P(qd), P(hd_), P(wd_), P(out), B, S_, heads, hd, None, 0, S()), "flash")
     assert max_abs(out.float(), ref) < 6e-3 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("B,S_,heads,hd", [(2, 64, 2, 80), (3, 14, 4, 80), (1, 64, 2, 64), (5, 14, 2, 64), (2, 16, 2, 32),
+                                            (4, 6, 2, 32)])
+def test_vit_flash_attention_x3(lib, dev, B, S_, heads, hd):
+    """The split-fp16 attention kernel (precision "f16x3"): fp32-grade against the fp64 attention of the same fp32 q / k / v —
+    three orders of magnitude tighter than the fp16 kernel's bar — including scores large enough that softmax is peaked."""
+    from sam_pt_amd.pack import x3_rows, x3_unrows
+    g = torch.Generator().manual_seed(S_ * hd + 1)
+    N, D = S_ * S_, heads * hd
+    qkv = torch.randn(B * N, 3 * D, generator=g) * 1.5
+    rel_h = torch.randn(2 * S_ - 1, hd, generator=g) * 0.3
+    rel_w = torch.randn(2 * S_ - 1, hd, generator=g) * 0.3
+    ref = _ref_vit_attention(qkv, rel_h, rel_w, B, S_, heads, hd)
+    qx = x3_rows(qkv).to(dev)
+    out = torch.empty(B * N, 2 * D, device=dev, dtype=torch.float16)
+    hd_, wd_ = rel_h.to(dev), rel_w.to(dev)
+    ok(lib.sampt_vit_attention_x3(P(qx), P(hd_), P(wd_), P(out), B, S_, heads, hd, S()), "flash x3")
+    assert max_abs(x3_unrows(out.cpu()), ref) < 4e-6 * float(ref.abs().max())
 
 
 @pytest.mark.parametrize("in_h,in_w,oh,ow", [(576, 1024, 576, 1024), (576, 1024, 480, 854), (1024, 683, 300, 200)])

@@ -1,7 +1,10 @@
 #!/usr/bin/env python
 """Correctness + micro-benchmark of the fp16 ViT GEMM through the C ABI (HIP events on the launching stream).
 
-  python tools/gemm_bench.py [frames] [zeros] [nocheck]
+  python tools/gemm_bench.py [frames] [zeros] [nocheck] [x3]
+
+``x3``: time the split-fp16 ("f16x3") variants of the same launches instead (x3 rows in, x3 rows / f32 out; correctness of
+those is tests/test_gpu_kernels.py::test_gemm_x3); TFLOP/s are fp32-equivalent (2 M N K / t: each product costs 3 MFMAs).
 
 Checks the kernel the dispatcher picks (256 x 256 8-phase persistent kernel for the big shapes) against a torch fp64
 product on the GPU for every epilogue the encoder uses (bias / GELU / residual / f16 out / row scatter / row gather / odd M),
@@ -20,7 +23,8 @@ lib = _lib.load()
 dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 8
 ZERO = "zeros" in sys.argv
-CHECK = "nocheck" not in sys.argv
+X3 = "x3" in sys.argv
+CHECK = "nocheck" not in sys.argv and not X3
 P, S = _lib.ptr, _lib.stream_ptr
 g = torch.Generator().manual_seed(0)
 
@@ -99,13 +103,22 @@ shapes = [("qkv  live", Ml, 3 * D, D, 2, 0, False), ("proj live", Ml, D, D, 1, 0
           ("square 8192", 8192, 8192, 8192, 2, 0, False)]
 tot_f = tot_t = 0.0
 for (name, M, N, K, dt, act, use_res) in shapes:
-    A = (torch.randn(M, K, generator=g) * 0.5).half().to(dev)
-    W = (torch.randn(N, K, generator=g) / K ** 0.5).half().to(dev)
+    A = (torch.randn(M, K, generator=g) * 0.5)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5)
+    if X3:
+        from sam_pt_amd.pack import F16X3_WSHIFT, x3_rows
+        A, W = x3_rows(A).to(dev), x3_rows(W, F16X3_WSHIFT).to(dev)
+    else:
+        A, W = A.half().to(dev), W.half().to(dev)
     if ZERO:
         A.zero_(), W.zero_()
     bias = torch.zeros(N, device=dev)
-    Cc = torch.zeros(M, N, device=dev, dtype=torch.float16 if dt == 2 else torch.float32)
+    Cc = torch.zeros(M, 2 * N if (X3 and dt == 2) else N, device=dev, dtype=torch.float16 if dt == 2 else torch.float32)
     res = Cc if use_res else None            # in place, as the encoder's residual stream
+    if X3:
+        def run(dt, A, W, bias, res, C, act, M=M, N=N, K=K):   # noqa: F811
+            _lib.check(lib.sampt_gemm_ex(4 if dt == 2 else 3, P(A), P(W), P(bias), P(res), P(C), M, N, K, act, 2.0 ** -8, None, None,
+                                         0, 0, S()), "gemm_ex x3")
     for _ in range(3):
         run(dt, A, W, bias, res, Cc, act)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -120,7 +133,7 @@ for (name, M, N, K, dt, act, use_res) in shapes:
     if "square" not in name:
         tot_f += fl * (7 if "live" in name else 25) / 32.0   # ViT-H, 16:9 frames: 7 blocks on the live rows, 25 at full size
         tot_t += t * (7 if "live" in name else 25) / 32.0
-    print(f"{name:12s} M={M:6d} N={N:5d} K={K:5d} out={'f16' if dt == 2 else 'f32'} act={act} res={int(use_res)} "
+    print(f"{name:12s} M={M:6d} N={N:5d} K={K:5d} {'x3 ' if X3 else ''}out={'f16' if dt == 2 else 'f32'} act={act} res={int(use_res)} "
           f"{t * 1e6:9.1f} us  {fl / t / 1e12:7.1f} TFLOP/s", flush=True)
     del A, W, Cc
 print(f"ViT-H block mix (7 live-row + 25 full-grid blocks): {tot_f / tot_t / 1e12:7.1f} TFLOP/s", flush=True)
