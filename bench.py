@@ -61,6 +61,14 @@ def parse():
                          "clip, its frame batches dealt over the ranks (strong scaling, BASELINE config #5); 'lpt' = a "
                          "DAVIS-2017-val-like set of --sequences clips (34-104 frames) LPT-assigned to the ranks (strong "
                          "scaling of BASELINE config #4, reports the load imbalance)")
+    ap.add_argument("--emulate-ranks", default="",
+                    help="one GPU stands in for every rank r of an N-rank --shard frames job in turn (comma-separated N, e.g. "
+                         "2,4,8): runs exactly rank r's share (its frames of the tracker encoder, the replicated window chain, its "
+                         "frame batches of the SAM stage), collectives stubbed; reports the predicted per-rank time and speed-up "
+                         "(`frame_sharding_model` in the JSON line)")
+    ap.add_argument("--allgather-gbs", type=float, default=250.0,
+                    help="--emulate-ranks: assumed RCCL all_gather rate per GPU over xGMI, GB/s of received bytes (7 links x 153 "
+                         "GB/s peak per GPU; ring collectives are per-link bound)")
     ap.add_argument("--sequences", type=int, default=30, help="--shard lpt: number of sequences of the DAVIS-17 val histogram")
     ap.add_argument("--native-480p", action="store_true",
                     help="feed the 480x854 frames as they are (tracker at 480p, SAM resizes inside) instead of the "
@@ -451,6 +459,56 @@ def secondary_lines(args, model, video, dev):
     return {"unit": "frames/s", "steps": 2, **res}
 
 
+def frame_sharding_model(args, model, video, steps=3):
+    """Predicted in-clip scaling (``--shard frames``: dist.sharded_forward) from ONE GPU: for every N in --emulate-ranks and
+    every rank r < N the GPU runs exactly rank r's share — tracker encoder on its frame share, the window chain (replicated),
+    SAM encoder + decoder on its frame batches — with the collectives stubbed: the pyramid all_gather is replaced by computing
+    the other ranks' frames between two events (that GPU time is subtracted) and priced at ``--allgather-gbs``; the final mask
+    gather (0.59 MB per frame) is priced the same way.  predicted step = max over ranks; speed-up against the same clip's
+    blocking forward on this GPU."""
+    from sam_pt_amd.dist import sharded_forward
+    T = len(video["image"])
+    H, W = video["target_hw"]
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3
+
+    base = timed(lambda: one_step(model, video, T))
+    res = {"one_gpu_ms_per_clip": round(base, 2), "assumed_allgather_GBps": args.allgather_gbs, "steps": steps, "by_world": {}}
+    for N in [int(v) for v in args.emulate_ranks.split(",") if v]:
+        ranks = []
+        for r in range(N):
+            stub = {"ms": 0.0, "bytes": 0}
+
+            def step():
+                _, out = sharded_forward(model, video, batch=8, emulate=(r, N))
+                fs = out.get("fnet_shard") if out else None
+                if fs is not None:
+                    stub["ms"] += fs.stub_ms()
+                    stub["bytes"] = fs.bytes_received
+            step()
+            torch.cuda.synchronize()
+            stub["ms"] = 0.0
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize()
+            wall = (time.perf_counter() - t0) / steps * 1e3
+            own = wall - stub["ms"] / steps
+            comm = (stub["bytes"] + T * H * W) / (args.allgather_gbs * 1e9) * 1e3     # pyramid all_gather + uint8 mask gather
+            ranks.append({"rank": r, "own_ms": round(own, 2), "stubbed_ms": round(stub["ms"] / steps, 2),
+                          "comm_ms_model": round(comm, 2), "predicted_ms": round(own + comm, 2)})
+        worst = max(x["predicted_ms"] for x in ranks)
+        res["by_world"][str(N)] = {"predicted_ms_per_clip": worst, "predicted_speedup": round(base / worst, 2), "ranks": ranks}
+    return res
+
+
 def self_launch(args):
     """``python bench.py --gpus N`` with N > 1 and no rendezvous in the environment: re-exec this very command line under
     ``torch.distributed.run`` (one rank per GPU, RCCL), exactly as the documented launch line does."""
@@ -615,6 +673,8 @@ def main():
             res["roofline"]["secondary"] = secondary_rooflines(args, dev)
         if world == 1 and not args.no_secondary:
             res["secondary"] = secondary_lines(args, model, video, dev)
+        if world == 1 and args.emulate_ranks:
+            res["frame_sharding_model"] = frame_sharding_model(args, model, video)
         if world == 1 and not args.no_cpu_baseline:
             # the timed configuration's result, compared with the oracle: with pipelined submission the clip that had the
             # next one submitted on top of it (its decoder chain ran beside that one's tracker encoder)

@@ -367,6 +367,16 @@ int sampt_cotracker_attention_f32(const float* qkv_dev, float* out_dev, int nbat
  * are unused (kept for ABI stability: K / V tiles are staged by LDS-DMA, nothing goes through HBM scratch). */
 int sampt_vit_attention_f16(const void* qkv_dev, const float* rel_h_dev, const float* rel_w_dev, void* out_dev, int B,
                             int S, int heads, int hd, void* workspace_dev, size_t workspace_bytes, sampt_stream_t stream);
+/* K-medoids query-point selection (SamPt in query_masks mode / point re-initialisation: sam_pt/utils/query_points.py:62-99,
+ * third-party sklearn_extra KMedoids(method="alternate", init="heuristic") restated in sam_pt_amd/query_points.py) on the
+ * device, bit-identical to that host restatement: fp64 distances, numpy's pairwise summation order, first-index ties.
+ * xy_dev: [n][2] f32 pixel coordinates (integers), n <= 2048.
+ *   rowsums:   out_dev[i] = sum_j |xy_i - xy_j|  (the heuristic initialisation partitions these on the host: np.argpartition)
+ *   alternate: medoids_dev int32 [K] holds the initial medoids on entry and the converged ones on return (K <= 64);
+ *              iters_dev (int32, may be NULL) receives the number of iterations run (<= max_iter). */
+int sampt_kmedoids_rowsums_f64(const float* xy_dev, int n, double* out_dev, sampt_stream_t stream);
+int sampt_kmedoids_alternate(const float* xy_dev, int n, int K, int32_t* medoids_dev, int max_iter, int32_t* iters_dev,
+                             sampt_stream_t stream);
 /* The same attention at fp32 grade (precision "f16x3": three split-fp16 MFMAs per product in Q.K^T, the bias tables and
  * P.V; fp32 softmax).  qkv_dev: x3 rows [B*S*S][2*3*heads*hd] halves (what the dtype-4 qkv GEMM writes), out_dev: x3 rows
  * [B*S*S][2*heads*hd].  Same geometries as sampt_vit_attention_f16; heads*hd % 32 == 0. */

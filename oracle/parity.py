@@ -90,17 +90,25 @@ def compare(out: Dict, ref: Dict) -> Dict:
            "traj_max_abs_px": float((tr_o - tr_r).abs().max())}
     ious, finite_ok, max_logit_err = [], True, 0.0
     M = len(out["logits"])
+    cached = bool(ref.get("cached"))          # compact form of oracle/cache.py: exact masks / rejections, sub-sampled logits
     for m in range(M):
         lo = out["logits"][m].cpu()
         if lo.shape[0] != len(ids):
             lo = lo[torch.as_tensor(ids, dtype=torch.long)]
-        lr = ref["logits"][m]
-        fo, fr = torch.isfinite(lo).flatten(1).all(1), torch.isfinite(lr).flatten(1).all(1)
+        fo = torch.isfinite(lo).flatten(1).all(1)
+        if cached:
+            from oracle.cache import LOGIT_STRIDE
+            fr, mr, lr = ref["finite"][m], ref["masks"][m], ref["logits_sub"][m]
+            lo_cmp = lo[..., ::LOGIT_STRIDE, ::LOGIT_STRIDE]
+        else:
+            lr = ref["logits"][m]
+            fr, mr, lo_cmp = torch.isfinite(lr).flatten(1).all(1), lr > 0, lo
         finite_ok &= bool((fo == fr).all())
         for j in range(len(ids)):
-            ious.append(mask_iou(lo[j] > 0, lr[j] > 0))
+            ious.append(mask_iou(lo[j] > 0, mr[j]))
             if bool(fo[j]) and bool(fr[j]):
-                max_logit_err = max(max_logit_err, float((lo[j] - lr[j]).abs().max()))
+                max_logit_err = max(max_logit_err, float((lo_cmp[j] - lr[j]).abs().max()))
     res.update({"mask_iou_min": float(min(ious)), "mask_iou_mean": float(np.mean(ious)), "masks_compared": len(ious),
-                "rejections_identical": finite_ok, "logit_max_abs": max_logit_err, "frames_checked": list(ids)})
+                "rejections_identical": finite_ok, "logit_max_abs": max_logit_err, "frames_checked": list(ids),
+                "oracle": "cached run (oracle/cache.py: exact masks, logits on every 8th pixel)" if cached else "live run"})
     return res

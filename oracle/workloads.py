@@ -1,0 +1,63 @@
+"""The seeded parity workloads shared by tests/test_gpu_bench_parity.py, bench.py's parity block and oracle/make_cache.py.
+TEST INFRASTRUCTURE ONLY (see oracle/parity.py).
+
+Each workload = the clip bench.py times for a BASELINE.json configuration (sam_pt_amd.synth.bench_clip, seed 72, random-init
+weights in the upstream key layout), the SamPt keywords, and the frames whose SAM stage the oracle repeats.
+
+  headline / config #2   ViT-H (ViT-B) + PIPS, 8 points, 1 object, 24 (8) x 576x1024 — SAM stage on every frame
+  config #4              ViT-H + PIPS, 8 points x 3 objects (other objects' positives as negatives, sam_pt.py:737-756), T = 8,
+                         SAM stage on all 8 frames (24 masks)
+  config #3              ViT-H + CoTracker, 8 + 8 points (two prompt passes per frame), T = 13, SAM stage on 8 frames
+  config #5              HQ-SAM ViT-H + CoTracker, 1024 x 1024, 16 points x 5 objects, T = 64 (T >= 64), SAM stage on
+                         4 frames (20 masks)
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+KW = dict(sam_iou_threshold=-1e9, positive_points_per_mask=8, negative_points_per_mask=0,
+          iterative_refinement_iterations=12, point_tracker_mask_batch_size=5)
+
+# name: (tracker, objects, positives, negatives, square, hq, T, SAM-stage frames or None = all)
+CONFIGS = {
+    "cfg4_pips_3obj": ("pips", 3, 8, 0, 0, False, 8, None),
+    "cfg3_cotracker_8p8": ("cotracker", 1, 8, 8, 0, False, 13, (0, 2, 4, 6, 8, 10, 11, 12)),
+    "cfg5_hq_cotracker_1024_5obj_16pts": ("cotracker", 5, 16, 0, 1024, True, 64, (0, 21, 42, 63)),
+}
+
+
+def bench_workload(variant: str, T: int) -> Dict:
+    """The metric's configuration: ``variant`` + PIPS, 8 points, 1 object, T frames of the bench clip."""
+    from sam_pt_amd.synth import bench_clip
+    from sam_pt_amd.weights import SAM_CONFIGS, init_pips_state_dict, init_sam_state_dict
+    cfg = SAM_CONFIGS[variant]
+    frames, qp = bench_clip(T=T, seed=72, n_pos=8)
+    psd = init_pips_state_dict(72)
+    return {"tag": f"bench_{variant}_T{T}", "cfg": cfg, "sd": init_sam_state_dict(cfg, 72), "psd": psd,
+            "tracker_sd": psd, "tracker": "pips", "frames": frames, "qp": qp, "kw": dict(KW), "ids": None, "hq": False,
+            "factory": None}
+
+
+def config_workload(name: str) -> Dict:
+    from sam_pt_amd.synth import bench_clip
+    from sam_pt_amd.weights import SAM_CONFIGS, init_cotracker_state_dict, init_pips_state_dict, init_sam_state_dict
+    tracker, M, P, Pn, square, hq, T, ids = CONFIGS[name]
+    cfg = SAM_CONFIGS["vit_h"]
+    frames, qp = bench_clip(T=T, seed=72, n_pos=P, n_objects=M, n_neg=Pn, square=square)
+    w = {"tag": name, "cfg": cfg, "sd": init_sam_state_dict(cfg, 72, hq=hq), "psd": None, "tracker_sd": None, "tracker": tracker,
+         "frames": frames, "qp": qp, "kw": dict(KW, positive_points_per_mask=P, negative_points_per_mask=Pn), "ids": ids, "hq": hq,
+         "factory": None}
+    if tracker == "pips":
+        w["psd"] = w["tracker_sd"] = init_pips_state_dict(72)
+    else:
+        from oracle.cotracker_ref import CoTrackerTrackerRef
+        csd = init_cotracker_state_dict(72)
+        w["tracker_sd"], w["factory"] = csd, (lambda: CoTrackerTrackerRef(csd))
+    return w
+
+
+def reference(w: Dict, threads=None) -> Dict:
+    """The oracle's result for workload ``w`` (through oracle/cache.py: compact cached form if present, else a live run)."""
+    from oracle.cache import cached_reference_run
+    return cached_reference_run(w["tag"], w["cfg"], w["sd"], w["psd"], w["frames"], w["qp"], w["kw"], frame_ids=w["ids"],
+                                hq=w["hq"], tracker_factory=w["factory"], threads=threads)

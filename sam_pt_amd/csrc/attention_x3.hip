@@ -233,7 +233,11 @@ __global__ __launch_bounds__(NW * 64, 1) void k_flash_x3(const half_t* __restric
     if (RPT == 1) mloc += rh[0];
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
     const float m_new = fmaxf(m_run, mloc);
-    const float msub = RPT == 1 ? m_new - rh[0] : m_new;
+    // P is kept scaled by 2^PSH (p' = exp2(s2 - m + PSH) <= 2^15 < 65504): the lo piece of its split, p' * 2^-12, then stays a
+    // NORMAL fp16 number down to p = 2^-17 of the row maximum instead of falling into the subnormals at p < 2^-3; the factor
+    // is common to O and to the softmax denominator and cancels in O / l.
+    constexpr float PSH = 15.f;
+    const float msub = (RPT == 1 ? m_new - rh[0] : m_new) - PSH;
     const f32x2 mv = (f32x2){msub, msub};
     float lsum = 0.f;
     h8 pbh[4], pbl[4];

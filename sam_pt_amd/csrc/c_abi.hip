@@ -577,6 +577,17 @@ int sampt_gemm_ex(int dtype, const void* A, const void* W, const float* bias, co
   return dtype == 0 ? gemm_f32(p, (hipStream_t)stream) : gemm_f16(p, (hipStream_t)stream);
 }
 
+int sampt_kmedoids_rowsums_f64(const float* xy, int n, double* out, sampt_stream_t stream) {
+  int rc = kmedoids_rowsums(xy, n, out, (hipStream_t)stream);
+  return rc == SAMPT_ERR_ARG ? fail(rc, "sampt_kmedoids_rowsums_f64: bad arguments (1 <= n <= 2048)") : rc;
+}
+
+int sampt_kmedoids_alternate(const float* xy, int n, int K, int32_t* medoids, int max_iter, int32_t* iters_out,
+                             sampt_stream_t stream) {
+  int rc = kmedoids_alternate(xy, n, K, (int*)medoids, max_iter, (int*)iters_out, (hipStream_t)stream);
+  return rc == SAMPT_ERR_ARG ? fail(rc, "sampt_kmedoids_alternate: bad arguments (1 <= K <= min(n, 64), n <= 2048)") : rc;
+}
+
 int sampt_split_rows_x3(const float* x, void* y, int M, int K, sampt_stream_t stream) {
   if (!x || !y) return fail(SAMPT_ERR_ARG, "sampt_split_rows_x3: bad arguments");
   return split_rows_x3(x, (half_t*)y, M, K, (hipStream_t)stream);

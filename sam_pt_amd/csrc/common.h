@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "gelu_poly.h"
+
 #define SAMPT_OK 0
 #define SAMPT_ERR_ARG (-1)       // bad argument (shape / alignment / null pointer)
 #define SAMPT_ERR_HIP (-2)       // a HIP runtime call failed (see sampt_last_error)
@@ -78,6 +80,45 @@ __device__ __forceinline__ void split_f16(float v, half_t& hi, half_t& lo) {
 }
 // column c of a logical row -> its position in an x3 row (the hi half; lo is 32 halves further)
 __device__ __forceinline__ long x3_col(int c) { return ((long)(c >> 5) << 6) + (c & 31); }
+
+typedef float f32x2_g __attribute__((ext_vector_type(2)));
+// ---- the two erf-GELUs of the fp16-input GEMM epilogues (gemm_f16_p8.hip, gemm_f16.hip, gemm.hip: all three kernels use the SAME
+// function per output type, so a GEMM row does not depend on which kernel its launch shape selected)
+// erf-GELU with the complementary error function of Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 absolute, no
+// cancellation on the negative side): 0.5 x erfc(-x / sqrt 2).  The epilogue of a one-workgroup-per-CU kernel is not
+// hidden behind another workgroup's MFMAs, so its VALU cost is on the critical path: 2 transcendentals + ~11 plain
+// operations per element instead of the ~35 of the library erff.
+__device__ __forceinline__ float gelu_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float pl = fmaf(1.061405429f, t, -1.453152027f);
+  pl = fmaf(pl, t, 1.421413741f);
+  pl = fmaf(pl, t, -0.284496736f);
+  pl = fmaf(pl, t, 0.254829592f);
+  const float e = pl * t * __builtin_amdgcn_exp2f(z * z * -1.44269504088896340736f);   // erfc(|z|)
+  const float phi = x < 0.f ? 0.5f * e : 1.0f - 0.5f * e;
+  return x * phi;
+}
+
+// erf-GELU without transcendentals for the fp16-output epilogue (gelu_poly.h, tools/gelu_poly_fit.py): x * (0.5 + xc * P(t)) with
+// a degree-12 polynomial, |error| < 3.4e-6 absolute in fp32 — far below the fp16 rounding of the stored result — on PAIRS of
+// elements so that the Horner chain issues as v_pk_fma_f32: ~10 VALU issue slots per element instead of ~25 for gelu_fast
+// (whose two quarter-rate transcendentals cost 8 of them).  The fp32-grade modes keep gelu_fast.
+__device__ __forceinline__ f32x2_g gelu_poly2(f32x2_g x) {
+  constexpr float cf[GELU_POLY_DEG + 1] = GELU_POLY_COEFS;
+  const f32x2_g xc = {__builtin_amdgcn_fmed3f(x[0], -GELU_POLY_C, GELU_POLY_C), __builtin_amdgcn_fmed3f(x[1], -GELU_POLY_C, GELU_POLY_C)};
+  const float k = 2.0f / (GELU_POLY_C * GELU_POLY_C);
+  const f32x2_g t = xc * xc * (f32x2_g){k, k} - (f32x2_g){1.f, 1.f};
+  f32x2_g pl = {cf[GELU_POLY_DEG], cf[GELU_POLY_DEG]};
+#pragma unroll
+  for (int i = GELU_POLY_DEG - 1; i >= 0; --i) pl = pl * t + (f32x2_g){cf[i], cf[i]};
+  return x * (xc * pl + (f32x2_g){0.5f, 0.5f});
+}
+
+// GELU of a half-input GEMM epilogue: fp16 result -> polynomial, f32 / x3-row result -> erfc form
+__device__ __forceinline__ float gelu_half_gemm(float v, int out_f16) {
+  return out_f16 == 1 ? gelu_poly2((f32x2_g){v, v})[0] : gelu_fast(v);
+}
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 

@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
         if (col >= p.N) continue;
         float v = acc[i][j][r] * p.alpha;
         if (p.bias) v += p.bias[col];
-        v = apply_act(v, p.act);
+        v = (sizeof(T) == 2 && p.act == ACT_GELU) ? gelu_half_gemm(v, p.out_f16) : apply_act(v, p.act);
         if (p.res) v += p.res[(long)rrow * p.ldr + col];
         if (sizeof(T) == 2 && p.out_f16 == 2) {
           half_t hi, lo;

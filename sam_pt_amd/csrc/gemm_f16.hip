@@ -188,7 +188,7 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64, 4) void gemm_f16_glds
         v[0] += bv.x, v[1] += bv.y, v[2] += bv.z, v[3] += bv.w;
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act);
+      for (int r = 0; r < 4; ++r) v[r] = p.act == ACT_GELU ? gelu_half_gemm(v[r], p.out_f16) : apply_act(v[r], p.act);
       if (p.res) {
         float4 rv = *(const float4*)(p.res + (long)rrow * p.ldr + col);
         v[0] += rv.x, v[1] += rv.y, v[2] += rv.z, v[3] += rv.w;

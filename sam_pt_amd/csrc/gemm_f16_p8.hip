@@ -44,6 +44,8 @@
 //
 // Launcher conditions: K % 128 == 0 (an even number of K-tiles: tile boundaries fall on buffer 0), N % 256 == 0, M >= 256.
 // Rows beyond M are clamped to the last valid row for the loads and never stored.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace sampt {
@@ -60,22 +62,6 @@ template <int V> struct IC { static constexpr int value = V; };
 #define P8_EPI_ROWS 2     // fragment rows (16 matrix rows each) whose residual is loaded in one batch: 2 x 4 x 16 B per lane
 #endif
 }  // namespace
-
-// erf-GELU with the complementary error function of Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 absolute, no
-// cancellation on the negative side): 0.5 x erfc(-x / sqrt 2).  The epilogue of a one-workgroup-per-CU kernel is not
-// hidden behind another workgroup's MFMAs, so its VALU cost is on the critical path: 2 transcendentals + ~11 plain
-// operations per element instead of the ~35 of the library erff.
-__device__ __forceinline__ float gelu_fast(float x) {
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-  float pl = fmaf(1.061405429f, t, -1.453152027f);
-  pl = fmaf(pl, t, 1.421413741f);
-  pl = fmaf(pl, t, -0.284496736f);
-  pl = fmaf(pl, t, 0.254829592f);
-  const float e = pl * t * __builtin_amdgcn_exp2f(z * z * -1.44269504088896340736f);   // erfc(|z|)
-  const float phi = x < 0.f ? 0.5f * e : 1.0f - 0.5f * e;
-  return x * phi;
-}
 
 // ACT: ACT_NONE or ACT_GELU (compile time; other activations are left to the generic kernels).  OUT: 0 = f32, 1 = f16,
 // 2 = f16 x3 rows.  X3: 3-term split-fp16 products.
@@ -240,6 +226,8 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_p8(GemmP p) {
     // The residual of RB fragment rows (RB x 4 fragments x 16 B per lane) is loaded in ONE batch into the registers the
     // operand fragments no longer need: the epilogue waits for 8 / RB memory round trips per tile instead of 32.
     constexpr int RB = P8_EPI_ROWS;
+    const int dbg = p.force_generic;   // TEMP diagnostics: 1 no stores, 2 no residual loads, 4 no epilogue, 8 no GELU
+    if (!(dbg & 4))
 #pragma unroll
     for (int hb = 0; hb < 8 / RB; ++hb) {
       int drow[RB];
@@ -251,7 +239,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_p8(GemmP p) {
         if (p.rowmap && d >= 0) d = p.rowmap[row];
         drow[ii] = d;
       }
-      if (p.res) {
+      if (p.res && !(dbg & 2)) {
 #pragma unroll
         for (int ii = 0; ii < RB; ++ii) {
           const int dr = drow[ii] < 0 ? 0 : drow[ii];
@@ -270,12 +258,17 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_p8(GemmP p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * p.alpha;
           v[0] += bv[j].x, v[1] += bv[j].y, v[2] += bv[j].z, v[3] += bv[j].w;
-          if (ACT == ACT_GELU) {
+          if (ACT == ACT_GELU && !(dbg & 8)) {
+            if (OUT == 1) {        // fp16 result: the transcendental-free polynomial, two elements per packed instruction
+              const f32x2_g g0 = gelu_poly2((f32x2_g){v[0], v[1]}), g1 = gelu_poly2((f32x2_g){v[2], v[3]});
+              v[0] = g0[0], v[1] = g0[1], v[2] = g1[0], v[3] = g1[1];
+            } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r]);
+              for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r]);
+            }
           }
-          if (p.res) v[0] += rv[ii][j].x, v[1] += rv[ii][j].y, v[2] += rv[ii][j].z, v[3] += rv[ii][j].w;
-          if (drow[ii] >= 0) {
+          if (p.res && !(dbg & 2)) v[0] += rv[ii][j].x, v[1] += rv[ii][j].y, v[2] += rv[ii][j].z, v[3] += rv[ii][j].w;
+          if (drow[ii] >= 0 && (!(dbg & 1) || v[0] == 1.2345e30f)) {
             if (OUT == 2) {        // x3 row: the 4 columns lie inside one 32-block (colbase + cj is a multiple of 4)
               h4 hi, lo;
 #pragma unroll
@@ -315,6 +308,7 @@ int gemm_f16_p8_launch(const GemmP& p, hipStream_t s) {
   if ((double)p.M * p.lda * 2.0 >= 4294967296.0 || (double)p.N * p.ldw * 2.0 >= 4294967296.0) return SAMPT_ERR_UNSUPPORTED;
   if (p.act != ACT_NONE && p.act != ACT_GELU) return SAMPT_ERR_UNSUPPORTED;
   GemmP q = p;
+  q.force_generic = getenv("SAMPT_P8_DBG") ? atoi(getenv("SAMPT_P8_DBG")) : 0;   // TEMP diagnostics
   const int nt_m = cdiv(p.M, 256), nt_n = p.N / 256;
   int R = 4;                      // strip height in row panels (2 / 8 measured: more L2 misses, profiles/r3_gemm_hbm_traffic_strip*)
   if (R > nt_m) R = nt_m;

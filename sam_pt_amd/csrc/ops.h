@@ -63,6 +63,12 @@ int vit_flash_attention_f16(const half_t* qkv, const float* rel_h, const float* 
 int vit_flash_attention_x3(const half_t* qkv, const float* rel_h, const float* rel_w, half_t* out, int B, int S, int heads,
                            int hd, hipStream_t s);
 
+// ---- kmedoids.hip (query-point selection, sam_pt/utils/query_points.py:62-99; bit-identical to query_points.kmedoids_alternate)
+// xy: device [n][2] f32 pixel coordinates (integers), n <= 2048.  rowsums: out[i] = sum_j dist(i, j) (fp64, numpy's pairwise order)
+int kmedoids_rowsums(const float* xy, int n, double* out, hipStream_t s);
+// medoids: device int [K], in = the initial medoids, out = the converged ones; iters_out (device int, optional) = iterations run
+int kmedoids_alternate(const float* xy, int n, int K, int* medoids, int max_iter, int* iters_out, hipStream_t s);
+
 // ---- pips.hip ---------------------------------------------------------------------------------
 struct PyramidLevels {
   const float* base[4];   // level l: [nframes][H_l][W_l][C] f32 NHWC

@@ -1,9 +1,15 @@
-"""Multi-GPU sharding of the SAM-PT hot path: one process per GPU, no data-path collective.
+"""Multi-GPU sharding of the SAM-PT hot path: one process per GPU.
 
-Sequences (or frame batches of one sequence) are independent, so ranks never exchange activations; the only
-communication is the final gather of the uint8 index masks to rank 0 (0.59 MB per 576x1024 frame), which replaces the
-reference's pickled-RLE ``comm.gather`` (vis_eval/mask2former_video/data_video/ytvis_eval.py:119-131).  On ROCm the
-``nccl`` backend is RCCL; the payload is far below one xGMI link's capacity: one fixed-shape gather to rank 0.
+* Sequences are independent: in the default mode (one clip per rank, ``lpt_assign`` for sets of unequal clips) ranks never
+  exchange activations; the only communication is the final gather of the uint8 index masks to rank 0 (0.59 MB per 576x1024
+  frame), which replaces the reference's pickled-RLE ``comm.gather``
+  (vis_eval/mask2former_video/data_video/ytvis_eval.py:119-131).
+* ONE clip over all ranks (``sharded_forward``, BASELINE config #5): the SAM stage (image encoder + mask decoder) is per frame
+  and is dealt out in frame batches; the tracker's per-frame encoder is frame-sharded too and the ranks ``all_gather`` its
+  feature pyramid (``FnetShard`` — the one real exchange step); the tracker's window chain is sequential in time by
+  construction (pips/tracker.py:67-148: a window starts where the previous one ended) and is replicated.
+
+On ROCm the ``nccl`` backend is RCCL over xGMI; every collective here is one fixed-shape call.
 """
 from __future__ import annotations
 
@@ -47,6 +53,64 @@ def lpt_assign(lengths: Sequence[int], world: int) -> List[List[int]]:
 # `lpt_assign` (the answer to the length imbalance of BASELINE config #4) on a timed path with synthetic clips.
 DAVIS17_VAL_LENGTHS = [69, 50, 80, 84, 90, 75, 40, 104, 90, 60, 66, 52, 50, 90, 78, 50, 81, 34, 50, 47, 49, 50, 79, 40, 80,
                        100, 79, 43, 40, 99]
+
+
+def frame_shares(n_frames: int, world: int) -> List[range]:
+    """Contiguous equal shares of a clip's frames (the last may be short or empty): rank r encodes ``frame_shares(T, N)[r]``
+    with the tracker's encoder."""
+    per = -(-n_frames // world)
+    return [range(min(r * per, n_frames), min((r + 1) * per, n_frames)) for r in range(world)]
+
+
+class FnetShard:
+    """Frame-sharded tracker encoder for ONE clip over all ranks (BASELINE config #5).
+
+    ``fnet`` (BasicEncoder, pips.py:139-188) is per frame — InstanceNorm normalises each sample on its own (App. B-7) — so rank r
+    encodes only its share of the frames and the ranks ``all_gather`` the 4-level feature pyramid (25 MB per 576x1024 frame in
+    fp32: [T][H/4 >> l][W/4 >> l][128], l = 0..3).  This is the one real exchange step of the in-clip mode: every rank then
+    holds the pyramid a single GPU would have computed, bit for bit, and runs the (latency-bound, sequential) window chain on it.
+    On ROCm the ``nccl`` backend is RCCL over xGMI; one ``all_gather_into_tensor`` per level, in place on the level's buffer.
+
+    ``emulate=True`` (bench.py --emulate-rank r/N, one GPU, no process group): the exchange is replaced by computing the other
+    ranks' frames locally between two events (``stub_ms`` = their GPU time, to be subtracted from the step) while
+    ``bytes_received`` records what the collective would have delivered."""
+
+    def __init__(self, rank: int, world: int, emulate: bool = False, group=None):
+        self.rank, self.world, self.emulate, self.group = rank, world, emulate, group
+        self.stub_events: list = []
+        self.bytes_received = 0
+
+    def padded_frames(self, T: int) -> int:
+        return -(-T // self.world) * self.world
+
+    def mine(self, T: int) -> range:
+        return frame_shares(T, self.world)[self.rank]
+
+    def exchange(self, pyr: List[torch.Tensor], T: int, compute_range=None) -> None:
+        """pyr: the levels, each [padded_frames(T)][h][w][C] with this rank's share already computed (on the current stream)."""
+        per = self.padded_frames(T) // self.world
+        lo = self.rank * per
+        self.bytes_received += sum(int(p[0].numel()) * p.element_size() * (T - len(self.mine(T))) for p in pyr)
+        if self.emulate:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for r, share in enumerate(frame_shares(T, self.world)):
+                if r != self.rank and len(share):
+                    compute_range(share.start, share.stop)
+            b.record()
+            self.stub_events.append((a, b))
+            return
+        for p in pyr:
+            dist.all_gather_into_tensor(p, p[lo:lo + per].clone(), group=self.group)
+
+    def stub_ms(self) -> float:
+        """GPU milliseconds of the emulation's stand-in work since the last call (synchronises)."""
+        ms = 0.0
+        for a, b in self.stub_events:
+            b.synchronize()
+            ms += a.elapsed_time(b)
+        self.stub_events = []
+        return ms
 
 
 def frame_batches(n_frames: int, world: int, rank: int, batch: int = 8) -> List[range]:
@@ -136,15 +200,26 @@ def gather_masks(masks: torch.Tensor, max_frames: int) -> Optional[torch.Tensor]
     return None
 
 
-def sharded_forward(model, video, batch: int = 8):
+def sharded_forward(model, video, batch: int = 8, shard_fnet: bool = True, emulate=None):
     """One clip over all ranks (BASELINE config #5 / SURVEY.md §8e): frame batches of ``batch`` frames are dealt round
-    robin (``frame_batches``); every rank tracks the whole clip (the tracker is cheap and needs every frame), runs the
-    image encoder and the mask decoder on ITS frames only and contributes their uint8 index masks to one fixed-shape
-    gather.  Returns (index masks (T,H,W) uint8 on rank 0 / None elsewhere, the rank's own SamPt output dict).
-    No activation ever crosses ranks."""
-    world = dist.get_world_size() if dist.is_initialized() else 1
-    rank = dist.get_rank() if dist.is_initialized() else 0
+    robin (``frame_batches``); a rank runs the image encoder and the mask decoder on ITS frames only and contributes their
+    uint8 index masks to one fixed-shape gather.  The tracker needs every frame: with ``shard_fnet`` its per-frame encoder is
+    frame-sharded too and the feature pyramid is all-gathered (``FnetShard``, the one exchange step of this mode); the window
+    chain — sequential in time by construction (pips/tracker.py:67-148), latency-bound, identical on every rank — is replicated.
+    Returns (index masks (T,H,W) uint8 on rank 0 / None elsewhere, the rank's own SamPt output dict).
+
+    ``emulate=(r, N)``: no process group — this process runs exactly rank r's share of an N-rank job, collectives stubbed
+    (``FnetShard(emulate=True)``; the mask gather is skipped); the FnetShard is returned in the output dict's place of honour
+    ``out["fnet_shard"]`` for the caller's clock corrections."""
+    if emulate is not None:
+        rank, world = int(emulate[0]), int(emulate[1])
+    else:
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        rank = dist.get_rank() if dist.is_initialized() else 0
     T = len(video["image"])
+    fs = FnetShard(rank, world, emulate=emulate is not None) if (shard_fnet and world > 1) else None
+    if fs is not None:
+        video = {**video, "fnet_shard": fs}
     batch = max(1, min(batch, -(-T // world)))          # short clips: shrink the batches so that most ranks get frames
     mine = [t for r in frame_batches(T, world, rank, batch) for t in r]
     if mine:
@@ -153,6 +228,10 @@ def sharded_forward(model, video, batch: int = 8):
     else:                                               # more ranks than frame batches: this rank only joins the gather
         out = None
         masks = torch.zeros((0,) + tuple(video["target_hw"]), dtype=torch.uint8, device=model.device)
+    if out is not None and fs is not None:
+        out["fnet_shard"] = fs
+    if emulate is not None:
+        return masks, out
     per_rank = max(len([t for r in frame_batches(T, world, k, batch) for t in r]) for k in range(world))
     gathered = gather_masks(masks, per_rank)
     if rank != 0:

@@ -125,39 +125,55 @@ class PipsPointTracker(PointTracker):
 
     # -- fnet + pyramid for a whole clip -----------------------------------------------------------
     @_lib.on_device(lambda self, frames, *a, **k: frames.device)
-    def compute_pyramid(self, frames: torch.Tensor, chunk_events: Optional[list] = None):
+    def compute_pyramid(self, frames: torch.Tensor, chunk_events: Optional[list] = None, shard=None):
         """frames (T,3,H,W) uint8 on device -> list of 4 NHWC f32 levels [T][H_l][W_l][128].  ``chunk_events``: a list that
-        receives one ``(first_frame, end_frame, torch.cuda.Event)`` per encoder chunk, recorded on the current stream."""
+        receives one ``(first_frame, end_frame, torch.cuda.Event)`` per encoder chunk, recorded on the current stream.
+        ``shard`` (sam_pt_amd.dist.FnetShard): encode only this rank's share of the frames and fill in the rest through
+        ``shard.exchange`` (all_gather of the pyramid over RCCL); one event for the whole pyramid."""
         self._ensure(frames.device)
         T, _, H, W = frames.shape
         H0, W0 = H // self.stride, W // self.stride
-        pyr = [torch.empty((T, H0 >> l, W0 >> l, 128), dtype=torch.float32, device=frames.device) for l in range(4)]
+        Tp = T if shard is None else shard.padded_frames(T)
+        pyr = [torch.empty((Tp, H0 >> l, W0 >> l, 128), dtype=torch.float32, device=frames.device) for l in range(4)]
         chunk = min(self.fnet_chunk, T)
         nbytes = C.c_size_t()
         _lib.check(self._lib.sampt_pips_fnet_workspace_bytes(self._h, chunk, H, W, C.byref(nbytes)), "fnet_workspace")
         ws = torch.empty(nbytes.value, dtype=torch.uint8, device=frames.device)
         frames = frames.contiguous()
-        for t0 in range(0, T, chunk):
-            nf = min(chunk, T - t0)
-            outs = _lib.ptr_array([p[t0:t0 + nf] for p in pyr])
-            _lib.check(self._lib.sampt_pips_fnet_f32(self._h, _lib.ptr(frames[t0:t0 + nf]), nf, H, W, outs, _lib.ptr(ws),
-                                                     nbytes.value, _lib.stream_ptr()), "sampt_pips_fnet_f32")
-            if chunk_events is not None and frames.is_cuda:
-                ev = torch.cuda.Event()
-                ev.record()
-                chunk_events.append((t0, t0 + nf, ev))
-        self.stats["fnet_frames"] += T
-        return pyr
+
+        def encode(lo, hi, events=None):
+            for t0 in range(lo, hi, chunk):
+                nf = min(chunk, hi - t0)
+                outs = _lib.ptr_array([p[t0:t0 + nf] for p in pyr])
+                _lib.check(self._lib.sampt_pips_fnet_f32(self._h, _lib.ptr(frames[t0:t0 + nf]), nf, H, W, outs, _lib.ptr(ws),
+                                                         nbytes.value, _lib.stream_ptr()), "sampt_pips_fnet_f32")
+                if events is not None and frames.is_cuda:
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    events.append((t0, t0 + nf, ev))
+                self.stats["fnet_frames"] += nf
+
+        if shard is None:
+            encode(0, T, chunk_events)
+            return pyr
+        mine = shard.mine(T)
+        encode(mine.start, mine.stop)
+        shard.exchange(pyr, T, encode)
+        if chunk_events is not None and frames.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+            chunk_events.append((0, T, ev))
+        return [p[:T] for p in pyr]
 
     # -- chained windows for a set of independent point chains (pips/tracker.py:42-153) --------------------------
-    def prepare(self, frames: torch.Tensor):
+    def prepare(self, frames: torch.Tensor, shard=None):
         """Optional: build the feature pyramid of ``frames`` (T,3,H,W) now, on the current stream; the next ``forward``
         on the same frames tensor reuses it.  Lets a caller keep the compute-bound fnet on its main stream and run only
         the latency-bound window rounds on a second stream (sam_pt_amd.SamPt).  One event per encoder chunk is kept: a
         ``forward`` running on ANOTHER stream makes every window round wait only for the chunks that hold its frames
         (``chunk_events_on_other_stream``), so the first rounds start while later frames are still being encoded."""
         evs: list = []
-        self._prepared = _prepared_entry(frames, self.compute_pyramid(frames, evs))
+        self._prepared = _prepared_entry(frames, self.compute_pyramid(frames, evs, shard=shard))
         self._prepared_events = evs
 
     chunk_events_on_other_stream = True      # SamPt: the side stream needs no event for the whole pyramid
@@ -312,7 +328,8 @@ class PipsPlusPlusPointTracker(PointTracker):
         self.stats["fnet_frames"] += T
         return pyr
 
-    def prepare(self, frames: torch.Tensor):
+    def prepare(self, frames: torch.Tensor, shard=None):
+        """``shard`` is accepted for interface parity and ignored: PIPS++ encodes the whole clip on every rank."""
         if self.image_size is not None:        # forward() encodes the RESIZED float video: a pyramid of `frames` is unused
             return
         self._prepared = _prepared_entry(frames, self.compute_pyramid(frames))
@@ -506,9 +523,10 @@ class CoTrackerPointTracker(PointTracker):
 
     # -- resize + encoder for a whole clip ---------------------------------------------------------------------
     @_lib.on_device(lambda self, frames, *a, **k: frames.device)
-    def compute_pyramid(self, frames: torch.Tensor):
+    def compute_pyramid(self, frames: torch.Tensor, shard=None):
         """frames (T,3,H,W) uint8 / float32 on device -> 4 NHWC f32 levels [T][h/4 >> l][w/4 >> l][128] of the video resized
-        to ``interp_shape`` (h, w)."""
+        to ``interp_shape`` (h, w).  ``shard`` (sam_pt_amd.dist.FnetShard): resize + encode this rank's frames only, the rest
+        arrives through ``shard.exchange`` (see PipsPointTracker.compute_pyramid)."""
         self._ensure(frames.device)
         dev = frames.device
         T, _, H, W = frames.shape
@@ -516,27 +534,40 @@ class CoTrackerPointTracker(PointTracker):
         frames = frames.contiguous()
         if frames.dtype != torch.uint8:
             frames = frames.float()
-        small = torch.empty((T, 3, h, w), dtype=torch.float32, device=dev)
-        _lib.check(self._lib.sampt_resize_frames_f32(_lib.ptr(frames), 1 if frames.dtype == torch.uint8 else 0, T * 3, H, W,
-                                                     _lib.ptr(small), h, w, _lib.stream_ptr()), "sampt_resize_frames_f32")
         H0, W0 = h // self.stride, w // self.stride
-        pyr = [torch.empty((T, H0 >> l, W0 >> l, 128), dtype=torch.float32, device=dev) for l in range(4)]
+        Tp = T if shard is None else shard.padded_frames(T)
+        pyr = [torch.empty((Tp, H0 >> l, W0 >> l, 128), dtype=torch.float32, device=dev) for l in range(4)]
         chunk = min(self.fnet_chunk, T)
         nbytes = C.c_size_t()
         _lib.check(self._lib.sampt_cotracker_fnet_workspace_bytes(self._h, chunk, h, w, C.byref(nbytes)), "fnet_workspace")
         ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
-        for t0 in range(0, T, chunk):
-            nf = min(chunk, T - t0)
-            outs = _lib.ptr_array([p[t0:t0 + nf] for p in pyr])
-            _lib.check(self._lib.sampt_cotracker_fnet_f32(self._h, _lib.ptr(small[t0:t0 + nf]), nf, h, w, outs, _lib.ptr(ws),
-                                                          nbytes.value, _lib.stream_ptr()), "sampt_cotracker_fnet_f32")
-        self.stats["fnet_frames"] += T
-        return pyr
 
-    def prepare(self, frames: torch.Tensor):
+        def encode(lo, hi):
+            if hi <= lo:
+                return
+            small = torch.empty((hi - lo, 3, h, w), dtype=torch.float32, device=dev)
+            _lib.check(self._lib.sampt_resize_frames_f32(_lib.ptr(frames[lo:hi]), 1 if frames.dtype == torch.uint8 else 0,
+                                                         (hi - lo) * 3, H, W, _lib.ptr(small), h, w, _lib.stream_ptr()),
+                       "sampt_resize_frames_f32")
+            for t0 in range(lo, hi, chunk):
+                nf = min(chunk, hi - t0)
+                outs = _lib.ptr_array([p[t0:t0 + nf] for p in pyr])
+                _lib.check(self._lib.sampt_cotracker_fnet_f32(self._h, _lib.ptr(small[t0 - lo:t0 - lo + nf]), nf, h, w, outs,
+                                                              _lib.ptr(ws), nbytes.value, _lib.stream_ptr()), "sampt_cotracker_fnet_f32")
+            self.stats["fnet_frames"] += hi - lo
+
+        if shard is None:
+            encode(0, T)
+            return pyr
+        mine = shard.mine(T)
+        encode(mine.start, mine.stop)
+        shard.exchange(pyr, T, encode)
+        return [p[:T] for p in pyr]
+
+    def prepare(self, frames: torch.Tensor, shard=None):
         """Build the (resized) clip's feature pyramid now, on the current stream; the next ``forward`` on the same frames
         tensor reuses it (see PipsPointTracker.prepare)."""
-        self._prepared = _prepared_entry(frames, self.compute_pyramid(frames))
+        self._prepared = _prepared_entry(frames, self.compute_pyramid(frames, shard=shard))
 
     def _pos_tables(self, H0: int, W0: int, dev):
         if (H0, W0) not in self._pos:

@@ -1,8 +1,10 @@
 """Query-point selection from a mask (reference: sam_pt/utils/query_points.py).
 
 Needed by ``SamPt`` in ``query_masks`` mode (every VOS run, sam_pt.py:171-177) and by point re-initialisation
-(sam_pt.py:529-533).  Like the reference this is host-side work done once per object per (re)initialisation on at most
-1800 sub-sampled mask pixels — not a hot kernel.
+(sam_pt.py:529-533), once per object per (re)initialisation on at most 1800 sub-sampled mask pixels.  The pixel draw (one
+``torch.randperm`` on the global generator, as the reference consumes it) stays on the host; the k-medoid clustering — 60 to
+160 ms of numpy per mask, inside the evaluator's timed window — runs on the HIP device when the caller passes one
+(``kmedoids_alternate_device``, csrc/kmedoids.hip), bit-identical to the host restatement below.
 
 * ``extract_random_mask_points`` — same RNG consumption as the reference (one ``torch.randperm`` on the global
   generator, query_points.py:55), so results are bit-identical for the same seed (pinned in tests).
@@ -59,8 +61,30 @@ def kmedoids_alternate(X: np.ndarray, n_clusters: int, max_iter: int = 300) -> n
     return medoids
 
 
-def extract_kmedoid_points(mask: torch.Tensor, n_points_to_select: int, subsample_size: int = 1800) -> torch.Tensor:
-    """K-medoid centres of (a random 1800-pixel subsample of) the mask, as (x, y) (query_points.py:62-99)."""
+def kmedoids_alternate_device(X: torch.Tensor, n_clusters: int, device, max_iter: int = 300) -> np.ndarray:
+    """``kmedoids_alternate`` on the HIP device, bit-identical to the host restatement (csrc/kmedoids.hip: fp64 distances, numpy's
+    pairwise summation order, first-index ties).  X: (n, 2) float32 pixel coordinates on the host, n <= 2048.  The heuristic
+    initialisation's ``np.argpartition`` stays on the host (its output order is numpy's introselect): the device returns the row
+    sums, the host partitions n doubles, the device iterates to convergence — two small round trips instead of 60 - 160 ms of
+    numpy on an n x n fp64 matrix."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    n = int(X.shape[0])
+    with _lib.device_guard(torch.device(device)):
+        xy = X.detach().to(torch.float32).contiguous().to(device)
+        sums = torch.empty(n, dtype=torch.float64, device=device)
+        _lib.check(lib.sampt_kmedoids_rowsums_f64(_lib.ptr(xy), n, _lib.ptr(sums), _lib.stream_ptr()), "sampt_kmedoids_rowsums_f64")
+        medoids = np.argpartition(sums.cpu().numpy(), n_clusters - 1)[:n_clusters]           # heuristic init (host: introselect order)
+        med = torch.from_numpy(np.ascontiguousarray(medoids.astype(np.int32))).to(device)
+        _lib.check(lib.sampt_kmedoids_alternate(_lib.ptr(xy), n, int(n_clusters), _lib.ptr(med), int(max_iter), None,
+                                                _lib.stream_ptr()), "sampt_kmedoids_alternate")
+        return med.cpu().numpy().astype(np.int64)
+
+
+def extract_kmedoid_points(mask: torch.Tensor, n_points_to_select: int, subsample_size: int = 1800, device=None) -> torch.Tensor:
+    """K-medoid centres of (a random 1800-pixel subsample of) the mask, as (x, y) (query_points.py:62-99).  ``device``: a HIP
+    device runs the clustering there (``kmedoids_alternate_device``: same result bit for bit); None = the numpy restatement."""
     if mask.sum() == 0:
         print("Warning: mask.sum() == 0 in extract_kmedoid_points")
         return torch.zeros((n_points_to_select, 2))
@@ -69,7 +93,10 @@ def extract_kmedoid_points(mask: torch.Tensor, n_points_to_select: int, subsampl
         sel = px.repeat(n_points_to_select // len(px) + 1, 1)[:n_points_to_select]
     else:
         px = px[torch.randperm(len(px))[:subsample_size]]
-        idx = kmedoids_alternate(px.numpy(), n_points_to_select)
+        if device is not None and torch.device(device).type == "cuda" and len(px) <= 2048 and n_points_to_select <= 64:
+            idx = kmedoids_alternate_device(px, n_points_to_select, device)
+        else:
+            idx = kmedoids_alternate(px.numpy(), n_points_to_select)
         sel = px[torch.as_tensor(idx, dtype=torch.long)].type(torch.float32)
     return sel.flip(1)
 
@@ -185,7 +212,7 @@ def good_features_to_track(gray: np.ndarray, max_corners: int, quality_level: fl
 
 
 def extract_corner_points(image: torch.Tensor, mask: torch.Tensor, n_points_to_select: int,
-                          kmedoid_subsample_size: int = 2000) -> torch.Tensor:
+                          kmedoid_subsample_size: int = 2000, device=None) -> torch.Tensor:
     """Shi-Tomasi corners inside the eroded mask, topped up with k-medoid points (query_points.py:102-162).
     image (3,H,W) uint8, mask (H,W) {0,1} -> (n,2) float32 (x, y).  PARITY UNPINNED (see the note above)."""
     if mask.sum() == 0:
@@ -205,12 +232,12 @@ def extract_corner_points(image: torch.Tensor, mask: torch.Tensor, n_points_to_s
     corners = torch.from_numpy(corners).type(torch.float32)
     if len(corners) < n_points_to_select:
         corners = torch.cat((corners, extract_kmedoid_points(mask, n_points_to_select - corners.shape[0],
-                                                             subsample_size=kmedoid_subsample_size)), dim=0)
+                                                             subsample_size=kmedoid_subsample_size, device=device)), dim=0)
     assert corners.shape == (n_points_to_select, 2)
     return corners
 
 
-def extract_mixed_points(query_masks, query_points_timestep, images, n_points: int) -> List[torch.Tensor]:
+def extract_mixed_points(query_masks, query_points_timestep, images, n_points: int, device=None) -> List[torch.Tensor]:
     """n/4 k-medoid + n/3 Shi-Tomasi + the rest random points per mask, in that order (query_points.py:197-237).  The
     shipped default (configs/model/sam_pt.yaml: 1 negative point, method "mixed") degenerates to ONE RANDOM point; the
     Shi-Tomasi share only exists from n = 3 on (see ``extract_corner_points`` for its parity status)."""
@@ -218,9 +245,9 @@ def extract_mixed_points(query_masks, query_points_timestep, images, n_points: i
     n_random = n_points - n_kmedoid - n_shi_tomasi
     parts = []
     if n_kmedoid > 0:
-        parts.append([extract_kmedoid_points(qm, n_kmedoid) for qm in query_masks])
+        parts.append([extract_kmedoid_points(qm, n_kmedoid, device=device) for qm in query_masks])
     if n_shi_tomasi > 0:
-        parts.append([extract_corner_points(images[int(t.item())], qm, n_shi_tomasi)
+        parts.append([extract_corner_points(images[int(t.item())], qm, n_shi_tomasi, device=device)
                       for qm, t in zip(query_masks, query_points_timestep)])
     if n_random > 0:
         parts.append([extract_random_mask_points(qm, n_random) for qm in query_masks])
@@ -229,15 +256,17 @@ def extract_mixed_points(query_masks, query_points_timestep, images, n_points: i
     return [torch.cat(x, dim=0) for x in zip(*parts)]
 
 
-def extract_query_points_xy(images, query_masks, query_points_timestep, method: str, points_per_mask: int) -> List[torch.Tensor]:
-    """Dispatch of SamPt._extract_query_points_xy (sam_pt.py:290-306)."""
+def extract_query_points_xy(images, query_masks, query_points_timestep, method: str, points_per_mask: int,
+                            device=None) -> List[torch.Tensor]:
+    """Dispatch of SamPt._extract_query_points_xy (sam_pt.py:290-306).  ``device``: run the k-medoid clustering on that HIP
+    device (same points, bit for bit)."""
     if method == "kmedoids":
-        return [extract_kmedoid_points(qm, points_per_mask) for qm in query_masks]
+        return [extract_kmedoid_points(qm, points_per_mask, device=device) for qm in query_masks]
     if method == "random":
         return [extract_random_mask_points(qm, points_per_mask) for qm in query_masks]
     if method == "shi-tomasi":
-        return [extract_corner_points(images[int(t.item())], qm, points_per_mask)
+        return [extract_corner_points(images[int(t.item())], qm, points_per_mask, device=device)
                 for qm, t in zip(query_masks, query_points_timestep)]
     if method == "mixed":
-        return extract_mixed_points(query_masks, query_points_timestep, images, points_per_mask)
+        return extract_mixed_points(query_masks, query_points_timestep, images, points_per_mask, device=device)
     raise NotImplementedError(f"Point selection method {method} not implemented")

@@ -219,7 +219,8 @@ class SamPt(nn.Module):
                 ready = torch.cuda.Event()
                 ready.record()                                               # frames valid on this stream
                 if hasattr(self.point_tracker, "prepare") and not self.overlap_tracker_encoder_fnet:
-                    self.point_tracker.to(self.device).prepare(images)
+                    fs = video.get("fnet_shard")          # frame-sharded tracker encoder + pyramid all_gather (dist.FnetShard)
+                    self.point_tracker.to(self.device).prepare(images, **({"shard": fs} if fs is not None else {}))
                     if not getattr(self.point_tracker, "chunk_events_on_other_stream", False):
                         ready = torch.cuda.Event()       # tracker without per-chunk events: wait for the whole pyramid
                         ready.record()
@@ -310,11 +311,13 @@ class SamPt(nn.Module):
         from .query_points import extract_query_points_xy
         query_masks = query_masks.cpu()
         query_points_timestep = query_points_timestep.cpu()
+        # k-medoid clustering on the device when the frames live there (same points bit for bit; query_points.py)
+        dev = images.device if isinstance(images, torch.Tensor) and images.is_cuda else None
         xy = extract_query_points_xy(images, query_masks, query_points_timestep, self.positive_point_selection_method,
-                                     self.positive_points_per_mask)
+                                     self.positive_points_per_mask, device=dev)
         if self.negative_points_per_mask > 0:
             neg = extract_query_points_xy(images, [1 - qm for qm in query_masks], query_points_timestep,
-                                          self.negative_point_selection_method, self.negative_points_per_mask)
+                                          self.negative_point_selection_method, self.negative_points_per_mask, device=dev)
             xy = [torch.cat(x, dim=0) for x in zip(xy, neg)]
         xy = torch.stack(xy, dim=0)
         t = query_points_timestep[:, None, None].repeat(1, xy.shape[1], 1)

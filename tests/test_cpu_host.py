@@ -732,3 +732,70 @@ def test_captured_decode_chain_is_kernel_nodes_only():
         assert lo < calls[0] < dec.index("hypernetwork MLP of mask token 0", lo)
     cabi = open(os.path.join(ROOT, "sam_pt_amd", "csrc", "c_abi.hip")).read()
     assert cabi.count("h->e.multimask = true") == 1 and cabi.count("h->e.multimask = false") == 1
+
+
+def test_gelu_polynomial_header_matches_erf_gelu():
+    """csrc/gelu_poly.h (the transcendental-free GELU of the fp16 GEMM epilogue) is what tools/gelu_poly_fit.py generates, and
+    its fp32 Horner evaluation stays within 4e-6 of the erf GELU (torch.nn.GELU default, the activation of SAM's MLPBlock)
+    everywhere — the fp16 rounding of the stored value is 1.2e-4 at |gelu| = 0.25."""
+    import importlib.util
+    import re
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gelu_poly_fit", os.path.join(root, "tools", "gelu_poly_fit.py"))
+    fit = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fit)
+    hdr = open(os.path.join(root, "sam_pt_amd", "csrc", "gelu_poly.h")).read()
+    coefs = [float(c.rstrip("f")) for c in re.search(r"GELU_POLY_COEFS \{(.*)\}", hdr).group(1).split(", ")]
+    assert len(coefs) == int(re.search(r"GELU_POLY_DEG (\d+)", hdr).group(1)) + 1
+    assert float(re.search(r"GELU_POLY_C ([0-9.]+)f", hdr).group(1)) == fit.C
+    x = np.concatenate([np.linspace(-12, 12, 240001), np.linspace(-1e-3, 1e-3, 2001)])
+    ref = torch.nn.functional.gelu(torch.from_numpy(x)).numpy()
+    assert np.abs(fit.gelu_poly_f32(x, np.array(coefs)) - ref).max() < 4e-6
+    assert np.allclose(fit.fit(), coefs, rtol=0, atol=5e-7), "gelu_poly.h is stale: regenerate with tools/gelu_poly_fit.py"
+
+
+def test_fnet_shard_pyramid_all_gather_two_ranks_gloo():
+    """dist.FnetShard (the exchange step of the in-clip multi-GPU mode): 2 gloo processes each "encode" their share of a
+    5-frame clip (uneven shares: 3 + 2, padded to 3 + 3) into a 4-level pyramid and all_gather it; every rank ends up with the
+    pyramid a single process computes, bit for bit.  The emulation mode (one process standing in for rank r of N) fills the
+    same buffers through its compute callback."""
+    code = r"""
+import os, sys, torch
+sys.path.insert(0, %r)
+import torch.distributed as dist
+from sam_pt_amd.dist import FnetShard, frame_shares, init_from_env
+rank, world, local = init_from_env("gloo")
+assert world == 2
+T = 5
+def level(l, lo, hi):                     # the "encoder": frame t of level l is a deterministic function of (t, l)
+    h, w = 8 >> l, 12 >> l
+    t = torch.arange(lo, hi, dtype=torch.float32).view(-1, 1, 1, 1)
+    return (t * 1000 + l * 100 + torch.arange(h * w * 4, dtype=torch.float32).view(1, h, w, 4)).contiguous()
+want = [level(l, 0, T) for l in range(3)]
+fs = FnetShard(rank, world)
+assert [list(r) for r in frame_shares(T, world)] == [[0, 1, 2], [3, 4]] and fs.padded_frames(T) == 6
+pyr = [torch.full((fs.padded_frames(T), 8 >> l, 12 >> l, 4), -1.0) for l in range(3)]
+mine = fs.mine(T)
+for l in range(3):
+    pyr[l][mine.start:mine.stop] = level(l, mine.start, mine.stop)
+fs.exchange(pyr, T)
+assert all(torch.equal(p[:T], w) for p, w in zip(pyr, want)), rank
+assert fs.bytes_received == sum(w[0].numel() * 4 * (T - len(mine)) for w in want)
+dist.barrier(); dist.destroy_process_group()
+print("PYRAMID_OK", rank)
+""" % ROOT
+    port = str(_free_port())
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:
+        f.write(code)
+        path = f.name
+    try:
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                            "--master-addr", "127.0.0.1", "--master-port", port, path], env=env, capture_output=True,
+                           text=True, timeout=300)
+    finally:
+        os.unlink(path)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert r.stdout.count("PYRAMID_OK") == 2

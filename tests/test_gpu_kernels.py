@@ -147,13 +147,15 @@ def test_gemm_x3(lib, dev, M, N, K, out_x3, act):
     A32, W32 = A[src.long()].contiguous().to(dev), W.to(dev)
     C32 = torch.empty(M, N, device=dev)
     ok(lib.sampt_gemm(0, P(A32), P(W32), P(bd), None, P(C32), M, N, K, act, 1.0, S()), "gemm f32")
-    # rows fed by the out-of-range operands are judged on their own scale, the others on theirs
+    # Rows fed by the out-of-range operands are judged on their own scale: a saturated element is 65504 + lo with a lo that is
+    # no longer small, so the dropped lo.lo term leaves it fp16-grade (2^-11 of that one product) — finite and sane, which is
+    # what saturation is for.  Every other row is held to the exact f32 MFMA path's error.
     big = torch.zeros(M, dtype=torch.bool)
     big[(src == 3) | (src == M - 1)] = True
-    for sel in (big & keep, ~big & keep):
+    for sel, floor, slack in ((big & keep, 3e-4, 2.0), (~big & keep, 2e-6, 2.0)):
         e32 = rel_err(C32.cpu()[sel], acc[sel])
         e3 = rel_err(got.cpu()[dest[sel].long()], ref[dest[sel].long()])
-        assert e3 < max(2e-6, 2.0 * e32), (e3, e32)
+        assert e3 < max(floor, slack * e32), (e3, e32)
     assert torch.equal(got.cpu()[[i for i in range(M + 5) if i not in set(dest[keep].tolist())]].float(),
                        torch.full((M + 5 - int(keep.sum()), N), 7.0)), "rows outside the row map were written"
     # the device-side splitter writes the very rows the host packer does
@@ -304,12 +306,13 @@ def test_corr_sample_vs_oracle(lib, dev):
     assert max_abs(out.permute(1, 0, 2), ref) < 2e-5 * float(ref.abs().max())
 
 
-def _ref_vit_attention(qkv, rel_h, rel_w, B, S_, heads, hd):
+def _ref_vit_attention(qkv, rel_h, rel_w, B, S_, heads, hd, dtype=torch.float64):
     N, D = S_ * S_, heads * hd
-    q, k, v = qkv.double().reshape(B, N, 3, heads, hd).permute(2, 0, 3, 1, 4).reshape(3, B * heads, N, hd).unbind(0)
+    qkv, rel_h, rel_w = qkv.to(dtype), rel_h.to(dtype), rel_w.to(dtype)
+    q, k, v = qkv.reshape(B, N, 3, heads, hd).permute(2, 0, 3, 1, 4).reshape(3, B * heads, N, hd).unbind(0)
     attn = (q * hd ** -0.5) @ k.transpose(-2, -1)
     idx = torch.arange(S_)[:, None] - torch.arange(S_)[None, :] + (S_ - 1)
-    Rh, Rw = rel_h.double()[idx], rel_w.double()[idx]
+    Rh, Rw = rel_h[idx], rel_w[idx]
     rq = q.reshape(B * heads, S_, S_, hd)
     attn = attn.view(-1, S_, S_, S_, S_) + torch.einsum("bhwc,hkc->bhwk", rq, Rh)[..., None] \
         + torch.einsum("bhwc,wkc->bhwk", rq, Rw)[:, :, :, None, :]
@@ -344,11 +347,16 @@ def test_vit_flash_attention_x3(lib, dev, B, S_, heads, hd):
     rel_h = torch.randn(2 * S_ - 1, hd, generator=g) * 0.3
     rel_w = torch.randn(2 * S_ - 1, hd, generator=g) * 0.3
     ref = _ref_vit_attention(qkv, rel_h, rel_w, B, S_, heads, hd)
+    e32 = max_abs(_ref_vit_attention(qkv, rel_h, rel_w, B, S_, heads, hd, dtype=torch.float32), ref)   # the same in plain fp32
     qx = x3_rows(qkv).to(dev)
     out = torch.empty(B * N, 2 * D, device=dev, dtype=torch.float16)
     hd_, wd_ = rel_h.to(dev), rel_w.to(dev)
     ok(lib.sampt_vit_attention_x3(P(qx), P(hd_), P(wd_), P(out), B, S_, heads, hd, S()), "flash x3")
-    assert max_abs(x3_unrows(out.cpu()), ref) < 4e-6 * float(ref.abs().max())
+    # fp32-grade = within a small factor of what plain fp32 arithmetic leaves on the same inputs: with scores of magnitude ~30
+    # (q, k ~ N(0, 1.5^2), peaked softmax) the fp32 rounding of the score itself dominates both (measured 3.1x at 64 x 64
+    # tokens / head dim 80, 1 - 2x elsewhere; the fp16 kernel is at 300x)
+    e3 = max_abs(x3_unrows(out.cpu()), ref)
+    assert e3 < max(4e-6 * float(ref.abs().max()), 5.0 * e32), (e3, e32)
 
 
 @pytest.mark.parametrize("in_h,in_w,oh,ow", [(576, 1024, 576, 1024), (576, 1024, 480, 854), (1024, 683, 300, 200)])
@@ -513,3 +521,44 @@ def test_cotracker_attention_kernel(lib, dev, nb, L, time_attn):
     bs, ts = (S_, 1) if time_attn else (1, S_)
     ok(lib.sampt_cotracker_attention_f32(P(qkv.to(dev)), P(out), nb, L, bs, ts, heads, hd, S()), "cot attention")
     assert max_abs(out.view(npts, S_, D), ref.reshape(npts, S_, D)) < 2e-5
+
+
+def test_kmedoids_device_equals_host_restatement(lib, dev):
+    """csrc/kmedoids.hip against sam_pt_amd.query_points.kmedoids_alternate (the host restatement of sklearn_extra's KMedoids that
+    sam_pt/utils/query_points.py:62-99 calls), BIT-IDENTICAL on 50 seeded masks: the fp64 row sums (numpy's pairwise summation
+    order), the medoids the alternating iterations converge to, and the query points ``extract_kmedoid_points`` returns."""
+    import numpy as np
+    from sam_pt_amd import query_points as Q
+    rng = np.random.default_rng(7)
+    yy, xx = np.mgrid[0:240, 0:320]
+    for case in range(50):
+        mask = np.zeros((240, 320), dtype=bool)
+        for _ in range(int(rng.integers(1, 4))):                  # a few random ellipses: blobs, holes, thin and tiny masks
+            cy, cx = rng.uniform(20, 220), rng.uniform(20, 300)
+            ry, rx = rng.uniform(2, 70), rng.uniform(2, 90)
+            mask |= ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 < 1.0
+        if case % 7 == 3:
+            mask &= (yy + xx) % 3 != 0                            # perforated: many exactly equidistant pixels
+        mt = torch.from_numpy(mask.astype(np.float32))
+        K = int(rng.choice([1, 2, 4, 8, 16]))
+        if int(mask.sum()) < K:
+            continue
+        px = mt.nonzero().float()
+        px = px[torch.randperm(len(px), generator=torch.Generator().manual_seed(case))[:1800]]
+        n = len(px)
+        # row sums: np.sum(D, axis=1) bit for bit
+        X = px.numpy().astype(np.float64)
+        D = np.sqrt(np.maximum(((X[:, None, :] - X[None, :, :]) ** 2).sum(-1), 0.0))
+        xy = px.contiguous().to(dev)
+        sums = torch.empty(n, dtype=torch.float64, device=dev)
+        ok(lib.sampt_kmedoids_rowsums_f64(P(xy), n, P(sums), S()), "rowsums")
+        assert np.array_equal(sums.cpu().numpy(), D.sum(axis=1)), f"case {case}: row sums differ"
+        want = Q.kmedoids_alternate(px.numpy(), K)
+        got = Q.kmedoids_alternate_device(px, K, dev)
+        assert np.array_equal(got, want), f"case {case} (n={n}, K={K}): medoids {got} != {want}"
+        # and through the public function, same RNG consumption on both paths
+        torch.manual_seed(100 + case)
+        a = Q.extract_kmedoid_points(mt, K)
+        torch.manual_seed(100 + case)
+        b = Q.extract_kmedoid_points(mt, K, device=dev)
+        assert torch.equal(a, b)

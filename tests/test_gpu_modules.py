@@ -1010,3 +1010,35 @@ def test_stream_of_clips_equals_forward(dev, pips_sd):
     out = model.forward_end(h)
     assert model.forward_end(h) is out
     assert torch.equal(torch.stack(out["logits"]), torch.stack(ref[0]["logits"]))
+
+
+# ------------------------------------------------------------------------------------------ one clip over N ranks
+@pytest.mark.parametrize("tracker", ["pips", "cotracker"])
+def test_frame_sharded_emulation_equals_full_forward(dev, pips_sd, tracker):
+    """dist.sharded_forward's in-clip split, one GPU standing in for each rank of a 3-rank job in turn (emulate=(r, N): its
+    share of the tracker encoder + the stubbed pyramid all_gather, the replicated window chain, its frame batches of the SAM
+    stage): trajectories are those of the full forward bit for bit on every "rank", and the ranks' masks tile the full result."""
+    from sam_pt_amd.dist import frame_batches, index_masks, sharded_forward
+    from sam_pt_amd.point_tracker import CoTrackerPointTracker, PipsPointTracker
+    from sam_pt_amd.sam_predictor import SamHip, SamPredictor
+    from sam_pt_amd.sam_pt import SamPt
+    from sam_pt_amd.weights import SAM_CONFIGS
+    cfg = SAM_CONFIGS["vit_test"]
+    frames, centres = synthetic_clip(T=10, H=128, W=256, seed=4)
+    q = disc_queries(centres, n_pos=4, r=9.0)[None]
+    kw = dict(sam_iou_threshold=-1e9, positive_points_per_mask=4, negative_points_per_mask=0, iterative_refinement_iterations=2)
+    trk = PipsPointTracker(state_dict=pips_sd, fnet_chunk=4) if tracker == "pips" else CoTrackerPointTracker(seed=72, fnet_chunk=4)
+    model = SamPt(trk, SamPredictor(SamHip(config=cfg, seed=72, precision="f32", max_batch=4).to(dev)), **kw).eval()
+    video = {"image": [f.to(dev) for f in frames], "target_hw": (128, 256), "query_points": q}
+    full = model(video)
+    want = index_masks(torch.stack(full["logits"], dim=0))
+    N, seen = 3, torch.zeros(10, dtype=torch.bool)
+    for r in range(N):
+        masks, out = sharded_forward(model, video, batch=2, emulate=(r, N))
+        ids = [t for b in frame_batches(10, N, r, 2) for t in b]
+        assert torch.equal(out["trajectories"], full["trajectories"]) and torch.equal(out["visibilities"], full["visibilities"])
+        assert torch.equal(masks, want[torch.as_tensor(ids, device=want.device)])
+        fs = out["fnet_shard"]
+        assert fs.bytes_received > 0 and fs.stub_ms() > 0.0
+        seen[ids] = True
+    assert bool(seen.all())
