@@ -37,6 +37,12 @@
 // L2) owns the x-th eighth of that list and its workgroups take consecutive tiles, so the tiles in flight on one XCD form
 // an R x (32 / R) patch that shares A panels and W tiles through that L2 while the panels of a strip stay resident.
 //
+// Tried and dropped (round 4, profiles/r4_c3_*, r4_c4_*): interleaving the two W fragments of a 32-column half (fragment fj = W
+// rows (n >> 2) * 8 + fj * 4 + (n & 3)) so that a lane of a 16-bit output owns 8 consecutive columns — one 16-byte store instead
+// of two 8-byte ones, 16 rows x 64 contiguous bytes per instruction.  Isolated and in steady state the fp16-output launches
+// gained 4 - 6 % (qkv 928 -> 982, fc1 870 -> 906 TFLOP/s; the stores are 13 % of a qkv launch), but inside the encoder the very
+// same build lost 2 % twice in an A / B of one call (in situ 885 -> 867 TFLOP/s, 113.3 -> 110.3 fps), so the plain mapping stays.
+//
 // GemmP::x3 (template X3): the operands are "x3 rows" (common.h: every 64-half K-tile row is [hi(32) | lo(32)] of 32 real k)
 // and a phase issues 24 MFMAs instead of 16 — hi.hi + hi.lo + lo.hi per fragment pair, fp32-grade products at a third of
 // the fp16 rate — on the very same stage / barrier schedule (the K-tile images in LDS are byte-identical in size and
@@ -44,8 +50,6 @@
 //
 // Launcher conditions: K % 128 == 0 (an even number of K-tiles: tile boundaries fall on buffer 0), N % 256 == 0, M >= 256.
 // Rows beyond M are clamped to the last valid row for the loads and never stored.
-#include <stdlib.h>
-
 #include "common.h"
 
 namespace sampt {
@@ -226,8 +230,6 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_p8(GemmP p) {
     // The residual of RB fragment rows (RB x 4 fragments x 16 B per lane) is loaded in ONE batch into the registers the
     // operand fragments no longer need: the epilogue waits for 8 / RB memory round trips per tile instead of 32.
     constexpr int RB = P8_EPI_ROWS;
-    const int dbg = p.force_generic;   // TEMP diagnostics: 1 no stores, 2 no residual loads, 4 no epilogue, 8 no GELU
-    if (!(dbg & 4))
 #pragma unroll
     for (int hb = 0; hb < 8 / RB; ++hb) {
       int drow[RB];
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_p8(GemmP p) {
         if (p.rowmap && d >= 0) d = p.rowmap[row];
         drow[ii] = d;
       }
-      if (p.res && !(dbg & 2)) {
+      if (p.res) {
 #pragma unroll
         for (int ii = 0; ii < RB; ++ii) {
           const int dr = drow[ii] < 0 ? 0 : drow[ii];
@@ -258,7 +260,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_p8(GemmP p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * p.alpha;
           v[0] += bv[j].x, v[1] += bv[j].y, v[2] += bv[j].z, v[3] += bv[j].w;
-          if (ACT == ACT_GELU && !(dbg & 8)) {
+          if (ACT == ACT_GELU) {
             if (OUT == 1) {        // fp16 result: the transcendental-free polynomial, two elements per packed instruction
               const f32x2_g g0 = gelu_poly2((f32x2_g){v[0], v[1]}), g1 = gelu_poly2((f32x2_g){v[2], v[3]});
               v[0] = g0[0], v[1] = g0[1], v[2] = g1[0], v[3] = g1[1];
@@ -267,8 +269,8 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_p8(GemmP p) {
               for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r]);
             }
           }
-          if (p.res && !(dbg & 2)) v[0] += rv[ii][j].x, v[1] += rv[ii][j].y, v[2] += rv[ii][j].z, v[3] += rv[ii][j].w;
-          if (drow[ii] >= 0 && (!(dbg & 1) || v[0] == 1.2345e30f)) {
+          if (p.res) v[0] += rv[ii][j].x, v[1] += rv[ii][j].y, v[2] += rv[ii][j].z, v[3] += rv[ii][j].w;
+          if (drow[ii] >= 0) {
             if (OUT == 2) {        // x3 row: the 4 columns lie inside one 32-block (colbase + cj is a multiple of 4)
               h4 hi, lo;
 #pragma unroll
@@ -308,7 +310,6 @@ int gemm_f16_p8_launch(const GemmP& p, hipStream_t s) {
   if ((double)p.M * p.lda * 2.0 >= 4294967296.0 || (double)p.N * p.ldw * 2.0 >= 4294967296.0) return SAMPT_ERR_UNSUPPORTED;
   if (p.act != ACT_NONE && p.act != ACT_GELU) return SAMPT_ERR_UNSUPPORTED;
   GemmP q = p;
-  q.force_generic = getenv("SAMPT_P8_DBG") ? atoi(getenv("SAMPT_P8_DBG")) : 0;   // TEMP diagnostics
   const int nt_m = cdiv(p.M, 256), nt_n = p.N / 256;
   int R = 4;                      // strip height in row panels (2 / 8 measured: more L2 misses, profiles/r3_gemm_hbm_traffic_strip*)
   if (R > nt_m) R = nt_m;

@@ -77,3 +77,26 @@ def bench_clip(T: int = 24, seed: int = 72, n_pos: int = 8, n_objects: int = 1, 
         q[:, 2] += (-120.0 if m % 2 else 90.0) * scale * (m > 0)
         qs.append(q)
     return frames, torch.stack(qs)
+
+
+def bench_query_masks(T: int = 24, seed: int = 72, n_objects: int = 1, native: bool = False, square: int = 0) -> torch.Tensor:
+    """Query masks (M, H, W) float {0, 1} at t = 0 for the ``bench_clip`` workload — what a VOS run hands ``SamPt`` instead of
+    points (``video["query_masks"]`` + ``query_point_timestep``, sam_pt.py:171-177): object 0 is the moving disc, further
+    objects are discs on the background patches ``bench_clip`` puts their query points on."""
+    if square:
+        H = W = square
+        scale, r0 = square / 1024.0, 72.0 * square / 1024.0
+        cx, cy = W * 0.35, H * 0.5
+    else:
+        H, W = (480, 854) if native else (576, 1024)
+        scale = 854.0 / 1024.0 if native else 1.0
+        up = 1.0 if native else 1024.0 / 854.0
+        cx, cy, r0 = 854 * 0.35 * up, 480 * 0.5 * up, 60.0 * up
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    masks = []
+    for m in range(n_objects):
+        ox = 260.0 * scale * (m % 3) * (1 if m < 3 else -1)
+        oy = (-120.0 if m % 2 else 90.0) * scale * (m > 0)
+        r = r0 if m == 0 else 50.0 * scale
+        masks.append((((xx - cx - ox) ** 2 + (yy - cy - oy) ** 2) <= r * r).float())
+    return torch.stack(masks)
