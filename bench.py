@@ -393,12 +393,15 @@ def cached_parity(args, frames, qp, out):
     None if there is no such file.  Development runs only — the default run computes the oracle live (``cpu_reference``)."""
     if args.tracker != "pips" or args.hq or args.square or args.neg_points or args.native_480p or args.pips_vis_bias != 2.0:
         return None
-    from oracle.cache import cache_key, load
+    from oracle import workloads as W
+    from oracle.cache import load
     from oracle.parity import compare
-    tag = f"bench_{args.model}_T{args.frames}" if args.objects == 1 else None
-    if tag is None:
+    if args.objects != 1 or args.points != 8:
         return None
-    ref = load(cache_key(tag, frames, qp, sampt_kwargs(args), None, False))
+    w = W.bench_workload(args.model, args.frames)
+    if not (torch.equal(w["frames"], frames) and torch.equal(w["qp"], qp) and w["kw"] == sampt_kwargs(args)):
+        return None
+    ref = load(W.key_of(w))
     if ref is None:
         return None
     par = compare(out, ref)

@@ -382,6 +382,14 @@ int sampt_kmedoids_alternate(const float* xy_dev, int n, int K, int32_t* medoids
  * [B*S*S][2*heads*hd].  Same geometries as sampt_vit_attention_f16; heads*hd % 32 == 0. */
 int sampt_vit_attention_x3(const void* qkv_dev, const float* rel_h_dev, const float* rel_w_dev, void* out_dev, int B, int S,
                            int heads, int hd, sampt_stream_t stream);
+/* The windowed blocks as the encoder runs them (SAM's window_partition, App. A-3): qkv_dev holds frames x nwy x nwx windows of
+ * S x S tokens in window order; token (iy, ix) of window (wy, wx) is zero PADDING when wy*S + iy >= grid_h or wx*S + ix >=
+ * grid_w.  SAM pads after norm1, so a padded token's qkv is the bias alone: the kernels take its K / V from bias_row_dev (the
+ * qkv bias as ONE row in the matrix's format: 3*heads*hd halves for precision 1, an x3 row of twice that for precision 2) and
+ * never read the qkv rows of padded tokens (they may be uninitialised; the output rows of padded queries are meaningless). */
+int sampt_vit_window_attention(int precision, const void* qkv_dev, const float* rel_h_dev, const float* rel_w_dev, void* out_dev,
+                               int frames, int S, int heads, int hd, const void* bias_row_dev, int nwx, int nwy, int grid_h,
+                               int grid_w, sampt_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -14,7 +14,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from oracle import workloads as W  # noqa: E402
-from oracle.cache import cache_key, path_for  # noqa: E402
+from oracle.cache import path_for  # noqa: E402
 
 ALL = {"bench_vit_b_T8": lambda: W.bench_workload("vit_b", 8), "bench_vit_h_T24": lambda: W.bench_workload("vit_h", 24),
        **{name: (lambda n=name: W.config_workload(n)) for name in W.CONFIGS}}
@@ -23,7 +23,7 @@ if __name__ == "__main__":
     names = sys.argv[1:] or list(ALL)
     for name in names:
         w = ALL[name]()
-        key = cache_key(w["tag"], w["frames"], w["qp"], w["kw"], w["ids"], w["hq"])
+        key = W.key_of(w)
         if os.path.exists(path_for(key)):
             print(f"{name}: cached ({path_for(key)})", flush=True)
             continue

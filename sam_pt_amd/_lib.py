@@ -105,6 +105,7 @@ _SIGS = {
     "sampt_vit_attention_f16": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
     "sampt_vit_attention_x3": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "sampt_split_rows_x3": (c_int, [_P, _P, c_int, c_int, _P]),
+    "sampt_vit_window_attention": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P]),
     "sampt_kmedoids_rowsums_f64": (c_int, [_P, c_int, _P, _P]),
     "sampt_kmedoids_alternate": (c_int, [_P, c_int, c_int, _P, c_int, _P, _P]),
 }

@@ -126,7 +126,7 @@ __device__ half_t g_flash_pad[16] = {(half_t)1.f, (half_t)0.f, (half_t)0.f, (hal
 template <int HD, int NW, int SG>
 __global__ __launch_bounds__(NW * 64, 2) void k_flash_f16(const half_t* __restrict__ qkv, const float* __restrict__ rel_h,
                                                        const float* __restrict__ rel_w, half_t* __restrict__ out, int N,
-                                                       int heads, float scale) {
+                                                       int heads, float scale, FlashPad pad) {
   constexpr int KS = HD / 16;            // k-steps of QK^T
   constexpr int DT = (HD + 31) / 32;     // 32-row tiles of O^T
   constexpr int QT = NW * 32;
@@ -158,6 +158,16 @@ __global__ __launch_bounds__(NW * 64, 2) void k_flash_f16(const half_t* __restri
   constexpr int RPT = SG >= 64 ? 1 : 64 / SG, KTV = SG >= 64 ? 64 : RPT * SG;
   constexpr float LOG2E = 1.4426950408889634f;
   const float c2 = scale * LOG2E;
+  // Window padding (FlashPad, ops.h): token (iy, ix) of window (wy, wx) lies outside the token grid when wy*SG + iy >= gh or
+  // wx*SG + ix >= gw.  SAM zero-pads AFTER norm1, so such a token's qkv is the bias alone: its K / V chunks are fetched from the
+  // block's bias row instead of the qkv matrix (whose pad rows nobody has written), its query is taken as zero (the
+  // output rows of pad queries are never read: the proj GEMM gathers real tokens only).
+  const int pw = pad.bias_row ? b % pad.nwin : 0;
+  const int pwy = pw / max(pad.nwx, 1), py0 = pwy * SG, px0 = (pw - pwy * max(pad.nwx, 1)) * SG;
+  auto is_pad = [&](int t) {
+    const int iy = t / SG, ix = t - iy * SG;
+    return pad.bias_row != nullptr && (py0 + iy >= pad.gh || px0 + ix >= pad.gw);
+  };
   // DMA staging: wave w issues the K instructions i = w, w + NW, ... (CPR of them, 64 lanes x 16 B each: LDS bytes
   // [i * 1024, +1024) of the K buffer = slots (i*64 + lane) / CPR) and likewise the CPV V instructions
   auto dma_tile = [&](int kt0, int buf) {
@@ -165,7 +175,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_flash_f16(const half_t* __restri
     for (int i = wave; i < CPR; i += NW) {
       const int e = i * 64 + lane, slot = e / CPR, c = e - slot * CPR;
       const int krow = min(kt0 + min(slot, KTV - 1), N - 1);
-      const half_t* src = kbase + (long)krow * 3 * D + ((c ^ ((slot >> KSH) & KSWZ)) * 8);
+      const half_t* rowp = is_pad(krow) ? pad.bias_row + D + h * HD : kbase + (long)krow * 3 * D;
+      const half_t* src = rowp + ((c ^ ((slot >> KSH) & KSWZ)) * 8);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)((char*)&Ks[buf][0][0] + i * 1024), 16, 0, 0);
     }
@@ -173,7 +184,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_flash_f16(const half_t* __restri
       const int e = i * 64 + lane, slot = e / CPV, c = e - slot * CPV;
       const int vrow = min(kt0 + min(slot, KTV - 1), N - 1);
       const int cs = HD == 64 ? c ^ (((slot >> 1) & 1) << 2) : c;
-      const half_t* src = c < CPR ? kbase + D + (long)vrow * 3 * D + cs * 8 : g_flash_pad + (c - CPR) * 8;
+      const half_t* rowp = is_pad(vrow) ? pad.bias_row + 2 * D + h * HD : kbase + D + (long)vrow * 3 * D;
+      const half_t* src = c < CPR ? rowp + cs * 8 : g_flash_pad + (c - CPR) * 8;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)((char*)&Vs[buf][0][0] + i * 1024), 16, 0, 0);
     }
@@ -194,7 +206,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_flash_f16(const half_t* __restri
   h8 qf[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
-    if (q < N) qf[ks] = *(const h8*)(qkv + (tok0 + q) * 3 * D + h * HD + ks * 16 + hi * 8);
+    if (q < N && !is_pad(q)) qf[ks] = *(const h8*)(qkv + (tok0 + q) * 3 * D + h * HD + ks * 16 + hi * 8);
     else qf[ks] = (h8){0, 0, 0, 0, 0, 0, 0, 0};
   }
   __syncthreads();
@@ -391,12 +403,13 @@ __global__ __launch_bounds__(NW * 64, 2) void k_flash_f16(const half_t* __restri
 
 // rel_h / rel_w: the block's rel_pos tables, f32 [2S-1][hd]
 int vit_flash_attention_f16(const half_t* qkv, const float* relh, const float* relw, half_t* out, int B, int S,
-                            int heads, int hd, hipStream_t s) {
+                            int heads, int hd, hipStream_t s, FlashPad pad) {
+  if (pad.bias_row && (pad.nwx <= 0 || pad.nwin <= 0 || B % pad.nwin)) return SAMPT_ERR_ARG;
   const int N = S * S;
   const float scale = 1.0f / sqrtf((float)hd);
 #define FL(HDv, NWv, SGv)                                                                                     \
   hipLaunchKernelGGL((k_flash_f16<HDv, NWv, SGv>), dim3(cdiv(N, NWv * 32), heads, B), dim3(NWv * 64), 0, s, qkv, relh, \
-                     relw, out, N, heads, scale)
+                     relw, out, N, heads, scale, pad)
   if (S == 64 && hd == 80) FL(80, 4, 64);
   else if (S == 64 && hd == 64) FL(64, 4, 64);
   // (a 7-wave workgroup per (window, head) — 224 query slots for the 196 tokens instead of 2 x 128 — measured 4 % slower,

@@ -40,7 +40,7 @@ struct FlashX3Geom {
 template <int HD, int NW, int SG>
 __global__ __launch_bounds__(NW * 64, 1) void k_flash_x3(const half_t* __restrict__ qkv, const float* __restrict__ rel_h,
                                                          const float* __restrict__ rel_w, half_t* __restrict__ out, int N,
-                                                         int heads, float scale) {
+                                                         int heads, float scale, FlashPad pad) {
   typedef FlashX3Geom<HD, NW, SG> G;
   constexpr int KS = HD / 16;
   constexpr int DT = G::DT;
@@ -73,6 +73,13 @@ __global__ __launch_bounds__(NW * 64, 1) void k_flash_x3(const half_t* __restric
 
   // x3 position (halves) of logical column c0 + 8 * chunk of a qkv row: a 16-byte chunk never straddles a 32-block
   auto xcol = [](int c) -> int { return ((c >> 5) << 6) + (c & 31); };
+  // window padding: pad tokens' K / V come from the block's bias row (an x3 row here), pad queries are zero (see k_flash_f16)
+  const int pw = pad.bias_row ? b % pad.nwin : 0;
+  const int pwy = pw / max(pad.nwx, 1), py0 = pwy * SG, px0 = (pw - pwy * max(pad.nwx, 1)) * SG;
+  auto is_pad = [&](int t) {
+    const int iy = t / SG, ix = t - iy * SG;
+    return pad.bias_row != nullptr && (py0 + iy >= pad.gh || px0 + ix >= pad.gw);
+  };
   auto dma_tile = [&](int kt0, int buf) {
     const half_t* rbase = qkv + tok0 * ldq;
 #pragma unroll
@@ -80,7 +87,8 @@ __global__ __launch_bounds__(NW * 64, 1) void k_flash_x3(const half_t* __restric
       for (int i = wave; i < CPR; i += NW) {
         const int e = i * 64 + lane, slot = e / CPR, c = e - slot * CPR;
         const int krow = min(kt0 + min(slot, KTV - 1), N - 1);
-        const half_t* src = rbase + (long)krow * ldq + xcol(D + h * HD + ((c ^ ((slot >> KSH) & KSWZ)) * 8)) + pl * 32;
+        const half_t* rowp = is_pad(krow) ? pad.bias_row : rbase + (long)krow * ldq;
+        const half_t* src = rowp + xcol(D + h * HD + ((c ^ ((slot >> KSH) & KSWZ)) * 8)) + pl * 32;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(Kp(buf, pl) + i * 1024), 16, 0, 0);
       }
@@ -89,7 +97,8 @@ __global__ __launch_bounds__(NW * 64, 1) void k_flash_x3(const half_t* __restric
         const int vrow = min(kt0 + min(slot, KTV - 1), N - 1);
         const int cs = HD == 64 ? c ^ (((slot >> 1) & 1) << 2) : c;
         // pad channels: hi plane = the page whose first half is 1.0 (channel HD of V is all ones), lo plane = zeros
-        const half_t* src = c < CPR ? rbase + (long)vrow * ldq + xcol(2 * D + h * HD + cs * 8) + pl * 32
+        const half_t* rowp = is_pad(vrow) ? pad.bias_row : rbase + (long)vrow * ldq;
+        const half_t* src = c < CPR ? rowp + xcol(2 * D + h * HD + cs * 8) + pl * 32
                                     : g_flash_pad_x3 + (pl == 0 ? (c - CPR) * 8 : 8);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(Vp(buf, pl) + i * 1024), 16, 0, 0);
@@ -102,7 +111,7 @@ __global__ __launch_bounds__(NW * 64, 1) void k_flash_x3(const half_t* __restric
   h8 qh[KS], qlo[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
-    if (q < N) {
+    if (q < N && !is_pad(q)) {
       const half_t* qp = qkv + (tok0 + q) * ldq + xcol(h * HD + ks * 16 + hi * 8);
       qh[ks] = *(const h8*)qp;
       qlo[ks] = *(const h8*)(qp + 32);
@@ -326,7 +335,8 @@ __global__ __launch_bounds__(NW * 64, 1) void k_flash_x3(const half_t* __restric
 
 // qkv / out: x3 rows (see the file header); rel_h / rel_w: the block's rel_pos tables, f32 [2S-1][hd]
 int vit_flash_attention_x3(const half_t* qkv, const float* relh, const float* relw, half_t* out, int B, int S, int heads,
-                           int hd, hipStream_t s) {
+                           int hd, hipStream_t s, FlashPad pad) {
+  if (pad.bias_row && (pad.nwx <= 0 || pad.nwin <= 0 || B % pad.nwin)) return SAMPT_ERR_ARG;
   const int N = S * S;
   const float scale = 1.0f / sqrtf((float)hd);
   if ((heads * hd) % 32) return SAMPT_ERR_UNSUPPORTED;
@@ -341,7 +351,7 @@ int vit_flash_attention_x3(const half_t* qkv, const float* relh, const float* re
       raised = true;                                                                                                    \
     }                                                                                                                   \
     hipLaunchKernelGGL((k_flash_x3<HDv, NWv, SGv>), dim3(cdiv(N, NWv * 32), heads, B), dim3(NWv * 64), G::LDS, s, qkv,  \
-                       relh, relw, out, N, heads, scale);                                                               \
+                       relh, relw, out, N, heads, scale, pad);                                                               \
   } while (0)
   if (S == 64 && hd == 80) FLX(80, 4, 64);
   else if (S == 64 && hd == 64) FLX(64, 4, 64);

@@ -158,12 +158,20 @@ int sampt_pips_track_f32(sampt_pips_t h, const float* const pyr[4], int H0, int 
   for (int i = 0; i < n; ++i)
     if (!(q_host[i * 3] >= 0.f && q_host[i * 3] <= (float)(T - 1)))
       return fail(SAMPT_ERR_ARG, "sampt_pips_track_f32: query frame outside the clip");
+  // The pinned termination flags and their events belong to the handle: ONE track call at a time per handle (callers that want
+  // concurrent clips create one tracker handle per stream).  Created on first use, all or nothing.
   if (!h->flag) {
-    if (hipHostMalloc((void**)&h->flag, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess)
-      return fail(SAMPT_ERR_HIP, "sampt_pips_track_f32: hipHostMalloc failed");
-    for (auto& ev : h->flag_ev)
-      if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess)
-        return fail(SAMPT_ERR_HIP, "sampt_pips_track_f32: hipEventCreate failed");
+    int* flag = nullptr;
+    hipEvent_t evs[2] = {nullptr, nullptr};
+    bool okay = hipHostMalloc((void**)&flag, 2 * sizeof(int), hipHostMallocDefault) == hipSuccess;
+    for (int i = 0; okay && i < 2; ++i) okay = hipEventCreateWithFlags(&evs[i], hipEventDisableTiming) == hipSuccess;
+    if (!okay) {
+      for (hipEvent_t e : evs)
+        if (e) (void)hipEventDestroy(e);
+      if (flag) (void)hipHostFree(flag);
+      return fail(SAMPT_ERR_HIP, "sampt_pips_track_f32: could not create the pinned flag / events");
+    }
+    h->flag = flag, h->flag_ev[0] = evs[0], h->flag_ev[1] = evs[1];
   }
   h->flag[0] = h->flag[1] = -1;
   Arena a(ws, ws_bytes);
@@ -682,6 +690,21 @@ int sampt_vit_attention_x3(const void* qkv, const float* rel_h, const float* rel
                            int hd, sampt_stream_t stream) {
   if (!qkv || !rel_h || !rel_w || !out) return fail(SAMPT_ERR_ARG, "sampt_vit_attention_x3: bad arguments");
   return vit_flash_attention_x3((const half_t*)qkv, rel_h, rel_w, (half_t*)out, B, S, heads, hd, (hipStream_t)stream);
+}
+
+int sampt_vit_window_attention(int precision, const void* qkv, const float* rel_h, const float* rel_w, void* out, int frames,
+                               int S, int heads, int hd, const void* bias_row, int nwx, int nwy, int grid_h, int grid_w,
+                               sampt_stream_t stream) {
+  if (!qkv || !rel_h || !rel_w || !out || !bias_row || frames <= 0 || nwx <= 0 || nwy <= 0)
+    return fail(SAMPT_ERR_ARG, "sampt_vit_window_attention: bad arguments");
+  FlashPad fp;
+  fp.bias_row = (const half_t*)bias_row, fp.nwx = nwx, fp.nwin = nwx * nwy, fp.gh = grid_h, fp.gw = grid_w;
+  const int B = frames * nwx * nwy;
+  if (precision == 1)
+    return vit_flash_attention_f16((const half_t*)qkv, rel_h, rel_w, (half_t*)out, B, S, heads, hd, (hipStream_t)stream, fp);
+  if (precision == 2)
+    return vit_flash_attention_x3((const half_t*)qkv, rel_h, rel_w, (half_t*)out, B, S, heads, hd, (hipStream_t)stream, fp);
+  return fail(SAMPT_ERR_ARG, "sampt_vit_window_attention: precision must be 1 (fp16) or 2 (x3 rows)");
 }
 
 int sampt_attention_f32(int kind, const float* q, const float* k, const float* v, float* out, int F, int Nq, int Nk,

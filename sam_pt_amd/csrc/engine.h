@@ -147,6 +147,7 @@ struct VitEngine {
   struct Blk {
     const float *ln1w, *ln1b, *ln2w, *ln2b, *qkv_b, *proj_b, *b1, *b2, *rel_h, *rel_w;
     const void *qkv_w, *proj_w, *w1, *w2;  // f16 or f32 depending on c.f16
+    const half_t* qkv_b16 = nullptr;       // 16-bit modes: the qkv bias as one row of the qkv matrix's format (fp16 / x3 row)
   };
   std::vector<Blk> blk;
   const void *patch_w, *neck0_w, *neck2_w;

@@ -31,6 +31,7 @@ int VitEngine::init(const WeightMap& w, const VitConfig& cfg, int wrb) {
     b.ln1w = w.f(p + ".norm1.weight"), b.ln1b = w.f(p + ".norm1.bias");
     b.ln2w = w.f(p + ".norm2.weight"), b.ln2b = w.f(p + ".norm2.bias");
     b.qkv_w = w.get(p + ".attn.qkv.weight" + sfx), b.qkv_b = w.f(p + ".attn.qkv.bias");
+    if (c.f16) b.qkv_b16 = w.h(p + ".attn.qkv.bias" + sfx);
     b.proj_w = w.get(p + ".attn.proj.weight" + sfx), b.proj_b = w.f(p + ".attn.proj.bias");
     b.rel_h = w.f(p + ".attn.rel_pos_h"), b.rel_w = w.f(p + ".attn.rel_pos_w");
     b.w1 = w.get(p + ".mlp.lin1.weight" + sfx), b.b1 = w.f(p + ".mlp.lin1.bias");
@@ -217,11 +218,18 @@ int VitEngine::encode(const uint8_t* frames, int chw, int B, int H, int W, float
     // real tokens go through the GEMM, the padded rows' qkv is the bias alone
     SAMPT_TRY(layernorm_rows(x, b.ln1w, b.ln1b, xn, Mg, D, 1e-6f, nullptr, c.f16, ACT_NONE, s));
     SAMPT_TRY(gm.run(xn, (int)Mg, D, b.qkv_w, b.qkv_b, qkv, 3 * D, ACT_NONE, act_out, nullptr, 0, inv, 0));
-    if (!glob) SAMPT_TRY(fill_rows_bias(qkv, c.f16, win_pad, (int)(M - Mg), b.qkv_b, 3 * D, s));
+    // the 16-bit attention kernels take the padded tokens' K / V from the bias row themselves (FlashPad); only the exact mode's
+    // materialised path needs the padded qkv rows written
+    FlashPad fp;
+    if (!glob && c.f16) {
+      fp.bias_row = b.qkv_b16, fp.nwx = nw1, fp.nwin = compact ? nwin_l : nwin, fp.gh = compact ? lh : g, fp.gw = g;
+    } else if (!glob) {
+      SAMPT_TRY(fill_rows_bias(qkv, 0, win_pad, (int)(M - Mg), b.qkv_b, 3 * D, s));
+    }
     if (c.f16 == 1) {
-      SAMPT_TRY(vit_flash_attention_f16((const half_t*)qkv, b.rel_h, b.rel_w, (half_t*)att, Bw, S, c.heads, hd, s));
+      SAMPT_TRY(vit_flash_attention_f16((const half_t*)qkv, b.rel_h, b.rel_w, (half_t*)att, Bw, S, c.heads, hd, s, fp));
     } else if (c.f16 == 2) {
-      SAMPT_TRY(vit_flash_attention_x3((const half_t*)qkv, b.rel_h, b.rel_w, (half_t*)att, Bw, S, c.heads, hd, s));
+      SAMPT_TRY(vit_flash_attention_x3((const half_t*)qkv, b.rel_h, b.rel_w, (half_t*)att, Bw, S, c.heads, hd, s, fp));
     } else {
       SAMPT_TRY(vit_rel_bias(qkv, 0, b.rel_h, b.rel_w, Bw, S, c.heads, hd, relh, relw, s));
       const float* q = (const float*)qkv;

@@ -42,6 +42,12 @@
 // of two 8-byte ones, 16 rows x 64 contiguous bytes per instruction.  Isolated and in steady state the fp16-output launches
 // gained 4 - 6 % (qkv 928 -> 982, fc1 870 -> 906 TFLOP/s; the stores are 13 % of a qkv launch), but inside the encoder the very
 // same build lost 2 % twice in an A / B of one call (in situ 885 -> 867 TFLOP/s, 113.3 -> 110.3 fps), so the plain mapping stays.
+// Where the epilogue time of the f32 + residual launches goes (proj, M = 32768, steady state, profiles/r4_c3_p8_diag.log): 146.6
+// us as shipped, 121.8 without the stores, 129.8 without the residual loads, 97.4 without both, 92.8 without any epilogue.  vmcnt
+// retires loads and stores in issue order, so the wait for residual batch b + 1 also waits for the stores of batch b to be
+// acknowledged, and the 64 MB all CUs write at the end of a round of tiles drain at memory bandwidth while only 1.75 K-tiles
+// of the next tile are prefetched.  A two-pass epilogue (all residual loads folded into the accumulators in place, then all
+// stores) removes those waits on paper but costs ~100 spilled VGPRs (the kernel sits at 250 of 256): not shipped.
 //
 // GemmP::x3 (template X3): the operands are "x3 rows" (common.h: every 64-half K-tile row is [hi(32) | lo(32)] of 32 real k)
 // and a phase issues 24 MFMAs instead of 16 — hi.hi + hi.lo + lo.hi per fragment pair, fp32-grade products at a third of

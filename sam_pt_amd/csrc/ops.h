@@ -53,15 +53,24 @@ int vit_rel_bias(const void* qkv, int qkv_f16, const float* rel_h, const float* 
                  int hd, float* relh, float* relw, hipStream_t s);
 // scores[bh][q][k] (already scaled) += relh[bh][q][k/S] + relw[bh][q][k%S]; softmax over k, in place (f32).
 int softmax_rel_rows(float* scores, const float* relh, const float* relw, long BH, int Nq, int S, hipStream_t s);
+// Window padding of SAM's window_partition inside the attention kernels: the B launches of S x S tokens are frames x nwin
+// windows, window w % nwin = (wy, wx) in row-major order over nwx windows per row; token (iy, ix) of it is PADDING when
+// wy*S + iy >= gh or wx*S + ix >= gw.  Padded tokens enter attention as keys with qkv = bias (zero padding comes after norm1,
+// App. A-3): the kernels fetch their K / V from ``bias_row`` (the qkv bias as one row in the qkv matrix's own format: 3D halves,
+// or an x3 row of 6D halves) and never read the qkv rows of padded tokens.  bias_row == nullptr: no padding anywhere.
+struct FlashPad {
+  const half_t* bias_row = nullptr;
+  int nwx = 0, nwin = 0, gh = 0, gw = 0;
+};
 // Fused flash-style attention, f16 operands, fp32 softmax/accumulate.  qkv f16 [B*S*S][3*D]; out f16 [B*S*S][D];
 // rel_h / rel_w: rel_pos tables f32 [2S-1][hd] (the decomposed bias is computed inside the kernel).
 int vit_flash_attention_f16(const half_t* qkv, const float* rel_h, const float* rel_w, half_t* out, int B, int S,
-                            int heads, int hd, hipStream_t s);
+                            int heads, int hd, hipStream_t s, FlashPad pad = FlashPad());
 
 // attention_x3.hip: the same attention at fp32 grade (3-term split-fp16 products).  qkv: x3 rows [B*S*S][2*3D] halves (common.h
 // GemmP::x3), out: x3 rows [B*S*S][2*D]
 int vit_flash_attention_x3(const half_t* qkv, const float* rel_h, const float* rel_w, half_t* out, int B, int S, int heads,
-                           int hd, hipStream_t s);
+                           int hd, hipStream_t s, FlashPad pad = FlashPad());
 
 // ---- kmedoids.hip (query-point selection, sam_pt/utils/query_points.py:62-99; bit-identical to query_points.kmedoids_alternate)
 // xy: device [n][2] f32 pixel coordinates (integers), n <= 2048.  rowsums: out[i] = sum_j dist(i, j) (fp64, numpy's pairwise order)

@@ -225,6 +225,11 @@ def pack_vit(sd: Dict[str, torch.Tensor], cfg: SamConfig, device, f16, win_batch
                 out[k + "_hl"] = split_f16x3(w)
             else:
                 out[k] = w
+        elif f16 and k.endswith(".attn.qkv.bias"):
+            # the 16-bit attention kernels read the qkv of SAM's zero-padded window tokens (= the bias) from ONE row in the qkv
+            # matrix's own format instead of from filled-in rows (csrc/ops.h FlashPad)
+            out[k] = v.contiguous()
+            out[k + (".x3" if mode == 2 else ".f16")] = x3_rows(v.view(1, -1)).view(-1) if mode == 2 else v.half().contiguous()
         elif k in gemm_keys:
             w = v.reshape(v.shape[0], -1).contiguous()
             if mode == 2:

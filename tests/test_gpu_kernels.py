@@ -562,3 +562,45 @@ def test_kmedoids_device_equals_host_restatement(lib, dev):
         torch.manual_seed(100 + case)
         b = Q.extract_kmedoid_points(mt, K, device=dev)
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("precision,S_,heads,hd,nwx,nwy,gh,gw", [(1, 14, 2, 80, 3, 2, 22, 36), (2, 14, 2, 80, 3, 2, 22, 36),
+                                                                   (1, 6, 2, 32, 3, 3, 16, 16), (2, 6, 2, 32, 3, 3, 16, 16),
+                                                                   (1, 14, 2, 64, 5, 3, 42, 64)])
+def test_vit_window_attention_padding_from_bias_row(lib, dev, precision, S_, heads, hd, nwx, nwy, gh, gw):
+    """Windowed blocks with SAM's zero padding (App. A-3: pad after norm1 -> a padded token's qkv is the bias): the kernels fetch
+    padded keys / values from the bias row and never touch the padded rows of the qkv matrix (filled with NaN here) — same result
+    as attention over a matrix whose padded rows hold the bias, on every real token."""
+    from sam_pt_amd.pack import x3_rows, x3_unrows
+    g = torch.Generator().manual_seed(S_ * hd + nwx)
+    frames, N, D = 2, S_ * S_, heads * hd
+    B = frames * nwx * nwy
+    qkv = torch.randn(B * N, 3 * D, generator=g) * 1.2
+    bias = torch.randn(3 * D, generator=g)
+    rel_h = torch.randn(2 * S_ - 1, hd, generator=g) * 0.3
+    rel_w = torch.randn(2 * S_ - 1, hd, generator=g) * 0.3
+    w = torch.arange(B) % (nwx * nwy)
+    iy, ix = torch.arange(N) // S_, torch.arange(N) % S_
+    pad = (((w // nwx) * S_)[:, None] + iy[None] >= gh) | (((w % nwx) * S_)[:, None] + ix[None] >= gw)      # (B, N)
+    assert bool(pad.any()) and not bool(pad.all())
+    if precision == 1:
+        qkv, bias = qkv.half().float(), bias.half().float()
+    filled = torch.where(pad.reshape(-1, 1), bias[None], qkv)
+    ref = _ref_vit_attention(filled, rel_h, rel_w, B, S_, heads, hd)
+    poisoned = torch.where(pad.reshape(-1, 1), torch.full_like(qkv, float("nan")), qkv)
+    if precision == 1:
+        qd, bd = poisoned.half().to(dev), bias.half().to(dev)
+        out = torch.empty(B * N, D, device=dev, dtype=torch.float16)
+    else:
+        qd = x3_rows(torch.nan_to_num(poisoned, nan=0.0))
+        qd[pad.reshape(-1)] = float("nan")
+        qd, bd = qd.to(dev), x3_rows(bias[None]).view(-1).to(dev)
+        out = torch.empty(B * N, 2 * D, device=dev, dtype=torch.float16)
+    hd_, wd_ = rel_h.to(dev), rel_w.to(dev)
+    ok(lib.sampt_vit_window_attention(precision, P(qd), P(hd_), P(wd_), P(out), frames, S_, heads, hd, P(bd), nwx, nwy, gh, gw,
+                                      S()), "window attention")
+    got = out.float().cpu() if precision == 1 else x3_unrows(out.cpu())
+    real = ~pad.reshape(-1)
+    assert bool(torch.isfinite(got[real]).all())
+    tol = 6e-3 if precision == 1 else 1e-5
+    assert max_abs(got[real], ref[real]) < tol * float(ref.abs().max())
