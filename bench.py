@@ -381,9 +381,13 @@ def cpu_reference(args, frames, qp, out):
                      f"predict_torch calls {sec['decoder'] / len(ids):.2f}s per frame, extrapolated to {T} frames"}
     par = compare(out, ref)
     par["precision"] = args.precision
-    par["bar"] = "mask IoU >= 1 - 1e-3 per frame; trajectories identical after round(); visibilities identical"
-    par["pass"] = bool(par["mask_iou_min"] >= 1 - 1e-3 and par["traj_index_identical"] and par["vis_identical"]
-                       and par["rejections_identical"])
+    # PIPS: strict index identity.  CoTracker chains many windows: coordinates the oracle itself puts within 2e-3 px of an x.5
+    # rounding boundary are not counted (oracle/parity.py: traj_index_identical_off_boundary; both figures are in the block)
+    strict = args.tracker != "cotracker"
+    par["bar"] = ("mask IoU >= 1 - 1e-3 per frame; trajectories identical after round()"
+                  + ("" if strict else " (coordinates within 2e-3 px of a rounding boundary in the oracle excepted)") + "; visibilities identical")
+    par["pass"] = bool(par["mask_iou_min"] >= 1 - 1e-3 and par["traj_index_identical" if strict else "traj_index_identical_off_boundary"]
+                       and par["vis_identical"] and par["rejections_identical"])
     return cpu, par
 
 

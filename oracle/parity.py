@@ -78,6 +78,9 @@ def mask_iou(a: torch.Tensor, b: torch.Tensor) -> float:
     return 1.0 if u == 0 else (a & b).sum().item() / u
 
 
+BOUNDARY_PX = 2e-3        # half-width of the band around x.5 in which round() of the oracle's own coordinate is not meaningful
+
+
 def compare(out: Dict, ref: Dict) -> Dict:
     """out: SamPt.forward result of the device path (logits list[M] of (T or len(frame_ids), H, W); trajectories,
     visibilities for the whole clip).  ref: ``reference_run`` result.  Logits are matched on ref["frame_ids"]: if ``out``
@@ -85,7 +88,14 @@ def compare(out: Dict, ref: Dict) -> Dict:
     ids = ref["frame_ids"]
     tr_o, vi_o = out["trajectories"].cpu(), out["visibilities"].cpu()
     tr_r, vi_r = ref["trajectories"], ref["visibilities"]
-    res = {"traj_index_identical": bool((tr_o.round() == tr_r.round()).all()),
+    # "identical in index space" = equal after round().  A coordinate that sits within ``BOUNDARY_PX`` of a rounding boundary
+    # (x.5) in the oracle is ambiguous for ANY implementation that is not bit-identical to it; those are counted apart:
+    # ``traj_index_identical`` is the strict statement, ``traj_index_identical_off_boundary`` ignores the ambiguous ones.
+    differs = tr_o.round() != tr_r.round()
+    near = ((tr_r - tr_r.floor()) - 0.5).abs() < BOUNDARY_PX
+    res = {"traj_index_identical": not bool(differs.any()),
+           "traj_index_identical_off_boundary": not bool((differs & ~near).any()),
+           "traj_index_differing": int(differs.sum()), "traj_coords_near_boundary": int(near.sum()),
            "vis_identical": bool((vi_o == vi_r).all()),
            "traj_max_abs_px": float((tr_o - tr_r).abs().max())}
     ious, finite_ok, max_logit_err = [], True, 0.0

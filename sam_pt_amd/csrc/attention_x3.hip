@@ -13,8 +13,7 @@
 //   * O^T = V^T.P^T       P = exp2(.) split in registers (ph = fp16(p), pl = fp16(p - ph)), V hi / lo planes in LDS
 // Softmax statistics, rescaling and the bias are fp32 exactly as in the fp16 kernel (log2 domain, v_exp_f32).  Structure,
 // key-tile geometry, LDS-DMA staging with source-side swizzles and the transposing V reads are those of k_flash_f16 — see
-// the comments there; this file only notes what differs.  LDS: 2 buffers x 2 planes x (K 64 x HD + V 64 x VP) halves + two
-// fp32 bias tables: 153 KiB for HD = 80 / 64 x 64 tokens, so one 4-wave workgroup per CU (dynamic LDS, raised limit).
+// the comments there; this file only notes what differs (one K / V tile buffer instead of two: see FlashX3Geom).
 #include "ops.h"
 
 namespace sampt {
@@ -25,6 +24,11 @@ __device__ half_t g_flash_pad_x3[16] = {(half_t)1.f, (half_t)0.f, (half_t)0.f, (
                                         (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f,
                                         (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
 
+// LDS budget.  With hi and lo planes a double-buffered K / V tile pair plus two fp32 bias tables is 153 KiB for 64 x 64 tokens /
+// head dim 80: ONE 4-wave workgroup per CU, one wave per SIMD.  Measured (profiles/r4_c6_attn_x3_nbuf*.log) that loses to ONE
+// tile buffer with the rel_w table — dead once its values sit in registers — aliased onto it: 77 KiB, TWO workgroups per CU, each
+// exposing its DMA latency once per tile while the other one multiplies (global 3779 -> 2806 us, windowed 717 -> 510 us per
+// 8 frames, 50.6 -> 56.0 fps end to end in the same call).  The double-buffered variant is gone.
 template <int HD, int NW, int SG>
 struct FlashX3Geom {
   static constexpr int DT = (HD + 31) / 32;
@@ -34,11 +38,12 @@ struct FlashX3Geom {
   static constexpr int K_PLANE = 64 * HD * 2, V_PLANE = 64 * VP * 2;           // bytes
   static constexpr int BUF = 2 * K_PLANE + 2 * V_PLANE;                        // one buffer: K hi | K lo | V hi | V lo
   static constexpr int REL = SG * RLD * 4;
-  static constexpr int LDS = 2 * BUF + 2 * REL;
+  static constexpr int TILES = BUF > REL ? BUF : REL;          // the tile buffer, which first holds the rel_w table
+  static constexpr int LDS = TILES + REL;
 };
 
 template <int HD, int NW, int SG>
-__global__ __launch_bounds__(NW * 64, 1) void k_flash_x3(const half_t* __restrict__ qkv, const float* __restrict__ rel_h,
+__global__ __launch_bounds__(NW * 64, 2) void k_flash_x3(const half_t* __restrict__ qkv, const float* __restrict__ rel_h,
                                                          const float* __restrict__ rel_w, half_t* __restrict__ out, int N,
                                                          int heads, float scale, FlashPad pad) {
   typedef FlashX3Geom<HD, NW, SG> G;
@@ -55,8 +60,8 @@ __global__ __launch_bounds__(NW * 64, 1) void k_flash_x3(const half_t* __restric
   // plane p (0 = hi, 1 = lo) of buffer b
   auto Kp = [&](int b, int p) -> char* { return smem + b * G::BUF + p * G::K_PLANE; };
   auto Vp = [&](int b, int p) -> char* { return smem + b * G::BUF + 2 * G::K_PLANE + p * G::V_PLANE; };
-  float* relh_s = (float*)(smem + 2 * G::BUF);          // [SG][RLD]
-  float* relw_s = relh_s + SG * RLD;
+  float* relh_s = (float*)(smem + G::TILES);            // [SG][RLD]
+  float* relw_s = (float*)smem;                         // lives in the (not yet used) tile buffer
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, hi = lane >> 5;
@@ -105,9 +110,9 @@ __global__ __launch_bounds__(NW * 64, 1) void k_flash_x3(const half_t* __restric
       }
     }
   };
-  dma_tile(0, 0);
+  // (tile 0 is requested only after the prologue: until then the buffer holds the rel_w table)
 
-  for (int i = tid; i < 2 * SG * RLD; i += NT) relh_s[i] = 0.f;
+  for (int i = tid; i < SG * RLD; i += NT) relh_s[i] = 0.f, relw_s[i] = 0.f;
   h8 qh[KS], qlo[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
@@ -189,11 +194,12 @@ __global__ __launch_bounds__(NW * 64, 1) void k_flash_x3(const half_t* __restric
     for (int dt = 0; dt < DT; ++dt)
       vl[dt] = (4 * hi + r4) * VP * 2 + ((dt * 64 + g16 * 32 + cc * 8) ^ (HD == 64 ? ((r4 >> 1) & 1) << 6 : 0));
   }
+  __syncthreads();                        // every wave has its rel_w values in registers: the buffer is free for tile 0
+  dma_tile(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int kt0 = 0, kh0 = 0, it = 0; kt0 < N; kt0 += KTV, kh0 += RPT, ++it) {
-    const int buf = it & 1;
-    if (kt0 + KTV < N) dma_tile(kt0 + KTV, buf ^ 1);
+    constexpr int buf = 0;
 
     // ---- S^T = K . Q^T, three products per k-step
     f32x16 st[2];
@@ -299,6 +305,10 @@ __global__ __launch_bounds__(NW * 64, 1) void k_flash_x3(const half_t* __restric
         o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[0], pbh[t], o[dt], 0, 0, 0);
       }
     }
+    if (kt0 + KTV < N) {
+      __syncthreads();                    // everyone is done reading the only buffer
+      dma_tile(kt0 + KTV, 0);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
@@ -351,7 +361,7 @@ int vit_flash_attention_x3(const half_t* qkv, const float* relh, const float* re
       raised = true;                                                                                                    \
     }                                                                                                                   \
     hipLaunchKernelGGL((k_flash_x3<HDv, NWv, SGv>), dim3(cdiv(N, NWv * 32), heads, B), dim3(NWv * 64), G::LDS, s, qkv,  \
-                       relh, relw, out, N, heads, scale, pad);                                                               \
+                       relh, relw, out, N, heads, scale, pad);                                                          \
   } while (0)
   if (S == 64 && hd == 80) FLX(80, 4, 64);
   else if (S == 64 && hd == 64) FLX(64, 4, 64);

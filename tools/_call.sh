@@ -1,9 +1,11 @@
 # scratch script of the current gpurun call (overwritten per call; the logs it leaves are copied to profiles/r4_*)
 set -u
-R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/r4_c5; mkdir -p $OUT; cd $R
-timeout 300 python -m pytest tests/test_gpu_kernels.py -q -m gpu -k "flash or window_attention or gemm" > $OUT/pytest_kernels.log 2>&1; tail -3 $OUT/pytest_kernels.log
-timeout 600 python -m pytest tests/test_gpu_modules.py -q -m gpu -k "vit_ or dead_row or hq_" > $OUT/pytest_vit.log 2>&1; tail -3 $OUT/pytest_vit.log
-timeout 900 python -m pytest tests/test_gpu_bench_parity.py -q -m gpu -s > $OUT/pytest_parity.log 2>&1; grep "parity\]\|passed\|failed" $OUT/pytest_parity.log | cut -c1-420
-timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary > $OUT/bench_f16.log 2>&1; tail -1 $OUT/bench_f16.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print(d['value'], d['value_per_forward'], 'insitu', r['achieved'], 'iso', r['isolated_achieved'], d.get('parity'))"
-timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-roofline --precision f16x3 > $OUT/bench_x3.log 2>&1; tail -1 $OUT/bench_x3.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['value_per_forward'], d.get('parity'))"
-timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-roofline --hq --tracker cotracker --square 1024 --points 16 --objects 5 --frames 64 --emulate-ranks 8 > $OUT/bench_cfg5_emulate.log 2>&1; tail -1 $OUT/bench_cfg5_emulate.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); m=d['frame_sharding_model']; print(d['value'], m['one_gpu_ms_per_clip'], {k:(v['predicted_ms_per_clip'], v['predicted_speedup']) for k,v in m['by_world'].items()}, m['by_world']['8']['ranks'][0], m['by_world']['8']['ranks'][7])"
+R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/r4_c6; mkdir -p $OUT; cd $R
+for nb in 1 2; do
+  SAMPT_X3_NBUF=$nb timeout 300 python -m pytest tests/test_gpu_kernels.py -q -m gpu -k "flash_attention_x3 or window_attention" > $OUT/pytest_x3_nbuf$nb.log 2>&1; tail -2 $OUT/pytest_x3_nbuf$nb.log
+  SAMPT_X3_NBUF=$nb timeout 100 python tools/attn_bench.py x3 > $OUT/attn_x3_nbuf$nb.log 2>&1; tail -2 $OUT/attn_x3_nbuf$nb.log
+done
+for nb in 1 2 1 2; do
+  SAMPT_X3_NBUF=$nb timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-roofline --precision f16x3 > $OUT/bench_x3_nbuf$nb.log 2>&1; tail -1 $OUT/bench_x3_nbuf$nb.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('nbuf $nb', d['value'], d['value_per_forward'], d['parity']['mask_iou_min'], d['parity']['pass'])"
+done
+timeout 600 python -m pytest tests/test_gpu_bench_parity.py -q -m gpu -s -k "cfg5" > $OUT/pytest_cfg5.log 2>&1; grep "parity\]\|passed\|failed" $OUT/pytest_cfg5.log | cut -c1-600
