@@ -78,6 +78,10 @@ def parse():
                     help="bias of the random PIPS visibility head (weights.py default 2.0 -> sigmoid 0.88, just under the 0.9 "
                          "link threshold: short hops, ~23 tracker rounds per clip; 4.0 behaves like a trained model on "
                          "trackable points: 7-frame hops).  Sensitivity knob only; the headline number uses the default.")
+    ap.add_argument("--cotracker-delta-scale", type=float, default=None,
+                    help="scale of the random CoTracker flow head (weights.init_cotracker_state_dict; default 0.003).  Over the 15 "
+                         "chained windows of a 64-frame clip the default makes the ORACLE ITSELF move by 0.4 px under a 1e-7 weight "
+                         "perturbation (DESIGN.md section 2): long-clip parity lines use 0.001")
     ap.add_argument("--fnet-exact", action="store_true",
                     help="tracker encoder convolutions as exact fp32 MFMAs instead of the 3-term split-fp16 MFMAs")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (cpu_baseline + parity)")
@@ -107,7 +111,9 @@ def build_model(args, dev):
         tracker = PipsPointTracker(state_dict=init_pips_state_dict(72, vis_bias=args.pips_vis_bias), fnet_chunk=8)
     elif args.tracker == "cotracker":
         from sam_pt_amd.point_tracker import CoTrackerPointTracker
-        tracker = CoTrackerPointTracker(seed=72, fnet_chunk=8)            # configs/model/point_tracker/cotracker.yaml
+        from sam_pt_amd.weights import init_cotracker_state_dict
+        ckw = {} if args.cotracker_delta_scale is None else {"delta_scale": args.cotracker_delta_scale}
+        tracker = CoTrackerPointTracker(state_dict=init_cotracker_state_dict(72, **ckw), fnet_chunk=8)   # configs/model/point_tracker/cotracker.yaml
     else:
         from sam_pt_amd.point_tracker import PipsPlusPlusPointTracker
         tracker = PipsPlusPlusPointTracker(seed=72, fnet_chunk=8)
@@ -366,7 +372,7 @@ def cpu_reference(args, frames, qp, out):
     else:
         from oracle.cotracker_ref import CoTrackerTrackerRef
         from sam_pt_amd.weights import init_cotracker_state_dict
-        csd = init_cotracker_state_dict(72)
+        csd = init_cotracker_state_dict(72, **({} if args.cotracker_delta_scale is None else {"delta_scale": args.cotracker_delta_scale}))
         factory = lambda: CoTrackerTrackerRef(csd)
     ref = reference_run(cfg, sd, psd, frames.cpu(), qp, sampt_kwargs(args), frame_ids=ids, hq=args.hq,
                         reference_cost=True, threads=cores, tracker_factory=factory)
