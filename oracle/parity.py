@@ -1,8 +1,11 @@
 """Parity checker shared by the GPU tests, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg.
 TEST INFRASTRUCTURE ONLY — nothing under ``sam_pt_amd/`` imports this file.
 
-``reference_run`` drives the reference protocol on the CPU: the ``SamPt`` host logic (pinned bit-identical to the
-reference ``SamPt`` on ``tests/golden/sampt_ref.npz``) over the oracle tracker (``oracle/pips_ref.py``, pinned on the
+``reference_run`` drives the reference protocol on the CPU: where ``/root/reference`` exists (the build container) the
+REFERENCE'S OWN ``SamPt`` class, imported in place (``oracle/reference_loader.load_sam_pt``) — so a regression in this package's
+call-by-call branch cannot move both sides of a comparison; elsewhere (the GPU box) this package's ``SamPt`` host logic, pinned
+bit-identical to the reference's on ``tests/golden/sampt_ref.npz`` (``test_reference_run_drivers_agree`` checks that the two
+drivers give the same result) — over the oracle tracker (``oracle/pips_ref.py``, pinned on the
 reference's own PIPS) and the oracle predictor (``oracle/sam_ref.py``, pinned on HF transformers) call by call —
 ``set_image`` per frame, 1-2 + R ``predict_torch`` per (frame, object) — i.e. sam_pt/modeling/sam_pt.py:545-576 and
 :694-866 (``predict_mask`` :760-837, the frame loop :848-858).  The SAM stage may be restricted to a subset of frames
@@ -22,12 +25,13 @@ import torch
 
 def reference_run(cfg, sd, psd, frames: torch.Tensor, query_points: torch.Tensor, sampt_kwargs: dict,
                   frame_ids: Optional[Sequence[int]] = None, hq: bool = False, reference_cost: bool = False,
-                  threads: Optional[int] = None, tracker_factory=None) -> Dict:
+                  threads: Optional[int] = None, tracker_factory=None, use_reference: Optional[bool] = None) -> Dict:
     """frames uint8 (T,3,H,W) on the CPU; query_points (M,P,3).  Returns trajectories (T,M,P,2), visibilities (T,M,P)
     [after the border rule of sam_pt.py:684-690], logits (M,len(frame_ids),H,W), scores_per_frame, the oracle
     embeddings of the SAM frames and the seconds each stage took on this host.  ``tracker_factory()`` -> an oracle tracker
     with ``forward(rgbs, query_points)`` (default: the PIPS oracle on ``psd``; ``reference_cost`` makes it spend the
-    reference's redundant work too — fnet per window, init pass)."""
+    reference's redundant work too — fnet per window, init pass).  ``use_reference``: drive the reference's own ``SamPt``
+    class (default: whenever /root/reference is importable), False = this package's host logic."""
     from oracle import pips_ref as PO
     from oracle import sam_ref as R
     from sam_pt_amd.point_tracker import PointTracker
@@ -62,14 +66,46 @@ def reference_run(cfg, sd, psd, frames: torch.Tensor, query_points: torch.Tensor
             return out
 
     pred = TimedPredictor(sd, cfg, hq=hq)
-    model = SamPt(OracleTracker(), pred, **sampt_kwargs).eval()
+    model = _driver(OracleTracker(), pred, sampt_kwargs, use_reference)
     with torch.no_grad():
         traj, vis = model._track_points(frames, query_points)
         sel = torch.as_tensor(ids, dtype=torch.long)
-        _, logits, spf = model._apply_sam_to_trajectories(frames[sel], traj[sel], vis[sel], None)
+        args = (frames[sel], traj[sel], vis[sel])
+        # (this package's SamPt takes the clip's precomputed embeddings as a 4th argument: none here)
+        _, logits, spf = model._apply_sam_to_trajectories(*args) if _is_reference(model) else model._apply_sam_to_trajectories(*args, None)
     sec["predict_calls"] = pred.n_predict
     return {"trajectories": traj, "visibilities": vis, "logits": logits, "scores_per_frame": spf, "frame_ids": ids,
             "embeddings": torch.stack(embeddings) if embeddings else None, "seconds": sec}
+
+
+# constructor keywords of the reference SamPt (sam_pt/modeling/sam_pt.py:28-50 has no defaults) = configs/model/sam_pt.yaml,
+# which are also the defaults of this package's SamPt
+_REF_DEFAULTS = dict(positive_point_selection_method="kmedoids", negative_point_selection_method="mixed", positive_points_per_mask=8,
+                     negative_points_per_mask=0, add_other_objects_positive_points_as_negative_points=True,
+                     max_other_objects_positive_points=None, point_tracker_mask_batch_size=5, iterative_refinement_iterations=12,
+                     use_patch_matching_filtering=False, patch_size=3, patch_similarity_threshold=0.01, use_point_reinit=False,
+                     reinit_point_tracker_horizon=24, reinit_horizon=24, reinit_variant="reinit-at-median-of-area-diff")
+
+
+def _is_reference(model) -> bool:
+    return type(model).__module__.startswith("sam_pt.")
+
+
+def _driver(tracker, predictor, sampt_kwargs: dict, use_reference: Optional[bool]):
+    """The object whose ``_track_points`` / ``_apply_sam_to_trajectories`` run the protocol: the reference's own SamPt when it
+    can be imported in place, this package's otherwise."""
+    from oracle import reference_loader as RL
+    if use_reference is None:
+        use_reference = RL.available()
+    if use_reference:
+        RefSamPt = RL.load_sam_pt()
+        if not hasattr(predictor, "model") or predictor.model is None or not isinstance(predictor.model, torch.nn.Module):
+            m = torch.nn.Module()                      # the reference keeps ``sam_predictor.model`` as a sub-module (sam_pt.py:96)
+            m.device, m.mask_threshold = torch.device("cpu"), getattr(getattr(predictor, "model", None), "mask_threshold", 0.0)
+            predictor.model = m
+        return RefSamPt(tracker, predictor, **{**_REF_DEFAULTS, **sampt_kwargs}).eval()
+    from sam_pt_amd.sam_pt import SamPt
+    return SamPt(tracker, predictor, **sampt_kwargs).eval()
 
 
 def mask_iou(a: torch.Tensor, b: torch.Tensor) -> float:

@@ -108,8 +108,8 @@ int softmax_rel_rows(float* scores, const float* relh, const float* relw, long B
 // P^T is fed to the second MFMA straight from the score registers (any k-slot permutation is legal as long as
 // the A operand uses the same one, and V^T is gathered from LDS with exactly that permutation).
 //
-// K and V tiles go HBM -> LDS by LDS-DMA straight from the packed qkv rows into TWO buffers: no staging registers,
-// no transposing stores, one barrier per tile, the next tile's DMA in flight while this one is multiplied.  V stays ROW-major
+// K and V tiles go HBM -> LDS by LDS-DMA straight from the packed qkv rows into ONE buffer: no staging registers, no
+// transposing stores; a workgroup exposes the DMA latency of every tile, the two other workgroups resident on its CU hide it.  V stays ROW-major
 // ([key slot][channel], as it lies in HBM); the A operand of O^T = V^T.P^T is gathered with ds_read_b64_tr_b16, gfx950's
 // transposing LDS read: within a 16-lane group, lane s passes the address of 4 consecutive channels of key (s >> 2), channel
 // chunk (s & 3), and lane c receives channel c of the 4 keys (tools/probes/tr_probe.hip) — exactly the 4 consecutive key
@@ -137,10 +137,17 @@ __global__ __launch_bounds__(NW * 64, 2) void k_flash_f16(const half_t* __restri
   constexpr int CPR = HD / 8, CPV = VP / 8;   // 16-byte chunks per K row / per LDS V row
   // K chunk ^= (row >> KSH) & KSWZ
   constexpr int KSWZ = CPR == 8 ? 7 : (CPR == 4 ? 3 : (CPR == 10 ? 1 : 0)), KSH = CPR == 4 ? 2 : (CPR == 10 ? 3 : 1);
-  __shared__ __attribute__((aligned(1024))) half_t Ks[2][64][HD];
-  __shared__ __attribute__((aligned(1024))) half_t Vs[2][64][VP];
+  // ONE K / V tile buffer, and the rel_w table — dead once its values sit in registers — aliased onto it: 39 KiB for 64 x 64
+  // tokens / head dim 80, three workgroups per CU.  (Rounds 2 - 3 double-buffered the tiles and kept both tables: 77 KiB, two
+  // workgroups per CU; occupancy beats the intra-workgroup overlap: global blocks 1407 -> 1227 us per 8 frames, windowed
+  // unchanged, 112.4 -> 115.0 fps in an A / B of one call, profiles/r4_c7_*.)
+  constexpr int KB = 64 * HD * 2, VB = 64 * VP * 2, RELB = SG * RLD * 2;
+  constexpr int BUFB = KB + VB > RELB ? KB + VB : ((RELB + 1023) / 1024) * 1024;
+  __shared__ __attribute__((aligned(1024))) char tile_s[BUFB];
   __shared__ half_t relh_s[SG][RLD];
-  __shared__ half_t relw_s[SG][RLD];
+  half_t(*Ks)[64][HD] = (half_t(*)[64][HD])tile_s;
+  half_t(*Vs)[64][VP] = (half_t(*)[64][VP])(tile_s + KB);
+  half_t(*relw_s)[RLD] = (half_t(*)[RLD])tile_s;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, hi = lane >> 5;
@@ -190,8 +197,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_flash_f16(const half_t* __restri
                                        (__attribute__((address_space(3))) void*)((char*)&Vs[buf][0][0] + i * 1024), 16, 0, 0);
     }
   };
-  // the first K / V tile is requested before anything else: its latency overlaps the Q loads and the rel-pos prologue
-  dma_tile(0, 0);
+  // (the first K / V tile is requested after the prologue: until then the buffer holds the rel_w table)
 
   // ---- prologue: Q fragments, then the decomposed rel-pos tables of THIS wave's 32 queries
   //      computed with MFMA straight into LDS (fp16): G[rho][q] = <rel_pos[rho], q_vec> for all 2*SG-1 table rows, and
@@ -275,12 +281,12 @@ __global__ __launch_bounds__(NW * 64, 2) void k_flash_f16(const half_t* __restri
     for (int dt = 0; dt < DT; ++dt)
       vl[dt] = (4 * hi + r4) * VP * 2 + ((dt * 64 + g16 * 32 + cc * 8) ^ (HD == 64 ? ((r4 >> 1) & 1) << 6 : 0));
   }
+  __syncthreads();                                   // every wave holds its rel_w values: the buffer is free for tile 0
+  dma_tile(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile 0 has landed: this wave's part; the barrier publishes all parts
   __syncthreads();
   for (int kt0 = 0, kh0 = 0, it = 0; kt0 < N; kt0 += KTV, kh0 += RPT, ++it) {
-    const int buf = it & 1;
-    // the other buffer was last read before the barrier that ended the previous iteration: refill it now, wait at the end
-    if (kt0 + KTV < N) dma_tile(kt0 + KTV, buf ^ 1);
+    constexpr int buf = 0;
 
     // ---- S^T = K . Q^T  (two 32-slot tiles)
     f32x16 st[2];
@@ -372,8 +378,12 @@ __global__ __launch_bounds__(NW * 64, 2) void k_flash_f16(const half_t* __restri
         o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pb[t], o[dt], 0, 0, 0);
       }
     }
-    // the next tile has landed (every wave waits for its own DMA, the barrier publishes all of it) and everyone is done
-    // reading this buffer
+    // everyone is done reading the buffer: refill it (the other resident workgroups multiply meanwhile), then wait for this
+    // wave's part of the DMA; the barrier publishes all parts
+    if (kt0 + KTV < N) {
+      __syncthreads();
+      dma_tile(kt0 + KTV, 0);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
