@@ -234,6 +234,10 @@ class SamPt(nn.Module):
             # workgroup owns its CU; measured on MI355X, profiles/r3_v3_timeline_wgs*.log: 32 / 30 workgroups per XCD
             # 248 ms per clip with the tracker ending 24 ms after the encoder, 28 per XCD 229 ms)
             reserve = self.encoder_gemm_workgroups_beside_tracker if overlap else None
+            # (the split-fp16 encoder takes twice as long, so the tracker's rounds end long before it either way: measured 59.5 fps
+            #  with every CU given to the GEMMs against 58.5 with 28 per XCD, profiles/r4_c8_bench_x3_wgs*.log)
+            if reserve == 28 and getattr(getattr(self.sam_predictor, "model", None), "precision", None) == "f16x3":
+                reserve = None
             kw = {"gemm_workgroups": reserve} if reserve else {}
             feats = self.sam_predictor.encode_frames(sam_images, chw=True, batch_events=batch_events, **kw)   # embeddings in HBM
             self._mark("encoded")
