@@ -373,6 +373,8 @@ int conv_f16x3(const GemmP& p_in, hipStream_t s) {
   }
   const int BN = p.N <= 32 ? 32 : (p.N <= 64 ? 64 : (p.N <= 96 ? 96 : 128));
   const size_t lds = (size_t)2 * (2 * 128 + 2 * BN) * (32 + 8) * sizeof(half_t);
+  // (A single LDS buffer — 40 KiB, four workgroups per CU instead of two, two barriers per slab — was measured in round 4 and is
+  // within noise: decode chain 24.0 vs 23.6 ms, 113.3 vs 112.9 fps, profiles/r4_c9_*.  These launches are not occupancy-bound.)
   // One K slab of register prefetch.  Two slabs in flight (a second register set) measured slower everywhere — decode chain
   // 24.70 vs 24.34 ms, tracker-encoder pass 6.54 vs 6.08 ms (profiles/r2_v16_*): these kernels are not bound by the latency of
   // their global loads, and the extra 30 registers cost the 64- and 96-column tiles a resident wave.
