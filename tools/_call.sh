@@ -1,14 +1,12 @@
 # scratch script of the current gpurun call (overwritten per call; the logs it leaves are copied to profiles/r4_*)
 set -u
-R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/r4_c9; mkdir -p $OUT; cd $R
-for sb in 1 0; do
-  SAMPT_CONV_SB=$sb timeout 300 python -m pytest tests/test_gpu_kernels.py -q -m gpu -k "conv_f16x3" > $OUT/pytest_conv_sb$sb.log 2>&1; tail -1 $OUT/pytest_conv_sb$sb.log
-  SAMPT_CONV_SB=$sb timeout 200 python tools/stage_times.py > $OUT/stage_times_sb$sb.log 2>&1; tail -4 $OUT/stage_times_sb$sb.log
-done
-SAMPT_CONV_SB=1 timeout 400 python -m pytest tests/test_gpu_modules.py -q -m gpu -k "predict_torch or hq_ or decoder or fnet or vit_b_encoder" > $OUT/pytest_modules_sb1.log 2>&1; tail -1 $OUT/pytest_modules_sb1.log
-for sb in 1 0 1 0; do
-  SAMPT_CONV_SB=$sb timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --no-roofline > $OUT/bench_sb$sb.log 2>&1; tail -1 $OUT/bench_sb$sb.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('sb $sb', d['value'], d['value_per_forward'], d['parity']['mask_iou_min'])"
-done
-for sb in 1 0; do
-  SAMPT_CONV_SB=$sb timeout 300 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-secondary --no-roofline --hq --tracker cotracker --square 1024 --points 16 --objects 5 > $OUT/bench_cfg5_sb$sb.log 2>&1; tail -1 $OUT/bench_cfg5_sb$sb.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('cfg5 sb $sb', d['value'], d['value_per_forward'])"
-done
+R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/r4_v4; mkdir -p $OUT; cd $R
+P="--steps 10 --warmup 3 --no-secondary --no-roofline --parity-frames 4"
+show() { tail -1 $1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); p=d['parity']; print('$2', d['value'], d['value_per_forward'], p['pass'], p['mask_iou_min'], p['masks_compared'], p['traj_index_identical'], p['traj_index_differing'], p['vis_identical'])"; }
+timeout 400 python bench.py $P --model vit_b > $OUT/bench_cfg2_vitb.log 2>&1; show $OUT/bench_cfg2_vitb.log cfg2
+timeout 400 python bench.py $P --tracker cotracker --neg-points 8 --frames 50 --cotracker-delta-scale 0.001 > $OUT/bench_cfg3_cotracker_T50_conditioned.log 2>&1; show $OUT/bench_cfg3_cotracker_T50_conditioned.log cfg3
+timeout 400 python bench.py $P --objects 3 > $OUT/bench_cfg4_3obj.log 2>&1; show $OUT/bench_cfg4_3obj.log cfg4
+timeout 600 python bench.py --steps 4 --warmup 2 --no-secondary --no-roofline --parity-frames 4 --hq --tracker cotracker --square 1024 --points 16 --objects 5 --frames 64 --cotracker-delta-scale 0.001 > $OUT/bench_cfg5_hq_T64.log 2>&1; show $OUT/bench_cfg5_hq_T64.log cfg5
+cd /tmp && export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace -d $OUT/prof -o vith -- python $R/bench.py --no-cpu-baseline --no-secondary --no-roofline --steps 5 --warmup 2 > $OUT/rocprof_f16.log 2>&1
+cd $R; python tools/rocprof_summary.py $(find $OUT/prof -name "*.db" | head -1) 312 > $OUT/vith_kernel_stats.txt 2>&1; head -12 $OUT/vith_kernel_stats.txt; rm -rf $OUT/prof
