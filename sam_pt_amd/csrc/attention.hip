@@ -140,7 +140,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_flash_f16(const half_t* __restri
   // ONE K / V tile buffer, and the rel_w table — dead once its values sit in registers — aliased onto it: 39 KiB for 64 x 64
   // tokens / head dim 80, three workgroups per CU.  (Rounds 2 - 3 double-buffered the tiles and kept both tables: 77 KiB, two
   // workgroups per CU; occupancy beats the intra-workgroup overlap: global blocks 1407 -> 1227 us per 8 frames, windowed
-  // unchanged, 112.4 -> 115.0 fps in an A / B of one call, profiles/r4_c7_*.)
+  // unchanged, 112.4 -> 115.0 fps in an A / B of one call, profiles/r4_c7_*.  The opposite trade for the 14 x 14 windows — the
+  // whole window's K / V resident, no DMA wait or barrier in the key loop, 78 KiB and two workgroups per CU — loses: 258 vs 228 us,
+  // profiles/r4_c10_*.  With three workgroups per CU these kernels are bound by their softmax VALU work, not by latency.)
   constexpr int KB = 64 * HD * 2, VB = 64 * VP * 2, RELB = SG * RLD * 2;
   constexpr int BUFB = KB + VB > RELB ? KB + VB : ((RELB + 1023) / 1024) * 1024;
   __shared__ __attribute__((aligned(1024))) char tile_s[BUFB];
