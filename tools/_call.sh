@@ -1,11 +1,27 @@
 # scratch script of the current gpurun call (overwritten per call; the logs it leaves are copied to profiles/r4_*)
 set -u
-R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/r4_c11; mkdir -p $OUT; cd /tmp && export TMPDIR=/tmp
-C1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
-C2="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM"
-timeout 250 rocprofv3 --pmc $C1 --output-format csv -d $OUT/g1 -- python $R/tools/gemm_bench.py 8 nocheck > $OUT/pmc_g1.log 2>&1
-timeout 250 rocprofv3 --pmc $C2 --output-format csv -d $OUT/g2 -- python $R/tools/gemm_bench.py 8 nocheck > $OUT/pmc_g2.log 2>&1
-timeout 300 rocprofv3 --pmc $C1 --output-format csv -d $OUT/g3 -- python $R/tools/gemm_bench.py 8 x3 > $OUT/pmc_g3.log 2>&1
-cd $R
-(echo "# rocprofv3 --pmc passes over tools/gemm_bench.py 8 (fp16: g1 / g2) and tools/gemm_bench.py 8 x3 (g3): per-kernel means over all launches of the run"; python tools/pmc_summary.py $OUT/g1 gemm_f16; python tools/pmc_summary.py $OUT/g2 gemm_f16; python tools/pmc_summary.py $OUT/g3 gemm_f16) > $OUT/gemm_sq_counters.txt 2>&1; cut -c1-110 $OUT/gemm_sq_counters.txt
-rm -rf $OUT/g1 $OUT/g2 $OUT/g3
+R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/r4_c12; mkdir -p $OUT; cd $R
+Q="--steps 4 --warmup 2 --no-cpu-baseline --no-secondary --no-roofline"
+show() { tail -1 $1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$2', d['value'], d['value_per_forward'], d.get('parity',{}).get('mask_iou_min'))" 2>&1 | tail -1; }
+timeout 300 python bench.py $Q --hq --precision f16x3 > $OUT/bench_hq_x3.log 2>&1; show $OUT/bench_hq_x3.log hq_x3
+timeout 300 python bench.py $Q --model vit_l --precision f16x3 > $OUT/bench_vitl_x3.log 2>&1; show $OUT/bench_vitl_x3.log vitl_x3
+timeout 300 python bench.py $Q --model vit_l > $OUT/bench_vitl_f16.log 2>&1; show $OUT/bench_vitl_f16.log vitl_f16
+timeout 300 python bench.py $Q --model vit_b --precision f16x3 > $OUT/bench_vitb_x3.log 2>&1; show $OUT/bench_vitb_x3.log vitb_x3
+timeout 300 python bench.py $Q --native-480p --precision f16x3 > $OUT/bench_native_x3.log 2>&1; show $OUT/bench_native_x3.log native_x3
+timeout 300 python - > $OUT/vitl_x3_vs_f32.log 2>&1 <<'PY'
+import torch, sys
+sys.path.insert(0, '.')
+from sam_pt_amd.sam_predictor import SamHip, SamPredictor
+from sam_pt_amd.synth import bench_clip
+dev = torch.device("cuda:0")
+frames, _ = bench_clip(T=2)
+embs = {}
+for prec in ("f32", "f16x3", "f16"):
+    pred = SamPredictor(SamHip("vit_l", precision=prec, seed=72, max_batch=2).to(dev))
+    embs[prec] = pred.encode_frames(frames.to(dev)).float().cpu()
+    del pred; torch.cuda.empty_cache()
+ref = embs["f32"]
+for prec in ("f16x3", "f16"):
+    print("vit_l", prec, "vs f32: rel err", float((embs[prec] - ref).abs().max() / ref.abs().max()))
+PY
+cat $OUT/vitl_x3_vs_f32.log | tail -3
