@@ -18,6 +18,7 @@ LayerNorm rows and attention windows are independent: ``test_vit_dead_row_skippi
 from __future__ import annotations
 
 import os
+import threading
 import weakref
 from typing import Optional
 
@@ -32,7 +33,9 @@ class _Clip:
         self.next_idx = 0
 
 
-_current: Optional[_Clip] = None
+# The published clip and the suspend counter are PER THREAD: the tracker call and the set_image calls of one SamPt.forward run on
+# one thread, and two models driven from two threads must not see (or suspend) each other's clips.
+_tls = threading.local()
 stats = {"published": 0, "hits": 0, "misses": 0, "clips_encoded": 0, "skipped_too_large": 0}
 
 
@@ -47,11 +50,16 @@ def _clip_bytes(frames: torch.Tensor) -> int:
     return int(frames.numel()) + int(frames.shape[0]) * (12 << 20)
 
 
-_suspended = 0
+def _get_current() -> Optional[_Clip]:
+    return getattr(_tls, "current", None)
+
+
+def _set_current(c: Optional[_Clip]) -> None:
+    _tls.current = c
 
 
 def enabled() -> bool:
-    return _suspended == 0 and os.environ.get("SAMPT_PREFETCH", "1") != "0"
+    return getattr(_tls, "suspended", 0) == 0 and os.environ.get("SAMPT_PREFETCH", "1") != "0"
 
 
 class suspended:
@@ -59,18 +67,15 @@ class suspended:
     they call do not publish."""
 
     def __enter__(self):
-        global _suspended
-        _suspended += 1
+        _tls.suspended = getattr(_tls, "suspended", 0) + 1
 
     def __exit__(self, *exc):
-        global _suspended
-        _suspended -= 1
+        _tls.suspended = getattr(_tls, "suspended", 0) - 1
         return False
 
 
 def publish(frames: torch.Tensor) -> None:
     """Called by the point trackers with the clip (T, 3, H, W) uint8 they are about to track."""
-    global _current
     if not enabled() or not isinstance(frames, torch.Tensor) or not frames.is_cuda or frames.dtype != torch.uint8 \
             or frames.dim() != 4 or frames.shape[1] != 3:
         return
@@ -78,22 +83,21 @@ def publish(frames: torch.Tensor) -> None:
     # encoder pass over the clip (embeddings cached across calls would outlive a weight / precision change of the predictor,
     # and would make a benchmark loop over one clip skip the encoder altogether).
     if _clip_bytes(frames) > max_bytes():
-        _current = None                           # a clip too long to keep embedded: per-frame set_image, as the reference does
+        _set_current(None)                        # a clip too long to keep embedded: per-frame set_image, as the reference does
         stats["skipped_too_large"] += 1
         return
-    _current = _Clip(frames.detach().clone())
+    _set_current(_Clip(frames.detach().clone()))
     stats["published"] += 1
 
 
 def clear() -> None:
-    global _current
-    _current = None
+    _set_current(None)
 
 
 def lookup(predictor, image_hwc: torch.Tensor):
     """image_hwc: the frame ``set_image`` was given, already on the predictor's device, uint8 (H, W, 3) RGB.  Returns the
     clip-embedding item of that frame (what ``encode_frames(...)[i]`` returns) or None."""
-    c = _current
+    c = _get_current()
     if c is None or not enabled() or image_hwc.dtype != torch.uint8 or image_hwc.device != c.frames.device \
             or tuple(image_hwc.shape) != (c.frames.shape[2], c.frames.shape[3], 3):
         return None

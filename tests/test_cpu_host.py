@@ -799,3 +799,36 @@ print("PYRAMID_OK", rank)
         os.unlink(path)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     assert r.stdout.count("PYRAMID_OK") == 2
+
+
+def test_x3_rows_packing_and_vit_pack_modes():
+    """pack.x3_rows (the operand format of the split-fp16 GEMM / attention kernels, csrc/common.h GemmP::x3): hi + lo reproduces the
+    fp32 value to 2^-22, blocks of 32 k are laid out hi(32) | lo(32), out-of-range magnitudes saturate into lo; and pack_vit emits
+    the per-mode keys the engine looks up (".f16" / ".x3" GEMM weights, the qkv bias as one row of the qkv matrix's format)."""
+    from sam_pt_amd.pack import F16X3_WSHIFT, pack_vit, x3_rows, x3_unrows
+    from sam_pt_amd.weights import SAM_CONFIGS, init_sam_state_dict
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(7, 96, generator=g) * 3
+    x[0, 0], x[1, 33], x[2, 64] = 1.0e5, -1.2e5, 3e-7
+    y = x3_rows(x)
+    assert y.shape == (7, 192) and y.dtype == torch.float16
+    assert torch.equal(y[:, 0:32], x[:, 0:32].clamp(-65504, 65504).half())            # block 0: hi
+    assert torch.equal(y[:, 64:96], x[:, 32:64].clamp(-65504, 65504).half())          # block 1 starts at 64
+    back = x3_unrows(y)
+    # 2^-22 relative for values whose lo piece is a normal fp16 number; an absolute floor of one fp16 subnormal quantum (6e-8) below
+    assert bool(((back - x).abs() <= torch.maximum(x.abs() * 2.0 ** -21, torch.tensor(6e-8))).all())
+    w = torch.randn(5, 64, generator=g) * 0.02
+    assert float((x3_unrows(x3_rows(w, F16X3_WSHIFT), F16X3_WSHIFT) - w).abs().max()) < 1e-9
+    with pytest.raises(ValueError):
+        x3_rows(torch.full((1, 32), 3.0e5))                                            # beyond 2 x 65504: cannot be split
+    cfg = SAM_CONFIGS["vit_test"]
+    sd = init_sam_state_dict(cfg, 72)
+    e = "image_encoder.blocks.0."
+    for mode, sfx in ((1, ".f16"), (2, ".x3")):
+        p = pack_vit(sd, cfg, "cpu", mode, 2)
+        D = cfg.embed_dim
+        assert p[e + "attn.qkv.weight" + sfx].shape == (3 * D, D * (2 if mode == 2 else 1))
+        assert p[e + "attn.qkv.bias" + sfx].numel() == 3 * D * (2 if mode == 2 else 1) and p[e + "attn.qkv.bias"].dtype == torch.float32
+        assert "image_encoder.neck.0.weight_hl" in p and e + "attn.qkv.weight" not in p
+    p0 = pack_vit(sd, cfg, "cpu", 0, 2)
+    assert e + "attn.qkv.weight" in p0 and e + "attn.qkv.bias.f16" not in p0

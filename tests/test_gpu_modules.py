@@ -949,7 +949,7 @@ def test_reference_protocol_with_clip_embedding_prefetch_is_exact(dev, pips_sd, 
             # query-mask pass (sam_pt.py:181): 1 set_image before the tracker has published anything -> a miss; then 6 hits
             assert prefetch.stats["hits"] == 6 and prefetch.stats["clips_encoded"] == 1, prefetch.stats
             assert pred.stats["encoded_frames"] <= 6 + 1 + 1, pred.stats      # clip + query frame (+ dead-row cache build)
-            assert prefetch._current is None, "the clip stays pinned after its last frame was served"
+            assert prefetch._get_current() is None, "the clip stays pinned after its last frame was served"
             again = model(video)                                           # the same clip again: encoded again
             assert prefetch.stats["clips_encoded"] == 2 and prefetch.stats["hits"] == 12, prefetch.stats
             assert all(torch.equal(a.cpu(), b.cpu()) for a, b in zip(again["logits"], outs[mode]["logits"]))
