@@ -7,7 +7,9 @@ weights in the upstream key layout), the SamPt keywords, and the frames whose SA
   headline / config #2   ViT-H (ViT-B) + PIPS, 8 points, 1 object, 24 (8) x 576x1024 — SAM stage on every frame
   config #4              ViT-H + PIPS, 8 points x 3 objects (other objects' positives as negatives, sam_pt.py:737-756), T = 8,
                          SAM stage on all 8 frames (24 masks)
-  config #3              ViT-H + CoTracker, 8 + 8 points (two prompt passes per frame), T = 13, SAM stage on 8 frames
+  config #3              ViT-H + CoTracker, 8 + 8 points (two prompt passes per frame), T = 13, SAM stage on 8 frames (flow head
+                         x 0.001 like config #5: with the default head the HIP / oracle difference at T = 13 was 2 - 3e-3 px,
+                         box-dependent, i.e. as large as the band around x.5 in which index identity is not asserted)
   config #5              HQ-SAM ViT-H + CoTracker, 1024 x 1024, 16 points x 5 objects, T = 64 (T >= 64), SAM stage on
                          4 frames (20 masks).  Conditioning: over 15 chained windows the seed weights' default flow head
                          (x 0.003, weights.init_cotracker_state_dict) makes the ORACLE ITSELF move by 0.42 px and flip 21
@@ -56,7 +58,7 @@ def config_workload(name: str) -> Dict:
         w["psd"] = w["tracker_sd"] = init_pips_state_dict(72)
     else:
         from oracle.cotracker_ref import CoTrackerTrackerRef
-        csd = init_cotracker_state_dict(72, **({"delta_scale": 0.001} if T >= 64 else {}))
+        csd = init_cotracker_state_dict(72, delta_scale=0.001)      # conditioning: see the module docstring
         w["tracker_sd"], w["factory"] = csd, (lambda: CoTrackerTrackerRef(csd))
     return w
 
