@@ -124,9 +124,9 @@ __device__ half_t g_flash_pad[16] = {(half_t)1.f, (half_t)0.f, (half_t)0.f, (hal
                                      (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
 
 template <int HD, int NW, int SG>
-__global__ __launch_bounds__(NW * 64, 2) void k_flash_f16(const half_t* __restrict__ qkv, const float* __restrict__ rel_h,
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void k_flash_f16(const half_t* __restrict__ qkv, const float* __restrict__ rel_h,
                                                        const float* __restrict__ rel_w, half_t* __restrict__ out, int N,
-                                                       int heads, float scale, FlashPad pad) {
+                                                       int heads, float scale, FlashPad pad, int B, int uh) {
   constexpr int KS = HD / 16;            // k-steps of QK^T
   constexpr int DT = (HD + 31) / 32;     // 32-row tiles of O^T
   constexpr int QT = NW * 32;
@@ -142,7 +142,10 @@ __global__ __launch_bounds__(NW * 64, 2) void k_flash_f16(const half_t* __restri
   // workgroups per CU; occupancy beats the intra-workgroup overlap: global blocks 1407 -> 1227 us per 8 frames, windowed
   // unchanged, 112.4 -> 115.0 fps in an A / B of one call, profiles/r4_c7_*.  The opposite trade for the 14 x 14 windows — the
   // whole window's K / V resident, no DMA wait or barrier in the key loop, 78 KiB and two workgroups per CU — loses: 258 vs 228 us,
-  // profiles/r4_c10_*.  With three workgroups per CU these kernels are bound by their softmax VALU work, not by latency.)
+  // profiles/r4_c10_*; so do, for the windows at three workgroups per CU, the rel_w table in its own LDS with tile 0 requested
+  // before the prologue (208 vs 210 us), a second tile buffer on top of that (213), and two-wave workgroups (231),
+  // profiles/r4_c17_*.  What did move the windowed kernel: keeping a window's 32 workgroups on one XCD (233 -> 217 us, common.h
+  // flash_wg_decode); what moved the global one: the DMA address table below (1087 -> 1041 us, profiles/r4_c18_*).)
   constexpr int KB = 64 * HD * 2, VB = 64 * VP * 2, RELB = SG * RLD * 2;
   constexpr int BUFB = KB + VB > RELB ? KB + VB : ((RELB + 1023) / 1024) * 1024;
   __shared__ __attribute__((aligned(1024))) char tile_s[BUFB];
@@ -150,15 +153,30 @@ __global__ __launch_bounds__(NW * 64, 2) void k_flash_f16(const half_t* __restri
   half_t(*Ks)[64][HD] = (half_t(*)[64][HD])tile_s;
   half_t(*Vs)[64][VP] = (half_t(*)[64][VP])(tile_s + KB);
   half_t(*relw_s)[RLD] = (half_t(*)[RLD])tile_s;
+  // What lane l of DMA instruction i fetches — slot (i*64 + l) / CPR, chunk (i*64 + l) % CPR, the swizzle, whether the token's
+  // grid column is window padding — does not depend on the tile: worked out once per workgroup into this table (one word per
+  // (instruction of this wave, lane), read back by the lane that wrote it), so that the per-tile address of a DMA instruction is
+  // a row pointer plus a table offset instead of two integer divisions and the swizzle — those were ~100 of the ~300 VALU
+  // instructions per tile and wave of the global kernel and more than half of the windowed kernel's (which are VALU-bound).
+  //   bits 0-7 slot (clamped to the tile's last key), 8-11 grid row of the slot inside the tile, 12 column is padding,
+  //   13 source is the constant pad page, 16-31 byte offset inside the K / V row of this head (or inside the pad page)
+  constexpr int NKI = (CPR + NW - 1) / NW, NVI = (CPV + NW - 1) / NW;
+  __shared__ unsigned dma_tab[NKI + NVI][NT];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, hi = lane >> 5;
-  const int h = blockIdx.y, b = blockIdx.z;
+  int bx, h, b;                                         // XCD-aware work order (common.h)
+  flash_wg_decode(blockIdx.x, (N + QT - 1) / QT, heads, B, uh, bx, h, b);
   const int D = heads * HD;
   const long tok0 = (long)b * N;
-  const int qblk = blockIdx.x * QT;
+  const int qblk = bx * QT;
   const int ql = wave * 32 + li;
   const int q = qblk + ql;
+  // A wave none of whose 32 query slots is a token (14 x 14 windows: 196 tokens on 2 x 128 slots, the last wave of the second
+  // workgroup) only helps staging the tiles; a half tile none of whose 32 key slots is a key (the last tile of a window holds grid
+  // rows 12, 13 in slots 0 - 27) is not multiplied: 15 of the 64 (wave, half tile) units of a (window, head).  (-2 % only,
+  // profiles/r4_c15_*: the kernel is not bound by its MFMA or softmax work.)
+  const bool wave_live = qblk + wave * 32 < N;
   // ---- key tiles.  A tile has 64 slots holding KTV = RPT*SG keys = RPT whole rows of the SG x SG token grid (global
   //      blocks: 1 row of 64; 14x14 windows: 4 rows = 56 keys + 8 pad slots), so that the rel_w bias of a lane's 32
   //      score slots is the same for every tile (registers) and rel_h is RPT values per tile.  Pad slots and rows
@@ -179,22 +197,51 @@ __global__ __launch_bounds__(NW * 64, 2) void k_flash_f16(const half_t* __restri
   };
   // DMA staging: wave w issues the K instructions i = w, w + NW, ... (CPR of them, 64 lanes x 16 B each: LDS bytes
   // [i * 1024, +1024) of the K buffer = slots (i*64 + lane) / CPR) and likewise the CPV V instructions
-  auto dma_tile = [&](int kt0, int buf) {
-    const half_t* kbase = qkv + tok0 * 3 * D + D + h * HD;
-    for (int i = wave; i < CPR; i += NW) {
+  {
+    int n = 0;
+    for (int i = wave; i < CPR; i += NW, ++n) {
       const int e = i * 64 + lane, slot = e / CPR, c = e - slot * CPR;
-      const int krow = min(kt0 + min(slot, KTV - 1), N - 1);
-      const half_t* rowp = is_pad(krow) ? pad.bias_row + D + h * HD : kbase + (long)krow * 3 * D;
-      const half_t* src = rowp + ((c ^ ((slot >> KSH) & KSWZ)) * 8);
+      const int sc = min(slot, KTV - 1), siy = sc / SG, six = sc - siy * SG;
+      const unsigned off = (unsigned)((c ^ ((slot >> KSH) & KSWZ)) * 16);
+      dma_tab[n][tid] = (unsigned)sc | (unsigned)siy << 8 | (pad.bias_row != nullptr && px0 + six >= pad.gw ? 1u << 12 : 0u) | off << 16;
+    }
+    n = NKI;
+    for (int i = wave; i < CPV; i += NW, ++n) {
+      const int e = i * 64 + lane, slot = e / CPV, c = e - slot * CPV;
+      const int sc = min(slot, KTV - 1), siy = sc / SG, six = sc - siy * SG;
+      const int cs = HD == 64 ? c ^ (((slot >> 1) & 1) << 2) : c;
+      const unsigned off = (unsigned)(c < CPR ? cs * 16 : (c - CPR) * 16);
+      dma_tab[n][tid] = (unsigned)sc | (unsigned)siy << 8 | (pad.bias_row != nullptr && px0 + six >= pad.gw ? 1u << 12 : 0u) |
+                        (c < CPR ? 0u : 1u << 13) | off << 16;
+    }
+  }
+  // kt0 / kh0: first key / first grid row of the tile
+  auto dma_tile = [&](int kt0, int kh0, int buf) {
+    const half_t* kbase = qkv + tok0 * 3 * D + D + h * HD;
+    // (32-bit row offsets: one (frame | window) of qkv rows is far below 4 GB; tok0 is part of the 64-bit base)
+    const unsigned stride = 3u * (unsigned)D * 2u;
+    const char* kb = (const char*)kbase;
+    const char* vb = (const char*)(kbase + D);
+    const char* pk = (const char*)(pad.bias_row ? pad.bias_row + D + h * HD : kbase);
+    const char* pv = (const char*)(pad.bias_row ? pad.bias_row + 2 * D + h * HD : kbase);
+    int n = 0;
+    for (int i = wave; i < CPR; i += NW, ++n) {
+      const unsigned t = dma_tab[n][tid];
+      const unsigned krow = min((unsigned)kt0 + (t & 255u), (unsigned)(N - 1));
+      const int gr = kh0 + (int)(t >> 8 & 15u);          // grid row; rows beyond the grid (weight 0) must not touch padded rows either
+      const bool pd = pad.bias_row != nullptr && ((t & 0x1000u) != 0 || gr >= SG || py0 + gr >= pad.gh);
+      const char* src = pd ? pk + (t >> 16) : kb + (__umul24(krow, stride) + (t >> 16));
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)((char*)&Ks[buf][0][0] + i * 1024), 16, 0, 0);
     }
-    for (int i = wave; i < CPV; i += NW) {
-      const int e = i * 64 + lane, slot = e / CPV, c = e - slot * CPV;
-      const int vrow = min(kt0 + min(slot, KTV - 1), N - 1);
-      const int cs = HD == 64 ? c ^ (((slot >> 1) & 1) << 2) : c;
-      const half_t* rowp = is_pad(vrow) ? pad.bias_row + 2 * D + h * HD : kbase + D + (long)vrow * 3 * D;
-      const half_t* src = c < CPR ? rowp + cs * 8 : g_flash_pad + (c - CPR) * 8;
+    n = NKI;
+    for (int i = wave; i < CPV; i += NW, ++n) {
+      const unsigned t = dma_tab[n][tid];
+      const unsigned vrow = min((unsigned)kt0 + (t & 255u), (unsigned)(N - 1));
+      const int gr = kh0 + (int)(t >> 8 & 15u);          // grid row; rows beyond the grid (weight 0) must not touch padded rows either
+      const bool pd = pad.bias_row != nullptr && ((t & 0x1000u) != 0 || gr >= SG || py0 + gr >= pad.gh);
+      const char* src = pd ? pv + (t >> 16) : vb + (__umul24(vrow, stride) + (t >> 16));
+      if (LROW && (t & 0x2000u)) src = (const char*)g_flash_pad + (t >> 16);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)((char*)&Vs[buf][0][0] + i * 1024), 16, 0, 0);
     }
@@ -284,11 +331,13 @@ __global__ __launch_bounds__(NW * 64, 2) void k_flash_f16(const half_t* __restri
       vl[dt] = (4 * hi + r4) * VP * 2 + ((dt * 64 + g16 * 32 + cc * 8) ^ (HD == 64 ? ((r4 >> 1) & 1) << 6 : 0));
   }
   __syncthreads();                                   // every wave holds its rel_w values: the buffer is free for tile 0
-  dma_tile(0, 0);
+  dma_tile(0, 0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile 0 has landed: this wave's part; the barrier publishes all parts
   __syncthreads();
   for (int kt0 = 0, kh0 = 0, it = 0; kt0 < N; kt0 += KTV, kh0 += RPT, ++it) {
     constexpr int buf = 0;
+    if (wave_live) {
+    const bool half1 = RPT == 1 || kh0 + 32 / SG < SG;      // slot 32 lies in grid row kh0 + 32 / SG (wave-uniform)
 
     // ---- S^T = K . Q^T  (two 32-slot tiles)
     f32x16 st[2];
@@ -296,6 +345,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_flash_f16(const half_t* __restri
     for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
+      if (kt == 1 && !half1) continue;            // its scores stay 0 + a -inf bias: p = 0
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const int krow = kt * 32 + li;
@@ -342,6 +392,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_flash_f16(const half_t* __restri
     h8 pb[4];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
+      if (kt == 1 && !half1) continue;
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
         const f32x2 e2 = sv2[kt][r >> 1] - mv;
@@ -367,6 +418,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_flash_f16(const half_t* __restri
     // ---- O^T += V^T . P^T : k-slot (hi, j) of step t is key slot 16t + 4hi + (j&3) + 8(j>>2) on BOTH operands
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
+      if (t >= 2 && !half1) continue;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
         // channel dt*32 + li of key slots 16t + 4hi + {0..3} and 16t + 8 + 4hi + {0..3}
@@ -380,11 +432,12 @@ __global__ __launch_bounds__(NW * 64, 2) void k_flash_f16(const half_t* __restri
         o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pb[t], o[dt], 0, 0, 0);
       }
     }
+    }   // wave_live
     // everyone is done reading the buffer: refill it (the other resident workgroups multiply meanwhile), then wait for this
     // wave's part of the DMA; the barrier publishes all parts
     if (kt0 + KTV < N) {
       __syncthreads();
-      dma_tile(kt0 + KTV, 0);
+      dma_tile(kt0 + KTV, kh0 + RPT, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -419,9 +472,11 @@ int vit_flash_attention_f16(const half_t* qkv, const float* relh, const float* r
   if (pad.bias_row && (pad.nwx <= 0 || pad.nwin <= 0 || B % pad.nwin)) return SAMPT_ERR_ARG;
   const int N = S * S;
   const float scale = 1.0f / sqrtf((float)hd);
+  // work order: windows are kept whole on one XCD (common.h flash_wg_decode); global blocks keep the plain order (grouping the
+  // 32 query blocks of a (frame, head) per XCD measured 0.7 % slower, profiles/r4_c16_*)
 #define FL(HDv, NWv, SGv)                                                                                     \
-  hipLaunchKernelGGL((k_flash_f16<HDv, NWv, SGv>), dim3(cdiv(N, NWv * 32), heads, B), dim3(NWv * 64), 0, s, qkv, relh, \
-                     relw, out, N, heads, scale, pad)
+  hipLaunchKernelGGL((k_flash_f16<HDv, NWv, SGv>), dim3(cdiv(N, NWv * 32) * heads * B), dim3(NWv * 64), 0, s, qkv, relh, relw, \
+                     out, N, heads, scale, pad, B, SGv < 64 ? heads : 0)
   if (S == 64 && hd == 80) FL(80, 4, 64);
   else if (S == 64 && hd == 64) FL(64, 4, 64);
   // (a 7-wave workgroup per (window, head) — 224 query slots for the 196 tokens instead of 2 x 128 — measured 4 % slower,

@@ -45,7 +45,7 @@ struct FlashX3Geom {
 template <int HD, int NW, int SG>
 __global__ __launch_bounds__(NW * 64, 2) void k_flash_x3(const half_t* __restrict__ qkv, const float* __restrict__ rel_h,
                                                          const float* __restrict__ rel_w, half_t* __restrict__ out, int N,
-                                                         int heads, float scale, FlashPad pad) {
+                                                         int heads, float scale, FlashPad pad, int B, int uh) {
   typedef FlashX3Geom<HD, NW, SG> G;
   constexpr int KS = HD / 16;
   constexpr int DT = G::DT;
@@ -65,13 +65,15 @@ __global__ __launch_bounds__(NW * 64, 2) void k_flash_x3(const half_t* __restric
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, hi = lane >> 5;
-  const int h = blockIdx.y, b = blockIdx.z;
+  int bx, h, b;                                         // XCD-aware work order (common.h)
+  flash_wg_decode(blockIdx.x, (N + QT - 1) / QT, heads, B, uh, bx, h, b);
   const int D = heads * HD;
   const long ldq = 6L * D;                              // halves per x3 qkv row
   const long tok0 = (long)b * N;
-  const int qblk = blockIdx.x * QT;
+  const int qblk = bx * QT;
   const int ql = wave * 32 + li;
   const int q = qblk + ql;
+  const bool wave_live = qblk + wave * 32 < N;   // attention.hip: token-less waves only stage, key-less half tiles are skipped
   constexpr int RPT = SG >= 64 ? 1 : 64 / SG, KTV = SG >= 64 ? 64 : RPT * SG;
   constexpr float LOG2E = 1.4426950408889634f;
   const float c2 = scale * LOG2E;
@@ -200,6 +202,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_flash_x3(const half_t* __restric
   __syncthreads();
   for (int kt0 = 0, kh0 = 0, it = 0; kt0 < N; kt0 += KTV, kh0 += RPT, ++it) {
     constexpr int buf = 0;
+    if (wave_live) {
+    // (the key-less half tile is skipped only where that keeps the register count: head dim 64 would drop from 3 to 2 waves per SIMD)
+    const bool half1 = RPT == 1 || HD == 64 || kh0 + 32 / SG < SG;
 
     // ---- S^T = K . Q^T, three products per k-step
     f32x16 st[2];
@@ -207,6 +212,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_flash_x3(const half_t* __restric
     for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
+      if (kt == 1 && !half1) continue;            // its scores stay 0 + a -inf bias: p = 0
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const int krow = kt * 32 + li;
@@ -258,6 +264,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_flash_x3(const half_t* __restric
     h8 pbh[4], pbl[4];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
+      if (kt == 1 && !half1) continue;
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
         const f32x2 e2 = sv2[kt][r >> 1] - mv;
@@ -287,6 +294,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_flash_x3(const half_t* __restric
     // ---- O^T += V^T . P^T, three products per k-step (the ones channel of V hi sums ph + pl: the softmax denominator)
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
+      if (t >= 2 && !half1) continue;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
         typedef short s4 __attribute__((ext_vector_type(4)));
@@ -305,6 +313,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_flash_x3(const half_t* __restric
         o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[0], pbh[t], o[dt], 0, 0, 0);
       }
     }
+    }   // wave_live
     if (kt0 + KTV < N) {
       __syncthreads();                    // everyone is done reading the only buffer
       dma_tile(kt0 + KTV, 0);
@@ -354,14 +363,14 @@ int vit_flash_attention_x3(const half_t* qkv, const float* relh, const float* re
   do {                                                                                                                  \
     typedef FlashX3Geom<HDv, NWv, SGv> G;                                                                               \
     static bool raised = false;                                                                                         \
+    auto kern = k_flash_x3<HDv, NWv, SGv>;                                                                              \
     if (!raised) {                                                                                                      \
-      if (hipFuncSetAttribute((const void*)k_flash_x3<HDv, NWv, SGv>, hipFuncAttributeMaxDynamicSharedMemorySize,       \
-                              G::LDS) != hipSuccess)                                                                    \
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) != hipSuccess)     \
         return SAMPT_ERR_HIP;                                                                                           \
       raised = true;                                                                                                    \
     }                                                                                                                   \
-    hipLaunchKernelGGL((k_flash_x3<HDv, NWv, SGv>), dim3(cdiv(N, NWv * 32), heads, B), dim3(NWv * 64), G::LDS, s, qkv,  \
-                       relh, relw, out, N, heads, scale, pad);                                                          \
+    hipLaunchKernelGGL(kern, dim3(cdiv(N, NWv * 32) * heads * B), dim3(NWv * 64), G::LDS, s, qkv, relh, relw, out, N,   \
+                       heads, scale, pad, B, SGv < 64 ? heads : 0);   /* work order: as attention.hip */                \
   } while (0)
   if (S == 64 && hd == 80) FLX(80, 4, 64);
   else if (S == 64 && hd == 64) FLX(64, 4, 64);

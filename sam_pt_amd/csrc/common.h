@@ -81,6 +81,35 @@ __device__ __forceinline__ void split_f16(float v, half_t& hi, half_t& lo) {
 // column c of a logical row -> its position in an x3 row (the hi half; lo is 32 halves further)
 __device__ __forceinline__ long x3_col(int c) { return ((long)(c >> 5) << 6) + (c & 31); }
 
+// XCD-aware work order of the flash attention kernels (attention.hip, attention_x3.hip).  Workgroups of a 1-D grid go round robin
+// over the 8 XCDs (L & 7), each with a private 4 MiB L2.  A "unit" is the set of workgroups that read the same K / V rows —
+// uh heads of one b (b = a window of a frame, or a frame) x nx query blocks — and is kept on ONE XCD: XCD x walks the units
+// 8u + x, all pu = uh * nx workgroups of a unit before the next.  14 x 14 windows use uh = heads: a token's K / V of one head is
+// 160 contiguous bytes inside a 7680-byte qkv row, i.e. every 128-byte line is shared by two heads and each (head, query block)
+// pair used to pull it into a different L2 — 3.2 x the window's bytes for K / V alone.  Global blocks use uh = 1: the 32 query
+// blocks of a (frame, head) stream the same 1.3 MB of K / V.  The units beyond the last multiple of 8 keep the plain order.
+// uh == 0: plain order (x fastest, then heads, then b).
+__device__ __forceinline__ void flash_wg_decode(int L, int nx, int heads, int B, int uh, int& x, int& h, int& b) {
+  if (uh <= 0) {
+    x = L % nx;
+    const int t = L / nx;
+    h = t % heads, b = t / heads;
+    return;
+  }
+  const int hg = heads / uh, units = B * hg, pu = uh * nx, full = units & ~7;
+  int unit, r;
+  if (L < full * pu) {
+    const int j = L >> 3;
+    unit = (j / pu) * 8 + (L & 7), r = j % pu;
+  } else {
+    const int lt = L - full * pu;
+    unit = full + lt / pu, r = lt % pu;
+  }
+  b = unit / hg;
+  h = (unit % hg) * uh + r / nx;
+  x = r % nx;
+}
+
 typedef float f32x2_g __attribute__((ext_vector_type(2)));
 // ---- the two erf-GELUs of the fp16-input GEMM epilogues (gemm_f16_p8.hip, gemm_f16.hip, gemm.hip: all three kernels use the SAME
 // function per output type, so a GEMM row does not depend on which kernel its launch shape selected)

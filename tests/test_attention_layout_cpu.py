@@ -125,3 +125,123 @@ def test_p_operand_slot_order_matches_the_v_quads():
                 p_slot = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi
                 v_slot = 16 * t + 8 * (j >> 2) + 4 * hi + (j & 3)     # quad j >> 2, key j & 3 of test_v_transposing_reads
                 assert p_slot == v_slot
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The per-workgroup DMA address table (dma_tab) and the XCD-aware work order (common.h flash_wg_decode), restated.
+# ---------------------------------------------------------------------------------------------------------------------------
+def _tile_geometry(SG):
+    RPT = 1 if SG >= 64 else 64 // SG
+    KTV = 64 if SG >= 64 else RPT * SG
+    return RPT, KTV
+
+
+def _dma_table(HD, NW, SG, wave, px0, gw, padded):
+    """dma_tab rows of one wave: per instruction and lane the packed word the kernel builds once per workgroup."""
+    DT, lrow, VP, CPR, CPV, KSWZ, KSH = _geometry(HD)
+    RPT, KTV = _tile_geometry(SG)
+    rows = []
+    for cp, is_v in ((CPR, False), (CPV, True)):
+        for i in range(wave, cp, NW):
+            words = []
+            for lane in range(64):
+                slot, c = divmod(i * 64 + lane, cp)
+                sc = min(slot, KTV - 1)
+                siy, six = divmod(sc, SG)
+                if not is_v:
+                    off, page = (c ^ ((slot >> KSH) & KSWZ)) * 16, 0
+                else:
+                    cs = c ^ (((slot >> 1) & 1) << 2) if HD == 64 else c
+                    off, page = (cs * 16, 0) if c < CPR else ((c - CPR) * 16, 1)
+                colpad = 1 if (padded and px0 + six >= gw) else 0
+                words.append(sc | siy << 8 | colpad << 12 | page << 13 | off << 16)
+            rows.append((is_v, i, words))
+    return rows
+
+
+@pytest.mark.parametrize("HD,NW,SG", [(80, 4, 64), (64, 4, 64), (80, 4, 14), (64, 4, 14), (32, 4, 16), (32, 2, 6)])
+def test_dma_table_reproduces_the_dma_image(HD, NW, SG):
+    """Decoding the table gives, for every LDS chunk, the (slot, source chunk) of the direct formula (_dma_images) — the fields
+    fit their bit ranges, every instruction of the tile is issued by exactly one wave."""
+    DT, lrow, VP, CPR, CPV, KSWZ, KSH = _geometry(HD)
+    RPT, KTV = _tile_geometry(SG)
+    kimg, vimg = _dma_images(HD)
+    seen_k, seen_v = set(), set()
+    for wave in range(NW):
+        for is_v, i, words in _dma_table(HD, NW, SG, wave, 0, 0, False):
+            for lane, t in enumerate(words):
+                e = i * 64 + lane
+                sc, siy, page, off = t & 255, (t >> 8) & 15, (t >> 13) & 1, t >> 16
+                assert t < 2 ** 32 and siy == sc // SG and siy < max(RPT, 1)
+                assert sc == min(e // (CPV if is_v else CPR), KTV - 1) and off % 16 == 0
+                if is_v and page:
+                    assert vimg[e] == ("pad", off // 16)
+                else:
+                    assert (vimg if is_v else kimg)[e] == (e // (CPV if is_v else CPR), off // 16)
+                (seen_v if is_v else seen_k).add(e)
+    assert len(seen_k) == 64 * CPR and len(seen_v) == 64 * CPV
+
+
+@pytest.mark.parametrize("SG,nwx,nwy,gh,gw", [(14, 3, 2, 22, 36), (14, 5, 5, 64, 64), (6, 3, 3, 16, 16), (14, 5, 3, 42, 64)])
+def test_dma_sources_never_touch_padded_rows(SG, nwx, nwy, gh, gw):
+    """FlashPad: whatever the slot — a key, a pad slot of the tile, a grid row beyond the window — the row a DMA lane fetches is
+    either the bias row or the qkv row of a REAL token of the same window, and a real key always fetches its own row (the
+    padded rows of the qkv matrix are never written by the qkv GEMM)."""
+    HD, NW = 80 if SG == 14 else 32, 4 if SG == 14 else 2
+    RPT, KTV = _tile_geometry(SG)
+    N = SG * SG
+    for w in range(nwx * nwy):
+        py0, px0 = (w // nwx) * SG, (w % nwx) * SG
+        for wave in range(NW):
+            for is_v, i, words in _dma_table(HD, NW, SG, wave, px0, gw, True):
+                for kt0, kh0 in zip(range(0, N, KTV), range(0, SG + RPT, RPT)):
+                    for t in words:
+                        sc, siy, colpad = t & 255, (t >> 8) & 15, (t >> 12) & 1
+                        if (t >> 13) & 1:
+                            continue                                        # constant pad page
+                        krow = min(kt0 + sc, N - 1)
+                        gr = kh0 + siy
+                        from_bias = bool(colpad) or gr >= SG or py0 + gr >= gh
+                        iy, ix = divmod(kt0 + sc, SG)
+                        real_key = kt0 + sc < N and py0 + iy < gh and px0 + ix < gw
+                        if real_key:
+                            assert not from_bias and krow == kt0 + sc
+                        if not from_bias:                                   # the row read is a real token of this window
+                            ry, rx = divmod(krow, SG)
+                            assert py0 + ry < gh and px0 + rx < gw
+
+
+def _wg_decode(L, nx, heads, B, uh):
+    if uh <= 0:
+        return L % nx, (L // nx) % heads, L // nx // heads
+    hg = heads // uh
+    units, pu = B * hg, uh * nx
+    full = units & ~7
+    if L < full * pu:
+        j = L >> 3
+        unit, r = (j // pu) * 8 + (L & 7), j % pu
+    else:
+        unit, r = full + (L - full * pu) // pu, (L - full * pu) % pu
+    return r % nx, (unit % hg) * uh + r // nx, unit // hg
+
+
+@pytest.mark.parametrize("nx,heads,B,uh", [(2, 16, 200, 16), (2, 16, 19, 16), (2, 2, 3, 2), (32, 16, 8, 1), (32, 3, 3, 1),
+                                           (32, 16, 8, 0), (1, 2, 11, 2)])
+def test_flash_work_order_is_a_bijection_that_keeps_units_on_one_xcd(nx, heads, B, uh):
+    """common.h flash_wg_decode: every (query block, head, b) exactly once; with uh > 0 the workgroups of a unit of the first
+    floor(units / 8) * 8 units all have the same L & 7 (= the XCD of a 1-D grid's round-robin dispatch)."""
+    total = nx * heads * B
+    seen = {}
+    for L in range(total):
+        x, h, b = _wg_decode(L, nx, heads, B, uh)
+        assert 0 <= x < nx and 0 <= h < heads and 0 <= b < B
+        assert (x, h, b) not in seen
+        seen[(x, h, b)] = L
+    assert len(seen) == total
+    if uh > 0:
+        hg = heads // uh
+        full = (B * hg) & ~7
+        for unit in range(full):
+            b, g = divmod(unit, hg)
+            xcds = {seen[(x, g * uh + hh, b)] & 7 for x in range(nx) for hh in range(uh)}
+            assert len(xcds) == 1

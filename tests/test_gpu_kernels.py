@@ -320,8 +320,10 @@ def _ref_vit_attention(qkv, rel_h, rel_w, B, S_, heads, hd, dtype=torch.float64)
     return (attn @ v).view(B, heads, N, hd).permute(0, 2, 1, 3).reshape(B * N, D)
 
 
-@pytest.mark.parametrize("B,S_,heads,hd", [(2, 64, 2, 80), (3, 14, 4, 80), (1, 64, 3, 64), (5, 14, 2, 64), (2, 16, 2, 32),
-                                            (4, 6, 2, 32)])
+# (19 windows / 3 x 3 (frame, head) pairs: two / one full groups of 8 units of the XCD-aware work order plus a tail, common.h
+#  flash_wg_decode)
+@pytest.mark.parametrize("B,S_,heads,hd", [(2, 64, 2, 80), (3, 14, 4, 80), (3, 64, 3, 64), (5, 14, 2, 64), (2, 16, 2, 32),
+                                            (4, 6, 2, 32), (19, 14, 2, 80), (11, 16, 2, 32)])
 def test_vit_flash_attention(lib, dev, B, S_, heads, hd):
     g = torch.Generator().manual_seed(S_ * hd)
     N, D = S_ * S_, heads * hd
@@ -336,7 +338,7 @@ def test_vit_flash_attention(lib, dev, B, S_, heads, hd):
 
 
 @pytest.mark.parametrize("B,S_,heads,hd", [(2, 64, 2, 80), (3, 14, 4, 80), (1, 64, 2, 64), (5, 14, 2, 64), (2, 16, 2, 32),
-                                            (4, 6, 2, 32)])
+                                            (4, 6, 2, 32), (19, 14, 2, 80), (11, 16, 2, 32)])
 def test_vit_flash_attention_x3(lib, dev, B, S_, heads, hd):
     """The split-fp16 attention kernel (precision "f16x3"): fp32-grade against the fp64 attention of the same fp32 q / k / v —
     three orders of magnitude tighter than the fp16 kernel's bar — including scores large enough that softmax is peaked."""
