@@ -15,8 +15,9 @@ Parity status: the reference has no tests / golden vectors for this boundary (SU
 the upstream source is absent, so the pin is a *secondary* one: ``tests/test_oracle_pins.py`` copies the
 weights into HuggingFace ``transformers.models.sam`` (an independent implementation of the same
 arithmetic that ships in this image) and requires agreement to fp32 round-off on image embeddings,
-low-res mask logits and IoU predictions.  Anything HF cannot check (SamPredictor plumbing,
-postprocess) is marked "parity unpinned" where it occurs.
+low-res mask logits and IoU predictions; ``postprocess_masks``, ``get_preprocess_shape`` and the prompt-coordinate transform
+are pinned bit for bit on HF's ``SamImageProcessor`` / ``SamProcessor`` (live, no weights involved).  What HF cannot check (the
+rest of the SamPredictor plumbing) is marked "parity unpinned" where it occurs.
 """
 from __future__ import annotations
 
@@ -313,7 +314,8 @@ def mask_decoder(sd: SD, cfg: SamConfig, image_embeddings, image_pe, sparse, den
 
 
 def postprocess_masks(cfg: SamConfig, masks, input_size, original_size):
-    """Sam.postprocess_masks (App. A-2).  parity unpinned (no HF equivalent with the same crop order)."""
+    """Sam.postprocess_masks (App. A-2).  Pinned on HuggingFace's SamImageProcessor.post_process_masks (same three steps, bit-identical:
+    tests/test_oracle_pins.py::test_postprocess_and_preprocess_shape_vs_hf)."""
     masks = F.interpolate(masks, (cfg.img_size, cfg.img_size), mode="bilinear", align_corners=False)
     masks = masks[..., :input_size[0], :input_size[1]]
     return F.interpolate(masks, original_size, mode="bilinear", align_corners=False)
