@@ -48,6 +48,9 @@
 // acknowledged, and the 64 MB all CUs write at the end of a round of tiles drain at memory bandwidth while only 1.75 K-tiles
 // of the next tile are prefetched.  A two-pass epilogue (all residual loads folded into the accumulators in place, then all
 // stores) removes those waits on paper but costs ~100 spilled VGPRs (the kernel sits at 250 of 256): not shipped.
+// The in-place residual add as f32 atomics in the L2 (C += v: no residual load, no round trip, the same single rounding) is correct
+// and 3.4 x slower — proj at M = 32768: 562 vs 164 us, 128 global_atomic_add_f32 per lane and tile against 32 + 32 16-byte
+// accesses (profiles/r4_c23_*): the L2 retires ~0.1 T dword atomics per second.
 //
 // GemmP::x3 (template X3): the operands are "x3 rows" (common.h: every 64-half K-tile row is [hi(32) | lo(32)] of 32 real k)
 // and a phase issues 24 MFMAs instead of 16 — hi.hi + hi.lo + lo.hi per fragment pair, fp32-grade products at a third of

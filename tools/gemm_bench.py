@@ -36,7 +36,7 @@ def run(dt, A, W, bias, res, C, act, rowmap=None, a_rowmap=None, M=None):
                "gemm_ex")
 
 
-def check(M, N, K, dt, act, use_res, scatter=False, gather=False):
+def check(M, N, K, dt, act, use_res, scatter=False, gather=False, inplace=False):
     A = (torch.randn(M, K, generator=g) * 0.5).half().to(dev)
     W = (torch.randn(N, K, generator=g) / K ** 0.5).half().to(dev)
     bias = torch.randn(N, generator=g).to(dev)
@@ -53,12 +53,16 @@ def check(M, N, K, dt, act, use_res, scatter=False, gather=False):
         Asrc = A[a_rowmap.long()]
     res = torch.randn(rows_out, N, generator=g).to(dev) if use_res else None
     C = torch.full((rows_out, N), 7.0, device=dev, dtype=torch.float16 if dt == 2 else torch.float32)
-    run(dt, A, W, bias, res, C, act, rowmap, a_rowmap)
+    if inplace:                      # the encoder's residual stream: C is the residual (rows no tile writes keep their value)
+        C, res = res.clone(), res.clone()
+        run(dt, A, W, bias, C, C, act, rowmap, a_rowmap)
+    else:
+        run(dt, A, W, bias, res, C, act, rowmap, a_rowmap)
     torch.cuda.synchronize()
     ref = Asrc.double() @ W.double().t() + bias.double()
     if act == 2:
         ref = F.gelu(ref)
-    full = torch.full((rows_out, N), 7.0, device=dev, dtype=torch.float64)
+    full = res.double().clone() if inplace else torch.full((rows_out, N), 7.0, device=dev, dtype=torch.float64)
     if scatter:
         keep = rowmap >= 0
         full[rowmap[keep].long()] = ref[keep] + (res[rowmap[keep].long()].double() if use_res else 0)
@@ -66,7 +70,7 @@ def check(M, N, K, dt, act, use_res, scatter=False, gather=False):
         full = ref + (res.double() if use_res else 0)
     err = (C.double() - full).abs().max().item() / full.abs().max().item()
     tol = 1.5e-3 if dt == 2 else 2e-5
-    tag = f"M={M} N={N} K={K} dt={dt} act={act} res={int(use_res)} scatter={int(scatter)} gather={int(gather)}"
+    tag = f"M={M} N={N} K={K} dt={dt} act={act} res={int(use_res)} scatter={int(scatter)} gather={int(gather)} inplace={int(inplace)}"
     print(f"check {tag}: max err / max |ref| = {err:.2e} {'OK' if err < tol else 'FAIL'}", flush=True)
     return err < tol
 
@@ -77,7 +81,8 @@ if CHECK:
                  (2688, 5120, 1280, 2, 2, False), (2688, 1280, 5120, 1, 0, True), (1000, 512, 256, 1, 2, True),
                  (4900, 3840, 1280, 2, 0, False, True, False), (4900, 1280, 1280, 1, 0, True, False, True),
                  (8 * 2688 + 77, 1280, 1280, 1, 0, True, True, True), (300, 256, 128, 2, 0, False),
-                 (257, 768, 3072, 1, 0, True), (16384, 2304, 768, 2, 0, False)]:
+                 (257, 768, 3072, 1, 0, True), (16384, 2304, 768, 2, 0, False),
+                 (2688, 1280, 1280, 1, 0, True, False, False, True), (2688 + 77, 1280, 5120, 1, 0, True, True, True, True)]:
         ok &= check(*args)
     # run-to-run determinism and independence of the launch's other rows: the first 2688 rows of a big launch == a small one
     A = (torch.randn(8 * 2688, 1280, generator=g) * 0.5).half().to(dev)
