@@ -1,6 +1,9 @@
 # scratch script of the current gpurun call (overwritten per call; the logs it leaves are copied to profiles/r4_*)
 set -u
-R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/r4_c23; mkdir -p $OUT; cd $R
-timeout 100 python tools/gemm_bench.py 8 2>&1 | grep -v amdgpu.ids > $OUT/gemm_atomic.log
-SAMPT_P8_ATOMIC=0 timeout 80 python tools/gemm_bench.py 8 nocheck 2>&1 | grep -v amdgpu.ids > $OUT/gemm_noatomic.log
-grep -E "inplace=1|ALL CHECKS|FAIL" $OUT/gemm_atomic.log | cut -c1-160; grep -E "proj|fc2|mix" $OUT/gemm_atomic.log; echo ---; grep -E "proj|fc2|mix" $OUT/gemm_noatomic.log
+R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/r4_c24; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
+ATTN_BENCH_LIB=$R/tools/_ab/libsampt_hip_head.so timeout 100 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/old -- python $R/tools/attn_bench.py > $OUT/old.log 2>&1
+timeout 100 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/new -- python $R/tools/attn_bench.py > $OUT/new.log 2>&1
+cd $R
+echo "# previous commit's kernels (3-D grid, dispatch order)" > $OUT/attn_fetch_size.txt; python tools/pmc_summary.py $OUT/old flash >> $OUT/attn_fetch_size.txt
+echo "# this build (1-D grid, windows XCD-aware)" >> $OUT/attn_fetch_size.txt; python tools/pmc_summary.py $OUT/new flash >> $OUT/attn_fetch_size.txt
+rm -rf $OUT/old $OUT/new; cat $OUT/attn_fetch_size.txt; tail -2 $OUT/new.log
