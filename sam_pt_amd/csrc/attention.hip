@@ -157,7 +157,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void k_flash_f16(const ha
   // grid column is window padding — does not depend on the tile: worked out once per workgroup into this table (one word per
   // (instruction of this wave, lane), read back by the lane that wrote it), so that the per-tile address of a DMA instruction is
   // a row pointer plus a table offset instead of two integer divisions and the swizzle — those were ~100 of the ~300 VALU
-  // instructions per tile and wave of the global kernel and more than half of the windowed kernel's (which are VALU-bound).
+  // instructions per tile and wave of the global kernel (-4 %: 1087 -> 1041 us per 8 frames) and more of the windowed kernel's
+  // (no change: profiles/r4_c25_* — that kernel is 70 us of prologue + 89 us of DMA / barrier skeleton + 55 us of arithmetic).
   //   bits 0-7 slot (clamped to the tile's last key), 8-11 grid row of the slot inside the tile, 12 column is padding,
   //   13 source is the constant pad page, 16-31 byte offset inside the K / V row of this head (or inside the pad page)
   constexpr int NKI = (CPR + NW - 1) / NW, NVI = (CPV + NW - 1) / NW;
