@@ -103,7 +103,9 @@ class SamPt(nn.Module):
         self.compute_unused_query_masks = False        # fused path: see forward()
         self.overlap_tracker_and_encoder = True        # fused path only: tracker on a second HIP stream (see forward)
         # persistent GEMM workgroups per XCD (of 32 CUs) for the encoder batches while the tracker runs beside them: an int or
-        # one entry per batch (the last repeats); None / 0 = every CU.  SAMPT_ENC_WGS="28,28,32" overrides (experiments).
+        # one entry per batch (the last repeats); None / 0 = every CU.  SAMPT_ENC_WGS="28,28,32" overrides (experiments; that one —
+        # every CU for the last batch, whose second half the tracker's rounds no longer share — measured 111.0 against 114.7 fps
+        # with clips in flight: the decoder chain and the next clip's tracker encoder want those CUs, profiles/r4_c27_*).
         env = os.environ.get("SAMPT_ENC_WGS")
         self.encoder_gemm_workgroups_beside_tracker = [int(v) for v in env.split(",")] if env else 28
         # fused path only.  The decoder chain always runs on a third (non-default, hence hipGraph-capturable) stream after
