@@ -377,6 +377,21 @@ int sampt_vit_attention_f16(const void* qkv_dev, const float* rel_h_dev, const f
 int sampt_kmedoids_rowsums_f64(const float* xy_dev, int n, double* out_dev, sampt_stream_t stream);
 int sampt_kmedoids_alternate(const float* xy_dev, int n, int K, int32_t* medoids_dev, int max_iter, int32_t* iters_dev,
                              sampt_stream_t stream);
+/* Shi-Tomasi query points and mask erosion on the device (replaces the cv2 calls of
+ * sam_pt/utils/query_points.py:102-162 extract_corner_points and :165-194 erode_mask_proportional_to_its_furthest_points_distance;
+ * bit-identical to the numpy restatement of OpenCV's algorithms in sam_pt_amd/query_points.py).
+ *   erode:      out = cv2.erode(mask, ones((k, k))) of a {0, 1} byte mask [H][W]; k = 0 means the default 3 x 3, k = 1 a copy;
+ *               tmp_dev: H*W scratch bytes.
+ *   shi_tomasi: image_dev u8 [3][H][W] RGB, mask_dev u8 {0, 1} [H][W].  Gray conversion, the 6 % / 2 % / 1 % / no erosion cascade
+ *               (>= 10 surviving pixels), cornerMinEigenVal(3, 3), threshold at quality_level x the maximum inside the eroded
+ *               mask, 3 x 3 local maxima, greedy selection of up to n_points (<= 64) corners at minDistance = the eroded mask's
+ *               bounding-box diagonal / n_points — one launch sequence without a host round trip.  out_xy_dev f32 [n_points][2]
+ *               (x, y); out_info_dev int32 [16]: [12] corners found, [10] k of the erosion kept (-1: the mask itself), [9] pixels
+ *               of the eroded mask, [5..8] its bounding box (ymin, ymax, xmin, xmax), [0..4] the mask's bounding box and count. */
+int sampt_qp_corners_workspace_bytes(int H, int W, size_t* bytes);
+int sampt_qp_erode_u8(const uint8_t* mask_dev, int H, int W, int k, uint8_t* tmp_dev, uint8_t* out_dev, sampt_stream_t stream);
+int sampt_qp_shi_tomasi(const uint8_t* image_dev, const uint8_t* mask_dev, int H, int W, int n_points, float quality_level,
+                        float* out_xy_dev, int32_t* out_info_dev, void* ws_dev, size_t ws_bytes, sampt_stream_t stream);
 /* The same attention at fp32 grade (precision "f16x3": three split-fp16 MFMAs per product in Q.K^T, the bias tables and
  * P.V; fp32 softmax).  qkv_dev: x3 rows [B*S*S][2*3*heads*hd] halves (what the dtype-4 qkv GEMM writes), out_dev: x3 rows
  * [B*S*S][2*heads*hd].  Same geometries as sampt_vit_attention_f16; heads*hd % 32 == 0. */

@@ -75,7 +75,10 @@ def reference_run(cfg, sd, psd, frames: torch.Tensor, query_points: torch.Tensor
         _, logits, spf = model._apply_sam_to_trajectories(*args) if _is_reference(model) else model._apply_sam_to_trajectories(*args, None)
     sec["predict_calls"] = pred.n_predict
     return {"trajectories": traj, "visibilities": vis, "logits": logits, "scores_per_frame": spf, "frame_ids": ids,
-            "embeddings": torch.stack(embeddings) if embeddings else None, "seconds": sec}
+            "embeddings": torch.stack(embeddings) if embeddings else None, "seconds": sec,
+            # which SamPt class drove the oracle modules: recorded in the cache file and in bench.py's parity block
+            "driver": "reference SamPt (/root/reference)" if _is_reference(model) else "sam_pt_amd.SamPt host logic (pinned on "
+                      "tests/golden/sampt_ref.npz)"}
 
 
 # constructor keywords of the reference SamPt (sam_pt/modeling/sam_pt.py:28-50 has no defaults) = configs/model/sam_pt.yaml,

@@ -108,6 +108,9 @@ _SIGS = {
     "sampt_vit_window_attention": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P]),
     "sampt_kmedoids_rowsums_f64": (c_int, [_P, c_int, _P, _P]),
     "sampt_kmedoids_alternate": (c_int, [_P, c_int, c_int, _P, c_int, _P, _P]),
+    "sampt_qp_corners_workspace_bytes": (c_int, [c_int, c_int, C.POINTER(c_size_t)]),
+    "sampt_qp_erode_u8": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
+    "sampt_qp_shi_tomasi": (c_int, [_P, _P, c_int, c_int, c_int, c_float, _P, _P, _P, c_size_t, _P]),
 }
 
 _lib = None

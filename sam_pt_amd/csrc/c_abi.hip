@@ -596,6 +596,24 @@ int sampt_kmedoids_alternate(const float* xy, int n, int K, int32_t* medoids, in
   return rc == SAMPT_ERR_ARG ? fail(rc, "sampt_kmedoids_alternate: bad arguments (1 <= K <= min(n, 64), n <= 2048)") : rc;
 }
 
+int sampt_qp_corners_workspace_bytes(int H, int W, size_t* bytes) {
+  if (!bytes || H < 3 || W < 3) return fail(SAMPT_ERR_ARG, "sampt_qp_corners_workspace_bytes: bad arguments");
+  *bytes = qp_corners_workspace_bytes(H, W);
+  return SAMPT_OK;
+}
+
+int sampt_qp_erode_u8(const uint8_t* mask, int H, int W, int k, uint8_t* tmp, uint8_t* out, sampt_stream_t stream) {
+  int rc = qp_erode(mask, H, W, k, tmp, out, (hipStream_t)stream);
+  return rc == SAMPT_ERR_ARG ? fail(rc, "sampt_qp_erode_u8: bad arguments") : rc;
+}
+
+int sampt_qp_shi_tomasi(const uint8_t* image, const uint8_t* mask, int H, int W, int n_points, float quality_level, float* out_xy,
+                        int32_t* out_info, void* ws, size_t ws_bytes, sampt_stream_t stream) {
+  int rc = qp_corners(image, mask, H, W, n_points, quality_level, out_xy, (int*)out_info, ws, ws_bytes, (hipStream_t)stream);
+  return rc == SAMPT_ERR_ARG ? fail(rc, "sampt_qp_shi_tomasi: bad arguments (H, W >= 3, 1 <= n_points <= 64, workspace of "
+                                        "sampt_qp_corners_workspace_bytes)") : rc;
+}
+
 int sampt_split_rows_x3(const float* x, void* y, int M, int K, sampt_stream_t stream) {
   if (!x || !y) return fail(SAMPT_ERR_ARG, "sampt_split_rows_x3: bad arguments");
   return split_rows_x3(x, (half_t*)y, M, K, (hipStream_t)stream);

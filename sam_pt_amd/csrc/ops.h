@@ -78,6 +78,17 @@ int kmedoids_rowsums(const float* xy, int n, double* out, hipStream_t s);
 // medoids: device int [K], in = the initial medoids, out = the converged ones; iters_out (device int, optional) = iterations run
 int kmedoids_alternate(const float* xy, int n, int K, int* medoids, int max_iter, int* iters_out, hipStream_t s);
 
+// ---- corners.hip (Shi-Tomasi query points + mask erosion, sam_pt/utils/query_points.py:102-194; bit-identical to the numpy
+// restatement in sam_pt_amd/query_points.py)
+size_t qp_corners_workspace_bytes(int H, int W);
+// out = cv2.erode(mask, ones((k, k))) for a {0, 1} byte mask [H][W] (k = 0: the default 3 x 3; k = 1: a copy); tmp: H*W bytes
+int qp_erode(const uint8_t* mask, int H, int W, int k, uint8_t* tmp, uint8_t* out, hipStream_t s);
+// image u8 [3][H][W] RGB, mask u8 {0, 1} [H][W] -> up to n_points corners (x, y) f32 in out_xy [n_points][2]; out_info: 16 int32
+// (device): [12] = corners found, [10] = k of the erosion that was kept (-1: none), [9] = pixels of the eroded mask, [5..8] its
+// bounding box (ymin, ymax, xmin, xmax), [0..4] the mask's bounding box and pixel count
+int qp_corners(const uint8_t* image, const uint8_t* mask, int H, int W, int n_points, float quality, float* out_xy, int* out_info,
+               void* ws, size_t ws_bytes, hipStream_t s);
+
 // ---- pips.hip ---------------------------------------------------------------------------------
 struct PyramidLevels {
   const float* base[4];   // level l: [nframes][H_l][W_l][C] f32 NHWC

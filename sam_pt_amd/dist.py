@@ -183,11 +183,12 @@ def _index_masks(logits: torch.Tensor, query_timestep=None, query_masks=None, ou
     return prob.argmax(dim=0).to(torch.uint8)
 
 
-def gather_masks(masks: torch.Tensor, max_frames: int) -> Optional[torch.Tensor]:
+def gather_masks(masks: torch.Tensor, max_frames: int, force: bool = False) -> Optional[torch.Tensor]:
     """All ranks call with their uint8 (T_local,H,W) masks; rank 0 receives (world, max_frames, H, W) (zero padded).
     Single fixed-shape ``gather`` to rank 0 over RCCL/xGMI (or gloo on CPU): every rank sends its own 0.59 MB/frame once —
-    the payload SURVEY.md §8e states — instead of an all_gather's N copies."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    the payload SURVEY.md §8e states — instead of an all_gather's N copies.  ``force``: issue the collective even in a
+    one-rank process group (the RCCL readiness test: the very same call path on hardware when only one GPU is available)."""
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return masks[None]
     T, H, W = masks.shape
     pad = torch.zeros((max_frames, H, W), dtype=torch.uint8, device=masks.device)
@@ -200,13 +201,27 @@ def gather_masks(masks: torch.Tensor, max_frames: int) -> Optional[torch.Tensor]
     return None
 
 
-def sharded_forward(model, video, batch: int = 8, shard_fnet: bool = True, emulate=None):
+def fnet_shard_usable(n_frames: int, world: int, batch: int) -> bool:
+    """The pyramid all_gather of ``FnetShard`` is entered from inside ``model(...)``, which a rank without a frame batch never
+    calls: the exchange is only safe when EVERY rank of the job owns at least one frame batch.  Pure function of (T, world,
+    batch), so every rank reaches the same verdict without talking to the others."""
+    return all(len(frame_batches(n_frames, world, k, batch)) > 0 for k in range(world))
+
+
+def sharded_forward(model, video, batch: int = 8, shard_fnet: bool = False, emulate=None, force_collectives: bool = False):
     """One clip over all ranks (BASELINE config #5 / SURVEY.md §8e): frame batches of ``batch`` frames are dealt round
     robin (``frame_batches``); a rank runs the image encoder and the mask decoder on ITS frames only and contributes their
-    uint8 index masks to one fixed-shape gather.  The tracker needs every frame: with ``shard_fnet`` its per-frame encoder is
-    frame-sharded too and the feature pyramid is all-gathered (``FnetShard``, the one exchange step of this mode); the window
-    chain — sequential in time by construction (pips/tracker.py:67-148), latency-bound, identical on every rank — is replicated.
+    uint8 index masks to one fixed-shape gather — with the default ``shard_fnet=False`` that gather is the ONLY collective,
+    which is the mode north_star describes ("RCCL over xGMI only for the final mask gather"): every rank runs the tracker
+    (encoder + window chain) on the whole clip.  ``shard_fnet=True`` is the opt-in extension: the tracker's per-frame encoder
+    is frame-sharded too and the feature pyramid is all-gathered (``FnetShard``, 25 MB per 576x1024 frame — a real exchange
+    step that north_star does not have); it is enabled only when every rank owns a frame batch (``fnet_shard_usable``: a rank
+    without frames never enters ``model`` and would leave the others waiting in the all_gather).  The window chain —
+    sequential in time by construction (pips/tracker.py:67-148), latency-bound, identical on every rank — is replicated.
     Returns (index masks (T,H,W) uint8 on rank 0 / None elsewhere, the rank's own SamPt output dict).
+
+    ``force_collectives``: run the pyramid all_gather (with ``shard_fnet``) and the mask gather even in a ONE-rank process group
+    (tests/test_gpu_dist_nccl.py: RCCL init + both collectives on hardware where only one GPU is available).
 
     ``emulate=(r, N)``: no process group — this process runs exactly rank r's share of an N-rank job, collectives stubbed
     (``FnetShard(emulate=True)``; the mask gather is skipped); the FnetShard is returned in the output dict's place of honour
@@ -217,10 +232,11 @@ def sharded_forward(model, video, batch: int = 8, shard_fnet: bool = True, emula
         world = dist.get_world_size() if dist.is_initialized() else 1
         rank = dist.get_rank() if dist.is_initialized() else 0
     T = len(video["image"])
-    fs = FnetShard(rank, world, emulate=emulate is not None) if (shard_fnet and world > 1) else None
+    batch = max(1, min(batch, -(-T // world)))          # short clips: shrink the batches so that most ranks get frames
+    use_fs = shard_fnet and (world > 1 or force_collectives) and fnet_shard_usable(T, world, batch)   # the same verdict on every rank
+    fs = FnetShard(rank, world, emulate=emulate is not None) if use_fs else None
     if fs is not None:
         video = {**video, "fnet_shard": fs}
-    batch = max(1, min(batch, -(-T // world)))          # short clips: shrink the batches so that most ranks get frames
     mine = [t for r in frame_batches(T, world, rank, batch) for t in r]
     if mine:
         out = model({**video, "frame_ids": mine})
@@ -233,7 +249,7 @@ def sharded_forward(model, video, batch: int = 8, shard_fnet: bool = True, emula
     if emulate is not None:
         return masks, out
     per_rank = max(len([t for r in frame_batches(T, world, k, batch) for t in r]) for k in range(world))
-    gathered = gather_masks(masks, per_rank)
+    gathered = gather_masks(masks, per_rank, force=force_collectives)
     if rank != 0:
         return None, out
     full = torch.zeros((T,) + tuple(masks.shape[1:]), dtype=torch.uint8, device=masks.device)

@@ -16,7 +16,9 @@ Needed by ``SamPt`` in ``query_masks`` mode (every VOS run, sam_pt.py:171-177) a
   of one negative point it is a single random point.
 * ``extract_corner_points`` — Shi-Tomasi corners on an eroded mask.  The reference uses ``cv2.cvtColor``, ``cv2.erode``
   and ``cv2.goodFeaturesToTrack``; OpenCV is absent, so its published algorithms are restated in numpy — **parity
-  unpinned**.
+  unpinned** against OpenCV itself (the erosion is pinned on ``scipy.ndimage.binary_erosion`` and the min-eigenvalue map
+  cross-checked against ``scipy.ndimage`` filters, tests/test_cpu_host.py).  With a HIP device the whole corner selection runs
+  there (``shi_tomasi_device``, csrc/corners.hip), bit-identical to the numpy restatement.
 """
 from __future__ import annotations
 
@@ -211,13 +213,59 @@ def good_features_to_track(gray: np.ndarray, max_corners: int, quality_level: fl
     return np.asarray(out, dtype=np.float32).reshape(-1, 2)
 
 
+def erode_device(mask: torch.Tensor, k: int, device) -> torch.Tensor:
+    """``_erode`` on the HIP device (csrc/corners.hip, separable): mask (H,W) {0,1} -> uint8 (H,W) on ``device``."""
+    from . import _lib
+    lib = _lib.load()
+    with _lib.device_guard(torch.device(device)):
+        m = (mask > 0).to(torch.uint8).contiguous().to(device)
+        tmp, out = torch.empty_like(m), torch.empty_like(m)
+        _lib.check(lib.sampt_qp_erode_u8(_lib.ptr(m), m.shape[0], m.shape[1], int(k), _lib.ptr(tmp), _lib.ptr(out), _lib.stream_ptr()),
+                   "sampt_qp_erode_u8")
+        return out
+
+
+def shi_tomasi_device(image: torch.Tensor, mask: torch.Tensor, n_points: int, device, quality_level: float = 0.001):
+    """The Shi-Tomasi half of ``extract_corner_points`` on the HIP device (csrc/corners.hip): gray conversion, the 6 % / 2 % / 1 %
+    erosion cascade, min-eigenvalue map, threshold, local maxima and the greedy minimum-distance selection in ONE launch sequence
+    without a host round trip; one download of (n, 2) corners + 16 ints at the end.  Bit-identical to the host functions above
+    (tests/test_gpu_kernels.py::test_shi_tomasi_device_equals_host_restatement).  -> (corners (n_found, 2) float32 (x, y) on the
+    host, info dict: k of the erosion kept (-1 = the mask itself), eroded pixel count / bounding box)."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    H, W = int(mask.shape[0]), int(mask.shape[1])
+    with _lib.device_guard(torch.device(device)):
+        img = image.to(device=device, dtype=torch.uint8).contiguous()
+        m = (mask > 0).to(torch.uint8).contiguous().to(device)
+        nb = C.c_size_t()
+        _lib.check(lib.sampt_qp_corners_workspace_bytes(H, W, C.byref(nb)), "sampt_qp_corners_workspace_bytes")
+        ws = torch.empty(nb.value, dtype=torch.uint8, device=device)
+        xy = torch.zeros((n_points, 2), dtype=torch.float32, device=device)
+        info = torch.zeros(16, dtype=torch.int32, device=device)
+        _lib.check(lib.sampt_qp_shi_tomasi(_lib.ptr(img), _lib.ptr(m), H, W, int(n_points), float(quality_level), _lib.ptr(xy),
+                                           _lib.ptr(info), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "sampt_qp_shi_tomasi")
+        inf = info.cpu().tolist()                                  # the one synchronisation
+        return xy.cpu()[:inf[12]], {"k": inf[10], "eroded_pixels": inf[9], "eroded_bbox": inf[5:9], "mask_bbox": inf[0:4],
+                                    "mask_pixels": inf[4]}
+
+
 def extract_corner_points(image: torch.Tensor, mask: torch.Tensor, n_points_to_select: int,
                           kmedoid_subsample_size: int = 2000, device=None) -> torch.Tensor:
     """Shi-Tomasi corners inside the eroded mask, topped up with k-medoid points (query_points.py:102-162).
-    image (3,H,W) uint8, mask (H,W) {0,1} -> (n,2) float32 (x, y).  PARITY UNPINNED (see the note above)."""
+    image (3,H,W) uint8, mask (H,W) {0,1} -> (n,2) float32 (x, y).  ``device``: a HIP device runs the corner selection there
+    (``shi_tomasi_device``: the same corners bit for bit).  PARITY UNPINNED against OpenCV (see the note above)."""
     if mask.sum() == 0:
         print("Warning: mask.sum() == 0 in extract_corner_points")
         return torch.zeros((n_points_to_select, 2))
+    if (device is not None and torch.device(device).type == "cuda" and 1 <= n_points_to_select <= 64
+            and min(mask.shape[-2:]) >= 3):
+        corners, _ = shi_tomasi_device(image, mask, n_points_to_select, device)
+        if len(corners) < n_points_to_select:
+            corners = torch.cat((corners, extract_kmedoid_points(mask.cpu(), n_points_to_select - corners.shape[0],
+                                                                 subsample_size=kmedoid_subsample_size, device=device)), dim=0)
+        assert corners.shape == (n_points_to_select, 2)
+        return corners
     img = image.permute(1, 2, 0).cpu().numpy()
     eroded = erode_mask_proportional_to_its_furthest_points_distance(mask, 0.06)
     for pct in (0.02, 0.01):

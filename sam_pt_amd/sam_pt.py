@@ -103,11 +103,13 @@ class SamPt(nn.Module):
         self.compute_unused_query_masks = False        # fused path: see forward()
         self.overlap_tracker_and_encoder = True        # fused path only: tracker on a second HIP stream (see forward)
         # persistent GEMM workgroups per XCD (of 32 CUs) for the encoder batches while the tracker runs beside them: an int or
-        # one entry per batch (the last repeats); None / 0 = every CU.  SAMPT_ENC_WGS="28,28,32" overrides (experiments; that one —
+        # one entry per batch (the last repeats); 0 = every CU; None (the default) = resolved per ViT precision in
+        # ``_encoder_gemm_workgroups`` (28 for fp16, every CU for f16x3).  An explicit setting — attribute or
+        # SAMPT_ENC_WGS="28,28,32" — is always honoured as given (experiments; that one —
         # every CU for the last batch, whose second half the tracker's rounds no longer share — measured 111.0 against 114.7 fps
         # with clips in flight: the decoder chain and the next clip's tracker encoder want those CUs, profiles/r4_c27_*).
         env = os.environ.get("SAMPT_ENC_WGS")
-        self.encoder_gemm_workgroups_beside_tracker = [int(v) for v in env.split(",")] if env else 28
+        self.encoder_gemm_workgroups_beside_tracker = [int(v) for v in env.split(",")] if env else None
         # fused path only.  The decoder chain always runs on a third (non-default, hence hipGraph-capturable) stream after
         # the encoder; pipeline_decoder=True instead starts the chains of each encoder batch as soon as that batch is done,
         # and overlap_tracker_encoder_fnet=True moves the tracker's own encoder to the side stream too.  Both were
@@ -235,11 +237,7 @@ class SamPt(nn.Module):
             # the tracker's window rounds run BESIDE the encoder on the side stream: leave them whole CUs (a persistent GEMM
             # workgroup owns its CU; measured on MI355X, profiles/r3_v3_timeline_wgs*.log: 32 / 30 workgroups per XCD
             # 248 ms per clip with the tracker ending 24 ms after the encoder, 28 per XCD 229 ms)
-            reserve = self.encoder_gemm_workgroups_beside_tracker if overlap else None
-            # (the split-fp16 encoder takes twice as long, so the tracker's rounds end long before it either way: measured 59.5 fps
-            #  with every CU given to the GEMMs against 58.5 with 28 per XCD, profiles/r4_c8_bench_x3_wgs*.log)
-            if reserve == 28 and getattr(getattr(self.sam_predictor, "model", None), "precision", None) == "f16x3":
-                reserve = None
+            reserve = self._encoder_gemm_workgroups() if overlap else None
             kw = {"gemm_workgroups": reserve} if reserve else {}
             feats = self.sam_predictor.encode_frames(sam_images, chw=True, batch_events=batch_events, **kw)   # embeddings in HBM
             self._mark("encoded")
@@ -304,6 +302,16 @@ class SamPt(nn.Module):
         else:
             trajectories, visibilities, logits, scores, scores_per_frame = self._forward_w_reinit(images, query_points, feats)
         return tail(trajectories, visibilities, logits, scores, scores_per_frame)
+
+    def _encoder_gemm_workgroups(self):
+        """The knob ``encoder_gemm_workgroups_beside_tracker`` resolved: an explicit value (int, list, SAMPT_ENC_WGS) as given;
+        the default None -> 28 per XCD for the fp16 ViT (measured: profiles/r3_v3_timeline_wgs*.log) and every CU for f16x3
+        (the split-fp16 encoder takes twice as long, so the tracker's rounds end long before it either way: 59.5 fps against
+        58.5 with 28 per XCD, profiles/r4_c8_bench_x3_wgs*.log)."""
+        v = self.encoder_gemm_workgroups_beside_tracker
+        if v is not None:
+            return v
+        return None if getattr(getattr(self.sam_predictor, "model", None), "precision", None) == "f16x3" else 28
 
     def _mark(self, name):
         if self.timeline is not None and torch.cuda.is_available():

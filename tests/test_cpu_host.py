@@ -509,6 +509,121 @@ dist.barrier(); dist.destroy_process_group()
     assert "SHARDED_OK" in r.stdout
 
 
+def test_erosion_and_min_eigenvalue_map_against_scipy():
+    """Independent pins of two pieces of the OpenCV restatement (cv2 itself is absent): ``_erode`` equals
+    ``scipy.ndimage.binary_erosion`` with a k x k structuring element and border_value = 1 bit for bit (odd and even k: same anchor
+    convention k // 2), and ``corner_min_eigen_val`` equals the textbook formula assembled from ``scipy.ndimage`` filters in fp64
+    (Sobel with mode 'mirror' = BORDER_REFLECT_101, 3 x 3 box sum, smaller eigenvalue) to fp32 round-off."""
+    import numpy as np
+    import scipy.ndimage as ndi
+    from sam_pt_amd import query_points as Q
+    rng = np.random.default_rng(0)
+    for k in (2, 3, 4, 5, 8, 11, 24):
+        m = (rng.random((40, 57)) > 0.12).astype(np.uint8)
+        m[:, :3] = 1
+        assert np.array_equal(Q._erode(m, k), ndi.binary_erosion(m, structure=np.ones((k, k)), border_value=1).astype(np.uint8)), k
+    g = rng.integers(0, 256, (50, 70)).astype(np.uint8)
+    g[10:30, 20:50] = 180
+    gf = g.astype(np.float64)
+    scale = 1.0 / (4.0 * 3 * 255.0)
+    dx = ndi.sobel(gf, axis=1, mode="mirror") * scale
+    dy = ndi.sobel(gf, axis=0, mode="mirror") * scale
+    box = lambda a: ndi.uniform_filter(a, size=3, mode="mirror") * 9.0
+    a, b, c = box(dx * dx) * 0.5, box(dx * dy), box(dy * dy) * 0.5
+    want = (a + c) - np.sqrt((a - c) ** 2 + b * b)
+    got = Q.corner_min_eigen_val(g).astype(np.float64)
+    assert np.abs(got - want).max() <= 2e-6 * max(1.0, np.abs(want).max()), np.abs(got - want).max()
+
+
+KMEDOIDS_GOLDEN = [[10, 24, 27], [32, 42, 95, 100, 126, 202, 205, 216], [241, 263, 684, 842, 888, 1301, 1478, 1524],
+                   [84, 141, 186, 271, 275, 358, 410, 475, 497, 528, 558, 599, 700, 740, 783, 786]]
+
+
+def test_kmedoids_host_restatement_golden():
+    """the device k-medoids is bit-identical to ``kmedoids_alternate`` by GPU tests only, and that identity leans on
+    numpy internals (pairwise summation, argpartition's introselect order).  Fixed point sets with their medoids written down: a
+    numpy upgrade that changes either shows up here, on the CPU."""
+    import numpy as np
+    from sam_pt_amd.query_points import kmedoids_alternate
+    rng = np.random.default_rng(1234)
+    got = []
+    for n, K in ((40, 3), (257, 8), (1800, 8), (900, 16)):
+        pts = np.unique(rng.integers(0, 200, (n, 2)), axis=0).astype(np.float32)
+        got.append(sorted(int(i) for i in kmedoids_alternate(pts, K)))
+    want = KMEDOIDS_GOLDEN
+    assert got == want, got
+
+
+def test_fnet_shard_is_enabled_only_when_every_rank_owns_a_frame_batch():
+    """the pyramid all_gather is entered from inside model(...), which a rank without a frame batch never calls.
+    ``fnet_shard_usable`` is a pure function of (T, world, batch) — every rank reaches the same verdict — and is False for
+    exactly the clip lengths that leave ranks idle (the advisor's list for 8 and 4 ranks)."""
+    from sam_pt_amd.dist import fnet_shard_usable, frame_batches
+
+    def usable(T, world):
+        batch = max(1, min(8, -(-T // world)))                      # sharded_forward's batch rule
+        return fnet_shard_usable(T, world, batch), batch
+
+    idle8 = {1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 12, 13, 14, 17, 18, 19, 20, 21, 25, 26, 27, 28, 33, 34, 35, 41, 42, 49}
+    idle4 = {1, 2, 3, 5, 6, 9}
+    for world, idle in ((8, idle8), (4, idle4)):
+        for T in range(1, 70):
+            ok, batch = usable(T, world)
+            has_idle = any(not frame_batches(T, world, k, batch) for k in range(world))
+            assert ok == (not has_idle)
+            assert (T in idle) == has_idle, (T, world)
+    assert usable(24, 8)[0] and usable(64, 8)[0] and not usable(9, 8)[0]
+
+
+def test_frame_sharded_forward_with_an_idle_rank_three_ranks_gloo():
+    """T = 2 frames over 3 ranks with ``shard_fnet=True``: rank 2 owns no frame batch and only joins the mask gather.  The job must
+    complete (before the fix the other ranks would wait for it in the pyramid all_gather) and no rank may have been handed a
+    FnetShard; rank 0's masks equal the single-process result."""
+    code = r"""
+import os, sys, torch
+sys.path.insert(0, %r)
+import torch.distributed as dist
+from sam_pt_amd.dist import init_from_env, sharded_forward
+rank, world, local = init_from_env("gloo")
+assert world == 3
+torch.set_num_threads(2)
+T, H, W = 2, 8, 12
+seen = []
+class Model:
+    device = torch.device("cpu")
+    def __call__(self, video):
+        seen.append("fnet_shard" in video)
+        ids = video["frame_ids"]
+        g = torch.Generator().manual_seed(5)
+        full = torch.randn(2, T, H, W, generator=g)
+        return {"logits": [full[m, ids] for m in range(2)], "trajectories": torch.zeros(T, 2, 1, 2)}
+video = {"image": [torch.zeros(3, H, W, dtype=torch.uint8) for _ in range(T)], "target_hw": (H, W)}
+full, own = sharded_forward(Model(), video, batch=8, shard_fnet=True)
+assert seen == ([False] if rank < 2 else []), seen          # ranks 0 and 1 run one frame each without a FnetShard; rank 2 is idle
+if rank == 0:
+    g = torch.Generator().manual_seed(5)
+    lg = torch.randn(2, T, H, W, generator=g)
+    want = torch.cat([torch.zeros(1, T, H, W), lg]).softmax(0).argmax(0).to(torch.uint8)
+    assert torch.equal(full, want)
+    print("IDLE_RANK_OK")
+dist.barrier(); dist.destroy_process_group()
+""" % ROOT
+    port = str(_free_port())
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:
+        f.write(code)
+        path = f.name
+    try:
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3",
+                            "--master-addr", "127.0.0.1", "--master-port", port, path], env=env, capture_output=True,
+                           text=True, timeout=300)
+    finally:
+        os.unlink(path)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "IDLE_RANK_OK" in r.stdout
+
+
 def test_pil_bilinear_tables_bit_exact_against_pil():
     """The fixed-point tables behind the device resize of SamPredictor.set_image reproduce PIL.Image.resize(BILINEAR)
     bit for bit (numpy evaluation of the same integer arithmetic the HIP kernel runs), up- and down-scaling."""
