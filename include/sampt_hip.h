@@ -170,6 +170,16 @@ int sampt_vit_encode_workspace_bytes(sampt_vit_t h, int B, size_t* bytes);
  * GEMM workgroup (512 threads, 128 KiB of LDS, 256 VGPRs) owns its CU: a caller that runs latency-bound kernels on another
  * stream beside the encoder (the point tracker's window rounds) leaves them a few CUs per XCD this way. */
 int sampt_vit_set_gemm_workgroups(sampt_vit_t h, int per_xcd);
+/* The same per launch kind — the qkv, proj, fc1 and fc2 GEMM of a block — each 0 .. 32, 0 = whatever
+ * sampt_vit_set_gemm_workgroups says.  The four shapes have different tile counts (N / 256 = 15, 5, 20, 5 column tiles for
+ * ViT-H), so the number of workgroups that wastes least of the last round of tiles differs per kind. */
+int sampt_vit_set_gemm_workgroups_kind(sampt_vit_t h, int qkv, int proj, int fc1, int fc2);
+/* Calibration hook of the fp16 mode's static bias correction (sam_pt_amd/sam_predictor.py: the rounding of a weight matrix to
+ * fp16 adds A.(W - fp16(W))^T to a GEMM's output; its token-mean part mean(A).(W - fp16(W))^T is a per-column constant that the
+ * packer folds into the bias once per frame geometry).  While colmeans_dev is set, every block GEMM of sampt_vit_encode (fp16 mode,
+ * plain entry point, one frame) also writes the column means of its A operand over the frame's real tokens to
+ * colmeans_dev[(block * 4 + kind) * ld + k], kind = 0 qkv, 1 proj, 2 fc1, 3 fc2; ld >= mlp_ratio * embed_dim.  NULL ends it. */
+int sampt_vit_calibrate(sampt_vit_t h, float* colmeans_dev, int ld);
 /* Measurement hook: between begin and end every fp16 GEMM launch of sampt_vit_encode is bracketed by HIP events on the
  * launching stream; end waits for them and returns the summed algorithmic FLOP (2*M*N*K), the summed kernel time and the
  * number of launches — the in-situ figures behind bench.py's `roofline`. */

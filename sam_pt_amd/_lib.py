@@ -92,6 +92,8 @@ _SIGS = {
     "sampt_pips_track_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_float, c_int, _P, _P, _P, c_int,
                                      _P, _P, _P, c_size_t, _P, C.POINTER(c_int)]),
     "sampt_vit_set_gemm_workgroups": (c_int, [_P, c_int]),
+    "sampt_vit_set_gemm_workgroups_kind": (c_int, [_P, c_int, c_int, c_int, c_int]),
+    "sampt_vit_calibrate": (c_int, [_P, _P, c_int]),
     "sampt_gemm_ex": (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, c_int, c_int, _P]),
     "sampt_conv2d_nhwc": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "sampt_instance_norm_nhwc": (c_int, [_P, c_int, c_int, c_int, c_float, c_int, _P, _P, c_size_t, _P]),

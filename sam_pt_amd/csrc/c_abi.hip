@@ -282,6 +282,22 @@ int sampt_vit_set_gemm_workgroups(sampt_vit_t h, int per_xcd) {
   return SAMPT_OK;
 }
 
+int sampt_vit_set_gemm_workgroups_kind(sampt_vit_t h, int qkv, int proj, int fc1, int fc2) {
+  const int v[4] = {qkv, proj, fc1, fc2};
+  if (!h) return fail(SAMPT_ERR_ARG, "sampt_vit_set_gemm_workgroups_kind: null handle");
+  for (int i = 0; i < 4; ++i)
+    if (v[i] < 0 || v[i] > 32) return fail(SAMPT_ERR_ARG, "sampt_vit_set_gemm_workgroups_kind: counts must be 0 .. 32");
+  for (int i = 0; i < 4; ++i) h->e.gemm_wgs_kind[i] = v[i];
+  return SAMPT_OK;
+}
+
+int sampt_vit_calibrate(sampt_vit_t h, float* colmeans_dev, int ld) {
+  if (!h || (colmeans_dev && ld < h->e.c.mlp_ratio * h->e.c.D))
+    return fail(SAMPT_ERR_ARG, "sampt_vit_calibrate: ld must be at least mlp_ratio * embed_dim");
+  h->e.calib = colmeans_dev, h->e.calib_ld = colmeans_dev ? ld : 0;
+  return SAMPT_OK;
+}
+
 int sampt_vit_profile_begin(sampt_vit_t h) {
   if (!h) return SAMPT_ERR_ARG;
   h->e.profiling = true;

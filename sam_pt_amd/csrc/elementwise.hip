@@ -472,6 +472,30 @@ __global__ __launch_bounds__(256) void k_layernorm_rows_d64(const float* __restr
                                              apply_act(d2 * rstd * wv.z + bv.z, act), apply_act(d3 * rstd * wv.w + bv.w, act));
 }
 
+// out[k] = mean over rows r < M of A[rowmap ? rowmap[r] : r][k] for an fp16 matrix: one workgroup per 64 columns, 4 row groups whose
+// partial sums meet in LDS in a fixed order (deterministic).  Calibration only (VitEngine::calib): not on the timed path.
+__global__ __launch_bounds__(256) void k_colmean_rows_f16(const half_t* __restrict__ A, long M, int K, int lda,
+                                                          const int* __restrict__ rowmap, float* __restrict__ out) {
+  __shared__ float part[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+  float acc = 0.f;
+  if (c < K)
+    for (long r = rg; r < M; r += 4) {
+      const long src = rowmap ? rowmap[r] : r;
+      acc += (float)A[src * lda + c];
+    }
+  part[rg][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (rg == 0 && c < K) out[c] = (((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x]) / (float)M;
+}
+
+int colmean_rows_f16(const half_t* A, long M, int K, int lda, const int* rowmap, float* out, hipStream_t s) {
+  if (!A || !out || M <= 0 || K <= 0) return SAMPT_ERR_ARG;
+  hipLaunchKernelGGL(k_colmean_rows_f16, dim3(cdiv(K, 64)), dim3(256), 0, s, A, M, K, lda, rowmap, out);
+  SAMPT_CHECK_LAUNCH("colmean_rows_f16");
+  return SAMPT_OK;
+}
+
 int layernorm_rows(const float* x, const float* w, const float* b, void* y, long M, int D, float eps,
                    const int* src_rows, int out_f16, int act, hipStream_t s) {
   if (D <= 0 || D > 2048 || M <= 0) return SAMPT_ERR_ARG;

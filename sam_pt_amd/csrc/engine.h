@@ -171,6 +171,14 @@ struct VitEngine {
   // persistent workgroups per XCD of the fp16 GEMMs (0 = one per CU).  A 512-thread, 128-KiB GEMM workgroup owns its CU, so
   // a caller that runs latency-bound kernels on another stream beside the encoder (the point tracker) asks for fewer.
   int gemm_wgs = 0;
+  // per launch kind (0 qkv, 1 proj, 2 fc1, 3 fc2): overrides gemm_wgs when > 0 (tile counts of the four shapes quantise
+  // differently on a given number of workgroups: sampt_vit_set_gemm_workgroups_kind)
+  int gemm_wgs_kind[4] = {0, 0, 0, 0};
+  // Calibration of the fp16 mode's static bias correction (sampt_vit_calibrate): while set, every block GEMM of encode() also
+  // writes the column means of its A operand (over the real tokens) to calib[(block * 4 + kind) * calib_ld + k].
+  float* calib = nullptr;
+  int calib_ld = 0;
+  mutable int cur_blk = 0;
   int profile_end(double* flop, double* ms, int* launches);
 
   int init(const WeightMap& w, const VitConfig& cfg, int win_rows_batches);

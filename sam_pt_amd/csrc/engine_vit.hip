@@ -79,12 +79,12 @@ struct G {
   // M, N, K are the logical sizes; in mode 2 A and W are x3 rows (2K halves per row).
   int run(const void* A, int M, int K, const void* W, const float* bias, void* C, int N, int act, int out,
           const float* res, int ldr, const int* rowmap, int res_mod, const int* a_rowmap = nullptr,
-          bool exact = false, const half_t* hl = nullptr) const {
+          bool exact = false, const half_t* hl = nullptr, int kind = -1) const {
     GemmP p;
     p.A = A, p.W = W, p.bias = bias, p.C = C, p.res = res, p.rowmap = rowmap, p.a_rowmap = a_rowmap;
     p.M = M, p.N = N, p.K = K, p.lda = K, p.ldw = K, p.ldc = N, p.ldr = ldr, p.act = act, p.res_mod = res_mod;
     p.out_f16 = out;
-    p.p8_wgs = eng ? eng->gemm_wgs : 0;
+    p.p8_wgs = eng ? (kind >= 0 && eng->gemm_wgs_kind[kind] > 0 ? eng->gemm_wgs_kind[kind] : eng->gemm_wgs) : 0;
     if (exact && hl) {   // fp32-grade on the fp16 pipe: the GEMM as a 1x1 convolution over an [1][M][1][K] image
       p.W = hl, p.W_lo = hl + (size_t)N * K;
       p.alpha = 1.0f / (float)(1 << F16X3_WSHIFT);
@@ -97,6 +97,8 @@ struct G {
       p.alpha = 1.0f / (float)(1 << F16X3_WSHIFT);
       if (out == 2) p.ldc = 2 * N;
     }
+    if (eng && eng->calib && kind >= 0 && mode == 1 && K <= eng->calib_ld)
+      SAMPT_TRY(colmean_rows_f16((const half_t*)A, M, K, K, a_rowmap, eng->calib + ((size_t)eng->cur_blk * 4 + kind) * eng->calib_ld, s));
     if (!eng || !eng->profiling) return gemm_f16(p, s);
     VitEngine::GemmEv ev;
     ev.flop = 2.0 * M * N * K;
@@ -190,6 +192,7 @@ int VitEngine::encode(const uint8_t* frames, int chw, int B, int H, int W, float
   }
   for (int i = 0; i < c.depth; ++i) {
     const Blk& b = blk[i];
+    cur_blk = i;
     const bool glob = (c.global_mask >> i) & 1;
     const bool compact = rect && i < g0;
     if (i == g0 && (rect || dead_mode == 1)) {
@@ -217,7 +220,7 @@ int VitEngine::encode(const uint8_t* frames, int chw, int B, int H, int W, float
     // norm1; the window partition (zero padding AFTER the norm, App. A-3) is a row scatter of the qkv GEMM: only the
     // real tokens go through the GEMM, the padded rows' qkv is the bias alone
     SAMPT_TRY(layernorm_rows(x, b.ln1w, b.ln1b, xn, Mg, D, 1e-6f, nullptr, c.f16, ACT_NONE, s));
-    SAMPT_TRY(gm.run(xn, (int)Mg, D, b.qkv_w, b.qkv_b, qkv, 3 * D, ACT_NONE, act_out, nullptr, 0, inv, 0));
+    SAMPT_TRY(gm.run(xn, (int)Mg, D, b.qkv_w, b.qkv_b, qkv, 3 * D, ACT_NONE, act_out, nullptr, 0, inv, 0, nullptr, false, nullptr, 0));
     // the 16-bit attention kernels take the padded tokens' K / V from the bias row themselves (FlashPad); only the exact mode's
     // materialised path needs the padded qkv rows written
     FlashPad fp;
@@ -251,11 +254,12 @@ int VitEngine::encode(const uint8_t* frames, int chw, int B, int H, int W, float
       SAMPT_TRY(gemm_f32(v, s));
     }
     // proj + bias + residual on the real tokens: A rows are gathered from the window-ordered attention output
-    SAMPT_TRY(gm.run(att, (int)Mg, D, b.proj_w, b.proj_b, x, D, ACT_NONE, 0, x, D, nullptr, 0, inv));
+    SAMPT_TRY(gm.run(att, (int)Mg, D, b.proj_w, b.proj_b, x, D, ACT_NONE, 0, x, D, nullptr, 0, inv, false, nullptr, 1));
     // MLP
     SAMPT_TRY(layernorm_rows(x, b.ln2w, b.ln2b, xn, Mg, D, 1e-6f, nullptr, c.f16, ACT_NONE, s));
-    SAMPT_TRY(gm.run(xn, (int)Mg, D, b.w1, b.b1, hid, c.mlp_ratio * D, ACT_GELU, act_out, nullptr, 0, nullptr, 0));
-    SAMPT_TRY(gm.run(hid, (int)Mg, c.mlp_ratio * D, b.w2, b.b2, x, D, ACT_NONE, 0, x, D, nullptr, 0));
+    SAMPT_TRY(gm.run(xn, (int)Mg, D, b.w1, b.b1, hid, c.mlp_ratio * D, ACT_GELU, act_out, nullptr, 0, nullptr, 0, nullptr, false,
+                     nullptr, 2));
+    SAMPT_TRY(gm.run(hid, (int)Mg, c.mlp_ratio * D, b.w2, b.b2, x, D, ACT_NONE, 0, x, D, nullptr, 0, nullptr, false, nullptr, 3));
     if (interm_out && glob && !tapped) {  // HQ-SAM: the first global block's output feeds compress_vit_feat
       if (hipMemcpyAsync(interm_out, x, (size_t)Mg * D * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
         return SAMPT_ERR_HIP;

@@ -27,6 +27,8 @@ int resize_bilinear_nhwc(const float* src, int n, int sh, int sw, int C, float* 
 int avgpool2x2_nhwc(const float* src, int n, int h, int w, int C, float* dst, hipStream_t s);
 // LayerNorm over the last dim of rows. src_rows: optional gather (row index into x, or -1 -> output row = 0).
 // out_f16: 1 = y is half; 2 = y is half "x3 rows" [M][2D] (common.h GemmP::x3; D % 32 == 0). act: applied after the affine transform (ACT_GELU for LayerNorm2d+GELU).
+// column means of an fp16 matrix over M (optionally gathered) rows; calibration of the fp16 ViT mode's bias correction
+int colmean_rows_f16(const half_t* A, long M, int K, int lda, const int* rowmap, float* out, hipStream_t s);
 int layernorm_rows(const float* x, const float* w, const float* b, void* y, long M, int D, float eps,
                    const int* src_rows, int out_f16, int act, hipStream_t s);
 // out[i] = a[i] + b[i % bmod] (f32).  n, bmod in elements.

@@ -257,8 +257,14 @@ class SamPredictor:
         # skip the frame-independent padding rows of landscape frames in the blocks before the first global one (exact)
         self.skip_dead_rows = os.environ.get("SAMPT_VIT_SKIP_DEAD", "1") != "0"
         self._dead_cache = {}
+        # fp16 ViT mode: static bias correction of the weight rounding, calibrated once per frame geometry (see
+        # ``_select_bias_set``); SAMPT_VIT_BIAS_CORR=0 disables
+        self.bias_correction = os.environ.get("SAMPT_VIT_BIAS_CORR", "1") != "0"
+        self._bias_orig: Optional[Dict[str, torch.Tensor]] = None
+        self._bias_sets: Dict[Tuple[int, int], Dict[str, torch.Tensor]] = {}
+        self._bias_live = None
         self.reset_image()
-        self.stats = {"set_image": 0, "predict": 0, "encoded_frames": 0}
+        self.stats = {"set_image": 0, "predict": 0, "encoded_frames": 0, "bias_calibrations": 0}
 
     @property
     def device(self):
@@ -287,6 +293,8 @@ class SamPredictor:
             self._ws_vit, self._ws_dec, self._ws_hq = {}, {}, None
             self._stage.clear()
             self._dead_cache.clear()
+            self._bias_orig, self._bias_live = None, None
+            self._bias_sets.clear()
             self.reset_image()
         cfg, m = self.model.cfg, self.model
         f16 = {"f32": 0, "f16": 1, "f16x3": 2}[m.precision]
@@ -319,10 +327,16 @@ class SamPredictor:
             pass
 
     @_lib.on_device(lambda self, *a, **k: self.model.device)
-    def set_gemm_workgroups(self, per_xcd: int):
-        """Persistent GEMM workgroups per XCD (of 32 CUs) for the following ``encode_frames`` calls; 0 = one per CU.  See
-        sampt_vit_set_gemm_workgroups (include/sampt_hip.h)."""
+    def set_gemm_workgroups(self, per_xcd):
+        """Persistent GEMM workgroups per XCD (of 32 CUs) for the following ``encode_frames`` calls; 0 = one per CU.  An int, or
+        four ints (qkv, proj, fc1, fc2): one count per launch kind.  See sampt_vit_set_gemm_workgroups(_kind)
+        (include/sampt_hip.h)."""
         self._ensure()
+        if isinstance(per_xcd, (tuple, list)):
+            q, p, f1, f2 = (int(v) for v in per_xcd)
+            _lib.check(self._lib.sampt_vit_set_gemm_workgroups_kind(self._vit, q, p, f1, f2), "sampt_vit_set_gemm_workgroups_kind")
+            return
+        _lib.check(self._lib.sampt_vit_set_gemm_workgroups_kind(self._vit, 0, 0, 0, 0), "sampt_vit_set_gemm_workgroups_kind")
         _lib.check(self._lib.sampt_vit_set_gemm_workgroups(self._vit, int(per_xcd)), "sampt_vit_set_gemm_workgroups")
 
     @_lib.on_device(lambda self, *a, **k: self.model.device)
@@ -337,6 +351,66 @@ class SamPredictor:
         fl, ms, n = C.c_double(), C.c_double(), C.c_int()
         _lib.check(self._lib.sampt_vit_profile_end(self._vit, C.byref(fl), C.byref(ms), C.byref(n)), "sampt_vit_profile_end")
         return fl.value, ms.value, n.value
+
+    _BIAS_KINDS = (("attn.qkv", 1), ("attn.proj", 1), ("mlp.lin1", 1), ("mlp.lin2", None))   # (module, K / embed_dim; None = mlp_ratio)
+
+    def _select_bias_set(self, H: int, W: int) -> None:
+        """Static bias correction of the fp16 mode's WEIGHT rounding ("fp16 error budget").
+
+        Rounding a weight matrix to fp16 adds A.(W - fp16(W))^T to a GEMM's output.  The part of that error that is the same for
+        every token — mean_tokens(A).(W - fp16(W))^T, one constant per output column — is the part attention's averaging over
+        keys does not damp, and it is 35 % of the mode's embedding error (tools/f16_error_budget.py; measured on the ViT-B bench
+        frame: rms 6.0e-4 -> 3.9e-4 with it removed).  The token means hardly depend on the picture — they follow the frame
+        GEOMETRY (which token rows are zero padding) and generic image statistics: calibrated on a seeded uniform-noise frame of
+        the same size the correction removes as much as the frame's own means do — so it is folded into the four bias vectors
+        of every block ONCE per frame geometry at no cost per frame: one calibration pass of the encoder over the noise frame
+        records the column means of every GEMM's A operand (sampt_vit_calibrate), the host adds (W - fp16(W)).mean in fp64 to
+        the fp32 biases.  The qkv of SAM's zero-padded window tokens keeps the ORIGINAL bias (a zero input has no weight-rounding
+        error; the attention kernels read it from the separate fp16 bias row).  Deterministic: the same geometry always gets
+        the same biases, whatever was encoded before."""
+        m = self.model
+        if not self.bias_correction or m.precision != "f16":
+            return
+        cfg, key = m.cfg, (int(H), int(W))
+        e = "image_encoder.blocks."
+        names = [f"{e}{i}.{mod}.bias" for i in range(cfg.depth) for mod, _ in self._BIAS_KINDS]
+        if self._bias_orig is None:
+            self._bias_orig = {k: self._wv[k].clone() for k in names}
+        if key not in self._bias_sets:
+            for k in names:                                   # calibrate on the uncorrected weights, whatever ran before
+                self._wv[k].copy_(self._bias_orig[k])
+            self._bias_live = None
+            D, ld = cfg.embed_dim, cfg.mlp_ratio * cfg.embed_dim
+            g = torch.Generator().manual_seed(0x5A17)
+            frame = torch.randint(0, 256, (1, 3, key[0], key[1]), generator=g, dtype=torch.uint8).to(self._dev)
+            cal = torch.zeros((cfg.depth, 4, ld), dtype=torch.float32, device=self._dev)
+            out = torch.empty((1, cfg.grid * cfg.grid, cfg.out_chans), dtype=torch.float32, device=self._dev)
+            interm = torch.empty((1, cfg.grid * cfg.grid, D), dtype=torch.float32, device=self._dev) if m.hq else None
+            ws = self._vit_ws(1)
+            _lib.check(self._lib.sampt_vit_calibrate(self._vit, _lib.ptr(cal), ld), "sampt_vit_calibrate")
+            try:
+                _lib.check(self._lib.sampt_vit_encode(self._vit, _lib.ptr(frame), 1, 1, key[0], key[1], _lib.ptr(out), _lib.ptr(interm),
+                                                      _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "sampt_vit_encode(calibration)")
+            finally:
+                _lib.check(self._lib.sampt_vit_calibrate(self._vit, None, 0), "sampt_vit_calibrate(end)")
+            abar = cal.cpu().double()                          # (depth, 4, ld)
+            bset = {}
+            for i in range(cfg.depth):
+                for kind, (mod, kf) in enumerate(self._BIAS_KINDS):
+                    K = D if kf is not None else ld
+                    w = m.sd[f"{e}{i}.{mod}.weight"].detach().float().reshape(-1, K).cpu()
+                    dw = (w - w.half().float()).double()      # exactly what pack_vit's .half() dropped
+                    bk = f"{e}{i}.{mod}.bias"
+                    bset[bk] = (self._bias_orig[bk].cpu().double() + dw @ abar[i, kind, :K]).float().to(self._dev)
+            if len(self._bias_sets) >= 8:
+                self._bias_sets.clear()
+            self._bias_sets[key] = bset
+            self.stats["bias_calibrations"] += 1
+        if self._bias_live != key:
+            for k, v in self._bias_sets[key].items():
+                self._wv[k].copy_(v)
+            self._bias_live = key
+            # (the dead-row cache of a geometry is computed after its biases are in place and keyed by the geometry)
 
     def _vit_ws(self, B: int) -> torch.Tensor:
         if B not in self._ws_vit:
@@ -403,9 +477,12 @@ class SamPredictor:
         if self.model.hq:
             hq = torch.empty((T, 16 * g * g, Cc // 8), dtype=torch.float32, device=self._dev)
             interm = torch.empty((min(Bm, T), g * g, self.model.cfg.embed_dim), dtype=torch.float32, device=self._dev)
+        self._select_bias_set(H, W)
         dead = self._dead_rows(frames, chw, H, W, self._vit_ws(min(Bm, T))) if self.skip_dead_rows else None
+        # one entry per batch (the last repeats); an entry is an int or a (qkv, proj, fc1, fc2) tuple
         wgs = None if gemm_workgroups is None else ([int(gemm_workgroups)] if isinstance(gemm_workgroups, int)
-                                                      else [int(v) for v in gemm_workgroups])
+                                                      else [tuple(int(x) for x in v) if isinstance(v, (tuple, list)) else int(v)
+                                                            for v in gemm_workgroups])
         for bi, t0 in enumerate(range(0, T, Bm)):
             B = min(Bm, T - t0)
             ws = self._vit_ws(B)

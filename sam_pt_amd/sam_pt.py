@@ -109,7 +109,9 @@ class SamPt(nn.Module):
         # every CU for the last batch, whose second half the tracker's rounds no longer share — measured 111.0 against 114.7 fps
         # with clips in flight: the decoder chain and the next clip's tracker encoder want those CUs, profiles/r4_c27_*).
         env = os.environ.get("SAMPT_ENC_WGS")
-        self.encoder_gemm_workgroups_beside_tracker = [int(v) for v in env.split(",")] if env else None
+        # (an entry "30/28/30/28" gives one count per launch kind: qkv / proj / fc1 / fc2)
+        self.encoder_gemm_workgroups_beside_tracker = ([tuple(int(x) for x in v.split("/")) if "/" in v else int(v)
+                                                        for v in env.split(",")] if env else None)
         # fused path only.  The decoder chain always runs on a third (non-default, hence hipGraph-capturable) stream after
         # the encoder; pipeline_decoder=True instead starts the chains of each encoder batch as soon as that batch is done,
         # and overlap_tracker_encoder_fnet=True moves the tracker's own encoder to the side stream too.  Both were

@@ -124,6 +124,46 @@ def test_vit_b_encoder_vs_oracle(dev, precision, tol):
     assert rel_err(got, ref) < tol
 
 
+def test_vit_b_f16_static_bias_correction(dev, monkeypatch):
+    """The fp16 mode's static bias correction (SamPredictor._select_bias_set: the token-mean part of the weight-rounding error
+    folded into the biases, calibrated per frame geometry on a seeded noise frame — VERDICT r3 / r4 "rank-1 correction"): the
+    embedding error against the fp32 oracle drops by about a third on a frame the calibration never saw (CPU emulation: rms
+    6.0e-4 -> 3.9e-4); the result depends on the frame geometry only, not on what was encoded before (a second predictor that
+    first encodes another geometry gives the same bits); the qkv bias row of padded window tokens is untouched."""
+    from oracle import sam_ref as R
+    from sam_pt_amd.weights import SAM_CONFIGS, init_sam_state_dict
+    cfg = SAM_CONFIGS["vit_b"]
+    sd = init_sam_state_dict(cfg, 72)
+    frames, _ = synthetic_clip(T=1, H=576, W=1024, seed=9, disc_r=60)
+    ref = R.image_encoder(sd, cfg, R.preprocess(cfg, frames.float()))
+    rms = lambda e: float(((e - ref).double().pow(2).mean().sqrt()) / ref.double().pow(2).mean().sqrt())
+    as_img = lambda f: f.view(1, 64, 64, 256).permute(0, 3, 1, 2).cpu()
+    pred = _sam("vit_b", "f16", max_batch=1)
+    assert pred.bias_correction
+    row16 = pred_row = None
+    e_corr = as_img(pred.encode_frames(frames.to(dev)))
+    assert pred.stats["bias_calibrations"] == 1
+    row16 = pred._wv["image_encoder.blocks.0.attn.qkv.bias.f16"].clone()
+    assert torch.equal(row16.float().cpu(), sd["image_encoder.blocks.0.attn.qkv.bias"].half().float())   # padded tokens: original bias
+    assert not torch.equal(pred._wv["image_encoder.blocks.0.attn.qkv.bias"].cpu(), sd["image_encoder.blocks.0.attn.qkv.bias"])
+    monkeypatch.setenv("SAMPT_VIT_BIAS_CORR", "0")
+    plain = _sam("vit_b", "f16", max_batch=1)
+    assert not plain.bias_correction
+    e_plain = as_img(plain.encode_frames(frames.to(dev)))
+    monkeypatch.delenv("SAMPT_VIT_BIAS_CORR")
+    print(f"\n[bias correction] ViT-B embedding rms error vs oracle: plain fp16 {rms(e_plain):.3e}, corrected {rms(e_corr):.3e}")
+    assert rms(e_corr) < 0.8 * rms(e_plain)
+    # history independence: another predictor, another geometry first (its own calibration), then this one
+    other = _sam("vit_b", "f16", max_batch=1)
+    sq, _ = synthetic_clip(T=1, H=1024, W=1024, seed=4, disc_r=60)
+    other.encode_frames(sq.to(dev))
+    e2 = as_img(other.encode_frames(frames.to(dev)))
+    assert other.stats["bias_calibrations"] == 2 and torch.equal(e2, e_corr)
+    e3 = as_img(other.encode_frames(frames.to(dev)))                      # and back and forth without recalibrating
+    other.encode_frames(sq.to(dev))
+    assert other.stats["bias_calibrations"] == 2 and torch.equal(e3, e_corr)
+
+
 @pytest.mark.parametrize("variant,precision,hw,T", [("vit_test", "f32", (144, 256), 3), ("vit_test", "f16", (100, 256), 3),
                                                      ("vit_b", "f16", (576, 1024), 3), ("vit_b", "f32", (480, 1024), 1),
                                                      ("vit_test", "f16x3", (100, 256), 3), ("vit_b", "f16x3", (576, 1024), 3)])
