@@ -174,6 +174,14 @@ int sampt_vit_set_gemm_workgroups(sampt_vit_t h, int per_xcd);
  * sampt_vit_set_gemm_workgroups says.  The four shapes have different tile counts (N / 256 = 15, 5, 20, 5 column tiles for
  * ViT-H), so the number of workgroups that wastes least of the last round of tiles differs per kind. */
 int sampt_vit_set_gemm_workgroups_kind(sampt_vit_t h, int qkv, int proj, int fc1, int fc2);
+/* Process-wide experiment knob of the 8-phase fp16 GEMM (csrc/gemm_f16_p8.hip): G > 1 phase groups — persistent workgroup w of an
+ * XCD belongs to group w % G and starts (w % G) / G of a tile's K-loop late, so that the groups' epilogue bursts interleave with
+ * the other groups' K-loops.  0 / 1 = off (the default). */
+int sampt_gemm_set_stagger(int groups);
+/* Process-wide A / B switch of the same kernel's stage schedule: 0 (default) = the LDS-DMA instructions of a phase are issued in
+ * its read segment, two phases after the half tile's last read; 1 = behind the first MFMAs of its multiply segment, one phase
+ * after the last read (the round-3 / round-4 schedule).  Results are bitwise identical. */
+int sampt_gemm_set_schedule(int sched);
 /* Calibration hook of the fp16 mode's static bias correction (sam_pt_amd/sam_predictor.py: the rounding of a weight matrix to
  * fp16 adds A.(W - fp16(W))^T to a GEMM's output; its token-mean part mean(A).(W - fp16(W))^T is a per-column constant that the
  * packer folds into the bias once per frame geometry).  While colmeans_dev is set, every block GEMM of sampt_vit_encode (fp16 mode,

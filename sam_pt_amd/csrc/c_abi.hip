@@ -291,6 +291,18 @@ int sampt_vit_set_gemm_workgroups_kind(sampt_vit_t h, int qkv, int proj, int fc1
   return SAMPT_OK;
 }
 
+int sampt_gemm_set_schedule(int sched) {
+  if (sched < 0 || sched > 1) return fail(SAMPT_ERR_ARG, "sampt_gemm_set_schedule: 0 or 1");
+  sampt::g_p8_sched = sched;
+  return SAMPT_OK;
+}
+
+int sampt_gemm_set_stagger(int groups) {
+  if (groups < 0 || groups > 8) return fail(SAMPT_ERR_ARG, "sampt_gemm_set_stagger: 0 .. 8 phase groups");
+  sampt::g_p8_stagger = groups;
+  return SAMPT_OK;
+}
+
 int sampt_vit_calibrate(sampt_vit_t h, float* colmeans_dev, int ld) {
   if (!h || (colmeans_dev && ld < h->e.c.mlp_ratio * h->e.c.D))
     return fail(SAMPT_ERR_ARG, "sampt_vit_calibrate: ld must be at least mlp_ratio * embed_dim");

@@ -192,6 +192,7 @@ struct GemmP {
   // split-K (set by the dispatcher; callers only provide the workspace): partial tiles [splitk][M][N] f32
   int xcd_swizzle = 0;           // set by the LDS-DMA fp16 launcher
   int p8_wgs = 0;                // gemm_f16_p8: persistent workgroups per XCD (0: one per CU = 32); fewer leaves whole CUs free
+  int p8_stagger = 0;            // gemm_f16_p8: phase groups of the persistent workgroups (0: the process-wide setting; 1: off)
   int force_generic = 0;         // tests: bypass the specialised LDS-DMA fp16 kernel
   int splitk = 1;
   float* splitk_ws = nullptr;
@@ -201,6 +202,8 @@ struct GemmP {
   int cpadw = -1;                // >= 0: padding along W differs from cpad (1-D convolutions over time: KW = 1, cpadw = 0)
 };
 
+extern int g_p8_sched;     // gemm_f16_p8.hip: 0 = stage in the read segments (default), 1 = the round-3 schedule (sampt_gemm_set_schedule)
+extern int g_p8_stagger;   // gemm_f16_p8.hip: process-wide default of GemmP::p8_stagger (sampt_gemm_set_stagger)
 int gemm_f32(const GemmP& p, hipStream_t s);
 int gemm_f16(const GemmP& p, hipStream_t s);
 // the split-K factor gemm_f32 will choose for this problem (1 = no split; needs p.splitk_ws / splitk_ws_floats set)
