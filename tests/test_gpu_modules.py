@@ -1072,13 +1072,18 @@ def test_frame_sharded_emulation_equals_full_forward(dev, pips_sd, tracker):
     video = {"image": [f.to(dev) for f in frames], "target_hw": (128, 256), "query_points": q}
     full = model(video)
     want = index_masks(torch.stack(full["logits"], dim=0))
-    N, seen = 3, torch.zeros(10, dtype=torch.bool)
-    for r in range(N):
-        masks, out = sharded_forward(model, video, batch=2, emulate=(r, N))
-        ids = [t for b in frame_batches(10, N, r, 2) for t in b]
-        assert torch.equal(out["trajectories"], full["trajectories"]) and torch.equal(out["visibilities"], full["visibilities"])
-        assert torch.equal(masks, want[torch.as_tensor(ids, device=want.device)])
-        fs = out["fnet_shard"]
-        assert fs.bytes_received > 0 and fs.stub_ms() > 0.0
-        seen[ids] = True
-    assert bool(seen.all())
+    N = 3
+    for shard_fnet in (True, False):          # the opt-in pyramid exchange, and the default (north_star) mode: mask gather only
+        seen = torch.zeros(10, dtype=torch.bool)
+        for r in range(N):
+            masks, out = sharded_forward(model, video, batch=2, shard_fnet=shard_fnet, emulate=(r, N))
+            ids = [t for b in frame_batches(10, N, r, 2) for t in b]
+            assert torch.equal(out["trajectories"], full["trajectories"]) and torch.equal(out["visibilities"], full["visibilities"])
+            assert torch.equal(masks, want[torch.as_tensor(ids, device=want.device)])
+            if shard_fnet:
+                fs = out["fnet_shard"]
+                assert fs.bytes_received > 0 and fs.stub_ms() > 0.0
+            else:
+                assert "fnet_shard" not in out
+            seen[ids] = True
+        assert bool(seen.all())
