@@ -182,6 +182,9 @@ int sampt_gemm_set_stagger(int groups);
  * its read segment, two phases after the half tile's last read; 1 = behind the first MFMAs of its multiply segment, one phase
  * after the last read (the round-3 / round-4 schedule).  Results are bitwise identical. */
 int sampt_gemm_set_schedule(int sched);
+/* Process-wide knob of the thin f32 GEMM (csrc/gemm.hip gemm_thin_f32: the tracker mixers' token-side products): the launcher grows
+ * the (16 * FM) x 16 tile only while at least n workgroups remain (default 256 = one per CU). */
+int sampt_gemm_set_thin_min_wgs(int n);
 /* Calibration hook of the fp16 mode's static bias correction (sam_pt_amd/sam_predictor.py: the rounding of a weight matrix to
  * fp16 adds A.(W - fp16(W))^T to a GEMM's output; its token-mean part mean(A).(W - fp16(W))^T is a per-column constant that the
  * packer folds into the bias once per frame geometry).  While colmeans_dev is set, every block GEMM of sampt_vit_encode (fp16 mode,

@@ -297,6 +297,12 @@ int sampt_gemm_set_schedule(int sched) {
   return SAMPT_OK;
 }
 
+int sampt_gemm_set_thin_min_wgs(int n) {
+  if (n < 1 || n > 4096) return fail(SAMPT_ERR_ARG, "sampt_gemm_set_thin_min_wgs: 1 .. 4096");
+  sampt::g_thin_min_wgs = n;
+  return SAMPT_OK;
+}
+
 int sampt_gemm_set_stagger(int groups) {
   if (groups < 0 || groups > 8) return fail(SAMPT_ERR_ARG, "sampt_gemm_set_stagger: 0 .. 8 phase groups");
   sampt::g_p8_stagger = groups;

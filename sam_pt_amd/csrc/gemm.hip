@@ -432,10 +432,12 @@ static bool thin_f32_eligible(const GemmP& p, bool plain) {
   return tiles64 < 128;
 }
 
+int g_thin_min_wgs = 256;    // experiment knob (sampt_gemm_set_thin_min_wgs): see gemm_thin_f32_launch
+
 static int gemm_thin_f32_launch(const GemmP& p, hipStream_t s) {
   const long cols = cdiv(p.N, 16);
   int FM = 4;                                  // the tallest tile that still yields >= 256 workgroups (>= 1 per CU)
-  while (FM > 1 && cols * cdiv(p.M, 16 * FM) < 256) FM >>= 1;
+  while (FM > 1 && cols * cdiv(p.M, 16 * FM) < g_thin_min_wgs) FM >>= 1;
   const int nchunk = cdiv(p.K, 16), per_wave = FM >= 4 ? 4 : 8;
   int NWV = nchunk > 8 * per_wave ? 16 : (nchunk > 4 * per_wave ? 8 : 4);   // a wave's K share: one batch of loads
   dim3 grid((unsigned)cols, (unsigned)cdiv(p.M, 16 * FM)), block(NWV * 64);
