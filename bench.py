@@ -261,8 +261,9 @@ def gemm_roofline(args, dev, insitu=None, frame_hw=(576, 1024)):
             "isolated_avg_launch_us": round(tot_t / launches * 1e6, 1),
             "traffic": None if tot_traffic is None else round(tot_traffic / launches),
             "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE; counts Infinity-Cache hits)",
-            "traffic_source": "committed --pmc passes of the shipped kernel (" + os.path.basename(tpath) + "), looked up per shape — "
-                              "not measured by this run (bench.py cannot run rocprofv3 on itself)",
+            "traffic_source": ("committed --pmc passes of the shipped kernel (" + os.path.basename(tpath) + "), looked up per shape — "
+                               "not measured by this run (bench.py cannot run rocprofv3 on itself)") if cands else
+                              "no --pmc passes are committed for this arithmetic (traffic: null)",
             "algorithmic_bytes_per_launch": None if tot_traffic is None else round(tot_alg_bytes / launches),
             "launches_per_encode_call": launches,
             "avg_launch_us": round(avg_us, 1), "encode_batch": B}
