@@ -352,3 +352,27 @@ def pack_decoder(sd: Dict[str, torch.Tensor], cfg: SamConfig, device, max_frames
             if out[k].shape[1] % 32 == 0 and out[k].shape[0] % 4 == 0:
                 _put_split(out, k + "_hl", out[k])
     return {k: v.to(device) for k, v in out.items()}
+
+
+# ---- fp16 ViT mode: static bias correction of the weight rounding (SamPredictor._select_bias_set) -----------------
+VIT_GEMM_KINDS = ("attn.qkv", "attn.proj", "mlp.lin1", "mlp.lin2")      # order of sampt_vit_calibrate's `kind` index
+
+
+def vit_bias_correction(sd: Dict[str, torch.Tensor], cfg: SamConfig, abar: torch.Tensor) -> Dict[str, torch.Tensor]:
+    """b' = b + (W - fp16(W)) . abar for the four GEMMs of every ViT block, in fp64 on the host.
+
+    ``abar`` (depth, 4, >= mlp_ratio * embed_dim): the column means of each GEMM's A operand over a calibration frame's tokens, as
+    ``sampt_vit_calibrate`` records them (kind index = ``VIT_GEMM_KINDS``).  ``W - fp16(W)`` is exactly what ``pack_vit``'s ``.half()``
+    dropped, so with these biases the token-mean of the fp16 GEMM's output error vanishes for inputs whose column means equal
+    ``abar``: mean_t[A.fp16(W)^T + b'] = mean_t[A.W^T + b].  -> {bias name: float32 tensor (CPU)}."""
+    D, ld = cfg.embed_dim, cfg.mlp_ratio * cfg.embed_dim
+    abar = abar.detach().cpu().double()
+    out = {}
+    for i in range(cfg.depth):
+        for kind, mod in enumerate(VIT_GEMM_KINDS):
+            K = ld if mod == "mlp.lin2" else D
+            name = f"image_encoder.blocks.{i}.{mod}"
+            w = sd[name + ".weight"].detach().float().reshape(-1, K).cpu()
+            dw = (w - w.half().float()).double()
+            out[name + ".bias"] = (sd[name + ".bias"].detach().cpu().double() + dw @ abar[i, kind, :K]).float()
+    return out

@@ -21,7 +21,7 @@ import torch
 from torch import nn
 
 from . import _lib
-from .pack import pack_decoder, pack_vit
+from .pack import VIT_GEMM_KINDS, pack_decoder, pack_vit, vit_bias_correction
 from .weights import SAM_CONFIGS, SamConfig, init_sam_state_dict
 
 
@@ -352,8 +352,6 @@ class SamPredictor:
         _lib.check(self._lib.sampt_vit_profile_end(self._vit, C.byref(fl), C.byref(ms), C.byref(n)), "sampt_vit_profile_end")
         return fl.value, ms.value, n.value
 
-    _BIAS_KINDS = (("attn.qkv", 1), ("attn.proj", 1), ("mlp.lin1", 1), ("mlp.lin2", None))   # (module, K / embed_dim; None = mlp_ratio)
-
     def _select_bias_set(self, H: int, W: int) -> None:
         """Static bias correction of the fp16 mode's WEIGHT rounding ("fp16 error budget").
 
@@ -373,7 +371,7 @@ class SamPredictor:
             return
         cfg, key = m.cfg, (int(H), int(W))
         e = "image_encoder.blocks."
-        names = [f"{e}{i}.{mod}.bias" for i in range(cfg.depth) for mod, _ in self._BIAS_KINDS]
+        names = [f"{e}{i}.{mod}.bias" for i in range(cfg.depth) for mod in VIT_GEMM_KINDS]
         if self._bias_orig is None:
             self._bias_orig = {k: self._wv[k].clone() for k in names}
         if key not in self._bias_sets:
@@ -393,15 +391,7 @@ class SamPredictor:
                                                       _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "sampt_vit_encode(calibration)")
             finally:
                 _lib.check(self._lib.sampt_vit_calibrate(self._vit, None, 0), "sampt_vit_calibrate(end)")
-            abar = cal.cpu().double()                          # (depth, 4, ld)
-            bset = {}
-            for i in range(cfg.depth):
-                for kind, (mod, kf) in enumerate(self._BIAS_KINDS):
-                    K = D if kf is not None else ld
-                    w = m.sd[f"{e}{i}.{mod}.weight"].detach().float().reshape(-1, K).cpu()
-                    dw = (w - w.half().float()).double()      # exactly what pack_vit's .half() dropped
-                    bk = f"{e}{i}.{mod}.bias"
-                    bset[bk] = (self._bias_orig[bk].cpu().double() + dw @ abar[i, kind, :K]).float().to(self._dev)
+            bset = {k: v.to(self._dev) for k, v in vit_bias_correction(m.sd, cfg, cal).items()}    # host, fp64 (pack.py)
             if len(self._bias_sets) >= 8:
                 self._bias_sets.clear()
             self._bias_sets[key] = bset

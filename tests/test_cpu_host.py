@@ -554,6 +554,40 @@ def test_kmedoids_host_restatement_golden():
     assert got == want, got
 
 
+def test_vit_bias_correction_removes_the_token_mean_of_the_weight_rounding_error():
+    """pack.vit_bias_correction (the host half of the fp16 ViT mode's static bias correction): with b' = b + (W - fp16(W)) . abar the
+    fp16-weight GEMM's output error has ZERO mean over any token set whose column means equal abar — for all four GEMMs of a block,
+    algebraically, whatever the tokens are; and the per-token error shrinks when the tokens share a common component."""
+    from sam_pt_amd.pack import VIT_GEMM_KINDS, vit_bias_correction
+    from sam_pt_amd.weights import SAM_CONFIGS, init_sam_state_dict
+    cfg = SAM_CONFIGS["vit_test"]
+    sd = init_sam_state_dict(cfg, 72)
+    D, ld = cfg.embed_dim, cfg.mlp_ratio * cfg.embed_dim
+    g = torch.Generator().manual_seed(3)
+    abar = torch.zeros(cfg.depth, 4, ld)
+    tokens = {}
+    for i in range(cfg.depth):
+        for kind, mod in enumerate(VIT_GEMM_KINDS):
+            K = ld if mod == "mlp.lin2" else D
+            common = torch.randn(K, generator=g) * 2.0                       # what every token shares (LayerNorm bias, outlier channels)
+            A = (common + 0.3 * torch.randn(200, K, generator=g)).half().float()
+            tokens[(i, kind)] = A
+            abar[i, kind, :K] = A.double().mean(0).float()
+    corr = vit_bias_correction(sd, cfg, abar)
+    for i in range(cfg.depth):
+        for kind, mod in enumerate(VIT_GEMM_KINDS):
+            name = f"image_encoder.blocks.{i}.{mod}"
+            W, b = sd[name + ".weight"].double().reshape(-1, tokens[(i, kind)].shape[1]), sd[name + ".bias"].double()
+            A = tokens[(i, kind)].double()
+            exact = A @ W.t() + b
+            plain = A @ W.float().half().double().t() + b
+            fixed = A @ W.float().half().double().t() + corr[name + ".bias"].double()
+            assert (fixed - exact).mean(0).abs().max() < 1e-6 * exact.abs().max()                 # fp32 rounding of b' only
+            assert (plain - exact).mean(0).abs().max() > 20 * (fixed - exact).mean(0).abs().max()
+            assert (fixed - exact).pow(2).mean() < 0.5 * (plain - exact).pow(2).mean(), (i, mod)
+            assert corr[name + ".bias"].dtype == torch.float32 and corr[name + ".bias"].shape == sd[name + ".bias"].shape
+
+
 def test_fnet_shard_is_enabled_only_when_every_rank_owns_a_frame_batch():
     """the pyramid all_gather is entered from inside model(...), which a rank without a frame batch never calls.
     ``fnet_shard_usable`` is a pure function of (T, world, batch) — every rank reaches the same verdict — and is False for
