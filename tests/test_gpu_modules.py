@@ -140,7 +140,6 @@ def test_vit_b_f16_static_bias_correction(dev, monkeypatch):
     as_img = lambda f: f.view(1, 64, 64, 256).permute(0, 3, 1, 2).cpu()
     pred = _sam("vit_b", "f16", max_batch=1)
     assert pred.bias_correction
-    row16 = pred_row = None
     e_corr = as_img(pred.encode_frames(frames.to(dev)))
     assert pred.stats["bias_calibrations"] == 1
     row16 = pred._wv["image_encoder.blocks.0.attn.qkv.bias.f16"].clone()
