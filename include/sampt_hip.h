@@ -185,6 +185,12 @@ int sampt_gemm_set_schedule(int sched);
 /* Process-wide knob of the thin f32 GEMM (csrc/gemm.hip gemm_thin_f32: the tracker mixers' token-side products): the launcher grows
  * the (16 * FM) x 16 tile only while at least n workgroups remain (default 256 = one per CU). */
 int sampt_gemm_set_thin_min_wgs(int n);
+/* Process-wide knob of the PIPS window's MLP-Mixer (csrc/pips_mixer.hip).  fused = 1 (default): two launches per mixer block —
+ * [sum of the previous channel MLP's slabs + residual -> token mixing] and [LayerNorm -> fc1 -> GELU -> fc2 over hidden slices];
+ * fused = 0: the four-launch blocks of rounds 1 - 5 (token mixing, LayerNorm, two thin GEMMs).  workgroups = how many
+ * workgroups a channel-MLP launch should reach (it uses 8, 16 or 32 hidden slices per group of two point chains; default 32 =
+ * the CUs the ViT encoder's persistent GEMMs leave free beside the tracker). */
+int sampt_pips_set_mixer(int fused, int workgroups);
 /* Calibration hook of the fp16 mode's static bias correction (sam_pt_amd/sam_predictor.py: the rounding of a weight matrix to
  * fp16 adds A.(W - fp16(W))^T to a GEMM's output; its token-mean part mean(A).(W - fp16(W))^T is a per-column constant that the
  * packer folds into the bias once per frame geometry).  While colmeans_dev is set, every block GEMM of sampt_vit_encode (fp16 mode,
@@ -358,6 +364,18 @@ int sampt_avgpool2x2_nhwc(const float* src_dev, int n, int h, int w, int C, floa
  * ffeats_dev [n][S][128]; coords_dev [S][n][2] (level-0 feature-map pixels); out_dev [n][S][196]. */
 int sampt_corr_sample_f32(const float* const pyr_dev[4], int H0, int W0, const int32_t* frame_idx_dev, int S, int n,
                           const float* ffeats_dev, const float* coords_dev, float* out_dev, sampt_stream_t stream);
+/* The two kernels of a fused MLP-Mixer block (csrc/pips_mixer.hip; pips.py:96-128), exported for the kernel tests.
+ * mlp: part_dev[slice][nseq*8][512] = fc2 over the slice's hidden units of gelu(fc1(LayerNorm(x)) + b1); x_dev [nseq*8][512],
+ *      w1 [2048][512], b1 [2048], w2 [512][2048]; slices = 8, 16 or 32 (what sampt_pips_set_mixer's workgroup target selects).
+ * reduce: x' = res + (sum of the `slices` slabs in order + bias) (slices = 0: x' = res, part / bias unused);
+ *      mode 0: out_dev [nseq*8][512] = x' + token-mix(LayerNorm(x')) with tw1 [32][8], tb1 [32], tw2 [8][32], tb2 [8];
+ *      mode 1: out_dev [nseq][512] = mean over the 8 tokens of LayerNorm(x') (token weights unused).  out_dev != res_dev. */
+int sampt_pips_mix_mlp_f32(const float* x_dev, const float* lnw_dev, const float* lnb_dev, const float* w1_dev,
+                           const float* b1_dev, const float* w2_dev, float* part_dev, int nseq, int slices,
+                           sampt_stream_t stream);
+int sampt_pips_mix_reduce_f32(const float* part_dev, int slices, const float* bias_dev, const float* res_dev, int nseq, int mode,
+                              const float* lnw_dev, const float* lnb_dev, const float* tw1_dev, const float* tb1_dev,
+                              const float* tw2_dev, const float* tb2_dev, float* out_dev, sampt_stream_t stream);
 /* ViT attention on a packed qkv matrix [B*S*S][3*heads*hd] (f16), decomposed rel-pos tables (2S-1, hd) f32.
  * out_dev f16 [B*S*S][heads*hd].  The bias tables are built inside the kernel; the workspace arguments are kept for
  * ABI stability and ignored (may be NULL / 0). */

@@ -97,6 +97,9 @@ _SIGS = {
     "sampt_gemm_set_stagger": (c_int, [c_int]),
     "sampt_gemm_set_schedule": (c_int, [c_int]),
     "sampt_gemm_set_thin_min_wgs": (c_int, [c_int]),
+    "sampt_pips_set_mixer": (c_int, [c_int, c_int]),
+    "sampt_pips_mix_mlp_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
+    "sampt_pips_mix_reduce_f32": (c_int, [_P, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "sampt_gemm_ex": (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, c_int, c_int, _P]),
     "sampt_conv2d_nhwc": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "sampt_instance_norm_nhwc": (c_int, [_P, c_int, c_int, c_int, c_float, c_int, _P, _P, c_size_t, _P]),
@@ -140,6 +143,8 @@ def load():
         fn.argtypes = args
     if os.environ.get("SAMPT_GEMM_SCHED"):            # A / B switch of the 8-phase GEMM's stage schedule (sampt_gemm_set_schedule)
         lib.sampt_gemm_set_schedule(int(os.environ["SAMPT_GEMM_SCHED"]))
+    if os.environ.get("SAMPT_PIPS_MIXER") or os.environ.get("SAMPT_PIPS_MIXER_WGS") or os.environ.get("SAMPT_PIPS_MIXER_DIAG"):   # csrc/pips_mixer.hip (A / B runs)
+        lib.sampt_pips_set_mixer(int(os.environ.get("SAMPT_PIPS_MIXER", "1")), int(os.environ.get("SAMPT_PIPS_MIXER_WGS", "32")))
     if os.environ.get("SAMPT_THIN_MIN_WGS"):          # thin f32 GEMM: tile growth threshold (sampt_gemm_set_thin_min_wgs)
         lib.sampt_gemm_set_thin_min_wgs(int(os.environ["SAMPT_THIN_MIN_WGS"]))
     if os.environ.get("SAMPT_GEMM_STAGGER"):          # experiment knob of the 8-phase GEMM (sampt_gemm_set_stagger)

@@ -303,6 +303,15 @@ int sampt_gemm_set_thin_min_wgs(int n) {
   return SAMPT_OK;
 }
 
+int sampt_pips_set_mixer(int fused, int workgroups) {
+  if (fused < 0 || fused > 1 || workgroups < 1 || workgroups > 1024)
+    return fail(SAMPT_ERR_ARG, "sampt_pips_set_mixer: fused 0 / 1, workgroups 1 .. 1024");
+  sampt::g_pips_mixer_fused = fused, sampt::g_pips_mixer_wgs = workgroups;
+  const char* d = getenv("SAMPT_PIPS_MIXER_DIAG");      // measurement builds only: see pips_mixer.hip g_pips_mixer_diag
+  sampt::g_pips_mixer_diag = d ? atoi(d) : 0;
+  return SAMPT_OK;
+}
+
 int sampt_gemm_set_stagger(int groups) {
   if (groups < 0 || groups > 8) return fail(SAMPT_ERR_ARG, "sampt_gemm_set_stagger: 0 .. 8 phase groups");
   sampt::g_p8_stagger = groups;
@@ -730,6 +739,20 @@ int sampt_index_masks(const float* logits, int M, long npix, uint8_t* out, sampt
 int sampt_corr_sample_f32(const float* const pyr[4], int H0, int W0, const int32_t* frame_idx, int S, int n,
                           const float* ffeats, const float* coords, float* out, sampt_stream_t stream) {
   return pips_corr_sample(make_pyr(pyr, H0, W0), frame_idx, S, n, 128, ffeats, coords, out, 196, 0, (hipStream_t)stream);
+}
+
+int sampt_pips_mix_mlp_f32(const float* x, const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
+                           float* part, int nseq, int slices, sampt_stream_t stream) {
+  if (!x || !lnw || !lnb || !w1 || !b1 || !w2 || !part) return fail(SAMPT_ERR_ARG, "sampt_pips_mix_mlp_f32: null pointer");
+  return pips_mix_mlp(x, lnw, lnb, w1, b1, w2, part, nseq, slices, (hipStream_t)stream);
+}
+
+int sampt_pips_mix_reduce_f32(const float* part, int slices, const float* bias, const float* res, int nseq, int mode,
+                              const float* lnw, const float* lnb, const float* tw1, const float* tb1, const float* tw2,
+                              const float* tb2, float* out, sampt_stream_t stream) {
+  if (!lnw || !lnb || (mode != 0 && mode != 1) || (mode == 0 && (!tw1 || !tb1 || !tw2 || !tb2)))
+    return fail(SAMPT_ERR_ARG, "sampt_pips_mix_reduce_f32: bad arguments");
+  return pips_mix_reduce(part, slices, bias, res, nseq, mode, lnw, lnb, tw1, tb1, tw2, tb2, out, (hipStream_t)stream);
 }
 
 int sampt_vit_attention_f16(const void* qkv, const float* rel_h, const float* rel_w, void* out, int B, int S, int heads,

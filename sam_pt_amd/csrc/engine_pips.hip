@@ -208,25 +208,44 @@ int PipsEngine::update(const PyramidLevels& pyr, const int* frame_idx, int n, co
   float* hid = ws.f32((size_t)R * 4 * D);
   float* mean = ws.f32((size_t)n * D);
   float* delta = ws.f32((size_t)n * S * 130);
+  // fused mixer (pips_mixer.hip): one slab [R][512] per hidden slice; always carved, so the size does not depend on the knob
+  float* part = ws.f32((size_t)32 * R * D);
   if (!ws.ok()) return SAMPT_ERR_WORKSPACE;
   if (dry) return SAMPT_OK;
+  const bool fused = g_pips_mixer_fused != 0;
+  const int NS = pips_mix_slices(n);
   SAMPT_TRY(pips_init_state(xys, feat_init, (float)stride, S, n, coords, coords0, ffeats, s));
   for (int it = 0; it < iters; ++it) {
-    SAMPT_TRY(pips_corr_sample(pyr, frame_idx, S, n, 128, ffeats, coords, x, LDX, 128, s));
-    SAMPT_TRY(pips_build_input(ffeats, coords, times, S, n, x, LDX, s));
-    SAMPT_TRY(lin(x, R, LDX, LDX, in_w, in_b, hbuf, D, ACT_NONE, nullptr, s));
-    // 12 mixer blocks, 4 launches each: token mixing, LayerNorm, fc1 + GELU, fc2 + residual (thin GEMMs: K split inside the
-    // workgroup, no split-K grid + reduction pass).  Measured alternatives (profiles/r3_v5_tracker_kernel_stats.txt): token
-    // mixing fused with the LayerNorm in one workgroup per sequence — 30.6 us, all of a sequence's VALU work on one CU.
-    for (int i = 0; i < 12; ++i) {
-      const MixBlk& m = mix[i];
-      SAMPT_TRY(pips_token_mix(hbuf, hbuf2, m.ln1w, m.ln1b, m.tw1, m.tb1, m.tw2, m.tb2, n, S, D, s));
-      SAMPT_TRY(layernorm_rows(hbuf2, m.ln2w, m.ln2b, lnb, R, D, 1e-5f, nullptr, 0, ACT_NONE, s));
-      SAMPT_TRY(lin(lnb, R, D, D, m.cw1, m.cb1, hid, 4 * D, ACT_GELU, nullptr, s));
-      SAMPT_TRY(lin(hid, R, 4 * D, 4 * D, m.cw2, m.cb2, hbuf, D, ACT_NONE, hbuf2, s));
+    if (fused) {
+      // 30 launches per iteration: input (1), in-projection (1), per block [sum of the previous block's slabs + residual ->
+      // token mixing] and [LayerNorm -> fc1 -> GELU -> fc2 slabs] (2 x 12), last sum + LayerNorm + token mean (1), head, update
+      SAMPT_TRY(pips_corr_sample(pyr, frame_idx, S, n, 128, ffeats, coords, x, LDX, 128, s, times));
+      SAMPT_TRY(lin(x, R, LDX, LDX, in_w, in_b, hbuf, D, ACT_NONE, nullptr, s));
+      float* xpp[2] = {hbuf2, lnb};
+      const float* prev = hbuf;
+      for (int i = 0; i < 12; ++i) {
+        const MixBlk& m = mix[i];
+        SAMPT_TRY(pips_mix_reduce(i ? part : nullptr, i ? NS : 0, i ? mix[i - 1].cb2 : nullptr, prev, n, 0, m.ln1w, m.ln1b,
+                                  m.tw1, m.tb1, m.tw2, m.tb2, xpp[i & 1], s));
+        SAMPT_TRY(pips_mix_mlp(xpp[i & 1], m.ln2w, m.ln2b, m.cw1, m.cb1, m.cw2, part, n, NS, s));
+        prev = xpp[i & 1];
+      }
+      SAMPT_TRY(pips_mix_reduce(part, NS, mix[11].cb2, prev, n, 1, oln_w, oln_b, nullptr, nullptr, nullptr, nullptr, mean, s));
+    } else {
+      SAMPT_TRY(pips_corr_sample(pyr, frame_idx, S, n, 128, ffeats, coords, x, LDX, 128, s));
+      SAMPT_TRY(pips_build_input(ffeats, coords, times, S, n, x, LDX, s));
+      SAMPT_TRY(lin(x, R, LDX, LDX, in_w, in_b, hbuf, D, ACT_NONE, nullptr, s));
+      // 12 mixer blocks, 4 launches each: token mixing, LayerNorm, fc1 + GELU, fc2 + residual (thin GEMMs: K split inside
+      // the workgroup, no split-K grid + reduction pass).
+      for (int i = 0; i < 12; ++i) {
+        const MixBlk& m = mix[i];
+        SAMPT_TRY(pips_token_mix(hbuf, hbuf2, m.ln1w, m.ln1b, m.tw1, m.tb1, m.tw2, m.tb2, n, S, D, s));
+        SAMPT_TRY(layernorm_rows(hbuf2, m.ln2w, m.ln2b, lnb, R, D, 1e-5f, nullptr, 0, ACT_NONE, s));
+        SAMPT_TRY(lin(lnb, R, D, D, m.cw1, m.cb1, hid, 4 * D, ACT_GELU, nullptr, s));
+        SAMPT_TRY(lin(hid, R, 4 * D, 4 * D, m.cw2, m.cb2, hbuf, D, ACT_NONE, hbuf2, s));
+      }
+      SAMPT_TRY(pips_ln_mean(hbuf, oln_w, oln_b, mean, n, S, D, s));
     }
-    const float* mixed = hbuf;
-    SAMPT_TRY(pips_ln_mean(mixed, oln_w, oln_b, mean, n, S, D, s));
     SAMPT_TRY(lin(mean, n, D, D, head_w, head_b, delta, S * 130, ACT_NONE, nullptr, s));
     SAMPT_TRY(pips_update(delta, gn_w, gn_b, up_wT, up_b, ffeats, coords, coords0, S, n, s));
   }

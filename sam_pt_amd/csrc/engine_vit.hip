@@ -147,6 +147,12 @@ int VitEngine::encode(const uint8_t* frames, int chw, int B, int H, int W, float
   const bool rect = dead_mode == 2 && lh < g;
   if (dead_mode != 0 && (lh >= g || !dead_cache)) return SAMPT_ERR_ARG;
   if (dead_mode == 1 && B != 1) return SAMPT_ERR_ARG;
+  // calibration (sampt_vit_calibrate) records ONE frame's column means through the plain path: anything else would average
+  // over frames or over the compacted live rows only, silently
+  if (calib && !ws.dry() && (B != 1 || dead_mode != 0)) {
+    error = "VitEngine::encode: calibration is set (sampt_vit_calibrate): one frame through the plain entry point only";
+    return SAMPT_ERR_ARG;
+  }
   const int Tl = lh * g, nwin_l = (lh / ws_) * nw1;
   const long Ml = (long)B * Tl;
   float* xl = rect ? ws.f32((size_t)Ml * D) : nullptr;

@@ -101,8 +101,9 @@ struct PyramidLevels {
 int pips_sample_feat(const float* fmap, int H, int W, int C, const int* frame_idx, const float* xy, int n, float* out,
                      hipStream_t s);
 // fused correlation + 7x7 window sampler (pips.py:364-407): writes x[n][s][xoff + lvl*49 + i*7+j]
+// times != nullptr: the level-0 workgroups also do pips_build_input's job (PIPS layout: xoff == 128, 519 <= ldx <= 580)
 int pips_corr_sample(const PyramidLevels& pyr, const int* frame_idx, int S, int n, int C, const float* ffeats,
-                     const float* coords, float* x, int ldx, int xoff, hipStream_t s);
+                     const float* coords, float* x, int ldx, int xoff, hipStream_t s, const float* times = nullptr);
 // mixer input assembly: x[n][s][0:128]=ffeats, x[...][324:519] = sincos embedding of (flow, t) (misc.py:30-55)
 // times: device [S] = torch.linspace(0, S, S) (pips.py:527)
 int pips_build_input(const float* ffeats, const float* coords, const float* times, int S, int n, float* x, int ldx,
@@ -137,6 +138,18 @@ int pips_round_begin(const int* cur, const unsigned char* flip, const float* tra
                      float* xy_feat, int* f0, float stride, hipStream_t s);
 int pips_round_end(int* cur, const float* tr, const float* vi, int T, int n, int S, float thr0, float* traj, float* vis,
                    int* n_active, hipStream_t s);
+// ---- pips_mixer.hip: the mixer's channel MLP + everything between two channel MLPs, two launches per block (file header)
+extern int g_pips_mixer_fused, g_pips_mixer_wgs, g_pips_mixer_diag;
+// hidden slices (8, 16 or 32) a channel-MLP launch over nseq sequences uses to reach g_pips_mixer_wgs workgroups
+int pips_mix_slices(int nseq);
+// part[slice][nseq*8][512] = fc2 over the slice's hidden units of gelu(fc1(LN(x)) + b1); x [nseq*8][512]
+int pips_mix_mlp(const float* x, const float* lnw, const float* lnb, const float* w1, const float* b1, const float* w2,
+                 float* part, int nseq, int NS, hipStream_t s);
+// x' = res + (sum of the NS slabs + bias) (NS = 0: x' = res); mode 0: out [nseq*8][512] = x' + token-mix(LN(x')) with the
+// token-mixing weights (w1 [32][8], w2 [8][32]); mode 1: out [nseq][512] = mean over the 8 tokens of LN(x').  out != res
+int pips_mix_reduce(const float* part, int NS, const float* bias, const float* res, int nseq, int mode, const float* lnw,
+                    const float* lnb, const float* w1, const float* b1, const float* w2, const float* b2, float* out,
+                    hipStream_t s);
 // mean over the S tokens of LN(x): out[n][D]
 int pips_ln_mean(const float* x, const float* lnw, const float* lnb, float* out, int nseq, int S, int D, hipStream_t s);
 // feature / coordinate update (pips.py:536-544): delta [n][S][130]; ffeats [n][S][128]; coords [S][n][2]

@@ -51,7 +51,7 @@ int pips_sample_feat(const float* fmap, int H, int W, int C, const int* frame_id
 __global__ __launch_bounds__(64) void k_pips_corr_sample(PyramidLevels pyr, const int* __restrict__ frame_idx, int S,
                                                           int n, const float* __restrict__ ffeats,
                                                           const float* __restrict__ coords, float* __restrict__ x,
-                                                          int ldx, int xoff) {
+                                                          int ldx, int xoff, const float* __restrict__ times) {
   constexpr int C = 128;
   __shared__ float cs[8][8];
   const int lane = threadIdx.x;
@@ -101,13 +101,33 @@ __global__ __launch_bounds__(64) void k_pips_corr_sample(PyramidLevels pyr, cons
     float v = cs[ry0][rx0] * (ss * e) + cs[ry0][rx1] * (ss * w) + cs[ry1][rx0] * (nn * e) + cs[ry1][rx1] * (nn * w);
     x[((long)pt * S + s) * ldx + xoff + lvl * 49 + lane] = v;
   }
+  // the level-0 unit of a row also writes the rest of the mixer input (k_pips_build_input's arithmetic, one launch less)
+  if (times && lvl == 0) {
+    float* xr = x + ((long)pt * S + s) * ldx;
+    const float* fr = ffeats + ((long)pt * S + s) * C;
+    xr[lane] = fr[lane], xr[lane + 64] = fr[lane + 64];
+    const float fx = coords[(s * n + pt) * 2] - coords[pt * 2];
+    const float fy = coords[(s * n + pt) * 2 + 1] - coords[pt * 2 + 1];
+    const float tz = times[s];
+#pragma unroll
+    for (int axis = 0; axis < 3; ++axis) {
+      const int k = lane;
+      const float v = axis == 0 ? fx : (axis == 1 ? fy : tz);
+      const float div = (float)(k & ~1) * (1000.0f / 64.0f);
+      const float a = v * div;
+      xr[324 + axis * 64 + k] = (k & 1) ? cosf(a) : sinf(a);
+    }
+    if (lane < 3) xr[324 + 192 + lane] = lane == 0 ? fx : (lane == 1 ? fy : tz);
+    else if (lane < 3 + (ldx - 519)) xr[324 + 192 + lane] = 0.f;  // K padding
+  }
 }
 
 int pips_corr_sample(const PyramidLevels& pyr, const int* frame_idx, int S, int n, int C, const float* ffeats,
-                     const float* coords, float* x, int ldx, int xoff, hipStream_t s) {
+                     const float* coords, float* x, int ldx, int xoff, hipStream_t s, const float* times) {
   if (C != 128 || n <= 0 || S <= 0) return SAMPT_ERR_ARG;
+  if (times && (xoff != 128 || ldx < 519 || ldx > 519 + 61)) return SAMPT_ERR_ARG;
   hipLaunchKernelGGL(k_pips_corr_sample, dim3(S * n, 4), dim3(64), 0, s, pyr, frame_idx, S, n, ffeats, coords, x, ldx,
-                     xoff);
+                     xoff, times);
   SAMPT_CHECK_LAUNCH("pips_corr_sample");
   return SAMPT_OK;
 }

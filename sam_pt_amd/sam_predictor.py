@@ -368,6 +368,11 @@ class SamPredictor:
         the same biases, whatever was encoded before."""
         m = self.model
         if not self.bias_correction or m.precision != "f16":
+            if self._bias_live is not None:       # switched off at run time: the original biases come back, and with them go
+                for k, v in self._bias_orig.items():      # the dead rows that were computed under the corrected ones
+                    self._wv[k].copy_(v)
+                self._bias_live = None
+                self._dead_cache.clear()
             return
         cfg, key = m.cfg, (int(H), int(W))
         e = "image_encoder.blocks."
@@ -392,11 +397,14 @@ class SamPredictor:
             finally:
                 _lib.check(self._lib.sampt_vit_calibrate(self._vit, None, 0), "sampt_vit_calibrate(end)")
             bset = {k: v.to(self._dev) for k, v in vit_bias_correction(m.sd, cfg, cal).items()}    # host, fp64 (pack.py)
-            if len(self._bias_sets) >= 8:
-                self._bias_sets.clear()
+            while len(self._bias_sets) >= 8:                   # least recently used geometry goes, not all of them
+                self._bias_sets.pop(next(iter(self._bias_sets)))
             self._bias_sets[key] = bset
             self.stats["bias_calibrations"] += 1
+        self._bias_sets[key] = self._bias_sets.pop(key)          # most recently used last
         if self._bias_live != key:
+            if self._bias_live is None:
+                self._dead_cache.pop(key, None)               # rows computed while the correction was switched off
             for k, v in self._bias_sets[key].items():
                 self._wv[k].copy_(v)
             self._bias_live = key
@@ -413,7 +421,7 @@ class SamPredictor:
         """Residual stream of the token rows no pixel of an (H, W) frame reaches (the zero padding of Sam.preprocess below
         a landscape frame) at the input of the first global-attention block: the same in every frame, computed once per
         geometry from the first frame that has it (sampt_vit_encode_live, include/sampt_hip.h).  None: nothing to skip."""
-        key = (H, W)
+        key = (H, W)      # (an entry is always computed under its geometry's bias set: _select_bias_set drops it on a toggle)
         if key not in self._dead_cache:
             lh, nb = C.c_int(), C.c_size_t()
             _lib.check(self._lib.sampt_vit_live_rows(self._vit, H, W, C.byref(lh), C.byref(nb)), "sampt_vit_live_rows")
@@ -423,8 +431,8 @@ class SamPredictor:
                 _lib.check(self._lib.sampt_vit_encode_live(self._vit, _lib.ptr(frames[:1]), 1 if chw else 0, 1, H, W, None,
                                                            None, _lib.ptr(cache), 1, _lib.ptr(ws), ws.numel(),
                                                            _lib.stream_ptr()), "sampt_vit_encode_live(build)")
-            if len(self._dead_cache) >= 8:
-                self._dead_cache.clear()
+            while len(self._dead_cache) >= 8:
+                self._dead_cache.pop(next(iter(self._dead_cache)))
             self._dead_cache[key] = cache
         return self._dead_cache[key]
 

@@ -745,3 +745,89 @@ def test_vit_window_attention_padding_from_bias_row(lib, dev, precision, S_, hea
     assert bool(torch.isfinite(got[real]).all())
     tol = 6e-3 if precision == 1 else 1e-5
     assert max_abs(got[real], ref[real]) < tol * float(ref.abs().max())
+
+
+# ---- fused MLP-Mixer block of the PIPS window (csrc/pips_mixer.hip; pips.py:96-128) -------------------------------------
+def _mixer_block_inputs(nseq, seed):
+    g = torch.Generator().manual_seed(seed)
+    R = nseq * 8
+    x = torch.randn(R, 512, generator=g) * 1.5 + 0.3
+    w = dict(lnw=1 + 0.2 * torch.randn(512, generator=g), lnb=0.1 * torch.randn(512, generator=g),
+             w1=torch.randn(2048, 512, generator=g) / 512 ** 0.5, b1=0.1 * torch.randn(2048, generator=g),
+             w2=torch.randn(512, 2048, generator=g) / 2048 ** 0.5, b2=0.1 * torch.randn(512, generator=g),
+             tlnw=1 + 0.2 * torch.randn(512, generator=g), tlnb=0.1 * torch.randn(512, generator=g),
+             tw1=torch.randn(32, 8, generator=g) / 8 ** 0.5, tb1=0.1 * torch.randn(32, generator=g),
+             tw2=torch.randn(8, 32, generator=g) / 32 ** 0.5, tb2=0.1 * torch.randn(8, generator=g))
+    return x, w
+
+
+@pytest.mark.parametrize("nseq,slices", [(8, 8), (8, 16), (8, 32), (3, 8), (1, 32), (24, 8), (5, 16)])
+def test_pips_mix_mlp_slabs(lib, dev, nseq, slices):
+    """Channel MLP of a mixer block as hidden slices: the slabs must sum to fc2(gelu(fc1(LN(x)))) (fp64 reference) and every
+    slab must be its own slice's product (a permuted slice order would still sum right)."""
+    x, w = _mixer_block_inputs(nseq, 100 + nseq + slices)
+    R = nseq * 8
+    xd = x.double()
+    y = F.layer_norm(xd, (512,), w["lnw"].double(), w["lnb"].double(), 1e-5)
+    h = F.gelu(y @ w["w1"].double().t() + w["b1"].double())
+    hs = 2048 // slices
+    ref = torch.stack([h[:, s * hs:(s + 1) * hs] @ w["w2"].double()[:, s * hs:(s + 1) * hs].t() for s in range(slices)])
+    d = {k: v.to(dev) for k, v in w.items()}
+    part = torch.full((slices, R, 512), float("nan"), device=dev)
+    x_d = x.to(dev)                                     # (named: a temporary's block could be handed out again before the launch)
+    ok(lib.sampt_pips_mix_mlp_f32(P(x_d), P(d["lnw"]), P(d["lnb"]), P(d["w1"]), P(d["b1"]), P(d["w2"]), P(part), nseq,
+                                  slices, S()), "mix_mlp")
+    torch.cuda.synchronize()
+    assert torch.isfinite(part).all()
+    scale = ref.abs().max().item()
+    assert (part.cpu().double() - ref).abs().max().item() < 3e-6 * max(scale, 1.0)
+    assert rel_err(part.sum(0), ref.sum(0)) < 2e-6
+
+
+@pytest.mark.parametrize("nseq,slices,mode", [(8, 8, 0), (8, 0, 0), (8, 16, 1), (3, 32, 0), (1, 8, 1), (24, 8, 0), (5, 0, 1)])
+def test_pips_mix_reduce(lib, dev, nseq, slices, mode):
+    """Slab sum + bias + residual, then token mixing (mode 0) or final LayerNorm + token mean (mode 1), against fp64 torch."""
+    x, w = _mixer_block_inputs(nseq, 200 + nseq + slices + mode)
+    R = nseq * 8
+    g = torch.Generator().manual_seed(7)
+    part = torch.randn(max(slices, 1), R, 512, generator=g) * 0.3
+    xp = x.double() + ((part[:slices].double().sum(0) + w["b2"].double()) if slices else 0.0)
+    y = F.layer_norm(xp, (512,), w["tlnw"].double(), w["tlnb"].double(), 1e-5)
+    if mode == 0:
+        ys = y.view(nseq, 8, 512)                                             # token mixing: Conv1d(k = 1) over the 8 tokens
+        hid = F.gelu(torch.einsum("ot,ntc->noc", w["tw1"].double(), ys) + w["tb1"].double()[None, :, None])
+        mixed = torch.einsum("to,noc->ntc", w["tw2"].double(), hid) + w["tb2"].double()[None, :, None]
+        ref = xp + mixed.reshape(R, 512)
+        out = torch.full((R, 512), float("nan"), device=dev)
+    else:
+        ref = y.view(nseq, 8, 512).mean(1)
+        out = torch.full((nseq, 512), float("nan"), device=dev)
+    d = {k: v.to(dev) for k, v in w.items()}
+    part_d, x_d = part.to(dev), x.to(dev)               # (named: two temporaries would share one recycled block)
+    ok(lib.sampt_pips_mix_reduce_f32(P(part_d) if slices else None, slices, P(d["b2"]) if slices else None, P(x_d),
+                                     nseq, mode, P(d["tlnw"]), P(d["tlnb"]), P(d["tw1"]), P(d["tb1"]), P(d["tw2"]), P(d["tb2"]),
+                                     P(out), S()), "mix_reduce")
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    assert rel_err(out, ref) < 2e-6
+
+
+def test_pips_mixer_fused_equals_four_launch_blocks(lib, dev):
+    """A clip's chained windows through both mixer paths (sampt_pips_set_mixer): same trajectories to fp32 round-off."""
+    from sam_pt_amd.point_tracker import PipsPointTracker
+    from sam_pt_amd.weights import init_pips_state_dict
+    from tests.util import disc_queries, synthetic_clip
+    frames, centres = synthetic_clip(T=12, H=128, W=256, seed=5)
+    q = disc_queries(centres, n_pos=5, r=9.0)[None]
+    outs = []
+    try:
+        for fused in (0, 1):
+            ok(lib.sampt_pips_set_mixer(fused, 32), "set_mixer")
+            trk = PipsPointTracker(state_dict=init_pips_state_dict(72)).to(dev)
+            tr, vi = trk(frames.to(dev)[None], q.to(dev))
+            outs.append((tr.cpu(), vi.cpu()))
+    finally:
+        ok(lib.sampt_pips_set_mixer(1, 32), "set_mixer")
+    assert max_abs(outs[0][0], outs[1][0]) < 2e-3, "trajectories of the two mixer paths differ"
+    assert (outs[0][0].round() == outs[1][0].round()).all()
+    assert (outs[0][1] == outs[1][1]).all()

@@ -1,6 +1,20 @@
-# scratch script of the current gpurun call: re-check after moving the bias-correction host math into pack.vit_bias_correction
+# scratch script of the current gpurun call: kernel traces of the window chain alone (fused mixer at 32 / 64 workgroups, four-launch
+# blocks) and of the blocking clip, launch-ordered excerpt of one iteration
 set -u
-R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/r5_c11; mkdir -p $OUT; cd $R
-timeout 400 python -m pytest tests/test_gpu_modules.py -q -s -k "bias_correction or vit_b_encoder or dead_row or prefetch" > $OUT/pytest_bias.log 2>&1
-timeout 200 python bench.py --no-cpu-baseline --no-secondary --no-roofline --steps 10 --warmup 3 > $OUT/bench_quick.log 2>&1
-tail -3 $OUT/pytest_bias.log; tail -1 $OUT/bench_quick.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['value_pipelined'], d['parity']['mask_iou_min'], d['parity']['pass'])"
+R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/r6_c2; mkdir -p $OUT; cd $R
+timeout 300 python -m pytest tests/test_gpu_kernels.py -q -k "pips_mix" > $OUT/pytest_kernels.log 2>&1
+tail -3 $OUT/pytest_kernels.log
+cd /tmp && export TMPDIR=/tmp
+for cfg in "1 32" "1 64" "0 32"; do set -- $cfg
+  SAMPT_PIPS_MIXER=$1 SAMPT_PIPS_MIXER_WGS=$2 timeout 300 rocprofv3 --kernel-trace -d $OUT/prof_$1_$2 -o trk -- python $R/tools/tracker_bench.py > $OUT/rocprof_$1_$2.log 2>&1
+  DB=$(find $OUT/prof_$1_$2 -name "*.db" | head -1)
+  [ -n "$DB" ] && python $R/tools/rocprof_summary.py "$DB" > $OUT/tracker_kernel_stats_m$1_w$2.txt 2>&1
+  [ -n "$DB" ] && python $R/tools/rocprof_sequence.py "$DB" 140 > $OUT/tracker_sequence_m$1_w$2.txt 2>&1
+  rm -rf $OUT/prof_$1_$2
+  head -12 $OUT/tracker_kernel_stats_m$1_w$2.txt
+done
+timeout 300 rocprofv3 --kernel-trace -d $OUT/prof_clip -o clip -- python $R/bench.py --no-cpu-baseline --no-secondary --no-roofline --no-pipelined --steps 4 --warmup 2 > $OUT/rocprof_clip.log 2>&1
+DB=$(find $OUT/prof_clip -name "*.db" | head -1)
+[ -n "$DB" ] && python $R/tools/rocprof_summary.py "$DB" 168 > $OUT/clip_kernel_stats.txt 2>&1
+rm -rf $OUT/prof_clip
+head -30 $OUT/clip_kernel_stats.txt
