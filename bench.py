@@ -55,6 +55,9 @@ def parse():
                     help="start the decoder chains of each encoder batch as soon as that batch is done (measured: loses)")
     ap.add_argument("--dec-split", type=int, default=0,
                     help="two decoder chains: frames of the first N encoder batches as soon as they are encoded, then the rest")
+    ap.add_argument("--side-cus", type=int, default=None,
+                    help="CUs per XCD reserved for the side streams (tracker window rounds, decoder chains); the image encoder runs on "
+                         "a stream confined to the other CUs (SamPt.side_cus_per_xcd; 0 = priority streams only)")
     ap.add_argument("--overlap-fnet", action="store_true", help="tracker encoder on the side stream too (measured: loses)")
     ap.add_argument("--no-dec-graph", action="store_true", help="decode chains as plain launches instead of hipGraph replays")
     ap.add_argument("--shard", default="sequences", choices=["sequences", "frames", "lpt"],
@@ -129,6 +132,8 @@ def build_model(args, dev):
     model = SamPt(tracker, pred, **sampt_kwargs(args)).eval()
     model.pipeline_decoder = args.dec_split if args.dec_split else args.dec_pipeline
     model.overlap_tracker_encoder_fnet = args.overlap_fnet
+    if args.side_cus is not None:
+        model.side_cus_per_xcd = args.side_cus
     return model
 
 
@@ -282,8 +287,8 @@ def secondary_rooflines(args, dev):
     cfg = SAM_CONFIGS[args.model]
     g = torch.Generator(device="cpu").manual_seed(1)
 
-    def timed(fn, reps=10):
-        for _ in range(3):
+    def timed(fn, reps=40):            # the GEMM block's steady-state protocol: 15 launches to warm up, 40 timed
+        for _ in range(15):
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -319,8 +324,16 @@ def secondary_rooflines(args, dev):
         t = timed(lambda: lib.sampt_vit_attention_f16(_lib.ptr(qkv), _lib.ptr(rh), _lib.ptr(rw), _lib.ptr(ao), B, S2, heads, hd,
                                                       None, 0, _lib.stream_ptr()))
         fl = 4.0 * B * heads * N * N * hd
-        out.append({"kernel": f"k_flash_f16, {name}", "bound": "mfma", "achieved": round(fl / t / 1e12, 1), "peak": 2500.0,
-                    "unit": "TFLOP/s", "frac": round(fl / t / 2.5e15, 4), "launch_us": round(t * 1e6, 1)})
+        ent = {"kernel": f"k_flash_f16, {name}", "bound": "mfma", "achieved": round(fl / t / 1e12, 1), "peak": 2500.0,
+               "unit": "TFLOP/s", "frac": round(fl / t / 2.5e15, 4), "launch_us": round(t * 1e6, 1)}
+        if S2 == 14:
+            # 4 N^2 hd FLOP over (q + k + v + out) = 4 N hd fp16 values per (window, head): N / 2 = 98 FLOP per byte against a
+            # machine balance of ~312 — the windowed launch is HBM-bound by construction; its roofline is the q / k / v / out bytes
+            nb = 4.0 * B * N * D * 2
+            ent.update({"bound": "hbm", "achieved": round(nb / t / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(nb / t / 8e12, 4),
+                        "algorithmic_bytes_per_launch": int(nb),
+                        "mfma": {"achieved": round(fl / t / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(fl / t / 2.5e15, 4)}})
+        out.append(ent)
         del qkv, ao
     # tracker encoder: the 64 -> 64 3x3 convolution at half resolution (the most frequent fnet layer), 3-term split-fp16 with
     # pre-split activation planes (what the encoder's InstanceNorm hands it): the LDS-DMA kernel k_conv_f16x3_dma<64>
@@ -332,7 +345,7 @@ def secondary_rooflines(args, dev):
     whl, b = split_f16x3(w).to(dev), torch.zeros(cc, device=dev)
     y = torch.empty(nimg, Hc, Wc, cc, device=dev)
     t = timed(lambda: lib.sampt_conv2d_nhwc(4, _lib.ptr(xhl), _lib.ptr(whl), _lib.ptr(b), _lib.ptr(y), nimg, Hc, Wc, ci, cc, 3, 3, 1, 1,
-                                            _lib.stream_ptr()), reps=5)
+                                            _lib.stream_ptr()), reps=20)
     fl = 2.0 * nimg * Hc * Wc * cc * 9 * ci
     out.append({"kernel": "k_conv_f16x3_dma<64> (fnet 64->64 3x3 @288x512, 8 frames, pre-split fp16 planes by LDS-DMA)", "bound": "mfma",
                 "achieved": round(fl / t / 1e12, 1), "peak": 833.3,
@@ -775,12 +788,39 @@ def main():
                "published_reference_fps_unstated_hw": {"vit_h": 1.4, "vit_l": 1.8, "vit_b": 2.6}[args.model]}
         if lpt_info:
             res["lpt"] = lpt_info
+        if world == 1 and not frames_sharded and not lpt:
+            # where one blocking forward spends its wall time (GPU-side event times, ms after the start of the forward): tracker
+            # encoder done, window chain done, image encoder done, decoder chain done (tools/forward_timeline.py)
+            tl_ms = {}
+            for _ in range(2):
+                model.timeline = {}
+                one_step(model, video, args.frames)
+                torch.cuda.synchronize()
+                e0 = model.timeline["start"][0]
+                tl_ms = {k: round(e0.elapsed_time(ev), 1) for k, (ev, _) in model.timeline.items() if k != "start"}
+            model.timeline = None
+            res["timeline"] = {"unit": "ms after the forward's first launch (GPU events), one blocking forward", **tl_ms}
+            lpr = getattr(model.point_tracker, "stats", {}).get("launches_per_round")
+            if lpr:
+                res["chain_launches_per_round"] = lpr
         if not args.no_roofline and args.precision in ("f16", "f16x3"):
             res["roofline"] = gemm_roofline(args, dev, insitu, (H, W))
             if args.precision == "f16":
                 res["roofline"]["secondary"] = secondary_rooflines(args, dev)
         if world == 1 and not args.no_secondary:
             res["secondary"] = secondary_lines(args, model, video, dev)
+            if headline and args.precision == "f16" and not args.no_roofline:
+                # the reference-grade arithmetic (split-fp16: the reference's fp32 ViT at fp32 grade) as a FULL line of its own —
+                # the same K timed steps, its own in-situ roofline block — from a child process running this very script
+                import subprocess
+                cmd = [sys.executable, os.path.abspath(__file__), "--precision", "f16x3", "--steps", str(args.steps), "--warmup",
+                       str(args.warmup), "--no-cpu-baseline", "--no-secondary", "--no-pipelined"]
+                try:
+                    pr = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+                    line = [l for l in pr.stdout.splitlines() if l.startswith("{")]
+                    res["secondary_line"] = json.loads(line[-1]) if line else {"error": (pr.stderr or "no output")[-400:]}
+                except Exception as ex:       # the headline line must not die with its side line
+                    res["secondary_line"] = {"error": repr(ex)[:400]}
         if world == 1 and args.emulate_ranks:
             res["frame_sharding_model"] = frame_sharding_model(args, model, video)
         if world == 1 and not args.no_cpu_baseline:

@@ -80,6 +80,9 @@ int sampt_pips_track_f32(sampt_pips_t h, const float* const pyr_dev[4], int H0, 
  * tracker.py:73-78).  Points are independent in PIPS, so points anchored at different frames share one call;
  * xys_dev: [n][2] pixels at the window's first frame; feat_init_dev: [n][128].
  * traj_out_dev: [S][n][2] pixels (last iteration); vis_out_dev: [S][n] in (0,1). */
+/* Kernel launches of one ROUND of the last sampt_pips_track_f32 call (one window of every chain: round begin, the window's
+ * iterations as counted at their launch sites, round end); 0 before the first call. */
+int sampt_pips_round_launches(sampt_pips_t h);
 int sampt_pips_update_workspace_bytes(sampt_pips_t h, int n, size_t* bytes);
 int sampt_pips_update_f32(sampt_pips_t h, const float* const pyr_dev[4], int H0, int W0, const int32_t* frame_idx_dev,
                           int n, const float* xys_dev, const float* feat_init_dev, int iters, float* traj_out_dev,
@@ -191,6 +194,14 @@ int sampt_gemm_set_thin_min_wgs(int n);
  * workgroups a channel-MLP launch should reach (it uses 8, 16 or 32 hidden slices per group of two point chains; default 32 =
  * the CUs the ViT encoder's persistent GEMMs leave free beside the tracker). */
 int sampt_pips_set_mixer(int fused, int workgroups);
+/* A HIP stream confined to the CUs [cu_lo, cu_hi) of EVERY XCD (hipExtStreamCreateWithCUMask; MI355X: 8 XCDs of 32 CUs, mask bit i
+ * = CU i / 8 of XCD i % 8 — tools/probes/cu_mask_probe.hip, profiles/r6_c3_cu_mask_probe.log; an XCD left without any CU gets all of
+ * them back, so every XCD keeps at least one).  The host orchestration uses two of them to split the chip in space between the ViT
+ * encoder and the latency-bound side work (tracker window rounds, decoder chains): kernels of one never wait for CUs of the other.
+ * priority: 0 normal, -1 high (the runtime's mask call has no priority argument: recorded for the caller, currently unused).
+ * Destroy with sampt_stream_destroy after the stream is idle. */
+int sampt_stream_create_cu_range(int cu_lo, int cu_hi, sampt_stream_t* out);
+int sampt_stream_destroy(sampt_stream_t stream);
 /* Calibration hook of the fp16 mode's static bias correction (sam_pt_amd/sam_predictor.py: the rounding of a weight matrix to
  * fp16 adds A.(W - fp16(W))^T to a GEMM's output; its token-mean part mean(A).(W - fp16(W))^T is a per-column constant that the
  * packer folds into the bias once per frame geometry).  While colmeans_dev is set, every block GEMM of sampt_vit_encode (fp16 mode,

@@ -98,6 +98,9 @@ _SIGS = {
     "sampt_gemm_set_schedule": (c_int, [c_int]),
     "sampt_gemm_set_thin_min_wgs": (c_int, [c_int]),
     "sampt_pips_set_mixer": (c_int, [c_int, c_int]),
+    "sampt_stream_create_cu_range": (c_int, [c_int, c_int, C.POINTER(_P)]),
+    "sampt_stream_destroy": (c_int, [_P]),
+    "sampt_pips_round_launches": (c_int, [_P]),
     "sampt_pips_mix_mlp_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
     "sampt_pips_mix_reduce_f32": (c_int, [_P, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "sampt_gemm_ex": (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, c_int, c_int, _P]),
@@ -175,6 +178,15 @@ def ptr(t: Optional[torch.Tensor]):
 def stream_ptr(device=None):
     """torch's current stream ON `device` (default: the current device — inside ``device_guard`` that is the guarded one)."""
     return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def cu_range_stream(device, cu_lo: int, cu_hi: int) -> "torch.cuda.Stream":
+    """A torch stream on `device` confined to CUs [cu_lo, cu_hi) of every XCD (sampt_stream_create_cu_range).  The HIP stream lives
+    as long as the process (a handful per model; the runtime frees them at exit)."""
+    h = c_void_p()
+    with device_guard(device):
+        check(load().sampt_stream_create_cu_range(int(cu_lo), int(cu_hi), C.byref(h)), "sampt_stream_create_cu_range")
+    return torch.cuda.ExternalStream(h.value, device=device)
 
 
 def device_guard(device):

@@ -184,6 +184,8 @@ int sampt_pips_track_f32(sampt_pips_t h, const float* const pyr[4], int H0, int 
   return rc;
 }
 
+int sampt_pips_round_launches(sampt_pips_t h) { return h && h->e.window_launches ? h->e.window_launches + 2 : 0; }
+
 int sampt_pips_update_workspace_bytes(sampt_pips_t h, int n, size_t* bytes) {
   if (!h || !bytes || n <= 0) return SAMPT_ERR_ARG;
   Arena a(nullptr, 0);
@@ -301,6 +303,28 @@ int sampt_gemm_set_thin_min_wgs(int n) {
   if (n < 1 || n > 4096) return fail(SAMPT_ERR_ARG, "sampt_gemm_set_thin_min_wgs: 1 .. 4096");
   sampt::g_thin_min_wgs = n;
   return SAMPT_OK;
+}
+
+int sampt_stream_create_cu_range(int cu_lo, int cu_hi, sampt_stream_t* out) {
+  if (!out || cu_lo < 0 || cu_hi > 32 || cu_lo >= cu_hi) return fail(SAMPT_ERR_ARG, "sampt_stream_create_cu_range: need 0 <= cu_lo < cu_hi <= 32");
+  hipDeviceProp_t p;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return fail(SAMPT_ERR_HIP, "sampt_stream_create_cu_range: no device");
+  const int ncu = p.multiProcessorCount, nxcd = 8;
+  if (ncu != nxcd * 32) return fail(SAMPT_ERR_UNSUPPORTED, "sampt_stream_create_cu_range: written for 8 XCDs x 32 CUs");
+  uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < ncu; ++i)              // bit i = CU i / 8 of XCD i % 8
+    if (i / nxcd >= cu_lo && i / nxcd < cu_hi) mask[i / 32] |= 1u << (i % 32);
+  hipStream_t s = nullptr;
+  const hipError_t e = hipExtStreamCreateWithCUMask(&s, 8, mask);
+  if (e != hipSuccess) { sampt::set_error("hipExtStreamCreateWithCUMask", e); return SAMPT_ERR_HIP; }
+  *out = (sampt_stream_t)s;
+  return SAMPT_OK;
+}
+
+int sampt_stream_destroy(sampt_stream_t stream) {
+  if (!stream) return SAMPT_OK;
+  return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? SAMPT_OK : SAMPT_ERR_HIP;
 }
 
 int sampt_pips_set_mixer(int fused, int workgroups) {

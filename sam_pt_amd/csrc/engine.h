@@ -65,6 +65,7 @@ struct PipsEngine {
   } mix[12];
   const float *gn_w, *gn_b, *up_wT, *up_b, *vis_w, *vis_b, *times;
   std::string error;
+  int window_launches = 0;   // kernel launches of the last update() call (one window of every chain = the body of a round)
 
   int init(const WeightMap& w);
   int init_fnet(const WeightMap& w);   // encoder only (shared with PIPS++: same BasicEncoder, other stride)

@@ -194,6 +194,8 @@ static int lin(const float* A, int M, int K, int lda, const float* W, const floa
   return gemm_f32(p, s);
 }
 
+#define PIPS_LAUNCH(expr) do { ++nl; SAMPT_TRY(expr); } while (0)     // every kernel launch of a window is counted where it is made
+
 int PipsEngine::update(const PyramidLevels& pyr, const int* frame_idx, int n, const float* xys, const float* feat_init,
                        int iters, float* traj_out, float* vis_out, Arena& ws, hipStream_t s) {
   const bool dry = ws.dry();
@@ -212,46 +214,49 @@ int PipsEngine::update(const PyramidLevels& pyr, const int* frame_idx, int n, co
   float* part = ws.f32((size_t)32 * R * D);
   if (!ws.ok()) return SAMPT_ERR_WORKSPACE;
   if (dry) return SAMPT_OK;
+  int nl = 0;                                  // kernel launches of this window (counted at the launch sites)
   const bool fused = g_pips_mixer_fused != 0;
   const int NS = pips_mix_slices(n);
-  SAMPT_TRY(pips_init_state(xys, feat_init, (float)stride, S, n, coords, coords0, ffeats, s));
+  PIPS_LAUNCH(pips_init_state(xys, feat_init, (float)stride, S, n, coords, coords0, ffeats, s));
   for (int it = 0; it < iters; ++it) {
     if (fused) {
       // 30 launches per iteration: input (1), in-projection (1), per block [sum of the previous block's slabs + residual ->
       // token mixing] and [LayerNorm -> fc1 -> GELU -> fc2 slabs] (2 x 12), last sum + LayerNorm + token mean (1), head, update
-      SAMPT_TRY(pips_corr_sample(pyr, frame_idx, S, n, 128, ffeats, coords, x, LDX, 128, s, times));
-      SAMPT_TRY(lin(x, R, LDX, LDX, in_w, in_b, hbuf, D, ACT_NONE, nullptr, s));
+      PIPS_LAUNCH(pips_corr_sample(pyr, frame_idx, S, n, 128, ffeats, coords, x, LDX, 128, s, times));
+      PIPS_LAUNCH(lin(x, R, LDX, LDX, in_w, in_b, hbuf, D, ACT_NONE, nullptr, s));
       float* xpp[2] = {hbuf2, lnb};
       const float* prev = hbuf;
       for (int i = 0; i < 12; ++i) {
         const MixBlk& m = mix[i];
-        SAMPT_TRY(pips_mix_reduce(i ? part : nullptr, i ? NS : 0, i ? mix[i - 1].cb2 : nullptr, prev, n, 0, m.ln1w, m.ln1b,
+        PIPS_LAUNCH(pips_mix_reduce(i ? part : nullptr, i ? NS : 0, i ? mix[i - 1].cb2 : nullptr, prev, n, 0, m.ln1w, m.ln1b,
                                   m.tw1, m.tb1, m.tw2, m.tb2, xpp[i & 1], s));
-        SAMPT_TRY(pips_mix_mlp(xpp[i & 1], m.ln2w, m.ln2b, m.cw1, m.cb1, m.cw2, part, n, NS, s));
+        PIPS_LAUNCH(pips_mix_mlp(xpp[i & 1], m.ln2w, m.ln2b, m.cw1, m.cb1, m.cw2, part, n, NS, s));
         prev = xpp[i & 1];
       }
-      SAMPT_TRY(pips_mix_reduce(part, NS, mix[11].cb2, prev, n, 1, oln_w, oln_b, nullptr, nullptr, nullptr, nullptr, mean, s));
+      PIPS_LAUNCH(pips_mix_reduce(part, NS, mix[11].cb2, prev, n, 1, oln_w, oln_b, nullptr, nullptr, nullptr, nullptr, mean, s));
     } else {
-      SAMPT_TRY(pips_corr_sample(pyr, frame_idx, S, n, 128, ffeats, coords, x, LDX, 128, s));
-      SAMPT_TRY(pips_build_input(ffeats, coords, times, S, n, x, LDX, s));
-      SAMPT_TRY(lin(x, R, LDX, LDX, in_w, in_b, hbuf, D, ACT_NONE, nullptr, s));
+      PIPS_LAUNCH(pips_corr_sample(pyr, frame_idx, S, n, 128, ffeats, coords, x, LDX, 128, s));
+      PIPS_LAUNCH(pips_build_input(ffeats, coords, times, S, n, x, LDX, s));
+      PIPS_LAUNCH(lin(x, R, LDX, LDX, in_w, in_b, hbuf, D, ACT_NONE, nullptr, s));
       // 12 mixer blocks, 4 launches each: token mixing, LayerNorm, fc1 + GELU, fc2 + residual (thin GEMMs: K split inside
       // the workgroup, no split-K grid + reduction pass).
       for (int i = 0; i < 12; ++i) {
         const MixBlk& m = mix[i];
-        SAMPT_TRY(pips_token_mix(hbuf, hbuf2, m.ln1w, m.ln1b, m.tw1, m.tb1, m.tw2, m.tb2, n, S, D, s));
-        SAMPT_TRY(layernorm_rows(hbuf2, m.ln2w, m.ln2b, lnb, R, D, 1e-5f, nullptr, 0, ACT_NONE, s));
-        SAMPT_TRY(lin(lnb, R, D, D, m.cw1, m.cb1, hid, 4 * D, ACT_GELU, nullptr, s));
-        SAMPT_TRY(lin(hid, R, 4 * D, 4 * D, m.cw2, m.cb2, hbuf, D, ACT_NONE, hbuf2, s));
+        PIPS_LAUNCH(pips_token_mix(hbuf, hbuf2, m.ln1w, m.ln1b, m.tw1, m.tb1, m.tw2, m.tb2, n, S, D, s));
+        PIPS_LAUNCH(layernorm_rows(hbuf2, m.ln2w, m.ln2b, lnb, R, D, 1e-5f, nullptr, 0, ACT_NONE, s));
+        PIPS_LAUNCH(lin(lnb, R, D, D, m.cw1, m.cb1, hid, 4 * D, ACT_GELU, nullptr, s));
+        PIPS_LAUNCH(lin(hid, R, 4 * D, 4 * D, m.cw2, m.cb2, hbuf, D, ACT_NONE, hbuf2, s));
       }
-      SAMPT_TRY(pips_ln_mean(hbuf, oln_w, oln_b, mean, n, S, D, s));
+      PIPS_LAUNCH(pips_ln_mean(hbuf, oln_w, oln_b, mean, n, S, D, s));
     }
-    SAMPT_TRY(lin(mean, n, D, D, head_w, head_b, delta, S * 130, ACT_NONE, nullptr, s));
-    SAMPT_TRY(pips_update(delta, gn_w, gn_b, up_wT, up_b, ffeats, coords, coords0, S, n, s));
+    PIPS_LAUNCH(lin(mean, n, D, D, head_w, head_b, delta, S * 130, ACT_NONE, nullptr, s));
+    PIPS_LAUNCH(pips_update(delta, gn_w, gn_b, up_wT, up_b, ffeats, coords, coords0, S, n, s));
   }
-  SAMPT_TRY(pips_finalize(ffeats, vis_w, vis_b, coords, (float)stride, S, n, traj_out, vis_out, s));
+  PIPS_LAUNCH(pips_finalize(ffeats, vis_w, vis_b, coords, (float)stride, S, n, traj_out, vis_out, s));
+  window_launches = nl;
   return SAMPT_OK;
 }
+#undef PIPS_LAUNCH
 
 int PipsEngine::track(const PyramidLevels& pyr, int T, int n, const float* q, const unsigned char* flip, const float* q_host,
                       const unsigned char* flip_host, float thr0, int iters, void* const* chunk_ev, const int* chunk_lo,

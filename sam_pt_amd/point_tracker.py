@@ -213,6 +213,7 @@ class PipsPointTracker(PointTracker):
             ev_arr if evs else None, lo_arr if evs else None, hi_arr if evs else None, len(evs), _lib.ptr(traj), _lib.ptr(vis),
             _lib.ptr(ws), ws.numel(), _lib.stream_ptr(), C.byref(rounds)), "sampt_pips_track_f32")
         self.stats["windows"] += rounds.value
+        self.stats["launches_per_round"] = int(self._lib.sampt_pips_round_launches(self._h))
         return traj.cpu(), vis.cpu() > 0.5
 
     @torch.no_grad()

@@ -120,8 +120,18 @@ class SamPt(nn.Module):
         # GPU time of one 24-item chain: 77.9 fps serial, 75.2 with the tracker encoder overlapped, 71.9 with both.
         self.pipeline_decoder = False
         self.overlap_tracker_encoder_fnet = False
+        # fused path only, round 6: split the chip IN SPACE while the tracker's window rounds run beside the encoder.  The side
+        # streams (window rounds, decoder chains) are created confined to the last `side_cus_per_xcd` CUs of every XCD and the image
+        # encoder runs on a stream confined to the others (hipExtStreamCreateWithCUMask through sampt_stream_create_cu_range), so a
+        # round's launches never queue behind an attention or LayerNorm launch that covers the whole chip (measured round 5 / 6:
+        # the chain takes 53 - 84 ms alone and 145 - 150 ms beside the encoder; its launches waited up to 1 ms for a CU) and
+        # the encoder's kernels never find "their" CUs taken.  0 = off (priority streams + the GEMM workgroup knob, rounds 3 - 5).
+        # SAMPT_SIDE_CUS overrides.
+        self.side_cus_per_xcd = int(os.environ.get("SAMPT_SIDE_CUS", "0"))
         self._side_stream = None
         self._dec_stream = None
+        self._enc_stream = None
+        self._streams_split = None
         self.timeline = None      # measurement hook: a dict that forward() fills with timed CUDA events / host stamps
 
     @property
@@ -230,9 +240,18 @@ class SamPt(nn.Module):
                     if not getattr(self.point_tracker, "chunk_events_on_other_stream", False):
                         ready = torch.cuda.Event()       # tracker without per-chunk events: wait for the whole pyramid
                         ready.record()
-                if self._side_stream is None:
-                    self._side_stream = torch.cuda.Stream(device=images.device, priority=-1)
-                    self._dec_stream = torch.cuda.Stream(device=images.device, priority=-1)
+                from . import _lib
+                split = int(self.side_cus_per_xcd) if 0 < int(self.side_cus_per_xcd) < 32 else 0
+                if self._side_stream is None or self._streams_split != split:
+                    if split:
+                        self._side_stream = _lib.cu_range_stream(images.device, 32 - split, 32)
+                        self._dec_stream = _lib.cu_range_stream(images.device, 32 - split, 32)
+                        self._enc_stream = _lib.cu_range_stream(images.device, 0, 32 - split)
+                    else:
+                        self._side_stream = torch.cuda.Stream(device=images.device, priority=-1)
+                        self._dec_stream = torch.cuda.Stream(device=images.device, priority=-1)
+                        self._enc_stream = None
+                    self._streams_split = split
             sam_images = images if frame_ids is None else images[torch.as_tensor(frame_ids, device=images.device)]
             batch_events = [] if overlap else None
             self._mark("prepared")
@@ -240,9 +259,18 @@ class SamPt(nn.Module):
             # workgroup owns its CU; measured on MI355X, profiles/r3_v3_timeline_wgs*.log: 32 / 30 workgroups per XCD
             # 248 ms per clip with the tracker ending 24 ms after the encoder, 28 per XCD 229 ms)
             reserve = self._encoder_gemm_workgroups() if overlap else None
+            enc_stream = self._enc_stream if overlap else None
+            if enc_stream is not None:                   # spatial split: one persistent GEMM workgroup per CU the encoder owns
+                reserve = 32 - self._streams_split
             kw = {"gemm_workgroups": reserve} if reserve else {}
-            feats = self.sam_predictor.encode_frames(sam_images, chw=True, batch_events=batch_events, **kw)   # embeddings in HBM
-            self._mark("encoded")
+            if enc_stream is not None:
+                enc_stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(enc_stream):
+                    feats = self.sam_predictor.encode_frames(sam_images, chw=True, batch_events=batch_events, **kw)
+                    self._mark("encoded")
+            else:
+                feats = self.sam_predictor.encode_frames(sam_images, chw=True, batch_events=batch_events, **kw)   # embeddings in HBM
+                self._mark("encoded")
             if overlap:
                 self._side_stream.wait_event(ready)
                 with torch.cuda.stream(self._side_stream):
@@ -251,6 +279,10 @@ class SamPt(nn.Module):
                     tracked = self._track_points(images, query_points)
                     self._mark("tracked")
                 torch.cuda.current_stream().wait_stream(self._side_stream)
+                if enc_stream is not None:
+                    torch.cuda.current_stream().wait_stream(enc_stream)
+                    if hasattr(feats, "record_stream"):
+                        feats.record_stream(torch.cuda.current_stream())
                 if batch_events:
                     if not self.pipeline_decoder:                            # one chain for the clip, after the last batch
                         batch_events = [(batch_events[-1][0], batch_events[-1][1])]
