@@ -73,6 +73,11 @@ def parse():
     ap.add_argument("--allgather-gbs", type=float, default=250.0,
                     help="--emulate-ranks: assumed RCCL all_gather rate per GPU over xGMI, GB/s of received bytes (7 links x 153 "
                          "GB/s peak per GPU; ring collectives are per-link bound)")
+    ap.add_argument("--lpt-model", default="",
+                    help="one GPU: time ONE blocking forward per distinct sequence length of the DAVIS-17-val histogram (--sequences), "
+                         "then predict the N-rank time of a sequence-sharded pass (comma-separated N, e.g. 2,4,8) from those MEASURED "
+                         "per-sequence times with an LPT assignment by time (`sequence_sharding_model` in the JSON line; a model: the "
+                         "ranks' host threads and the final mask gather are not in it)")
     ap.add_argument("--sequences", type=int, default=30, help="--shard lpt: number of sequences of the DAVIS-17 val histogram")
     ap.add_argument("--native-480p", action="store_true",
                     help="feed the 480x854 frames as they are (tracker at 480p, SAM resizes inside) instead of the "
@@ -596,6 +601,54 @@ def frame_sharding_model(args, model, video, steps=3):
     return res
 
 
+def sequence_sharding_model(args, model, dev, steps=2):
+    """Predicted sequence-sharded scaling (BASELINE config #4: one DAVIS sequence per rank, north_star's >= 6 x at 8 GPUs) from
+    ONE GPU: every distinct length of the DAVIS-2017-val histogram is timed as a blocking SamPt.forward of a synthetic clip of that
+    length (so the fixed per-clip head and tail — tracker encoder start-up, window chain, decoder chain — are IN the numbers), the
+    30 sequences are LPT-assigned to N ranks by measured time, predicted pass time = the slowest rank's sum.  A MODEL: per-rank host
+    threads, PCIe and the uint8 mask gather (0.59 MB per frame) are not in it; no N > 1 run exists on this pool."""
+    from sam_pt_amd.dist import DAVIS17_VAL_LENGTHS, lpt_assign
+    from sam_pt_amd.synth import bench_clip
+    lengths = DAVIS17_VAL_LENGTHS[:args.sequences]
+    frames, qp = bench_clip(T=max(lengths), seed=72, n_pos=args.points, n_objects=args.objects, native=args.native_480p,
+                            n_neg=args.neg_points, square=args.square)
+    fd = frames.to(dev)
+    H, W = frames.shape[-2:]
+    ms = {}
+    for L in sorted(set(lengths)):
+        v = {"image": [f for f in fd[:L]], "target_hw": (H, W), "query_points": qp}
+        one_step(model, v, L)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one_step(model, v, L)
+        torch.cuda.synchronize()
+        ms[L] = (time.perf_counter() - t0) / steps * 1e3
+    times = [ms[L] for L in lengths]
+    total = sum(times)
+    # least-squares line ms = a + b * frames: a is the fixed cost per clip the frame-count model of rounds 4 - 5 ignored
+    n = len(ms)
+    xs, ys = list(ms.keys()), list(ms.values())
+    mx, my = sum(xs) / n, sum(ys) / n
+    b = sum((x - mx) * (y - my) for x, y in zip(xs, ys)) / max(sum((x - mx) ** 2 for x in xs), 1e-9)
+    a = my - b * mx
+    res = {"sequences": len(lengths), "frames_total": sum(lengths), "one_gpu_ms": round(total, 1),
+           "one_gpu_fps": round(sum(lengths) / total * 1e3, 2),
+           "measured_ms_by_length": {str(k): round(v, 1) for k, v in ms.items()},
+           "fit_ms": {"fixed_per_clip": round(a, 1), "per_frame": round(b, 3)}, "by_world": {},
+           "note": "model from per-sequence times measured on ONE GPU; LPT assignment by measured time"}
+    for N in [int(v) for v in args.lpt_model.split(",") if v]:
+        assign = lpt_assign([int(round(t * 1000)) for t in times], N)
+        loads = [sum(times[i] for i in a_) for a_ in assign]
+        by_frames = lpt_assign(lengths, N)
+        loads_f = [sum(times[i] for i in a_) for a_ in by_frames]
+        res["by_world"][str(N)] = {"predicted_ms": round(max(loads), 1), "predicted_speedup": round(total / max(loads), 2),
+                                   "predicted_fps": round(sum(lengths) / max(loads) * 1e3, 1),
+                                   "imbalance_max_over_mean": round(max(loads) / (total / N), 4),
+                                   "predicted_speedup_lpt_by_frame_count": round(total / max(loads_f), 2)}
+    return res
+
+
 def self_launch(args):
     """``python bench.py --gpus N`` with N > 1 and no rendezvous in the environment: re-exec this very command line under
     ``torch.distributed.run`` (one rank per GPU, RCCL), exactly as the documented launch line does."""
@@ -823,6 +876,8 @@ def main():
                     res["secondary_line"] = {"error": repr(ex)[:400]}
         if world == 1 and args.emulate_ranks:
             res["frame_sharding_model"] = frame_sharding_model(args, model, video)
+        if world == 1 and args.lpt_model:
+            res["sequence_sharding_model"] = sequence_sharding_model(args, model, dev)
         if world == 1 and not args.no_cpu_baseline:
             # the timed configuration's result, compared with the oracle: with pipelined submission the clip that had the
             # next one submitted on top of it (its decoder chain ran beside that one's tracker encoder)

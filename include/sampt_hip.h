@@ -190,7 +190,9 @@ int sampt_gemm_set_schedule(int sched);
 int sampt_gemm_set_thin_min_wgs(int n);
 /* Process-wide knob of the PIPS window's MLP-Mixer (csrc/pips_mixer.hip).  fused = 1 (default): two launches per mixer block —
  * [sum of the previous channel MLP's slabs + residual -> token mixing] and [LayerNorm -> fc1 -> GELU -> fc2 over hidden slices];
- * fused = 0: the four-launch blocks of rounds 1 - 5 (token mixing, LayerNorm, two thin GEMMs).  workgroups = how many
+ * fused = 0: the four-launch blocks of rounds 1 - 5 (token mixing, LayerNorm, two thin GEMMs); fused = 2: the two-launch blocks with
+ * the channel MLP as 3-term split-fp16 MFMA products at fp32 grade (csrc/pips_mixer_x3.hip; needs the packed operand streams
+ * "delta_block.to_delta.<i>.__x3s16" / "__x3s32" among the weights, else it falls back to fused = 1).  workgroups = how many
  * workgroups a channel-MLP launch should reach (it uses 8, 16 or 32 hidden slices per group of two point chains; default 32 =
  * the CUs the ViT encoder's persistent GEMMs leave free beside the tracker). */
 int sampt_pips_set_mixer(int fused, int workgroups);
@@ -387,6 +389,18 @@ int sampt_pips_mix_mlp_f32(const float* x_dev, const float* lnw_dev, const float
 int sampt_pips_mix_reduce_f32(const float* part_dev, int slices, const float* bias_dev, const float* res_dev, int nseq, int mode,
                               const float* lnw_dev, const float* lnb_dev, const float* tw1_dev, const float* tb1_dev,
                               const float* tw2_dev, const float* tb2_dev, float* out_dev, sampt_stream_t stream);
+/* The split-fp16 generation of the same block (csrc/pips_mixer_x3.hip), exported for the kernel tests.
+ * pre: x' = res + (slab sum + bias) (slices = 0: x' = res); xout_dev [nseq*8][512] = x' + token-mix(LayerNorm1(x')); xop_dev = the
+ *      operand images of 2^6 LayerNorm2(xout) split into fp16 hi / lo, sampt_pips_mix_xop_halves(nseq) halves.
+ * mlp_x3: part_dev[slice][nseq*8][512] from xop_dev and the block's packed weight stream wstream_dev [slices][(2048/slices/16)*64*512]
+ *      halves (sam_pt_amd/pack.py pips_mixer_x3_stream; slices = 16 or 32) and the fc1 bias b1_dev [2048]. */
+size_t sampt_pips_mix_xop_halves(int nseq);
+int sampt_pips_mix_pre_f32(const float* part_dev, int slices, const float* bias_dev, const float* res_dev, int nseq,
+                           const float* ln1w_dev, const float* ln1b_dev, const float* tw1_dev, const float* tb1_dev,
+                           const float* tw2_dev, const float* tb2_dev, const float* ln2w_dev, const float* ln2b_dev,
+                           float* xout_dev, void* xop_dev, sampt_stream_t stream);
+int sampt_pips_mix_mlp_x3(const void* xop_dev, const void* wstream_dev, const float* b1_dev, float* part_dev, int nseq, int slices,
+                          sampt_stream_t stream);
 /* ViT attention on a packed qkv matrix [B*S*S][3*heads*hd] (f16), decomposed rel-pos tables (2S-1, hd) f32.
  * out_dev f16 [B*S*S][heads*hd].  The bias tables are built inside the kernel; the workspace arguments are kept for
  * ABI stability and ignored (may be NULL / 0). */

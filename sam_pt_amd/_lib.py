@@ -102,6 +102,9 @@ _SIGS = {
     "sampt_stream_destroy": (c_int, [_P]),
     "sampt_pips_round_launches": (c_int, [_P]),
     "sampt_pips_mix_mlp_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
+    "sampt_pips_mix_xop_halves": (c_size_t, [c_int]),
+    "sampt_pips_mix_pre_f32": (c_int, [_P, c_int, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "sampt_pips_mix_mlp_x3": (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
     "sampt_pips_mix_reduce_f32": (c_int, [_P, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "sampt_gemm_ex": (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, c_int, c_int, _P]),
     "sampt_conv2d_nhwc": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),

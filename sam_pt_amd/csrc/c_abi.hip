@@ -328,9 +328,9 @@ int sampt_stream_destroy(sampt_stream_t stream) {
 }
 
 int sampt_pips_set_mixer(int fused, int workgroups) {
-  if (fused < 0 || fused > 1 || workgroups < 1 || workgroups > 1024)
-    return fail(SAMPT_ERR_ARG, "sampt_pips_set_mixer: fused 0 / 1, workgroups 1 .. 1024");
-  sampt::g_pips_mixer_fused = fused, sampt::g_pips_mixer_wgs = workgroups;
+  if (fused < 0 || fused > 2 || workgroups < 1 || workgroups > 1024)
+    return fail(SAMPT_ERR_ARG, "sampt_pips_set_mixer: fused 0 / 1 / 2, workgroups 1 .. 1024");
+  sampt::g_pips_mixer_fused = fused ? 1 : 0, sampt::g_pips_mixer_x3 = fused == 2, sampt::g_pips_mixer_wgs = workgroups;
   const char* d = getenv("SAMPT_PIPS_MIXER_DIAG");      // measurement builds only: see pips_mixer.hip g_pips_mixer_diag
   sampt::g_pips_mixer_diag = d ? atoi(d) : 0;
   return SAMPT_OK;
@@ -777,6 +777,20 @@ int sampt_pips_mix_reduce_f32(const float* part, int slices, const float* bias, 
   if (!lnw || !lnb || (mode != 0 && mode != 1) || (mode == 0 && (!tw1 || !tb1 || !tw2 || !tb2)))
     return fail(SAMPT_ERR_ARG, "sampt_pips_mix_reduce_f32: bad arguments");
   return pips_mix_reduce(part, slices, bias, res, nseq, mode, lnw, lnb, tw1, tb1, tw2, tb2, out, (hipStream_t)stream);
+}
+
+size_t sampt_pips_mix_xop_halves(int nseq) { return nseq > 0 ? pips_mix_xop_halves(nseq) : 0; }
+
+int sampt_pips_mix_pre_f32(const float* part, int slices, const float* bias, const float* res, int nseq, const float* ln1w,
+                           const float* ln1b, const float* tw1, const float* tb1, const float* tw2, const float* tb2,
+                           const float* ln2w, const float* ln2b, float* xout, void* xop, sampt_stream_t stream) {
+  if (!ln1w || !ln1b || !tw1 || !tb1 || !tw2 || !tb2 || !ln2w || !ln2b) return fail(SAMPT_ERR_ARG, "sampt_pips_mix_pre_f32: null pointer");
+  return pips_mix_pre(part, slices, bias, res, nseq, ln1w, ln1b, tw1, tb1, tw2, tb2, ln2w, ln2b, xout, (half_t*)xop, (hipStream_t)stream);
+}
+
+int sampt_pips_mix_mlp_x3(const void* xop, const void* wstream, const float* b1, float* part, int nseq, int slices,
+                          sampt_stream_t stream) {
+  return pips_mix_mlp_x3((const half_t*)xop, (const half_t*)wstream, b1, part, nseq, slices, (hipStream_t)stream);
 }
 
 int sampt_vit_attention_f16(const void* qkv, const float* rel_h, const float* rel_w, void* out, int B, int S, int heads,

@@ -62,6 +62,7 @@ struct PipsEngine {
   const float *in_w, *in_b, *head_w, *head_b, *oln_w, *oln_b;
   struct MixBlk {
     const float *ln1w, *ln1b, *tw1, *tb1, *tw2, *tb2, *ln2w, *ln2b, *cw1, *cb1, *cw2, *cb2;
+    const half_t* x3s[2];      // optional: the channel MLP's weights as split-fp16 operand streams for 16 / 32 hidden slices
   } mix[12];
   const float *gn_w, *gn_b, *up_wT, *up_b, *vis_w, *vis_b, *times;
   std::string error;

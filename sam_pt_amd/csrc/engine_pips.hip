@@ -55,6 +55,8 @@ int PipsEngine::init(const WeightMap& w) {
     m.ln2w = w.f(p + ".1.norm.weight"), m.ln2b = w.f(p + ".1.norm.bias");
     m.cw1 = w.f(p + ".1.fn.0.weight"), m.cb1 = w.f(p + ".1.fn.0.bias");
     m.cw2 = w.f(p + ".1.fn.3.weight"), m.cb2 = w.f(p + ".1.fn.3.bias");
+    m.x3s[0] = w.has(p + ".__x3s16") ? w.h(p + ".__x3s16") : nullptr;
+    m.x3s[1] = w.has(p + ".__x3s32") ? w.h(p + ".__x3s32") : nullptr;
   }
   oln_w = w.f(d + "13.weight"), oln_b = w.f(d + "13.bias");
   head_w = w.f(d + "15.weight"), head_b = w.f(d + "15.bias");
@@ -212,14 +214,34 @@ int PipsEngine::update(const PyramidLevels& pyr, const int* frame_idx, int n, co
   float* delta = ws.f32((size_t)n * S * 130);
   // fused mixer (pips_mixer.hip): one slab [R][512] per hidden slice; always carved, so the size does not depend on the knob
   float* part = ws.f32((size_t)32 * R * D);
+  half_t* xop = ws.f16(pips_mix_xop_halves(n));
   if (!ws.ok()) return SAMPT_ERR_WORKSPACE;
   if (dry) return SAMPT_OK;
   int nl = 0;                                  // kernel launches of this window (counted at the launch sites)
   const bool fused = g_pips_mixer_fused != 0;
   const int NS = pips_mix_slices(n);
+  // split-fp16 channel MLP: when asked for and the packer delivered the operand streams (weights outside the splittable range: f32)
+  const int x3i = g_pips_mixer_wgs >= 32 ? 1 : 0, NSx = x3i ? 32 : 16;
+  bool x3 = fused && g_pips_mixer_x3 != 0;
+  for (int i = 0; i < 12 && x3; ++i) x3 = mix[i].x3s[x3i] != nullptr;
   PIPS_LAUNCH(pips_init_state(xys, feat_init, (float)stride, S, n, coords, coords0, ffeats, s));
   for (int it = 0; it < iters; ++it) {
-    if (fused) {
+    if (x3) {
+      // the same 30 launches with the channel MLP as split-fp16 products (pips_mixer_x3.hip): [slab sum + residual -> token
+      // mixing -> LayerNorm2 -> operand images] and [fc1 -> GELU -> fc2 slabs from the packed weight stream]
+      PIPS_LAUNCH(pips_corr_sample(pyr, frame_idx, S, n, 128, ffeats, coords, x, LDX, 128, s, times));
+      PIPS_LAUNCH(lin(x, R, LDX, LDX, in_w, in_b, hbuf, D, ACT_NONE, nullptr, s));
+      float* xpp[2] = {hbuf2, lnb};
+      const float* prev = hbuf;
+      for (int i = 0; i < 12; ++i) {
+        const MixBlk& m = mix[i];
+        PIPS_LAUNCH(pips_mix_pre(i ? part : nullptr, i ? NSx : 0, i ? mix[i - 1].cb2 : nullptr, prev, n, m.ln1w, m.ln1b, m.tw1,
+                                 m.tb1, m.tw2, m.tb2, m.ln2w, m.ln2b, xpp[i & 1], xop, s));
+        PIPS_LAUNCH(pips_mix_mlp_x3(xop, m.x3s[x3i], m.cb1, part, n, NSx, s));
+        prev = xpp[i & 1];
+      }
+      PIPS_LAUNCH(pips_mix_reduce(part, NSx, mix[11].cb2, prev, n, 1, oln_w, oln_b, nullptr, nullptr, nullptr, nullptr, mean, s));
+    } else if (fused) {
       // 30 launches per iteration: input (1), in-projection (1), per block [sum of the previous block's slabs + residual ->
       // token mixing] and [LayerNorm -> fc1 -> GELU -> fc2 slabs] (2 x 12), last sum + LayerNorm + token mean (1), head, update
       PIPS_LAUNCH(pips_corr_sample(pyr, frame_idx, S, n, 128, ffeats, coords, x, LDX, 128, s, times));

@@ -150,6 +150,15 @@ int pips_mix_mlp(const float* x, const float* lnw, const float* lnb, const float
 int pips_mix_reduce(const float* part, int NS, const float* bias, const float* res, int nseq, int mode, const float* lnw,
                     const float* lnb, const float* w1, const float* b1, const float* w2, const float* b2, float* out,
                     hipStream_t s);
+// ---- pips_mixer_x3.hip: the same block with the channel MLP as 3-term split-fp16 products (file header)
+extern int g_pips_mixer_x3;
+size_t pips_mix_xop_halves(int nseq);            // size of the operand-image buffer between the two kernels
+// x' = res + (slab sum + bias); xout = x' + token-mix(LN1(x')) (f32, the next residual); xop = operand images of 2^6 LN2(xout)
+int pips_mix_pre(const float* part, int NS, const float* bias, const float* res, int nseq, const float* ln1w, const float* ln1b,
+                 const float* tw1, const float* tb1, const float* tw2, const float* tb2, const float* ln2w, const float* ln2b,
+                 float* xout, half_t* xop, hipStream_t s);
+// part[slice][nseq*8][512] from the operand images and the packed weight stream of the block (pack.pips_mixer_x3_stream, NS = 16 | 32)
+int pips_mix_mlp_x3(const half_t* xop, const half_t* wstream, const float* b1, float* part, int nseq, int NS, hipStream_t s);
 // mean over the S tokens of LN(x): out[n][D]
 int pips_ln_mean(const float* x, const float* lnw, const float* lnb, float* out, int nseq, int S, int D, hipStream_t s);
 // feature / coordinate update (pips.py:536-544): delta [n][S][130]; ffeats [n][S][128]; coords [S][n][2]

@@ -90,6 +90,35 @@ def _add_fnet_split(out: Dict[str, torch.Tensor], sd: Dict[str, torch.Tensor], d
             _put_split(out, k + "_hl", out[k])
 
 
+MIXER_X3_ASHIFT = 6       # csrc/pips_mixer_x3.hip: activations are split as v * 2^6 = hi + lo (lo stays a normal fp16 down to |v| = 2e-3)
+MIXER_X3_SLICES = (16, 32)   # hidden slices the split-fp16 mixer kernels exist for (8 / 4 fragments of 16 hidden units per slice)
+
+
+def pips_mixer_x3_stream(w1: torch.Tensor, w2: torch.Tensor, NS: int):
+    """Channel-MLP weights of one mixer block (w1 [2048][512], w2 [512][2048], fp32) -> half [NS][NF * 64 * 512], NF = 2048 / NS / 16:
+    per hidden slice the LINEAR stream of 1-KB MFMA operand images k_pips_mix_mlp_x3 consumes, in consumption order, so that every
+    LDS-DMA instruction of the kernel copies 1 KB of contiguous memory and every wave reads its operand back at lane * 16.
+    An image is [lane 0..63][8 halves]: lane (lr = lane & 15, lq = lane >> 4) of v_mfma_f32_16x16x32_f16 supplies row lr, k slots
+    8 lq .. 8 lq + 7.  Weights are scaled by 2^8 and split into hi / lo fp16 planes (``split_f16x3``).
+      fc1: for ks (16 steps of 32 k), fragment f, plane:  image[lane][e] = W1[h0 + 16 f + lr][32 ks + 8 lq + e]
+      fc2: for output fragment o (32), k pair kp (NF / 2), plane:  image[lane][e] = W2[16 o + lr][h0 + 32 kp + perm(lq, e)] with
+           perm(lq, e) = 4 lq + e (e < 4) | 16 + 4 lq + e - 4 (e >= 4): the k slots of the hidden activations as the first product's
+           accumulators hold them (fragments 2 kp and 2 kp + 1, four consecutive hidden units per lane each).
+    Returns None when a weight is outside the splittable range (the engine then keeps the exact-f32 kernels)."""
+    H, D = w1.shape
+    assert w2.shape == (D, H) and H % (16 * NS) == 0 and D % 32 == 0
+    p1, p2 = split_f16x3(w1, strict=False), split_f16x3(w2, strict=False)
+    if p1 is None or p2 is None:
+        return None
+    NF = H // NS // 16
+    # pure permutations of the planes (lane = 16 lq + lr):
+    #   fc1  [plane][NS][f][lr][ks][lq][e]            -> [NS][ks][f][plane][lq][lr][e]
+    #   fc2  [plane][o][lr][NS][kp][half][lq][e4]     -> [NS][o][kp][plane][lq][lr][half][e4]      (e = 4 half + e4)
+    img1 = p1.view(2, NS, NF, 16, D // 32, 4, 8).permute(1, 4, 2, 0, 5, 3, 6).reshape(NS, -1)
+    img2 = p2.view(2, D // 16, 16, NS, NF // 2, 2, 4, 4).permute(3, 1, 4, 0, 6, 2, 5, 7).reshape(NS, -1)
+    return torch.cat([img1, img2], dim=1).contiguous()
+
+
 def pack_pips(sd: Dict[str, torch.Tensor], device, S: int = 8) -> Dict[str, torch.Tensor]:
     out: Dict[str, torch.Tensor] = {}
     for k, v in sd.items():
@@ -106,6 +135,25 @@ def pack_pips(sd: Dict[str, torch.Tensor], device, S: int = 8) -> Dict[str, torc
     out["vis_predictor.0.weight"] = sd["vis_predictor.0.weight"].detach().float().reshape(-1).contiguous()
     out["__times"] = torch.linspace(0, S, S)  # pips.py:527
     _add_fnet_split(out, sd, default=True)
+    # channel-MLP weights of the 12 mixer blocks as split-fp16 operand streams (csrc/pips_mixer_x3.hip), one per supported slice
+    # count; left out when a weight cannot be split (the engine then keeps the exact-f32 kernels) or with SAMPT_PIPS_MIXER_X3=0
+    if os.environ.get("SAMPT_PIPS_MIXER_X3", "1") != "0":
+        streams = {}
+        for i in range(1, 13):
+            p = f"delta_block.to_delta.{i}"
+            if p + ".1.fn.0.weight" not in sd:
+                streams = None
+                break
+            for ns in MIXER_X3_SLICES:
+                st = pips_mixer_x3_stream(out[p + ".1.fn.0.weight"], out[p + ".1.fn.3.weight"], ns) if streams is not None else None
+                if st is None:
+                    streams = None
+                    break
+                streams[f"{p}.__x3s{ns}"] = st
+            if streams is None:
+                break
+        if streams:
+            out.update(streams)
     return {k: v.to(device) for k, v in out.items()}
 
 

@@ -244,8 +244,10 @@ class SamPt(nn.Module):
                 split = int(self.side_cus_per_xcd) if 0 < int(self.side_cus_per_xcd) < 32 else 0
                 if self._side_stream is None or self._streams_split != split:
                     if split:
+                        # (the decoder chains need the whole chip — on the window rounds' 32 CUs a clip's chain took 115 ms
+                        #  instead of 22, profiles/r6_c4_* — so only the rounds and the encoder are confined)
                         self._side_stream = _lib.cu_range_stream(images.device, 32 - split, 32)
-                        self._dec_stream = _lib.cu_range_stream(images.device, 32 - split, 32)
+                        self._dec_stream = torch.cuda.Stream(device=images.device, priority=-1)
                         self._enc_stream = _lib.cu_range_stream(images.device, 0, 32 - split)
                     else:
                         self._side_stream = torch.cuda.Stream(device=images.device, priority=-1)

@@ -831,3 +831,93 @@ def test_pips_mixer_fused_equals_four_launch_blocks(lib, dev):
     assert max_abs(outs[0][0], outs[1][0]) < 2e-3, "trajectories of the two mixer paths differ"
     assert (outs[0][0].round() == outs[1][0].round()).all()
     assert (outs[0][1] == outs[1][1]).all()
+
+
+# ---- split-fp16 generation of the mixer block (csrc/pips_mixer_x3.hip) ---------------------------------------------------------
+def _xop_to_rows(xop, R):
+    """Operand images [frag][ks][plane][lane][8] halves -> (hi + lo) rows [R][512] as float64 (the layout k_pips_mix_pre writes)."""
+    nf = (R + 15) // 16
+    v = xop.view(nf, 16, 2, 4, 16, 8).double()                 # [frag][ks][plane][lq][lr][e]
+    rows = (v[:, :, 0] + v[:, :, 1]).permute(0, 3, 1, 2, 4)    # [frag][lr][ks][lq][e]
+    return rows.reshape(nf * 16, 512)[:R]
+
+
+@pytest.mark.parametrize("nseq,slices", [(8, 16), (8, 0), (3, 32), (1, 16), (24, 16), (5, 0)])
+def test_pips_mix_pre(lib, dev, nseq, slices):
+    """Slab sum + bias + residual + token mixing -> x'' (fp32) and the operand images of 2^6 LayerNorm2(x'') (fp16 hi + lo)."""
+    x, w = _mixer_block_inputs(nseq, 300 + nseq + slices)
+    R = nseq * 8
+    g = torch.Generator().manual_seed(11)
+    part = torch.randn(max(slices, 1), R, 512, generator=g) * 0.3
+    xp = x.double() + ((part[:slices].double().sum(0) + w["b2"].double()) if slices else 0.0)
+    y = F.layer_norm(xp, (512,), w["tlnw"].double(), w["tlnb"].double(), 1e-5)
+    ys = y.view(nseq, 8, 512)
+    hid = F.gelu(torch.einsum("ot,ntc->noc", w["tw1"].double(), ys) + w["tb1"].double()[None, :, None])
+    mixed = torch.einsum("to,noc->ntc", w["tw2"].double(), hid) + w["tb2"].double()[None, :, None]
+    xpp = xp + mixed.reshape(R, 512)
+    y2 = F.layer_norm(xpp, (512,), w["lnw"].double(), w["lnb"].double(), 1e-5)
+    d = {k: v.to(dev) for k, v in w.items()}
+    part_d, x_d = part.to(dev), x.to(dev)
+    xout = torch.full((R, 512), float("nan"), device=dev)
+    xop = torch.zeros(lib.sampt_pips_mix_xop_halves(nseq), dtype=torch.float16, device=dev)
+    ok(lib.sampt_pips_mix_pre_f32(P(part_d) if slices else None, slices, P(d["b2"]) if slices else None, P(x_d), nseq,
+                                  P(d["tlnw"]), P(d["tlnb"]), P(d["tw1"]), P(d["tb1"]), P(d["tw2"]), P(d["tb2"]), P(d["lnw"]),
+                                  P(d["lnb"]), P(xout), P(xop), S()), "mix_pre")
+    torch.cuda.synchronize()
+    assert rel_err(xout, xpp) < 2e-6
+    got = _xop_to_rows(xop.cpu(), R) / 64.0
+    assert (got - y2).abs().max().item() < 4e-6 * max(1.0, y2.abs().max().item())
+
+
+@pytest.mark.parametrize("nseq,slices", [(8, 16), (8, 32), (3, 16), (1, 32), (24, 16), (9, 32)])
+def test_pips_mix_mlp_x3_slabs(lib, dev, nseq, slices):
+    """fc1 -> GELU -> fc2 over hidden slices as 3-term split-fp16 products from the packed weight stream: every slab against
+    the fp64 product of its own slice, at fp32 grade."""
+    from sam_pt_amd.pack import pips_mixer_x3_stream
+    x, w = _mixer_block_inputs(nseq, 400 + nseq + slices)
+    R = nseq * 8
+    y = F.layer_norm(x.double(), (512,), w["lnw"].double(), w["lnb"].double(), 1e-5)
+    h = F.gelu(y @ w["w1"].double().t() + w["b1"].double())
+    hs = 2048 // slices
+    ref = torch.stack([h[:, s * hs:(s + 1) * hs] @ w["w2"].double()[:, s * hs:(s + 1) * hs].t() for s in range(slices)])
+    # operand images of the input, built on the host the way k_pips_mix_pre writes them
+    nf = (R + 15) // 16
+    ys = torch.zeros(nf * 16, 512)
+    ys[:R] = (y * 64.0).float()
+    hi = ys.half()
+    lo = (ys - hi.float()).half()
+    img = torch.stack([hi, lo]).view(2, nf, 16, 16, 4, 8).permute(1, 3, 0, 4, 2, 5).contiguous()   # [frag][ks][plane][lq][lr][e]
+    xop = img.reshape(-1).to(dev)
+    ws = pips_mixer_x3_stream(w["w1"], w["w2"], slices).to(dev)
+    b1 = w["b1"].to(dev)
+    part = torch.full((slices, R, 512), float("nan"), device=dev)
+    ok(lib.sampt_pips_mix_mlp_x3(P(xop), P(ws), P(b1), P(part), nseq, slices, S()), "mix_mlp_x3")
+    torch.cuda.synchronize()
+    assert torch.isfinite(part).all()
+    scale = ref.abs().max().item()
+    assert (part.cpu().double() - ref).abs().max().item() < 6e-6 * max(scale, 1.0)
+    assert rel_err(part.sum(0), ref.sum(0)) < 4e-6
+
+
+def test_pips_mixer_x3_equals_f32_paths(lib, dev):
+    """A clip's chained windows through the split-fp16 mixer (sampt_pips_set_mixer(2, .)) and the two exact-f32 paths: same
+    trajectories to fp32 round-off, identical in index space, same visibilities."""
+    from sam_pt_amd.point_tracker import PipsPointTracker
+    from sam_pt_amd.weights import init_pips_state_dict
+    from tests.util import disc_queries, synthetic_clip
+    frames, centres = synthetic_clip(T=12, H=128, W=256, seed=5)
+    q = disc_queries(centres, n_pos=5, r=9.0)[None]
+    outs = []
+    try:
+        for mode, wgs in ((0, 32), (2, 16), (2, 32)):
+            ok(lib.sampt_pips_set_mixer(mode, wgs), "set_mixer")
+            trk = PipsPointTracker(state_dict=init_pips_state_dict(72)).to(dev)
+            tr, vi = trk(frames.to(dev)[None], q.to(dev))
+            outs.append((tr.cpu(), vi.cpu()))
+    finally:
+        ok(lib.sampt_pips_set_mixer(1, 32), "set_mixer")
+    for o in outs[1:]:
+        print(f"\n[mixer x3 vs f32] max |d traj| = {max_abs(outs[0][0], o[0]):.3e} px")
+        assert max_abs(outs[0][0], o[0]) < 2e-3, "trajectories of the two mixer paths differ"
+        assert (outs[0][0].round() == o[0].round()).all()
+        assert (outs[0][1] == o[1]).all()
