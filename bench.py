@@ -677,7 +677,8 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     # host-side weight generation / packing: keep N ranks from oversubscribing the host cores
-    torch.set_num_threads(max(1, min(32, (os.cpu_count() or 8) // max(world, 1))))
+    from sam_pt_amd.dist import host_threads
+    torch.set_num_threads(host_threads(world))
     frames_sharded = args.shard == "frames" and world > 1
     lpt = args.shard == "lpt"
     lpt_info = None

@@ -150,7 +150,7 @@ def load():
     if os.environ.get("SAMPT_GEMM_SCHED"):            # A / B switch of the 8-phase GEMM's stage schedule (sampt_gemm_set_schedule)
         lib.sampt_gemm_set_schedule(int(os.environ["SAMPT_GEMM_SCHED"]))
     if os.environ.get("SAMPT_PIPS_MIXER") or os.environ.get("SAMPT_PIPS_MIXER_WGS") or os.environ.get("SAMPT_PIPS_MIXER_DIAG"):   # csrc/pips_mixer.hip (A / B runs)
-        lib.sampt_pips_set_mixer(int(os.environ.get("SAMPT_PIPS_MIXER", "1")), int(os.environ.get("SAMPT_PIPS_MIXER_WGS", "32")))
+        lib.sampt_pips_set_mixer(int(os.environ.get("SAMPT_PIPS_MIXER", "2")), int(os.environ.get("SAMPT_PIPS_MIXER_WGS", "16")))
     if os.environ.get("SAMPT_THIN_MIN_WGS"):          # thin f32 GEMM: tile growth threshold (sampt_gemm_set_thin_min_wgs)
         lib.sampt_gemm_set_thin_min_wgs(int(os.environ["SAMPT_THIN_MIN_WGS"]))
     if os.environ.get("SAMPT_GEMM_STAGGER"):          # experiment knob of the 8-phase GEMM (sampt_gemm_set_stagger)

@@ -318,7 +318,10 @@ __global__ __launch_bounds__(1024) void k_pips_mix_reduce(const float* __restric
 }
 
 int g_pips_mixer_fused = 1;     // sampt_pips_set_mixer: 1 = the two-launch blocks of this file, 0 = four launches per block
-int g_pips_mixer_wgs = 32;      // workgroups a channel-MLP launch should reach (it picks 8, 16 or 32 hidden slices)
+// workgroups a channel-MLP launch should reach: the exact-f32 kernel picks 8, 16 or 32 hidden slices per group of two chains, the
+// split-fp16 kernel 16 (< 32) or 32 slices per 64 rows.  Default 16: beside the encoder's 30 persistent GEMM workgroups per XCD
+// the chain then needs exactly the two CUs per XCD they leave (profiles/r6_c5_*, r6_c7_*: 113.9 fps against 111.8 with 32 / 28).
+int g_pips_mixer_wgs = 16;
 int g_pips_mixer_diag = 0;      // measurement only (SAMPT_PIPS_MIXER_DIAG=1): steady-state weight loads skipped — WRONG results, the
                                 // launch's time without its weight stream
 

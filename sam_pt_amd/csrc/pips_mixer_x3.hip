@@ -44,7 +44,7 @@ template <int NF>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_pips_mix_mlp_x3(
     const half_t* __restrict__ xop, const half_t* __restrict__ wstream, const float* __restrict__ b1, float* __restrict__ part,
     int R, int NS) {
-  extern __shared__ __attribute__((aligned(1024))) char lds[];      // 3 stages x 32 KB
+  extern __shared__ __attribute__((aligned(1024))) char lds[];      // 4 stages x 32 KB: three in flight ahead of the multiply
   constexpr int STG = 32 * 1024, NSTG = 2 * NF;                     // NF stages of fc1 images, NF of fc2 images
   constexpr int KS_PER = 16 / NF;                                   // fc1: 32-deep k steps per stage (2 NF images each)
   constexpr int O_PER = 32 / NF;                                    // fc2: output fragments per stage (NF images each)
@@ -55,16 +55,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const bool live = r0 < R;                                         // a wave without rows still stages and keeps the barriers
   const int h0 = slice * 16 * NF;
   const char* wsrc = (const char*)(wstream + (size_t)slice * (64 * NF * 512)) + lane * 16;
-  auto stage = [&](int t) {                                         // images 32 t .. 32 t + 31 -> slot t % 3; this wave: wave + 4 i
-    char* dst = lds + (t % 3) * STG;
+  // The kernel is bound by what ONE CU can pull from memory (every weight byte is read by one workgroup once per iteration, so it
+  // always comes from HBM / the Infinity Cache): 20 - 25 GB/s per CU with two stages in flight (profiles/r6_c5_*: 25.1 us for 512 KB).
+  // Hence three stages in flight and non-temporal loads (aux = 2: a one-touch stream, MI355X_MICROARCH.md "nt-weights").
+  auto stage = [&](int t) {                                         // images 32 t .. 32 t + 31 -> slot t % 4; this wave: wave + 4 i
+    char* dst = lds + (t % 4) * STG;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int img = wave + 4 * i;
-      __builtin_amdgcn_global_load_lds((glb_void*)(wsrc + (size_t)(t * 32 + img) * 1024), (lds_void*)(dst + img * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void*)(wsrc + (size_t)(t * 32 + img) * 1024), (lds_void*)(dst + img * 1024), 16, 0, 2);
     }
   };
   stage(0);
   stage(1);
+  stage(2);
   // ---- this wave's 16 rows as MFMA operands (already LayerNorm'ed, scaled and split by k_pips_mix_pre)
   h8 xh[16][2];
   {
@@ -89,15 +93,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
   static_for<0, NSTG>([&](auto tc) {
     constexpr int t = decltype(tc)::value;
-    // this wave's share of stage t has landed (vmcnt retires in order; younger: stage t + 1's eight and this wave's output
-    // stores, which the stricter count also waits for); the barrier publishes every wave's share and says that everybody is done
-    // reading stage t - 1, whose slot stage t + 2 then takes
-    if (t + 1 < NSTG) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    // this wave's share of stage t has landed (vmcnt retires in order; younger: the eight instructions each of stages t + 1 and
+    // t + 2 and this wave's output stores, which the stricter count also waits for); the barrier publishes every wave's share
+    // and says that everybody is done reading stage t - 1, whose slot stage t + 3 then takes
+    if (t + 2 < NSTG) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (t + 1 < NSTG) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (t + 2 < NSTG) stage(t + 2);
-    const char* slot = lds + (t % 3) * STG + lane * 16;
+    if (t + 3 < NSTG) stage(t + 3);
+    const char* slot = lds + (t % 4) * STG + lane * 16;
     if (t < NF) {
       // ---- fc1: acc1[f] lane (lr, lq) reg r = 2^14 x pre-activation of hidden unit h0 + 16 f + 4 lq + r, row lr
 #pragma unroll
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 //   operand images of 2^6 LayerNorm2(x'') split into fp16 hi / lo  -> xop (k_pips_mix_mlp_x3's input layout)
 // Token-mixing arithmetic and summation order as k_pips_token_mix / k_pips_mix_reduce<0> (four 8-unit partial sums per channel,
 // (p0 + p1) + (p2 + p3)).
-template <bool PART>
+template <int NSB>          // slabs of the first batch (0: no slabs, x' = res; 8 or 16: all in flight together)
 __global__ __launch_bounds__(1024) void k_pips_mix_pre(const float* __restrict__ part, int NS, const float* __restrict__ bias,
                                                        const float* __restrict__ res, int R, const float* __restrict__ ln1w,
                                                        const float* __restrict__ ln1b, const float* __restrict__ w1,
@@ -176,10 +181,11 @@ __global__ __launch_bounds__(1024) void k_pips_mix_pre(const float* __restrict__
   const int seq = blockIdx.x;
   const int row = tid >> 7, c4 = (tid & 127) * 4;
   const long idx = ((long)seq * S + row) * XD + c4;
-  float4 t0[8];
+  constexpr bool PART = NSB > 0;
+  float4 t0[PART ? NSB : 1];
   if (PART) {
 #pragma unroll
-    for (int s = 0; s < 8; ++s) t0[s] = ld4(part + (long)s * R * XD + idx);
+    for (int s = 0; s < NSB; ++s) t0[s] = ld4(part + (long)s * R * XD + idx);
   }
   const float4 rv = ld4(res + idx);
   const float4 bv = PART ? ld4(bias + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -195,14 +201,14 @@ __global__ __launch_bounds__(1024) void k_pips_mix_pre(const float* __restrict__
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
   if (PART) {
 #pragma unroll
-    for (int s = 0; s < 8; ++s) v.x += t0[s].x, v.y += t0[s].y, v.z += t0[s].z, v.w += t0[s].w;
+    for (int s = 0; s < NSB; ++s) v.x += t0[s].x, v.y += t0[s].y, v.z += t0[s].z, v.w += t0[s].w;
     const long slab = (long)R * XD;
-    for (int s0 = 8; s0 < NS; s0 += 8) {
-      float4 t[8];
+    for (int s0 = NSB; s0 < NS; s0 += NSB) {
+      float4 t[PART ? NSB : 1];
 #pragma unroll
-      for (int s = 0; s < 8; ++s) t[s] = ld4(part + (long)(s0 + s) * slab + idx);
+      for (int s = 0; s < NSB; ++s) t[s] = ld4(part + (long)(s0 + s) * slab + idx);
 #pragma unroll
-      for (int s = 0; s < 8; ++s) v.x += t[s].x, v.y += t[s].y, v.z += t[s].z, v.w += t[s].w;
+      for (int s = 0; s < NSB; ++s) v.x += t[s].x, v.y += t[s].y, v.z += t[s].z, v.w += t[s].w;
     }
   }
   v.x += bv.x, v.y += bv.y, v.z += bv.z, v.w += bv.w;
@@ -294,14 +300,14 @@ __global__ __launch_bounds__(1024) void k_pips_mix_pre(const float* __restrict__
   *(h4*)(op + 512) = lo;
 }
 
-int g_pips_mixer_x3 = 0;        // sampt_pips_set_mixer_precision: 1 = split-fp16 channel MLP (this file), 0 = exact f32 (pips_mixer.hip)
+int g_pips_mixer_x3 = 1;        // sampt_pips_set_mixer(2 | 1, .): 1 = split-fp16 channel MLP (this file, the default), 0 = exact f32 (pips_mixer.hip)
 
 size_t pips_mix_xop_halves(int nseq) { return (size_t)((nseq * 8 + 15) / 16) * 16 * 2 * 512; }
 
 int pips_mix_mlp_x3(const half_t* xop, const half_t* wstream, const float* b1, float* part, int nseq, int NS, hipStream_t s) {
   if (nseq <= 0 || (NS != 16 && NS != 32) || !xop || !wstream || !b1 || !part) return SAMPT_ERR_ARG;
   const int R = nseq * 8, rts = (R + 63) / 64;
-  constexpr int LDSB = 3 * 32 * 1024;
+  constexpr int LDSB = 4 * 32 * 1024;
   dim3 grid(rts * NS), block(256);
 #define MIXX(NFv)                                                                                                        \
   do {                                                                                                                   \
@@ -326,8 +332,10 @@ int pips_mix_pre(const float* part, int NS, const float* bias, const float* res,
   if (nseq <= 0 || NS < 0 || NS % 8 || (NS > 0 && (!part || !bias)) || !res || !xout || !xop || res == xout) return SAMPT_ERR_ARG;
   const int R = nseq * 8;
   dim3 grid(nseq), block(1024);
-  if (NS) hipLaunchKernelGGL(k_pips_mix_pre<true>, grid, block, 0, s, part, NS, bias, res, R, ln1w, ln1b, tw1, tb1, tw2, tb2, ln2w, ln2b, xout, xop);
-  else hipLaunchKernelGGL(k_pips_mix_pre<false>, grid, block, 0, s, part, NS, bias, res, R, ln1w, ln1b, tw1, tb1, tw2, tb2, ln2w, ln2b, xout, xop);
+#define MIXP(NSBv) \
+  hipLaunchKernelGGL(k_pips_mix_pre<NSBv>, grid, block, 0, s, part, NS, bias, res, R, ln1w, ln1b, tw1, tb1, tw2, tb2, ln2w, ln2b, xout, xop)
+  if (NS == 0) MIXP(0); else if (NS % 16 == 0) MIXP(16); else MIXP(8);
+#undef MIXP
   SAMPT_CHECK_LAUNCH("pips_mix_pre");
   return SAMPT_OK;
 }

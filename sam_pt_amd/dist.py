@@ -36,6 +36,15 @@ def init_from_env(backend: Optional[str] = None):
     return rank, world, local
 
 
+def host_threads(world: int, cpus: Optional[int] = None) -> int:
+    """PyTorch host threads for ONE of `world` rank processes sharing a node: weight generation / packing and the prompt assembly
+    are host work, and N ranks each spawning a thread per core collapse (PyTorch-CPU oversubscription on the 256-thread GPU hosts).
+    At most 32, at least 1, never more than an equal share of the cores."""
+    import os
+    cpus = cpus or os.cpu_count() or 8
+    return max(1, min(32, cpus // max(int(world), 1)))
+
+
 def lpt_assign(lengths: Sequence[int], world: int) -> List[List[int]]:
     """Longest-processing-time-first assignment of sequences to ranks (balanced version of detectron2's contiguous
     InferenceSampler, vis_eval/mask2former_video/data_video/build.py:222-229).  Returns per-rank lists of indices."""

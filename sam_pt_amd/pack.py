@@ -119,7 +119,11 @@ def pips_mixer_x3_stream(w1: torch.Tensor, w2: torch.Tensor, NS: int):
     return torch.cat([img1, img2], dim=1).contiguous()
 
 
+stats = {"packs": 0}     # weight-packing calls of this process (tests: none may happen inside a timed step loop)
+
+
 def pack_pips(sd: Dict[str, torch.Tensor], device, S: int = 8) -> Dict[str, torch.Tensor]:
+    stats["packs"] += 1
     out: Dict[str, torch.Tensor] = {}
     for k, v in sd.items():
         v = v.detach().float()
@@ -242,6 +246,7 @@ def window_row_map(grid: int, window: int, batches: int, rows: int = 0) -> torch
 def pack_vit(sd: Dict[str, torch.Tensor], cfg: SamConfig, device, f16, win_batches: int) -> Dict[str, torch.Tensor]:
     """``f16``: False / 0 = exact fp32, True / 1 = fp16 block GEMMs (".f16" copies), 2 = split-fp16 block GEMMs (".x3" x3 rows
     of w * 2^8); the encoder's two ends are split-fp16 planes ("_hl") in both 16-bit modes."""
+    stats["packs"] += 1
     out: Dict[str, torch.Tensor] = {}
     mode = int(f16)
     f16 = mode != 0

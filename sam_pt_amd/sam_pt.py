@@ -260,7 +260,7 @@ class SamPt(nn.Module):
             # the tracker's window rounds run BESIDE the encoder on the side stream: leave them whole CUs (a persistent GEMM
             # workgroup owns its CU; measured on MI355X, profiles/r3_v3_timeline_wgs*.log: 32 / 30 workgroups per XCD
             # 248 ms per clip with the tracker ending 24 ms after the encoder, 28 per XCD 229 ms)
-            reserve = self._encoder_gemm_workgroups() if overlap else None
+            reserve = self._encoder_gemm_workgroups(int(query_points.shape[0] * query_points.shape[1])) if overlap else None
             enc_stream = self._enc_stream if overlap else None
             if enc_stream is not None:                   # spatial split: one persistent GEMM workgroup per CU the encoder owns
                 reserve = 32 - self._streams_split
@@ -339,15 +339,20 @@ class SamPt(nn.Module):
             trajectories, visibilities, logits, scores, scores_per_frame = self._forward_w_reinit(images, query_points, feats)
         return tail(trajectories, visibilities, logits, scores, scores_per_frame)
 
-    def _encoder_gemm_workgroups(self):
+    def _encoder_gemm_workgroups(self, n_chains: int = 8):
         """The knob ``encoder_gemm_workgroups_beside_tracker`` resolved: an explicit value (int, list, SAMPT_ENC_WGS) as given;
-        the default None -> 28 per XCD for the fp16 ViT (measured: profiles/r3_v3_timeline_wgs*.log) and every CU for f16x3
-        (the split-fp16 encoder takes twice as long, so the tracker's rounds end long before it either way: 59.5 fps against
-        58.5 with 28 per XCD, profiles/r4_c8_bench_x3_wgs*.log)."""
+        the default None -> for the fp16 ViT 30 per XCD when the tracker runs up to 8 chains (its split-fp16 mixer launches then
+        fit the two CUs per XCD that leaves: 207 - 211 ms per clip against 214 with 28, profiles/r6_c5_*, r6_c7_*, r6_c8_*), 28 for
+        more chains or another tracker (rounds 3 - 5: profiles/r3_v3_timeline_wgs*.log); every CU for f16x3 (the split-fp16
+        encoder takes twice as long, so the tracker's rounds end long before it either way: 59.5 fps against 58.5 with 28 per
+        XCD, profiles/r4_c8_bench_x3_wgs*.log)."""
         v = self.encoder_gemm_workgroups_beside_tracker
         if v is not None:
             return v
-        return None if getattr(getattr(self.sam_predictor, "model", None), "precision", None) == "f16x3" else 28
+        if getattr(getattr(self.sam_predictor, "model", None), "precision", None) == "f16x3":
+            return None
+        small = n_chains <= 8 and type(self.point_tracker).__name__ == "PipsPointTracker" and os.environ.get("SAMPT_PIPS_MIXER", "2") == "2"
+        return 30 if small else 28
 
     def _mark(self, name):
         if self.timeline is not None and torch.cuda.is_available():

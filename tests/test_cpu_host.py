@@ -982,3 +982,55 @@ def test_x3_rows_packing_and_vit_pack_modes():
         assert "image_encoder.neck.0.weight_hl" in p and e + "attn.qkv.weight" not in p
     p0 = pack_vit(sd, cfg, "cpu", 0, 2)
     assert e + "attn.qkv.weight" in p0 and e + "attn.qkv.bias.f16" not in p0
+
+
+def test_eight_ranks_gloo_host_threads_lpt_and_no_packing_in_the_step_loop():
+    """`bench.py --gpus 8` as far as it can be exercised without GPUs: 8 gloo processes each cap their host
+    threads to an equal share of the cores (dist.host_threads), build their tracker weights ONCE before the step loop (pack.stats
+    does not move inside it), own a disjoint LPT share of the 30 DAVIS-17-val-like sequences that together cover all of them, and
+    issue their ragged uint8 mask gathers in the same order."""
+    code = r"""
+import os, sys, torch
+sys.path.insert(0, %r)
+import torch.distributed as dist
+from sam_pt_amd import pack
+from sam_pt_amd.dist import DAVIS17_VAL_LENGTHS, gather_masks, host_threads, init_from_env, lpt_assign
+from sam_pt_amd.weights import init_pips_state_dict
+rank, world, local = init_from_env("gloo")
+assert world == 8
+torch.set_num_threads(host_threads(world))
+assert torch.get_num_threads() * world <= max(os.cpu_count() or 8, world), (torch.get_num_threads(), os.cpu_count())
+assert host_threads(8, 256) == 32 and host_threads(1, 256) == 32 and host_threads(8, 8) == 1 and host_threads(3, 8) == 2
+w = pack.pack_pips(init_pips_state_dict(72 + rank), "cpu")            # model build: before the loop, once
+assert any(k.endswith("__x3s16") for k in w)
+packs = pack.stats["packs"]
+assign = lpt_assign(DAVIS17_VAL_LENGTHS, world)
+mine = [DAVIS17_VAL_LENGTHS[i] for i in assign[rank]]
+for step in range(2):                                                  # the step loop: only gathers, no packing
+    for L in mine[:2]:
+        out = gather_masks(torch.full((L, 2, 3), rank + 1, dtype=torch.uint8), max_frames=max(DAVIS17_VAL_LENGTHS))
+        if rank == 0:
+            assert out.shape[0] == world and all(out[r, 0].eq(r + 1).all() for r in range(world))
+assert pack.stats["packs"] == packs
+flat = sorted(i for a in assign for i in a)
+assert flat == list(range(len(DAVIS17_VAL_LENGTHS)))
+loads = [sum(DAVIS17_VAL_LENGTHS[i] for i in a) for a in assign]
+assert max(loads) / (sum(loads) / world) < 1.06
+if rank == 0:
+    print("EIGHT_OK", loads)
+dist.barrier(); dist.destroy_process_group()
+""" % ROOT
+    port = str(_free_port())
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="1")
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:
+        f.write(code)
+        path = f.name
+    try:
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8",
+                            "--master-addr", "127.0.0.1", "--master-port", port, path], env=env, capture_output=True,
+                           text=True, timeout=400)
+    finally:
+        os.unlink(path)
+    assert r.returncode == 0, r.stderr[-2500:]
+    assert "EIGHT_OK" in r.stdout

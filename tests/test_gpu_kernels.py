@@ -827,7 +827,7 @@ def test_pips_mixer_fused_equals_four_launch_blocks(lib, dev):
             tr, vi = trk(frames.to(dev)[None], q.to(dev))
             outs.append((tr.cpu(), vi.cpu()))
     finally:
-        ok(lib.sampt_pips_set_mixer(1, 32), "set_mixer")
+        ok(lib.sampt_pips_set_mixer(2, 16), "set_mixer")       # the library's default
     assert max_abs(outs[0][0], outs[1][0]) < 2e-3, "trajectories of the two mixer paths differ"
     assert (outs[0][0].round() == outs[1][0].round()).all()
     assert (outs[0][1] == outs[1][1]).all()
@@ -915,7 +915,7 @@ def test_pips_mixer_x3_equals_f32_paths(lib, dev):
             tr, vi = trk(frames.to(dev)[None], q.to(dev))
             outs.append((tr.cpu(), vi.cpu()))
     finally:
-        ok(lib.sampt_pips_set_mixer(1, 32), "set_mixer")
+        ok(lib.sampt_pips_set_mixer(2, 16), "set_mixer")       # the library's default
     for o in outs[1:]:
         print(f"\n[mixer x3 vs f32] max |d traj| = {max_abs(outs[0][0], o[0]):.3e} px")
         assert max_abs(outs[0][0], o[0]) < 2e-3, "trajectories of the two mixer paths differ"
