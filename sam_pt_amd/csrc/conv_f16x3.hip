@@ -361,6 +361,11 @@ int conv_f16x3(const GemmP& p_in, hipStream_t s) {
   if (((uintptr_t)p.A | (uintptr_t)p.A_lo | (uintptr_t)p.W | (uintptr_t)p.W_lo | (uintptr_t)p.C | (uintptr_t)p.bias |
        (uintptr_t)p.res) & 15)
     return SAMPT_ERR_ARG;
+  // (Round 6 tried a kernel of its own for the tall, short-K 1 x 1 case — the mask decoder's image-side projections, M = 98 304,
+  //  K = 256, N = 256 .. 512: 128 rows x all N per workgroup, A straight into operand registers, W through a 4-slot LDS-DMA ring —
+  //  and measured 99.7 / 132.6 / 169.6 us against 98.6 / 152.2 / 190.1 us here, 208.1 vs 209.0 ms per clip: both sit at ~2 TB/s of
+  //  A + C because every workgroup re-fetches W and a CU moves ~25 GB/s through LDS-DMA whatever the source; not kept.
+  //  profiles/r6_c9_gemm_x3_rows_vs_register_staged.log)
   if (p.A_lo) {   // pre-split activations: the LDS-DMA kernel
     if (p.shuf_g) return SAMPT_ERR_UNSUPPORTED;
     const int BNd = p.N <= 64 ? 64 : (p.N <= 96 ? 96 : 128);

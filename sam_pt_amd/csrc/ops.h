@@ -69,6 +69,7 @@ struct FlashPad {
 int vit_flash_attention_f16(const half_t* qkv, const float* rel_h, const float* rel_w, half_t* out, int B, int S,
                             int heads, int hd, hipStream_t s, FlashPad pad = FlashPad());
 
+extern int g_flash_nw_global, g_flash_nw_window;   // attention.hip: waves per workgroup of the two fp16 launch kinds (4 = default)
 // attention_x3.hip: the same attention at fp32 grade (3-term split-fp16 products).  qkv: x3 rows [B*S*S][2*3D] halves (common.h
 // GemmP::x3), out: x3 rows [B*S*S][2*D]
 int vit_flash_attention_x3(const half_t* qkv, const float* rel_h, const float* rel_w, half_t* out, int B, int S, int heads,

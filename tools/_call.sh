@@ -1,14 +1,12 @@
-# scratch script of the current gpurun call: x3 mixer with the 4-slot ring / nt loads / 16-slab batches (kernel tests + chain alone),
-# encoder batch size x GEMM workgroups per XCD (tile-count quantisation: 12 frames x 30 workgroups gives whole rounds)
+# scratch script of the current gpurun call: flash attention with more queries per workgroup (global: 6 / 8 waves, windowed: 7) —
+# kernel tests under every setting, micro-benchmark, bench lines
 set -u
-R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/r6_c8; mkdir -p $OUT; cd $R
-timeout 300 python -m pytest tests/test_gpu_kernels.py -q -k "pips_mix" > $OUT/pytest_kernels.log 2>&1; tail -2 $OUT/pytest_kernels.log
-for cfg in "2 16" "2 32"; do set -- $cfg
-  SAMPT_PIPS_MIXER=$1 SAMPT_PIPS_MIXER_WGS=$2 timeout 200 python tools/tracker_bench.py 2>&1 | grep -v amdgpu.ids > $OUT/tracker_bench_m$1_w$2.log
-  echo "mixer=$1 wgs=$2: $(tail -1 $OUT/tracker_bench_m$1_w$2.log)"
+R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/r6_c10; mkdir -p $OUT; cd $R
+for w in "4,4" "6,4" "8,4" "4,7"; do
+  SAMPT_ATTN_WAVES=$w timeout 300 python -m pytest tests/test_gpu_kernels.py -q -k "flash or window_attention or vit_attention" > $OUT/pytest_attn_$w.log 2>&1; echo "waves=$w: $(tail -1 $OUT/pytest_attn_$w.log)"
+  SAMPT_ATTN_WAVES=$w timeout 100 python tools/attn_bench.py 2>&1 | grep -v amdgpu.ids > $OUT/attn_bench_$w.log; cat $OUT/attn_bench_$w.log
 done
-export SAMPT_PIPS_MIXER=2 SAMPT_PIPS_MIXER_WGS=16
-for cfg in "8 30" "12 30" "24 30" "12 28" "12 31" "6 30" "12 30/30/30/32"; do set -- $cfg
-  SAMPT_ENC_WGS=$2 timeout 300 python bench.py --no-cpu-baseline --no-secondary --no-roofline --no-pipelined --steps 8 --warmup 3 --encode-batch $1 > "$OUT/bench_b$1_e${2//\//-}.log" 2>&1
-  tail -1 "$OUT/bench_b$1_e${2//\//-}.log" | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('batch=$1 enc=$2', d['value'], d.get('timeline'))"
+for w in "4,4" "6,4" "8,4" "6,7"; do
+  SAMPT_ATTN_WAVES=$w timeout 300 python bench.py --no-cpu-baseline --no-secondary --no-roofline --no-pipelined --steps 10 --warmup 3 > $OUT/bench_$w.log 2>&1
+  tail -1 $OUT/bench_$w.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('waves=$w', d['value'], d.get('timeline'), d['parity']['mask_iou_min'], d['parity']['pass'])"
 done
