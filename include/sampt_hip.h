@@ -188,10 +188,6 @@ int sampt_gemm_set_schedule(int sched);
 /* Process-wide knob of the thin f32 GEMM (csrc/gemm.hip gemm_thin_f32: the tracker mixers' token-side products): the launcher grows
  * the (16 * FM) x 16 tile only while at least n workgroups remain (default 256 = one per CU). */
 int sampt_gemm_set_thin_min_wgs(int n);
-/* Process-wide A / B knob of the fp16 flash-attention kernel (csrc/attention.hip): waves (of 32 queries) per workgroup for the
- * global 64 x 64-token launches (4, 6 or 8) and the windowed 14 x 14 ones (4 or 7) of head dim 80.  More queries per workgroup =
- * fewer re-stagings of a (frame, head)'s K / V tiles. */
-int sampt_vit_set_attention_waves(int global_waves, int window_waves);
 /* Process-wide knob of the PIPS window's MLP-Mixer (csrc/pips_mixer.hip).  fused = 1 (default): two launches per mixer block —
  * [sum of the previous channel MLP's slabs + residual -> token mixing] and [LayerNorm -> fc1 -> GELU -> fc2 over hidden slices];
  * fused = 0: the four-launch blocks of rounds 1 - 5 (token mixing, LayerNorm, two thin GEMMs); fused = 2: the two-launch blocks with

@@ -336,13 +336,6 @@ int sampt_pips_set_mixer(int fused, int workgroups) {
   return SAMPT_OK;
 }
 
-int sampt_vit_set_attention_waves(int global_waves, int window_waves) {
-  if ((global_waves != 4 && global_waves != 6 && global_waves != 8) || (window_waves != 4 && window_waves != 7))
-    return fail(SAMPT_ERR_ARG, "sampt_vit_set_attention_waves: global 4 / 6 / 8, windowed 4 / 7");
-  sampt::g_flash_nw_global = global_waves, sampt::g_flash_nw_window = window_waves;
-  return SAMPT_OK;
-}
-
 int sampt_gemm_set_stagger(int groups) {
   if (groups < 0 || groups > 8) return fail(SAMPT_ERR_ARG, "sampt_gemm_set_stagger: 0 .. 8 phase groups");
   sampt::g_p8_stagger = groups;

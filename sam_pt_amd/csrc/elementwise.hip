@@ -203,7 +203,7 @@ __global__ void k_instnorm_apply(const float4* __restrict__ x, const float* __re
     o[2] = fmaxf(o[2] + k.z, 0.f);
     o[3] = fmaxf(o[3] + k.w, 0.f);
   }
-  y[i] = make_float4(o[0], o[1], o[2], o[3]);
+  if (y) y[i] = make_float4(o[0], o[1], o[2], o[3]);        // (null: the map is only ever read as fp16 planes — 4 of 12 bytes less)
   if (HL) {
     const h4 hi = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
     const h4 lo = {(half_t)(o[0] - (float)hi[0]), (half_t)(o[1] - (float)hi[1]), (half_t)(o[2] - (float)hi[2]),
@@ -214,7 +214,7 @@ __global__ void k_instnorm_apply(const float4* __restrict__ x, const float* __re
 
 int instnorm_apply(const float* x, const float* mean_rstd, const float* skip, float* y, int nimg, long hw, int C,
                    int relu1, hipStream_t s, half_t* y_hi, half_t* y_lo) {
-  if (C % 4) return SAMPT_ERR_ARG;
+  if (C % 4 || (!y && !(y_hi && y_lo))) return SAMPT_ERR_ARG;
   long n4 = (long)nimg * hw * C / 4;
   if (y_hi && y_lo)
     hipLaunchKernelGGL(k_instnorm_apply<true>, dim3(cdiv(n4, 256)), dim3(256), 0, s, (const float4*)x, mean_rstd,

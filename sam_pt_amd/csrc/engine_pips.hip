@@ -101,12 +101,13 @@ struct NormCtx {
   float* mean_rstd;
 };
 
-// InstanceNorm (+ReLU) (+skip add + ReLU), in place on y
+// InstanceNorm (+ReLU) (+skip add + ReLU), in place on y.  planes_only: the normalised map is only ever read by a split-fp16
+// convolution (through out.hi / out.lo), so its f32 copy is not written (y keeps the raw convolution output)
 static int run_inorm(const NormCtx& nc, float* y, int n, long hw, int C, int relu1, const float* skip, bool dry,
-                     hipStream_t s, Planes out = Planes()) {
+                     hipStream_t s, Planes out = Planes(), bool planes_only = false) {
   if (dry) return SAMPT_OK;
   SAMPT_TRY(instnorm_stats(y, n, hw, C, 1e-5f, nc.partials, nc.mean_rstd, s));
-  return instnorm_apply(y, nc.mean_rstd, skip, y, n, hw, C, relu1, s, out.hi, out.lo);
+  return instnorm_apply(y, nc.mean_rstd, skip, planes_only && out.hi ? nullptr : y, n, hw, C, relu1, s, out.hi, out.lo);
 }
 
 int PipsEngine::fnet(const uint8_t* frames, int nf, int H, int W, float* const out[4], Arena& ws, hipStream_t s) {
@@ -146,7 +147,7 @@ int PipsEngine::fnet(const uint8_t* frames, int nf, int H, int W, float* const o
       const bool last = li == 3 && bi == 1;
       Planes y2_p = last ? Planes() : planes(oel, bi == 0 ? blk[li][1][0] : blk[li + 1][0][0]);
       SAMPT_TRY(run_conv(c1, cur, nf, h, w, y1, oh, ow, dry, s, cur_p));
-      SAMPT_TRY(run_inorm(nc, y1, nf, (long)oh * ow, dims[li], 1, nullptr, dry, s, y1_p));
+      SAMPT_TRY(run_inorm(nc, y1, nf, (long)oh * ow, dims[li], 1, nullptr, dry, s, y1_p, true));   // y1 feeds conv2 only
       SAMPT_TRY(run_conv(c2, y1, nf, oh, ow, y2, oh2, ow2, dry, s, y1_p));
       const float* skip = cur;
       if (has_down[li][bi]) {
@@ -175,7 +176,7 @@ int PipsEngine::fnet(const uint8_t* frames, int nf, int H, int W, float* const o
   int oh, ow;
   Planes y_p = planes((size_t)nf * H4 * W4 * 256, conv3);
   SAMPT_TRY(run_conv(conv2, cat, nf, H4, W4, y, oh, ow, dry, s, cat_p));
-  SAMPT_TRY(run_inorm(nc, y, nf, (long)oh * ow, 256, 1, nullptr, dry, s, y_p));
+  SAMPT_TRY(run_inorm(nc, y, nf, (long)oh * ow, 256, 1, nullptr, dry, s, y_p, true));             // feeds the 1 x 1 conv3 only
   SAMPT_TRY(run_conv(conv3, y, nf, oh, ow, out[0], oh, ow, dry, s, y_p));
   if (!dry) {
     int ph = H4, pw = W4;

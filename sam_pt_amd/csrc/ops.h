@@ -16,7 +16,7 @@ int instnorm_stats(const float* x, int nimg, long hw, int C, float eps, double* 
                    hipStream_t s);
 // y = (x-mean)*rstd ; if relu1: y = max(y,0) ; if skip: y = max(y + skip, 0)
 // y_hi / y_lo (optional, both or none): y additionally split into two fp16 planes (hi = fp16(y), lo = fp16(y - hi)), the
-// operand format of conv_f16x3's pre-split path
+// operand format of conv_f16x3's pre-split path.  y == nullptr (planes given): the f32 result is not written at all
 int instnorm_apply(const float* x, const float* mean_rstd, const float* skip, float* y, int nimg, long hw, int C,
                    int relu1, hipStream_t s, half_t* y_hi = nullptr, half_t* y_lo = nullptr);
 // bilinear resize of an NHWC f32 tensor into channels [c_off, c_off+C) of a dstC-channel NHWC tensor
@@ -69,7 +69,6 @@ struct FlashPad {
 int vit_flash_attention_f16(const half_t* qkv, const float* rel_h, const float* rel_w, half_t* out, int B, int S,
                             int heads, int hd, hipStream_t s, FlashPad pad = FlashPad());
 
-extern int g_flash_nw_global, g_flash_nw_window;   // attention.hip: waves per workgroup of the two fp16 launch kinds (4 = default)
 // attention_x3.hip: the same attention at fp32 grade (3-term split-fp16 products).  qkv: x3 rows [B*S*S][2*3D] halves (common.h
 // GemmP::x3), out: x3 rows [B*S*S][2*D]
 int vit_flash_attention_x3(const half_t* qkv, const float* rel_h, const float* rel_w, half_t* out, int B, int S, int heads,
