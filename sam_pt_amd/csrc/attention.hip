@@ -124,7 +124,7 @@ __device__ half_t g_flash_pad[16] = {(half_t)1.f, (half_t)0.f, (half_t)0.f, (hal
                                      (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
 
 template <int HD, int NW, int SG>
-__global__ __launch_bounds__(NW * 64, NW == 4 || NW == 6 ? 3 : 2) void k_flash_f16(const half_t* __restrict__ qkv, const float* __restrict__ rel_h,
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void k_flash_f16(const half_t* __restrict__ qkv, const float* __restrict__ rel_h,
                                                        const float* __restrict__ rel_w, half_t* __restrict__ out, int N,
                                                        int heads, float scale, FlashPad pad, int B, int uh) {
   constexpr int KS = HD / 16;            // k-steps of QK^T
@@ -467,9 +467,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 || NW == 6 ? 3 : 2) void k_flash_f
   }
 }
 
-// waves per workgroup of the global (64 x 64 tokens) and the windowed (14 x 14) launches: sampt_vit_set_attention_waves (A / B)
-int g_flash_nw_global = 4, g_flash_nw_window = 4;
-
 // rel_h / rel_w: the block's rel_pos tables, f32 [2S-1][hd]
 int vit_flash_attention_f16(const half_t* qkv, const float* relh, const float* relw, half_t* out, int B, int S,
                             int heads, int hd, hipStream_t s, FlashPad pad) {
@@ -481,13 +478,10 @@ int vit_flash_attention_f16(const half_t* qkv, const float* relh, const float* r
 #define FL(HDv, NWv, SGv)                                                                                     \
   hipLaunchKernelGGL((k_flash_f16<HDv, NWv, SGv>), dim3(cdiv(N, NWv * 32) * heads * B), dim3(NWv * 64), 0, s, qkv, relh, relw, \
                      out, N, heads, scale, pad, B, SGv < 64 ? heads : 0)
-  // Global blocks are bound by the K / V tiles they move L2 -> LDS: every workgroup stages ALL of a (frame, head)'s 1.3 MB, i.e.
-  // 5.4 GB per 8-frame launch at 128 queries per workgroup against the ~6.4 TB/s all CUs together move by LDS-DMA (1.0 - 1.1 ms
-  // measured).  192 / 256 queries per workgroup (6 / 8 waves) cut that traffic to 2/3 and 1/2.
-  if (S == 64 && hd == 80 && g_flash_nw_global == 6) FL(80, 6, 64);
-  else if (S == 64 && hd == 80 && g_flash_nw_global == 8) FL(80, 8, 64);
-  else if (S == 14 && hd == 80 && g_flash_nw_window == 7) FL(80, 7, 14);
-  else if (S == 64 && hd == 80) FL(80, 4, 64);
+  // (round 6, profiles/r6_c10_*: more queries per workgroup — so that a (frame, head)'s K / V tiles are staged fewer times — LOSES
+  //  for the global blocks too: 6 waves / 192 queries 1607 us, 8 waves / 256 queries 1304 us against 1064 us per 8 frames with 4;
+  //  7-wave windows 269 vs 210 us.  Resident workgroups, not staged bytes, are what these kernels run on.)
+  if (S == 64 && hd == 80) FL(80, 4, 64);
   else if (S == 64 && hd == 64) FL(64, 4, 64);
   // (a 7-wave workgroup per (window, head) — 224 query slots for the 196 tokens instead of 2 x 128 — measured 4 % slower,
   //  profiles/r2_v7_attn_nw7.log; an 8-wave one whose two query-less waves only help staging the K / V tiles, staged once per
