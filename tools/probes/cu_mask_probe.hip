@@ -41,8 +41,9 @@ static void run(const char* name, const std::vector<uint32_t>& mask, unsigned* d
     const unsigned cu = (hw >> 8) & 0xf, sh = (hw >> 12) & 1, se = (hw >> 13) & 0x7;
     per_xcc[xcc].insert(se << 8 | sh << 4 | cu);
   }
-  int total = 0;
-  printf("%-34s %4d blocks in %7.3f ms:", name, nblk, ms);
+  int total = 0, rr = 0;
+  for (int b = 0; b < nblk; ++b) rr += (int)((h[b * 2 + 1] & 0xf) == (unsigned)(b % 8));
+  printf("%-34s %4d blocks in %7.3f ms, block b on XCC b %% 8: %5.1f %%:", name, nblk, ms, 100.0 * rr / nblk);
   for (auto& kv : per_xcc) { printf(" xcc%u:%zu", kv.first, kv.second.size()); total += (int)kv.second.size(); }
   printf("  | distinct CUs %d\n", total);
   hipStreamDestroy(s);
@@ -58,6 +59,10 @@ int main() {
   hipMalloc(&d, nblk * 8);
   auto mk = [&](auto pred) { std::vector<uint32_t> m(words, 0); for (int i = 0; i < ncu; ++i) if (pred(i)) m[i / 32] |= 1u << (i % 32); return m; };
   run("all", mk([](int) { return true; }), d, nblk);
+  run("all (240 blocks)", mk([](int) { return true; }), d, 240);
+  run("CUs 0..29 of every XCD (240 blocks)", mk([](int i) { return i / 8 < 30; }), d, 240);
+  run("CUs 0..27 of every XCD (224 blocks)", mk([](int i) { return i / 8 < 28; }), d, 224);
+  run("CUs 30..31 of every XCD (16 blocks)", mk([](int i) { return i / 8 >= 30; }), d, 16);
   run("first 32 bits", mk([](int i) { return i < 32; }), d, nblk);
   run("bits 0..223", mk([](int i) { return i < 224; }), d, nblk);
   run("bits 224..255", mk([](int i) { return i >= 224; }), d, nblk);
