@@ -188,6 +188,9 @@ int sampt_gemm_set_schedule(int sched);
 /* Process-wide knob of the thin f32 GEMM (csrc/gemm.hip gemm_thin_f32: the tracker mixers' token-side products): the launcher grows
  * the (16 * FM) x 16 tile only while at least n workgroups remain (default 256 = one per CU). */
 int sampt_gemm_set_thin_min_wgs(int n);
+/* Process-wide A / B switch: 1 (default) = 3 x 3 stride-1 split-fp16 convolutions over pre-split planes (the tracker encoder's) run on
+ * the halo-tiled kernel of csrc/conv_halo_x3.hip; 0 = on the implicit-GEMM LDS-DMA kernel of rounds 3 - 5 (csrc/conv_f16x3.hip). */
+int sampt_conv_set_halo(int on);
 /* Process-wide knob of the PIPS window's MLP-Mixer (csrc/pips_mixer.hip).  fused = 1 (default): two launches per mixer block —
  * [sum of the previous channel MLP's slabs + residual -> token mixing] and [LayerNorm -> fc1 -> GELU -> fc2 over hidden slices];
  * fused = 0: the four-launch blocks of rounds 1 - 5 (token mixing, LayerNorm, two thin GEMMs); fused = 2: the two-launch blocks with

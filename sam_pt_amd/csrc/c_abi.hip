@@ -336,6 +336,11 @@ int sampt_pips_set_mixer(int fused, int workgroups) {
   return SAMPT_OK;
 }
 
+int sampt_conv_set_halo(int on) {
+  sampt::g_conv_halo = on ? 1 : 0;
+  return SAMPT_OK;
+}
+
 int sampt_gemm_set_stagger(int groups) {
   if (groups < 0 || groups > 8) return fail(SAMPT_ERR_ARG, "sampt_gemm_set_stagger: 0 .. 8 phase groups");
   sampt::g_p8_stagger = groups;

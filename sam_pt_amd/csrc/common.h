@@ -213,5 +213,10 @@ int gemm_f32_plan_splitk(const GemmP& p);
 // 2^F16X3_WSHIFT (conv_f16x3.hip); the caller sets alpha = 2^-F16X3_WSHIFT.  Cin % 32 == 0.
 #define F16X3_WSHIFT 8
 int conv_f16x3(const GemmP& p, hipStream_t s);
+// conv_halo_x3.hip: the 3 x 3 stride-1 pad-1 case over pre-split planes with the input halo staged once per 16 x 16 pixel tile;
+// conv_f16x3 hands eligible launches over unless g_conv_halo == 0
+extern int g_conv_halo;
+bool conv3x3_halo_eligible(const GemmP& p);
+int conv3x3_halo_x3(const GemmP& p, hipStream_t s);
 
 }  // namespace sampt

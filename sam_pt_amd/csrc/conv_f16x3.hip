@@ -366,6 +366,7 @@ int conv_f16x3(const GemmP& p_in, hipStream_t s) {
   //  and measured 99.7 / 132.6 / 169.6 us against 98.6 / 152.2 / 190.1 us here, 208.1 vs 209.0 ms per clip: both sit at ~2 TB/s of
   //  A + C because every workgroup re-fetches W and a CU moves ~25 GB/s through LDS-DMA whatever the source; not kept.
   //  profiles/r6_c9_gemm_x3_rows_vs_register_staged.log)
+  if (g_conv_halo && conv3x3_halo_eligible(p)) return conv3x3_halo_x3(p, s);
   if (p.A_lo) {   // pre-split activations: the LDS-DMA kernel
     if (p.shuf_g) return SAMPT_ERR_UNSUPPORTED;
     const int BNd = p.N <= 64 ? 64 : (p.N <= 96 ? 96 : 128);

@@ -1,0 +1,229 @@
+// 3 x 3 (stride 1, pad 1) split-fp16 convolution over pre-split NHWC planes with the input tile's HALO staged once.
+//
+// Why: k_conv_f16x3_dma (conv_f16x3.hip) is an implicit GEMM whose K loop walks (tap, channel chunk) and fetches the 128 A rows of
+// its tile again for every tap: 9 x the input bytes through the CU, plus the whole weight tile per 128 pixels.  A CU moves
+// 35 - 38 GB/s through LDS-DMA on these launches (L2 hits included) and that, not the matrix pipe (22 - 35 % busy), is what they
+// run at: 64 -> 64 at 288 x 512 x 8 frames 419 us for 442 KB per workgroup, the 416 -> 256 convolution 1.92 ms for 3.8 MB per
+// workgroup (profiles/r6_c7_clip_kernels_by_grid*).  Here a workgroup owns a 16 x 16 pixel tile:
+//   * per 32-channel chunk the 18 x 18 halo is staged ONCE (both planes, 42 KB, double-buffered) and all nine taps read it at
+//     shifted rows — 9 x fewer input bytes;
+//   * the weights of a (chunk, tap) are a 4-slot LDS ring of BN x 64 B x 2 planes, three stages in flight, ONE barrier per stage;
+//     256 pixels per workgroup halve the weight bytes per pixel;
+//   * a wave owns 4 image rows of the tile (4 fragments of 16 pixels) x all BN output channels: 12 BN / 16 MFMAs per stage against
+//     4 + BN / 8 ds_read_b128 — the matrix pipe, not LDS or DMA issue, is the longest pole of a stage.
+// Same arithmetic as the kernel it replaces (hi.lo + lo.hi + hi.hi, fp32 accumulate, 2^-8, bias), same swizzle convention (an
+// LDS-DMA image is lane-linear, so the lane that fills chunk position q of LDS row r fetches source chunk q ^ F[(r >> 2) & 3],
+// F = {0, 3, 2, 1}; fragment reads apply the same XOR), taps outside the image read a page of zeros.
+#include <type_traits>
+
+#include "ops.h"
+
+namespace sampt {
+
+namespace {
+typedef __attribute__((address_space(1))) void glb_void;
+typedef __attribute__((address_space(3))) void lds_void;
+template <int T, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (T < N) {
+    f(std::integral_constant<int, T>{});
+    static_for<T + 1, N>(f);
+  }
+}
+__device__ __attribute__((aligned(128))) half_t g_halo_zero_page[64];
+constexpr int HT = 16, HW = 18, NPX = HW * HW;          // output tile edge, halo edge, halo pixels (324)
+constexpr int APIECES = 21;                             // 16-row DMA pieces per plane (336 rows >= 324)
+constexpr int APL = APIECES * 1024;                     // bytes of one A plane
+constexpr int ABUF = 2 * APL;                           // one halo chunk: hi | lo
+}  // namespace
+
+template <int BN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_conv3x3_halo_x3(GemmP p, int ntx, int nty) {
+  constexpr int FN = BN / 16;                  // output-channel fragments per wave
+  constexpr int NW = BN / 32;                  // W DMA instructions per wave and stage (BN / 16 pieces x 2 planes / 4 waves)
+  constexpr int NA = 12;                       // A DMA instructions per wave and chunk (6 pieces x 2 planes; padded with dummies)
+  constexpr int WSTG = BN * 64 * 2;            // bytes of one weight stage (hi rows | lo rows)
+  extern __shared__ __attribute__((aligned(1024))) char lds[];      // [A buf 0 | A buf 1 | dummy 1 KB | W ring (4 stages)]
+  char* const a_lds = lds;
+  char* const dummy_lds = lds + 2 * ABUF;
+  char* const w_lds = lds + 2 * ABUF + 1024;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lq = lane >> 4;
+  // ---- tile: blockIdx.x = ((img * nty + ty) * ntx + tx) * ntn + tn
+  const int ntn = (p.N + BN - 1) / BN;
+  int b = blockIdx.x;
+  const int tn = b % ntn;  b /= ntn;
+  const int tx = b % ntx;  b /= ntx;
+  const int ty = b % nty;
+  const int img = b / nty;
+  const int x0 = tx * HT, y0 = ty * HT, n0 = tn * BN;
+  const int H = p.cH, W = p.cW, C = p.cC;
+  const int nchunk = C / 32, nstage = nchunk * 9;
+  const char* __restrict__ Ah = (const char*)p.A;
+  const char* __restrict__ Al = (const char*)p.A_lo;
+  const char* __restrict__ Wh = (const char*)p.W;
+  const char* __restrict__ Wl = (const char*)p.W_lo;
+  const char* zero = (const char*)g_halo_zero_page;
+
+  // ---- DMA roles.  Lane l of an instruction fills LDS row (l >> 2), chunk position (l & 3) of a 16-row piece.
+  const int prow = lane >> 2;
+  const int fsw = (4 - (lane >> 4)) & 3;                                 // F[(row >> 2) & 3] with (row >> 2) & 3 == lane >> 4
+  const int csrc = ((lane & 3) ^ fsw) * 16;                              // byte offset of this lane's source chunk in a 64-B slab row
+  // A: this wave fills halo pieces wave + 4 k (k = 0 .. 5; pieces >= 21 are dummies): byte offset of the halo pixel's channel 0 in
+  // a plane, or -1 when the pixel lies outside the image (zero page) / the piece does not exist
+  long a_off[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const int piece = wave + 4 * k, hl = piece * 16 + prow;
+    const int hy = hl / HW, hx = hl - hy * HW;
+    const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+    const bool ok = piece < APIECES && hl < NPX && y >= 0 && y < H && x >= 0 && x < W;
+    a_off[k] = ok ? (((long)img * H + y) * W + x) * C * 2 + csrc : -1;
+  }
+  // W: pieces q = wave + 4 j over [hi rows | lo rows]; row n of the weight matrix is [9 taps][C] halves
+  long w_off[NW];
+  bool w_lo[NW];
+  int w_dst[NW];
+#pragma unroll
+  for (int j = 0; j < NW; ++j) {
+    const int q = wave + 4 * j;
+    w_lo[j] = q >= FN;
+    const int piece = w_lo[j] ? q - FN : q;
+    int n = n0 + piece * 16 + prow;
+    n = n < p.N ? n : p.N - 1;
+    w_off[j] = (long)n * p.ldw * 2 + csrc;
+    w_dst[j] = (w_lo[j] ? BN * 64 : 0) + piece * 1024;
+  }
+  auto stage_a = [&](int c) {                                            // halo chunk c (clamped: a dummy re-issue past the end)
+    const int cc = c < nchunk ? c : nchunk - 1;
+    char* dst = a_lds + (c & 1) * ABUF;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int piece = wave + 4 * k;                                    // uniform
+      const bool real = piece < APIECES;
+      const char* sh = a_off[k] >= 0 ? Ah + a_off[k] + cc * 64 : zero + csrc;
+      const char* sl = a_off[k] >= 0 ? Al + a_off[k] + cc * 64 : zero + csrc;
+      char* d = real ? dst + piece * 1024 : dummy_lds;
+      __builtin_amdgcn_global_load_lds((glb_void*)sh, (lds_void*)d, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void*)sl, (lds_void*)(real ? d + APL : dummy_lds), 16, 0, 0);
+    }
+  };
+  auto stage_w = [&](int s) {                                            // weights of stage s = chunk s / 9, tap s % 9
+    const int ss = s < nstage ? s : nstage - 1;
+    const int c = ss / 9, t = ss - c * 9;
+    const long koff = ((long)t * C + c * 32) * 2;
+    char* dst = w_lds + (s & 3) * WSTG;
+#pragma unroll
+    for (int j = 0; j < NW; ++j)
+      __builtin_amdgcn_global_load_lds((glb_void*)((w_lo[j] ? Wl : Wh) + w_off[j] + koff), (lds_void*)(dst + w_dst[j]), 16, 0, 0);
+  };
+
+  f32x4 acc[4][FN];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  stage_a(0);
+  stage_w(0);
+  stage_w(1);
+  stage_w(2);
+  const int wsw = ((lq ^ ((4 - ((lr >> 2) & 3)) & 3)) * 16);             // swizzled chunk of weight row j * 16 + lr
+  for (int c = 0; c < nchunk; ++c) {
+    const char* abuf = a_lds + (c & 1) * ABUF;
+    static_for<0, 9>([&](auto tc) {
+      constexpr int t = decltype(tc)::value;
+      constexpr int ky = t / 3, kx = t % 3;
+      const int s = c * 9 + t;
+      // this wave's share of W(s) — and, at t = 0, of the halo chunk issued a whole chunk ago — has landed.  Younger than W(s): the
+      // NW instructions each of W(s + 1), W(s + 2), and for t = 1 .. 3 the NA of halo chunk c + 1 (issued at t = 0 behind W(s + 3))
+      if (t >= 1 && t <= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NW + NA) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NW) : "memory");
+      __builtin_amdgcn_s_barrier();                                      // publishes all shares; everybody is done with stage s - 1
+      asm volatile("" ::: "memory");
+      stage_w(s + 3);                                                    // into the slot of stage s - 1
+      if (t == 0) stage_a(c + 1);                                        // into the buffer of chunk c - 1
+      const char* wslot = w_lds + (s & 3) * WSTG;
+      h8 ah[4], al[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = (4 * wave + i + ky) * HW + lr + kx;                // halo row of output pixel (4 wave + i, lr) for this tap
+        const int off = r * 64 + ((lq ^ ((4 - ((r >> 2) & 3)) & 3)) * 16);
+        ah[i] = *(const h8*)(abuf + off);
+        al[i] = *(const h8*)(abuf + APL + off);
+      }
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const h8 bh = *(const h8*)(wslot + (j * 16 + lr) * 64 + wsw);
+        const h8 bl = *(const h8*)(wslot + BN * 64 + (j * 16 + lr) * 64 + wsw);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, al[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ah[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, ah[i], acc[i][j], 0, 0, 0);
+      }
+    });
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // the dummy tail stages must land before the LDS is handed on
+
+  // ---- epilogue: lane (lr, lq) reg r = channel n0 + 16 j + 4 lq + r of pixel (y0 + 4 wave + i, x0 + lr).  The bias is loaded
+  // once, unconditionally (clamped columns): a load under the per-fragment branches would wait for every earlier store.
+  float4 bb[FN];
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    const int col = n0 + j * 16 + lq * 4;
+    bb[j] = p.bias ? *(const float4*)(p.bias + (col < p.N ? col : 0)) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int j = 0; j < FN; ++j)      // "use" every bias register HERE: hipcc otherwise waits vmcnt(0) at each first use inside the
+    asm volatile("" ::"v"(bb[j].x), "v"(bb[j].y), "v"(bb[j].z), "v"(bb[j].w));   // store branches — i.e. for the previous store
+  const int x = x0 + lr;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int y = y0 + 4 * wave + i;
+    const bool pix_ok = y < H && x < W;
+    float* orow = (float*)p.C + (((long)img * H + (pix_ok ? y : 0)) * W + (pix_ok ? x : 0)) * p.ldc;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int col = n0 + j * 16 + lq * 4;
+      if (pix_ok && col < p.N)
+        *(float4*)(orow + col) = make_float4(acc[i][j][0] * p.alpha + bb[j].x, acc[i][j][1] * p.alpha + bb[j].y,
+                                             acc[i][j][2] * p.alpha + bb[j].z, acc[i][j][3] * p.alpha + bb[j].w);
+    }
+  }
+}
+
+int g_conv_halo = 1;     // sampt_conv_set_halo: 0 = the 3 x 3 stride-1 launches go back to k_conv_f16x3_dma (A / B)
+
+bool conv3x3_halo_eligible(const GemmP& p) {
+  return p.conv && p.A_lo && p.KH == 3 && p.KW == 3 && p.cstride == 1 && p.cpad == 1 && p.cpadw < 0 && p.cC % 32 == 0 &&
+         p.K == 9 * p.cC && p.ldw == p.K && p.OH == p.cH && p.OW == p.cW && p.act == ACT_NONE && !p.res && !p.shuf_g &&
+         p.N % 4 == 0 && p.ldc % 4 == 0 && p.M == (p.M / (p.OH * p.OW)) * p.OH * p.OW;
+}
+
+int conv3x3_halo_x3(const GemmP& p, hipStream_t s) {
+  const int nimg = p.M / (p.OH * p.OW);
+  const int ntx = cdiv(p.cW, HT), nty = cdiv(p.cH, HT);
+  const int BN = p.N <= 64 ? 64 : (p.N <= 96 ? 96 : 128);
+  const int ntn = cdiv(p.N, BN);
+  dim3 grid((unsigned)((long)nimg * nty * ntx * ntn)), block(256);
+#define HALO(BNv)                                                                                                        \
+  do {                                                                                                                   \
+    constexpr int LDSB = 2 * ABUF + 1024 + 4 * (BNv * 64 * 2);                                                           \
+    static bool raised = false;                                                                                          \
+    auto kern = k_conv3x3_halo_x3<BNv>;                                                                                  \
+    if (!raised) {                                                                                                       \
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) != hipSuccess)        \
+        return SAMPT_ERR_HIP;                                                                                            \
+      raised = true;                                                                                                     \
+    }                                                                                                                    \
+    hipLaunchKernelGGL(kern, grid, block, LDSB, s, p, ntx, nty);                                                         \
+  } while (0)
+  if (BN == 64) HALO(64); else if (BN == 96) HALO(96); else HALO(128);
+#undef HALO
+  SAMPT_CHECK_LAUNCH("conv3x3_halo_x3");
+  return SAMPT_OK;
+}
+
+}  // namespace sampt
