@@ -37,16 +37,21 @@ constexpr int APL = APIECES * 1024;                     // bytes of one A plane
 constexpr int ABUF = 2 * APL;                           // one halo chunk: hi | lo
 }  // namespace
 
-template <int BN>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_conv3x3_halo_x3(GemmP p, int ntx, int nty) {
+// A2: the halo chunk is double-buffered (the next chunk arrives under this chunk's nine taps; 150 KB of LDS at BN = 128, one
+// workgroup per CU).  A2 = false (BN = 64): ONE halo buffer, 76 KB, TWO workgroups per CU — with two chunks per tile (the 64-channel
+// layers) a workgroup's fixed costs (first DMA round trip, epilogue stores: ~14 of its ~20 us) weigh more than the one exposed
+// chunk boundary, and the second workgroup's waves fill the matrix pipe meanwhile.
+template <int BN, bool A2>
+__global__ __launch_bounds__(256, A2 ? 1 : 2) void k_conv3x3_halo_x3(GemmP p, int ntx, int nty) {
   constexpr int FN = BN / 16;                  // output-channel fragments per wave
   constexpr int NW = BN / 32;                  // W DMA instructions per wave and stage (BN / 16 pieces x 2 planes / 4 waves)
   constexpr int NA = 12;                       // A DMA instructions per wave and chunk (6 pieces x 2 planes; padded with dummies)
   constexpr int WSTG = BN * 64 * 2;            // bytes of one weight stage (hi rows | lo rows)
-  extern __shared__ __attribute__((aligned(1024))) char lds[];      // [A buf 0 | A buf 1 | dummy 1 KB | W ring (4 stages)]
+  constexpr int NAB = A2 ? 2 : 1;
+  extern __shared__ __attribute__((aligned(1024))) char lds[];      // [A buf 0 (| A buf 1) | dummy 1 KB | W ring (4 stages)]
   char* const a_lds = lds;
-  char* const dummy_lds = lds + 2 * ABUF;
-  char* const w_lds = lds + 2 * ABUF + 1024;
+  char* const dummy_lds = lds + NAB * ABUF;
+  char* const w_lds = lds + NAB * ABUF + 1024;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lq = lane >> 4;
   // ---- tile: blockIdx.x = ((img * nty + ty) * ntx + tx) * ntn + tn
@@ -96,7 +101,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
   auto stage_a = [&](int c) {                                            // halo chunk c (clamped: a dummy re-issue past the end)
     const int cc = c < nchunk ? c : nchunk - 1;
-    char* dst = a_lds + (c & 1) * ABUF;
+    char* dst = a_lds + (A2 ? (c & 1) : 0) * ABUF;
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
       const int piece = wave + 4 * k;                                    // uniform
@@ -130,19 +135,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   stage_w(2);
   const int wsw = ((lq ^ ((4 - ((lr >> 2) & 3)) & 3)) * 16);             // swizzled chunk of weight row j * 16 + lr
   for (int c = 0; c < nchunk; ++c) {
-    const char* abuf = a_lds + (c & 1) * ABUF;
+    const char* abuf = a_lds + (A2 ? (c & 1) : 0) * ABUF;
     static_for<0, 9>([&](auto tc) {
       constexpr int t = decltype(tc)::value;
       constexpr int ky = t / 3, kx = t % 3;
       const int s = c * 9 + t;
       // this wave's share of W(s) — and, at t = 0, of the halo chunk issued a whole chunk ago — has landed.  Younger than W(s): the
       // NW instructions each of W(s + 1), W(s + 2), and for t = 1 .. 3 the NA of halo chunk c + 1 (issued at t = 0 behind W(s + 3))
-      if (t >= 1 && t <= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NW + NA) : "memory");
+      // (A2 = false: the halo chunk is the YOUNGEST thing in flight at t = 0 of every chunk but the first — everything must land)
+      if (A2 && t >= 1 && t <= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NW + NA) : "memory");
+      else if (!A2 && t == 0 && c > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NW) : "memory");
       __builtin_amdgcn_s_barrier();                                      // publishes all shares; everybody is done with stage s - 1
       asm volatile("" ::: "memory");
       stage_w(s + 3);                                                    // into the slot of stage s - 1
-      if (t == 0) stage_a(c + 1);                                        // into the buffer of chunk c - 1
+      if (A2 && t == 0) stage_a(c + 1);                                  // into the buffer of chunk c - 1
       const char* wslot = w_lds + (s & 3) * WSTG;
       h8 ah[4], al[4];
 #pragma unroll
@@ -162,6 +169,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ah[i], acc[i][j], 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, ah[i], acc[i][j], 0, 0, 0);
+      }
+      if (!A2 && t == 8 && c + 1 < nchunk) {                             // single halo buffer: refill it once nobody reads it any more
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        stage_a(c + 1);
       }
     });
   }
@@ -210,9 +222,10 @@ int conv3x3_halo_x3(const GemmP& p, hipStream_t s) {
   dim3 grid((unsigned)((long)nimg * nty * ntx * ntn)), block(256);
 #define HALO(BNv)                                                                                                        \
   do {                                                                                                                   \
-    constexpr int LDSB = 2 * ABUF + 1024 + 4 * (BNv * 64 * 2);                                                           \
+    constexpr bool A2v = BNv != 64;                                                                                      \
+    constexpr int LDSB = (A2v ? 2 : 1) * ABUF + 1024 + 4 * (BNv * 64 * 2);                                               \
     static bool raised = false;                                                                                          \
-    auto kern = k_conv3x3_halo_x3<BNv>;                                                                                  \
+    auto kern = k_conv3x3_halo_x3<BNv, A2v>;                                                                                \
     if (!raised) {                                                                                                       \
       if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) != hipSuccess)        \
         return SAMPT_ERR_HIP;                                                                                            \

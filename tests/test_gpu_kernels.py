@@ -183,7 +183,10 @@ def test_conv_f32(lib, dev, n, H, W, Cin, Cout, k, s, p):
 
 @pytest.mark.parametrize("n,H,W,Cin,Cout,k,s,p", [(2, 20, 28, 64, 64, 3, 1, 1), (2, 20, 28, 64, 96, 3, 2, 1),
                                                   (2, 17, 23, 96, 128, 1, 2, 0), (1, 16, 24, 416, 256, 3, 1, 1),
-                                                  (3, 9, 11, 128, 128, 3, 1, 1), (1, 40, 56, 96, 96, 3, 1, 1)])
+                                                  (3, 9, 11, 128, 128, 3, 1, 1), (1, 40, 56, 96, 96, 3, 1, 1),
+                                                  # halo-tiled kernel: whole tiles, one pixel, a ragged channel tile, three chunks
+                                                  (2, 32, 48, 64, 64, 3, 1, 1), (1, 1, 1, 32, 64, 3, 1, 1), (1, 33, 17, 96, 100, 3, 1, 1),
+                                                  (1, 18, 35, 128, 256, 3, 1, 1)])
 def test_conv_f16x3(lib, dev, n, H, W, Cin, Cout, k, s, p):
     """Split-fp16 convolution (three fp16 MFMAs per fp32 product, csrc/conv_f16x3.hip): as close to the fp64 convolution
     as the exact-fp32 MFMA path is."""
@@ -209,6 +212,17 @@ def test_conv_f16x3(lib, dev, n, H, W, Cin, Cout, k, s, p):
     ok(lib.sampt_conv2d_nhwc(4, P(xhl), P(whl), P(bd), P(y4), n, H, W, Cin, Cout, k, k, s, p, S()), "conv f16x3 planes")
     e4 = rel_err(y4, ref)
     assert e4 < max(2e-6, 1.5 * e32), (e4, e32)
+    # ... and, where the halo-tiled kernel takes the launch (3 x 3, stride 1: csrc/conv_halo_x3.hip), the implicit-GEMM LDS-DMA kernel
+    # it replaced must agree with it to the products' fp32 round-off
+    if k == 3 and s == 1:
+        try:
+            ok(lib.sampt_conv_set_halo(0), "set_halo")
+            y5 = torch.full(ref.shape, 7.0, device=dev)
+            ok(lib.sampt_conv2d_nhwc(4, P(xhl), P(whl), P(bd), P(y5), n, H, W, Cin, Cout, k, k, s, p, S()), "conv f16x3 planes, implicit GEMM")
+        finally:
+            ok(lib.sampt_conv_set_halo(1), "set_halo")
+        assert rel_err(y5, ref) < max(2e-6, 1.5 * e32)
+        assert max_abs(y4, y5) < 5e-5 * max(1.0, float(ref.abs().max()))
     # unsupported shapes are refused, never silently computed another way
     assert lib.sampt_conv2d_nhwc(3, P(xd), P(whl), P(bd), P(y), n, H, W, Cin - 4, Cout, k, k, s, p, S()) == -3
 
