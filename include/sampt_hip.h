@@ -189,7 +189,8 @@ int sampt_gemm_set_schedule(int sched);
  * the (16 * FM) x 16 tile only while at least n workgroups remain (default 256 = one per CU). */
 int sampt_gemm_set_thin_min_wgs(int n);
 /* Process-wide A / B switch: 1 (default) = 3 x 3 stride-1 split-fp16 convolutions over pre-split planes (the tracker encoder's) run on
- * the halo-tiled kernel of csrc/conv_halo_x3.hip; 0 = on the implicit-GEMM LDS-DMA kernel of rounds 3 - 5 (csrc/conv_f16x3.hip). */
+ * the halo-tiled kernel of csrc/conv_halo_x3.hip; 0 = on the implicit-GEMM LDS-DMA kernel of rounds 3 - 5 (csrc/conv_f16x3.hip);
+ * 2 = halo-tiled with 4-wave workgroups at every tile width (1 uses 8 waves from 96 output channels up). */
 int sampt_conv_set_halo(int on);
 /* Process-wide knob of the PIPS window's MLP-Mixer (csrc/pips_mixer.hip).  fused = 1 (default): two launches per mixer block —
  * [sum of the previous channel MLP's slabs + residual -> token mixing] and [LayerNorm -> fc1 -> GELU -> fc2 over hidden slices];

@@ -337,7 +337,7 @@ int sampt_pips_set_mixer(int fused, int workgroups) {
 }
 
 int sampt_conv_set_halo(int on) {
-  sampt::g_conv_halo = on ? 1 : 0;
+  sampt::g_conv_halo = on < 0 ? 0 : (on > 2 ? 1 : on);
   return SAMPT_OK;
 }
 

@@ -40,12 +40,18 @@ constexpr int ABUF = 2 * APL;                           // one halo chunk: hi | 
 // A2: the halo chunk is double-buffered (the next chunk arrives under this chunk's nine taps; 150 KB of LDS at BN = 128, one
 // workgroup per CU).  A2 = false (BN = 64): ONE halo buffer, 76 KB, TWO workgroups per CU — with two chunks per tile (the 64-channel
 // layers) a workgroup's fixed costs (first DMA round trip, epilogue stores: ~14 of its ~20 us) weigh more than the one exposed
-// chunk boundary, and the second workgroup's waves fill the matrix pipe meanwhile.
-template <int BN, bool A2>
-__global__ __launch_bounds__(256, A2 ? 1 : 2) void k_conv3x3_halo_x3(GemmP p, int ntx, int nty) {
-  constexpr int FN = BN / 16;                  // output-channel fragments per wave
-  constexpr int NW = BN / 32;                  // W DMA instructions per wave and stage (BN / 16 pieces x 2 planes / 4 waves)
-  constexpr int NA = 12;                       // A DMA instructions per wave and chunk (6 pieces x 2 planes; padded with dummies)
+// chunk boundary, and the second workgroup's waves fill the matrix pipe meanwhile (356 -> 280 us, profiles/r6_c14_*).
+// NWV: waves per workgroup.  4: a wave owns 4 image rows x all BN channels.  8 (BN >= 96, where registers and LDS allow only one
+// workgroup per CU): waves w and w + 4 share the 4 rows and split the channels, so every SIMD holds TWO waves — one multiplies while
+// the other issues its LDS-DMA (60 - 185 issue cycles per instruction) or waits for LDS.
+template <int BN, bool A2, int NWV>
+__global__ __launch_bounds__(NWV * 64, (A2 && NWV == 4) ? 1 : 2) void k_conv3x3_halo_x3(GemmP p, int ntx, int nty) {
+  constexpr int FN = BN / 16;                  // output-channel fragments of the tile
+  constexpr int FNW = FN / (NWV / 4);          // ... of one wave
+  constexpr int NBP = 2 * FN;                  // W DMA pieces per stage: [hi rows | lo rows], 16 rows each
+  constexpr int NW = (NBP + NWV - 1) / NWV;    // W DMA instructions per wave and stage (padded with dummies)
+  constexpr int KA = (APIECES + NWV - 1) / NWV;   // halo pieces per wave and plane
+  constexpr int NA = 2 * KA;                   // A DMA instructions per wave and chunk (padded with dummies)
   constexpr int WSTG = BN * 64 * 2;            // bytes of one weight stage (hi rows | lo rows)
   constexpr int NAB = A2 ? 2 : 1;
   extern __shared__ __attribute__((aligned(1024))) char lds[];      // [A buf 0 (| A buf 1) | dummy 1 KB | W ring (4 stages)]
@@ -53,6 +59,7 @@ __global__ __launch_bounds__(256, A2 ? 1 : 2) void k_conv3x3_halo_x3(GemmP p, in
   char* const dummy_lds = lds + NAB * ABUF;
   char* const w_lds = lds + NAB * ABUF + 1024;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pw = wave & 3, ch = wave >> 2;     // pixel-row group, channel half
   const int lr = lane & 15, lq = lane >> 4;
   // ---- tile: blockIdx.x = ((img * nty + ty) * ntx + tx) * ntn + tn
   const int ntn = (p.N + BN - 1) / BN;
@@ -74,37 +81,37 @@ __global__ __launch_bounds__(256, A2 ? 1 : 2) void k_conv3x3_halo_x3(GemmP p, in
   const int prow = lane >> 2;
   const int fsw = (4 - (lane >> 4)) & 3;                                 // F[(row >> 2) & 3] with (row >> 2) & 3 == lane >> 4
   const int csrc = ((lane & 3) ^ fsw) * 16;                              // byte offset of this lane's source chunk in a 64-B slab row
-  // A: this wave fills halo pieces wave + 4 k (k = 0 .. 5; pieces >= 21 are dummies): byte offset of the halo pixel's channel 0 in
-  // a plane, or -1 when the pixel lies outside the image (zero page) / the piece does not exist
-  long a_off[6];
+  // A: this wave fills halo pieces wave + NWV k (pieces >= 21 are dummies): byte offset of the halo pixel's channel 0 in a plane,
+  // or -1 when the pixel lies outside the image (zero page) / the piece does not exist
+  long a_off[KA];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    const int piece = wave + 4 * k, hl = piece * 16 + prow;
+  for (int k = 0; k < KA; ++k) {
+    const int piece = wave + NWV * k, hl = piece * 16 + prow;
     const int hy = hl / HW, hx = hl - hy * HW;
     const int y = y0 - 1 + hy, x = x0 - 1 + hx;
     const bool ok = piece < APIECES && hl < NPX && y >= 0 && y < H && x >= 0 && x < W;
     a_off[k] = ok ? (((long)img * H + y) * W + x) * C * 2 + csrc : -1;
   }
-  // W: pieces q = wave + 4 j over [hi rows | lo rows]; row n of the weight matrix is [9 taps][C] halves
+  // W: pieces q = wave + NWV j over [hi rows | lo rows] (q >= NBP: dummy); row n of the weight matrix is [9 taps][C] halves
   long w_off[NW];
   bool w_lo[NW];
-  int w_dst[NW];
+  int w_dst[NW];                                                         // byte offset inside a stage, or -1: dummy
 #pragma unroll
   for (int j = 0; j < NW; ++j) {
-    const int q = wave + 4 * j;
+    const int q = wave + NWV * j;
     w_lo[j] = q >= FN;
     const int piece = w_lo[j] ? q - FN : q;
-    int n = n0 + piece * 16 + prow;
+    int n = n0 + (piece < FN ? piece : 0) * 16 + prow;
     n = n < p.N ? n : p.N - 1;
     w_off[j] = (long)n * p.ldw * 2 + csrc;
-    w_dst[j] = (w_lo[j] ? BN * 64 : 0) + piece * 1024;
+    w_dst[j] = q < NBP ? (w_lo[j] ? BN * 64 : 0) + piece * 1024 : -1;
   }
   auto stage_a = [&](int c) {                                            // halo chunk c (clamped: a dummy re-issue past the end)
     const int cc = c < nchunk ? c : nchunk - 1;
     char* dst = a_lds + (A2 ? (c & 1) : 0) * ABUF;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      const int piece = wave + 4 * k;                                    // uniform
+    for (int k = 0; k < KA; ++k) {
+      const int piece = wave + NWV * k;                                  // uniform
       const bool real = piece < APIECES;
       const char* sh = a_off[k] >= 0 ? Ah + a_off[k] + cc * 64 : zero + csrc;
       const char* sl = a_off[k] >= 0 ? Al + a_off[k] + cc * 64 : zero + csrc;
@@ -120,14 +127,15 @@ __global__ __launch_bounds__(256, A2 ? 1 : 2) void k_conv3x3_halo_x3(GemmP p, in
     char* dst = w_lds + (s & 3) * WSTG;
 #pragma unroll
     for (int j = 0; j < NW; ++j)
-      __builtin_amdgcn_global_load_lds((glb_void*)((w_lo[j] ? Wl : Wh) + w_off[j] + koff), (lds_void*)(dst + w_dst[j]), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void*)((w_lo[j] ? Wl : Wh) + w_off[j] + koff),
+                                       (lds_void*)(w_dst[j] >= 0 ? dst + w_dst[j] : dummy_lds), 16, 0, 0);
   };
 
-  f32x4 acc[4][FN];
+  f32x4 acc[4][FNW];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < FNW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   stage_a(0);
   stage_w(0);
@@ -154,15 +162,16 @@ __global__ __launch_bounds__(256, A2 ? 1 : 2) void k_conv3x3_halo_x3(GemmP p, in
       h8 ah[4], al[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int r = (4 * wave + i + ky) * HW + lr + kx;                // halo row of output pixel (4 wave + i, lr) for this tap
+        const int r = (4 * pw + i + ky) * HW + lr + kx;                  // halo row of output pixel (4 pw + i, lr) for this tap
         const int off = r * 64 + ((lq ^ ((4 - ((r >> 2) & 3)) & 3)) * 16);
         ah[i] = *(const h8*)(abuf + off);
         al[i] = *(const h8*)(abuf + APL + off);
       }
 #pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        const h8 bh = *(const h8*)(wslot + (j * 16 + lr) * 64 + wsw);
-        const h8 bl = *(const h8*)(wslot + BN * 64 + (j * 16 + lr) * 64 + wsw);
+      for (int j = 0; j < FNW; ++j) {
+        const int jg = ch * FNW + j;
+        const h8 bh = *(const h8*)(wslot + (jg * 16 + lr) * 64 + wsw);
+        const h8 bl = *(const h8*)(wslot + BN * 64 + (jg * 16 + lr) * 64 + wsw);
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, al[i], acc[i][j], 0, 0, 0);
 #pragma unroll
@@ -179,26 +188,26 @@ __global__ __launch_bounds__(256, A2 ? 1 : 2) void k_conv3x3_halo_x3(GemmP p, in
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // the dummy tail stages must land before the LDS is handed on
 
-  // ---- epilogue: lane (lr, lq) reg r = channel n0 + 16 j + 4 lq + r of pixel (y0 + 4 wave + i, x0 + lr).  The bias is loaded
+  // ---- epilogue: lane (lr, lq) reg r = channel n0 + 16 jg + 4 lq + r of pixel (y0 + 4 pw + i, x0 + lr).  The bias is loaded
   // once, unconditionally (clamped columns): a load under the per-fragment branches would wait for every earlier store.
-  float4 bb[FN];
+  float4 bb[FNW];
 #pragma unroll
-  for (int j = 0; j < FN; ++j) {
-    const int col = n0 + j * 16 + lq * 4;
+  for (int j = 0; j < FNW; ++j) {
+    const int col = n0 + (ch * FNW + j) * 16 + lq * 4;
     bb[j] = p.bias ? *(const float4*)(p.bias + (col < p.N ? col : 0)) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 #pragma unroll
-  for (int j = 0; j < FN; ++j)      // "use" every bias register HERE: hipcc otherwise waits vmcnt(0) at each first use inside the
+  for (int j = 0; j < FNW; ++j)     // "use" every bias register HERE: hipcc otherwise waits vmcnt(0) at each first use inside the
     asm volatile("" ::"v"(bb[j].x), "v"(bb[j].y), "v"(bb[j].z), "v"(bb[j].w));   // store branches — i.e. for the previous store
   const int x = x0 + lr;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int y = y0 + 4 * wave + i;
+    const int y = y0 + 4 * pw + i;
     const bool pix_ok = y < H && x < W;
     float* orow = (float*)p.C + (((long)img * H + (pix_ok ? y : 0)) * W + (pix_ok ? x : 0)) * p.ldc;
 #pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      const int col = n0 + j * 16 + lq * 4;
+    for (int j = 0; j < FNW; ++j) {
+      const int col = n0 + (ch * FNW + j) * 16 + lq * 4;
       if (pix_ok && col < p.N)
         *(float4*)(orow + col) = make_float4(acc[i][j][0] * p.alpha + bb[j].x, acc[i][j][1] * p.alpha + bb[j].y,
                                              acc[i][j][2] * p.alpha + bb[j].z, acc[i][j][3] * p.alpha + bb[j].w);
@@ -206,7 +215,8 @@ __global__ __launch_bounds__(256, A2 ? 1 : 2) void k_conv3x3_halo_x3(GemmP p, in
   }
 }
 
-int g_conv_halo = 1;     // sampt_conv_set_halo: 0 = the 3 x 3 stride-1 launches go back to k_conv_f16x3_dma (A / B)
+int g_conv_halo = 1;     // sampt_conv_set_halo: 0 = the 3 x 3 stride-1 launches go back to k_conv_f16x3_dma (A / B); 2 = 4-wave
+                         // workgroups for every tile width (the first version of this kernel)
 
 bool conv3x3_halo_eligible(const GemmP& p) {
   return p.conv && p.A_lo && p.KH == 3 && p.KW == 3 && p.cstride == 1 && p.cpad == 1 && p.cpadw < 0 && p.cC % 32 == 0 &&
@@ -219,21 +229,24 @@ int conv3x3_halo_x3(const GemmP& p, hipStream_t s) {
   const int ntx = cdiv(p.cW, HT), nty = cdiv(p.cH, HT);
   const int BN = p.N <= 64 ? 64 : (p.N <= 96 ? 96 : 128);
   const int ntn = cdiv(p.N, BN);
-  dim3 grid((unsigned)((long)nimg * nty * ntx * ntn)), block(256);
-#define HALO(BNv)                                                                                                        \
+  dim3 grid((unsigned)((long)nimg * nty * ntx * ntn));
+#define HALO(BNv, NWVv)                                                                                                  \
   do {                                                                                                                   \
     constexpr bool A2v = BNv != 64;                                                                                      \
     constexpr int LDSB = (A2v ? 2 : 1) * ABUF + 1024 + 4 * (BNv * 64 * 2);                                               \
     static bool raised = false;                                                                                          \
-    auto kern = k_conv3x3_halo_x3<BNv, A2v>;                                                                                \
+    auto kern = k_conv3x3_halo_x3<BNv, A2v, NWVv>;                                                                       \
     if (!raised) {                                                                                                       \
       if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) != hipSuccess)        \
         return SAMPT_ERR_HIP;                                                                                            \
       raised = true;                                                                                                     \
     }                                                                                                                    \
-    hipLaunchKernelGGL(kern, grid, block, LDSB, s, p, ntx, nty);                                                         \
+    hipLaunchKernelGGL(kern, grid, dim3(NWVv * 64), LDSB, s, p, ntx, nty);                                               \
   } while (0)
-  if (BN == 64) HALO(64); else if (BN == 96) HALO(96); else HALO(128);
+  const bool w8 = g_conv_halo != 2;
+  if (BN == 64) HALO(64, 4);
+  else if (BN == 96) { if (w8) HALO(96, 8); else HALO(96, 4); }
+  else { if (w8) HALO(128, 8); else HALO(128, 4); }
 #undef HALO
   SAMPT_CHECK_LAUNCH("conv3x3_halo_x3");
   return SAMPT_OK;
