@@ -192,6 +192,18 @@ int sampt_gemm_set_thin_min_wgs(int n);
  * the halo-tiled kernel of csrc/conv_halo_x3.hip; 0 = on the implicit-GEMM LDS-DMA kernel of rounds 3 - 5 (csrc/conv_f16x3.hip);
  * 2 = halo-tiled with 4-wave workgroups at every tile width (1 uses 8 waves from 96 output channels up). */
 int sampt_conv_set_halo(int on);
+/* The mask decoder's image-side projection as an operator: C [M][N] = act(A W^T + bias) + res[row % res_mod (0: row)] with f32 A
+ * [M][K] (K % 32 == 0) and W as split-fp16 planes [2][N][K] scaled by 2^8 (pack.split_f16x3) — 3-term fp16 MFMA products, fp32-grade
+ * (reference: segment_anything/modeling/transformer.py:185-232 q / k / v / out projections over the image tokens).  shuf_g > 0: the
+ * ConvTranspose2d(k = 2, s = 2) form (mask_decoder.py:53-61): N = 4 * cout columns ordered (dy, dx, channel), GEMM row f g^2 + y g + x
+ * goes to pixel row f 4 g^2 + (2 y + dy) 2 g + 2 x + dx of C [.][cout]; bias has cout entries; res must be null.  act: 0 none, 1 ReLU,
+ * 2 GELU (erf). */
+int sampt_gemm_x3_rows(const float* A, const void* w_hl, const float* bias, const float* res, int res_mod, float* C, int M, int N,
+                       int K, int act, int shuf_g, sampt_stream_t stream);
+/* Process-wide A / B switch: 1 (default) = 1 x 1 split-fp16 "convolutions" over f32 activations with M >= 16384 rows and K = 64 /
+ * 128 / 256 (the mask decoder's image-side projections and transposed convolutions) run on the weights-resident-in-LDS kernel of
+ * csrc/gemm_x3_wres.hip; 0 = on the tiled kernel of rounds 2 - 5 (csrc/conv_f16x3.hip k_conv_f16x3).  Results are bitwise identical. */
+int sampt_gemm_set_wres(int on);
 /* Process-wide knob of the PIPS window's MLP-Mixer (csrc/pips_mixer.hip).  fused = 1 (default): two launches per mixer block —
  * [sum of the previous channel MLP's slabs + residual -> token mixing] and [LayerNorm -> fc1 -> GELU -> fc2 over hidden slices];
  * fused = 0: the four-launch blocks of rounds 1 - 5 (token mixing, LayerNorm, two thin GEMMs); fused = 2: the two-launch blocks with

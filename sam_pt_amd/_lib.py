@@ -98,6 +98,8 @@ _SIGS = {
     "sampt_gemm_set_schedule": (c_int, [c_int]),
     "sampt_gemm_set_thin_min_wgs": (c_int, [c_int]),
     "sampt_conv_set_halo": (c_int, [c_int]),
+    "sampt_gemm_set_wres": (c_int, [c_int]),
+    "sampt_gemm_x3_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "sampt_pips_set_mixer": (c_int, [c_int, c_int]),
     "sampt_stream_create_cu_range": (c_int, [c_int, c_int, C.POINTER(_P)]),
     "sampt_stream_destroy": (c_int, [_P]),
@@ -152,6 +154,8 @@ def load():
         lib.sampt_gemm_set_schedule(int(os.environ["SAMPT_GEMM_SCHED"]))
     if os.environ.get("SAMPT_PIPS_MIXER") or os.environ.get("SAMPT_PIPS_MIXER_WGS") or os.environ.get("SAMPT_PIPS_MIXER_DIAG"):   # csrc/pips_mixer.hip (A / B runs)
         lib.sampt_pips_set_mixer(int(os.environ.get("SAMPT_PIPS_MIXER", "2")), int(os.environ.get("SAMPT_PIPS_MIXER_WGS", "16")))
+    if os.environ.get("SAMPT_GEMM_WRES"):              # A / B switch of csrc/gemm_x3_wres.hip (sampt_gemm_set_wres)
+        lib.sampt_gemm_set_wres(int(os.environ["SAMPT_GEMM_WRES"]))
     if os.environ.get("SAMPT_CONV_HALO"):              # A / B switch of csrc/conv_halo_x3.hip (sampt_conv_set_halo)
         lib.sampt_conv_set_halo(int(os.environ["SAMPT_CONV_HALO"]))
     if os.environ.get("SAMPT_THIN_MIN_WGS"):          # thin f32 GEMM: tile growth threshold (sampt_gemm_set_thin_min_wgs)

@@ -341,6 +341,11 @@ int sampt_conv_set_halo(int on) {
   return SAMPT_OK;
 }
 
+int sampt_gemm_set_wres(int on) {
+  sampt::g_gemm_x3_wres = on ? 1 : 0;
+  return SAMPT_OK;
+}
+
 int sampt_gemm_set_stagger(int groups) {
   if (groups < 0 || groups > 8) return fail(SAMPT_ERR_ARG, "sampt_gemm_set_stagger: 0 .. 8 phase groups");
   sampt::g_p8_stagger = groups;
@@ -705,6 +710,17 @@ int sampt_conv2d_nhwc(int dtype, const void* x, const void* w, const float* bias
     return conv_f16x3(p, (hipStream_t)stream);
   }
   return dtype == 0 ? gemm_f32(p, (hipStream_t)stream) : gemm_f16(p, (hipStream_t)stream);
+}
+
+int sampt_gemm_x3_rows(const float* A, const void* w_hl, const float* bias, const float* res, int res_mod, float* C, int M, int N,
+                       int K, int act, int shuf_g, sampt_stream_t stream) {
+  GemmP p;
+  p.A = A, p.W = w_hl, p.W_lo = (const half_t*)w_hl + (size_t)N * K, p.bias = bias, p.res = res, p.res_mod = res_mod, p.C = C;
+  p.alpha = 1.0f / (float)(1 << F16X3_WSHIFT), p.act = act;
+  p.M = M, p.N = N, p.K = K, p.ldw = K, p.ldc = shuf_g ? N / 4 : N, p.ldr = p.ldc;
+  p.conv = 1, p.cH = M, p.cW = 1, p.cC = K, p.KH = 1, p.KW = 1, p.cstride = 1, p.cpad = 0, p.OH = M, p.OW = 1;
+  p.shuf_g = shuf_g, p.shuf_n = shuf_g ? N / 4 : 0;
+  return conv_f16x3(p, (hipStream_t)stream);
 }
 
 size_t sampt_instance_norm_workspace_bytes(int n, int hw, int C) {

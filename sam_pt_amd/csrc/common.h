@@ -217,6 +217,11 @@ int conv_f16x3(const GemmP& p, hipStream_t s);
 // conv_f16x3 hands eligible launches over unless g_conv_halo == 0
 extern int g_conv_halo;
 bool conv3x3_halo_eligible(const GemmP& p);
+// gemm_x3_wres.hip: the tall short-K 1 x 1 case over f32 activations (the mask decoder's image-side projections) with the weight
+// slice resident in LDS; conv_f16x3 hands eligible launches over unless g_gemm_x3_wres == 0
+extern int g_gemm_x3_wres;
+bool gemm_x3_wres_eligible(const GemmP& p);
+int gemm_x3_wres(const GemmP& p, hipStream_t s);
 int conv3x3_halo_x3(const GemmP& p, hipStream_t s);
 
 }  // namespace sampt

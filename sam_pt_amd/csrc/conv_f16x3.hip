@@ -367,6 +367,7 @@ int conv_f16x3(const GemmP& p_in, hipStream_t s) {
   //  A + C because every workgroup re-fetches W and a CU moves ~25 GB/s through LDS-DMA whatever the source; not kept.
   //  profiles/r6_c9_gemm_x3_rows_vs_register_staged.log)
   if (g_conv_halo && conv3x3_halo_eligible(p)) return conv3x3_halo_x3(p, s);
+  if (g_gemm_x3_wres && gemm_x3_wres_eligible(p)) return gemm_x3_wres(p, s);
   if (p.A_lo) {   // pre-split activations: the LDS-DMA kernel
     if (p.shuf_g) return SAMPT_ERR_UNSUPPORTED;
     const int BNd = p.N <= 64 ? 64 : (p.N <= 96 ? 96 : 128);

@@ -227,6 +227,53 @@ def test_conv_f16x3(lib, dev, n, H, W, Cin, Cout, k, s, p):
     assert lib.sampt_conv2d_nhwc(3, P(xd), P(whl), P(bd), P(y), n, H, W, Cin - 4, Cout, k, k, s, p, S()) == -3
 
 
+@pytest.mark.parametrize("M,N,K,res,act,shuf_g", [
+    (4 * 4096, 384, 256, "mod", 0, 0),        # fused K | V | Q' projection + projected positional embedding (engine_dec fused_proj)
+    (4 * 4096 + 37, 256, 128, "full", 0, 0),  # image -> token block's output projection + residual stream; ragged last group
+    (5 * 4096, 128, 256, None, 0, 0),         # final attention's k / v projections
+    (4 * 4096, 256, 256, None, 0, 64),        # output_upscaling stage 0 as one GEMM over the four sub-pixels
+    (16 * 4096, 128, 64, None, 2, 128),       # ... stage 1 with GELU
+    (17000, 200, 64, "full", 0, 0),           # ragged column slice, K = 64 with the residual ring (two groups per loop body)
+    (16500, 100, 128, None, 2, 0),
+])
+def test_gemm_x3_rows_weights_resident(lib, dev, M, N, K, res, act, shuf_g):
+    """The decoder's image-side projections on the weights-resident kernel (csrc/gemm_x3_wres.hip): fp32-grade against the fp64
+    product, and BITWISE the tiled kernel it replaces (same per-accumulator sequence of MFMAs, same epilogue order)."""
+    from sam_pt_amd.pack import split_f16x3
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g) * 1.3
+    A[5, 3], A[M - 1, K - 1] = 6.0e4, -3.0e-6                       # near the top of the fp16 range, and tiny
+    w = torch.randn(N, K, generator=g) * (1.0 / K) ** 0.5
+    cout = N // 4 if shuf_g else N
+    b = torch.randn(cout, generator=g)
+    P_ = 4096
+    r = None if res is None else (torch.randn(P_ if res == "mod" else M, N, generator=g))
+    ref = A.double() @ w.double().T
+    if shuf_g:
+        G_ = shuf_g
+        F_ = M // (G_ * G_)
+        ref = ref.view(F_, G_, G_, 2, 2, cout).permute(0, 1, 3, 2, 4, 5).reshape(F_ * 4 * G_ * G_, cout)   # (f, y, dy, x, dx, c)
+    ref = ref + b.double()
+    if act == 2:
+        ref = F.gelu(ref)
+    if r is not None:
+        ref = ref + (r.double().repeat(M // P_, 1) if res == "mod" else r.double())
+    Ad, whl, bd = A.to(dev), split_f16x3(w).to(dev), b.to(dev)
+    rd = None if r is None else r.to(dev)
+    outs = []
+    try:
+        for on in (1, 0):
+            ok(lib.sampt_gemm_set_wres(on), "set_wres")
+            y = torch.full(ref.shape, 7.0, device=dev)
+            ok(lib.sampt_gemm_x3_rows(P(Ad), P(whl), P(bd), P(rd) if rd is not None else None, P_ if res == "mod" else 0, P(y), M, N, K,
+                                      act, shuf_g, S()), "gemm_x3_rows")
+            outs.append(y)
+    finally:
+        ok(lib.sampt_gemm_set_wres(1), "set_wres")
+    assert rel_err(outs[0], ref) < 2e-6
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_conv_f16(lib, dev):
     n, H, W, Cin, Cout = 2, 16, 16, 256, 256
     g = torch.Generator().manual_seed(5)
