@@ -190,8 +190,15 @@ int sampt_gemm_set_schedule(int sched);
 int sampt_gemm_set_thin_min_wgs(int n);
 /* Process-wide A / B switch: 1 (default) = 3 x 3 stride-1 split-fp16 convolutions over pre-split planes (the tracker encoder's) run on
  * the halo-tiled kernel of csrc/conv_halo_x3.hip; 0 = on the implicit-GEMM LDS-DMA kernel of rounds 3 - 5 (csrc/conv_f16x3.hip);
- * 2 = halo-tiled with 4-wave workgroups at every tile width (1 uses 8 waves from 96 output channels up). */
+ * 2 = halo-tiled with 4-wave workgroups at every tile width (1 uses 8 waves from 96 output channels up); 3 = as 1, but the tracker
+ * encoder's InstanceNorms sum their statistics in a pass of their own instead of in the convolution's epilogue. */
 int sampt_conv_set_halo(int on);
+/* 3 x 3 stride-1 pad-1 split-fp16 convolution over pre-split planes (sampt_conv2d_nhwc dtype 4) that ALSO produces the statistics of
+ * the InstanceNorm2d that follows it in the tracker's encoder (pips.py:191-287 BasicEncoder: every convolution is followed by
+ * norm_fn = "instance"): mean_rstd [n][Cout][2] = (mean, 1 / sqrt(biased var + eps)) of y over H x W, summed from the convolution's
+ * registers per 16 x 16 tile (fp32 over 64 pixels, fp64 beyond).  ws: n * ceil(H / 16) * ceil(W / 16) * Cout * 16 bytes. */
+int sampt_conv3x3_planes_instnorm_stats(const void* x_hl, const void* w_hl, const float* bias, float* y, int n, int H, int W, int Cin,
+                                        int Cout, float eps, float* mean_rstd, void* ws, size_t ws_bytes, sampt_stream_t stream);
 /* The mask decoder's image-side projection as an operator: C [M][N] = act(A W^T + bias) + res[row % res_mod (0: row)] with f32 A
  * [M][K] (K % 32 == 0) and W as split-fp16 planes [2][N][K] scaled by 2^8 (pack.split_f16x3) — 3-term fp16 MFMA products, fp32-grade
  * (reference: segment_anything/modeling/transformer.py:185-232 q / k / v / out projections over the image tokens).  shuf_g > 0: the

@@ -337,6 +337,7 @@ int sampt_pips_set_mixer(int fused, int workgroups) {
 }
 
 int sampt_conv_set_halo(int on) {
+  sampt::g_conv_in_stats = on == 3 ? 0 : 1;          // 3: halo kernel without the fused InstanceNorm statistics
   sampt::g_conv_halo = on < 0 ? 0 : (on > 2 ? 1 : on);
   return SAMPT_OK;
 }
@@ -721,6 +722,22 @@ int sampt_gemm_x3_rows(const float* A, const void* w_hl, const float* bias, cons
   p.conv = 1, p.cH = M, p.cW = 1, p.cC = K, p.KH = 1, p.KW = 1, p.cstride = 1, p.cpad = 0, p.OH = M, p.OW = 1;
   p.shuf_g = shuf_g, p.shuf_n = shuf_g ? N / 4 : 0;
   return conv_f16x3(p, (hipStream_t)stream);
+}
+
+int sampt_conv3x3_planes_instnorm_stats(const void* x_hl, const void* w_hl, const float* bias, float* y, int n, int H, int W, int Cin,
+                                        int Cout, float eps, float* mean_rstd, void* ws, size_t ws_bytes, sampt_stream_t stream) {
+  GemmP p;
+  p.OH = H, p.OW = W;
+  p.A = x_hl, p.A_lo = (const half_t*)x_hl + (size_t)n * H * W * Cin, p.W = w_hl, p.W_lo = (const half_t*)w_hl + (size_t)Cout * 9 * Cin;
+  p.bias = bias, p.C = y, p.alpha = 1.0f / (float)(1 << F16X3_WSHIFT);
+  p.M = n * H * W, p.N = Cout, p.K = 9 * Cin, p.ldw = p.K, p.ldc = Cout;
+  p.conv = 1, p.cH = H, p.cW = W, p.cC = Cin, p.KH = 3, p.KW = 3, p.cstride = 1, p.cpad = 1;
+  if (!conv3x3_halo_eligible(p)) return fail(SAMPT_ERR_UNSUPPORTED, "sampt_conv3x3_planes_instnorm_stats: Cin % 32, Cout % 4");
+  const int chunks = conv3x3_halo_tiles(p);
+  if (ws_bytes < (size_t)n * chunks * Cout * 2 * sizeof(double)) return SAMPT_ERR_WORKSPACE;
+  p.in_part = (double*)ws;
+  SAMPT_TRY(conv3x3_halo_x3(p, (hipStream_t)stream));
+  return instnorm_finalize(p.in_part, n, chunks, (long)H * W, Cout, eps, mean_rstd, (hipStream_t)stream);
 }
 
 size_t sampt_instance_norm_workspace_bytes(int n, int hw, int C) {

@@ -200,6 +200,9 @@ struct GemmP {
   int conv = 0;
   int cH = 0, cW = 0, cC = 0, KH = 0, KW = 0, cstride = 1, cpad = 0, OH = 0, OW = 0;
   int cpadw = -1;                // >= 0: padding along W differs from cpad (1-D convolutions over time: KW = 1, cpadw = 0)
+  // conv3x3_halo_x3 only: non-null = also write this launch's share of the following InstanceNorm's statistics — per (image, 16 x 16
+  // pixel tile, channel) the pair sum(v), sum(v^2) as doubles, [nimg][conv3x3_halo_tiles(p)][N][2]: the layout k_instnorm_final reads
+  double* in_part = nullptr;
 };
 
 extern int g_p8_sched;     // gemm_f16_p8.hip: 0 = stage in the read segments (default), 1 = the round-3 schedule (sampt_gemm_set_schedule)
@@ -216,6 +219,8 @@ int conv_f16x3(const GemmP& p, hipStream_t s);
 // conv_halo_x3.hip: the 3 x 3 stride-1 pad-1 case over pre-split planes with the input halo staged once per 16 x 16 pixel tile;
 // conv_f16x3 hands eligible launches over unless g_conv_halo == 0
 extern int g_conv_halo;
+extern int g_conv_in_stats;    // conv_halo_x3.hip: 1 (default) = the tracker encoder's halo convolutions also sum the following InstanceNorm's
+                               // statistics (sampt_conv_set_halo(3) turns it off for A / B runs)
 bool conv3x3_halo_eligible(const GemmP& p);
 // gemm_x3_wres.hip: the tall short-K 1 x 1 case over f32 activations (the mask decoder's image-side projections) with the weight
 // slice resident in LDS; conv_f16x3 hands eligible launches over unless g_gemm_x3_wres == 0
@@ -223,5 +228,6 @@ extern int g_gemm_x3_wres;
 bool gemm_x3_wres_eligible(const GemmP& p);
 int gemm_x3_wres(const GemmP& p, hipStream_t s);
 int conv3x3_halo_x3(const GemmP& p, hipStream_t s);
+int conv3x3_halo_tiles(const GemmP& p);
 
 }  // namespace sampt

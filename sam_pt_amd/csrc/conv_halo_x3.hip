@@ -200,29 +200,72 @@ __global__ __launch_bounds__(NWV * 64, (A2 && NWV == 4) ? 1 : 2) void k_conv3x3_
   for (int j = 0; j < FNW; ++j)     // "use" every bias register HERE: hipcc otherwise waits vmcnt(0) at each first use inside the
     asm volatile("" ::"v"(bb[j].x), "v"(bb[j].y), "v"(bb[j].z), "v"(bb[j].w));   // store branches — i.e. for the previous store
   const int x = x0 + lr;
+  float* orow[4];
+  bool pix_ok[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int y = y0 + 4 * pw + i;
-    const bool pix_ok = y < H && x < W;
-    float* orow = (float*)p.C + (((long)img * H + (pix_ok ? y : 0)) * W + (pix_ok ? x : 0)) * p.ldc;
+    pix_ok[i] = y < H && x < W;
+    orow[i] = (float*)p.C + (((long)img * H + (pix_ok[i] ? y : 0)) * W + (pix_ok[i] ? x : 0)) * p.ldc;
+  }
+  // p.in_part: the InstanceNorm that follows wants sum(v), sum(v^2) per (image, channel) — this tile's share is summed here, from
+  // the registers that are being stored, instead of in a pass of its own over the map: fp32 over the wave's 64 pixels (a 4-term
+  // chain, then a 16-lane butterfly), fp64 across the four row groups of the tile and, in k_instnorm_final, across tiles.
+  float* const red = (float*)lds;               // [row group 4][BN][2] — the staging buffers are dead (barrier below)
+  if (p.in_part) __syncthreads();
 #pragma unroll
-    for (int j = 0; j < FNW; ++j) {
-      const int col = n0 + (ch * FNW + j) * 16 + lq * 4;
-      if (pix_ok && col < p.N)
-        *(float4*)(orow + col) = make_float4(acc[i][j][0] * p.alpha + bb[j].x, acc[i][j][1] * p.alpha + bb[j].y,
-                                             acc[i][j][2] * p.alpha + bb[j].z, acc[i][j][3] * p.alpha + bb[j].w);
+  for (int j = 0; j < FNW; ++j) {
+    const int jg = ch * FNW + j, col = n0 + jg * 16 + lq * 4;
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 v = make_float4(acc[i][j][0] * p.alpha + bb[j].x, acc[i][j][1] * p.alpha + bb[j].y,
+                                   acc[i][j][2] * p.alpha + bb[j].z, acc[i][j][3] * p.alpha + bb[j].w);
+      if (pix_ok[i] && col < p.N) *(float4*)(orow[i] + col) = v;
+      if (p.in_part && pix_ok[i]) {
+        s1.x += v.x, s1.y += v.y, s1.z += v.z, s1.w += v.w;
+        s2.x += v.x * v.x, s2.y += v.y * v.y, s2.z += v.z * v.z, s2.w += v.w * v.w;
+      }
+    }
+    if (p.in_part) {
+      float r[8] = {s1.x, s1.y, s1.z, s1.w, s2.x, s2.y, s2.z, s2.w};
+#pragma unroll
+      for (int m = 1; m < 16; m <<= 1)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] += __shfl_xor(r[e], m, 64);
+      if (lr == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          red[((pw * BN) + jg * 16 + lq * 4 + e) * 2] = r[e];
+          red[((pw * BN) + jg * 16 + lq * 4 + e) * 2 + 1] = r[4 + e];
+        }
+      }
+    }
+  }
+  if (p.in_part) {
+    __syncthreads();
+    if (tid < BN && n0 + tid < p.N) {
+      double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) t1 += (double)red[(g * BN + tid) * 2], t2 += (double)red[(g * BN + tid) * 2 + 1];
+      double* o = p.in_part + ((((long)img * nty + ty) * ntx + tx) * p.N + n0 + tid) * 2;
+      o[0] = t1, o[1] = t2;
     }
   }
 }
 
 int g_conv_halo = 1;     // sampt_conv_set_halo: 0 = the 3 x 3 stride-1 launches go back to k_conv_f16x3_dma (A / B); 2 = 4-wave
                          // workgroups for every tile width (the first version of this kernel)
+int g_conv_in_stats = 1; // 0 (sampt_conv_set_halo(3)): callers do not ask for GemmP::in_part
 
 bool conv3x3_halo_eligible(const GemmP& p) {
   return p.conv && p.A_lo && p.KH == 3 && p.KW == 3 && p.cstride == 1 && p.cpad == 1 && p.cpadw < 0 && p.cC % 32 == 0 &&
          p.K == 9 * p.cC && p.ldw == p.K && p.OH == p.cH && p.OW == p.cW && p.act == ACT_NONE && !p.res && !p.shuf_g &&
          p.N % 4 == 0 && p.ldc % 4 == 0 && p.M == (p.M / (p.OH * p.OW)) * p.OH * p.OW;
 }
+
+// tiles per image = chunks of GemmP::in_part
+int conv3x3_halo_tiles(const GemmP& p) { return cdiv(p.cW, HT) * cdiv(p.cH, HT); }
 
 int conv3x3_halo_x3(const GemmP& p, hipStream_t s) {
   const int nimg = p.M / (p.OH * p.OW);

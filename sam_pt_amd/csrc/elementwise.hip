@@ -146,6 +146,16 @@ __global__ __launch_bounds__(256) void k_instnorm_partial_v4(const float* __rest
   }
 }
 
+// second stage alone: the partials were written by the producer of the map (conv3x3_halo_x3 with GemmP::in_part)
+int instnorm_finalize(const double* partials, int nimg, int nchunks, long hw, int C, float eps, float* mean_rstd, hipStream_t s) {
+  if (C > 1024 || C <= 0 || nchunks <= 0) return SAMPT_ERR_ARG;
+  const int nyf = 1024 / C > 16 ? 16 : (1024 / C < 1 ? 1 : 1024 / C);
+  hipLaunchKernelGGL(k_instnorm_final, dim3(nimg), dim3(C, nyf), (size_t)nyf * C * 2 * sizeof(double), s, partials, nchunks, hw, C, eps,
+                     mean_rstd);
+  SAMPT_CHECK_LAUNCH("instnorm_final");
+  return SAMPT_OK;
+}
+
 int instnorm_stats(const float* x, int nimg, long hw, int C, float eps, double* partials, float* mean_rstd,
                    hipStream_t s) {
   if (C > 1024 || C <= 0) return SAMPT_ERR_ARG;

@@ -76,8 +76,15 @@ struct Planes {          // an activation map pre-split into fp16 planes (writte
   half_t *hi = nullptr, *lo = nullptr;
 };
 
+struct NormCtx {
+  double* partials;
+  float* mean_rstd;
+  int chunks = 0;          // > 0: the convolution that produced the map already wrote its InstanceNorm partial sums (this many per image)
+};
+
+// nc non-null: an InstanceNorm follows — a convolution that can (the halo-tiled 3 x 3 kernel) sums its share of the statistics
 static int run_conv(const ConvW& c, const float* x, int n, int H, int W, float* y, int& OH, int& OW, bool dry,
-                    hipStream_t s, Planes xp = Planes()) {
+                    hipStream_t s, Planes xp = Planes(), NormCtx* nc = nullptr) {
   OH = (H + 2 * c.pad - c.k) / c.stride + 1;
   OW = (W + 2 * c.pad - c.k) / c.stride + 1;
   if (dry) return SAMPT_OK;
@@ -91,22 +98,20 @@ static int run_conv(const ConvW& c, const float* x, int n, int H, int W, float* 
     p.W = c.w_hl, p.W_lo = c.w_hl + (size_t)c.cout * p.K;
     p.alpha = 1.0f / (float)(1 << F16X3_WSHIFT);
     if (xp.hi) p.A = xp.hi, p.A_lo = xp.lo;     // activations already split by the producing InstanceNorm
+    if (nc && g_conv_halo && g_conv_in_stats && conv3x3_halo_eligible(p)) p.in_part = nc->partials, nc->chunks = conv3x3_halo_tiles(p);
     return conv_f16x3(p, s);
   }
   return gemm_f32(p, s);
 }
 
-struct NormCtx {
-  double* partials;
-  float* mean_rstd;
-};
-
 // InstanceNorm (+ReLU) (+skip add + ReLU), in place on y.  planes_only: the normalised map is only ever read by a split-fp16
 // convolution (through out.hi / out.lo), so its f32 copy is not written (y keeps the raw convolution output)
-static int run_inorm(const NormCtx& nc, float* y, int n, long hw, int C, int relu1, const float* skip, bool dry,
+static int run_inorm(NormCtx& nc, float* y, int n, long hw, int C, int relu1, const float* skip, bool dry,
                      hipStream_t s, Planes out = Planes(), bool planes_only = false) {
   if (dry) return SAMPT_OK;
-  SAMPT_TRY(instnorm_stats(y, n, hw, C, 1e-5f, nc.partials, nc.mean_rstd, s));
+  if (nc.chunks > 0) SAMPT_TRY(instnorm_finalize(nc.partials, n, nc.chunks, hw, C, 1e-5f, nc.mean_rstd, s));
+  else SAMPT_TRY(instnorm_stats(y, n, hw, C, 1e-5f, nc.partials, nc.mean_rstd, s));
+  nc.chunks = 0;
   return instnorm_apply(y, nc.mean_rstd, skip, planes_only && out.hi ? nullptr : y, n, hw, C, relu1, s, out.hi, out.lo);
 }
 
@@ -114,8 +119,14 @@ int PipsEngine::fnet(const uint8_t* frames, int nf, int H, int W, float* const o
   const bool dry = ws.dry();
   const int H2 = (H + 6 - 7) / 2 + 1, W2 = (W + 6 - 7) / 2 + 1;
   NormCtx nc;
-  nc.partials = (double*)ws.get(instnorm_partial_doubles(nf, (long)H2 * W2, 256) * sizeof(double));
+  // (chunk partials of instnorm_stats: 512 pixels x <= 256 channels; tile partials of the halo convolution: 16 x 16 pixels x the
+  //  layer's channels — 64 at the largest map, 256 at H/4 x W/4)
+  const size_t tile_part = (size_t)nf * 2 * std::max<size_t>((size_t)cdiv(H2, 16) * cdiv(W2, 16) * 64,
+                                                            (size_t)cdiv(H / stride, 16) * cdiv(W / stride, 16) * 256);
+  nc.partials = (double*)ws.get(std::max(instnorm_partial_doubles(nf, (long)H2 * W2, 256), tile_part) * sizeof(double));
   nc.mean_rstd = ws.f32((size_t)nf * 256 * 2);
+  NormCtx nc2 = nc;        // a block's conv2 sums its statistics before the downsample branch's InstanceNorm uses nc.partials
+  nc2.partials = (double*)ws.get(tile_part * sizeof(double));
   float* x0 = ws.f32((size_t)nf * H * W * 4);
   if (!dry) SAMPT_TRY(rgb_u8chw_to_nhwc4(frames, frames_f32, x0, nf, H, W, s));
   int h, w;
@@ -146,9 +157,9 @@ int PipsEngine::fnet(const uint8_t* frames, int nf, int H, int W, float* const o
       // the block's output feeds the next block's conv1 (and its 1x1 downsample); the last block's only the resize
       const bool last = li == 3 && bi == 1;
       Planes y2_p = last ? Planes() : planes(oel, bi == 0 ? blk[li][1][0] : blk[li + 1][0][0]);
-      SAMPT_TRY(run_conv(c1, cur, nf, h, w, y1, oh, ow, dry, s, cur_p));
+      SAMPT_TRY(run_conv(c1, cur, nf, h, w, y1, oh, ow, dry, s, cur_p, &nc));
       SAMPT_TRY(run_inorm(nc, y1, nf, (long)oh * ow, dims[li], 1, nullptr, dry, s, y1_p, true));   // y1 feeds conv2 only
-      SAMPT_TRY(run_conv(c2, y1, nf, oh, ow, y2, oh2, ow2, dry, s, y1_p));
+      SAMPT_TRY(run_conv(c2, y1, nf, oh, ow, y2, oh2, ow2, dry, s, y1_p, &nc2));
       const float* skip = cur;
       if (has_down[li][bi]) {
         float* dn = y1;  // y1 is dead after conv2 has consumed it (stream order)
@@ -157,7 +168,7 @@ int PipsEngine::fnet(const uint8_t* frames, int nf, int H, int W, float* const o
         SAMPT_TRY(run_inorm(nc, dn, nf, (long)dh * dw, dims[li], 0, nullptr, dry, s));
         skip = dn;
       }
-      SAMPT_TRY(run_inorm(nc, y2, nf, (long)oh2 * ow2, dims[li], 1, skip, dry, s, y2_p));
+      SAMPT_TRY(run_inorm(nc2, y2, nf, (long)oh2 * ow2, dims[li], 1, skip, dry, s, y2_p));
       cur = y2, cur_p = y2_p, h = oh2, w = ow2;
     }
     scale_out[li] = cur, sh[li] = h, sw[li] = w;
@@ -175,7 +186,7 @@ int PipsEngine::fnet(const uint8_t* frames, int nf, int H, int W, float* const o
   float* y = ws.f32((size_t)nf * H4 * W4 * 256);
   int oh, ow;
   Planes y_p = planes((size_t)nf * H4 * W4 * 256, conv3);
-  SAMPT_TRY(run_conv(conv2, cat, nf, H4, W4, y, oh, ow, dry, s, cat_p));
+  SAMPT_TRY(run_conv(conv2, cat, nf, H4, W4, y, oh, ow, dry, s, cat_p, &nc));
   SAMPT_TRY(run_inorm(nc, y, nf, (long)oh * ow, 256, 1, nullptr, dry, s, y_p, true));             // feeds the 1 x 1 conv3 only
   SAMPT_TRY(run_conv(conv3, y, nf, oh, ow, out[0], oh, ow, dry, s, y_p));
   if (!dry) {

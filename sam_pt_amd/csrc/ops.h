@@ -12,6 +12,7 @@ int rgb_u8chw_to_nhwc4(const void* src, int src_f32, float* dst, int T, int H, i
 // per-(image, channel) mean / rstd over H*W of an NHWC f32 tensor (InstanceNorm2d, eps, biased variance)
 // partials: workspace of at least instnorm_partial_floats(nimg, hw, C) doubles
 size_t instnorm_partial_doubles(int nimg, long hw, int C);
+int instnorm_finalize(const double* partials, int nimg, int nchunks, long hw, int C, float eps, float* mean_rstd, hipStream_t s);
 int instnorm_stats(const float* x, int nimg, long hw, int C, float eps, double* partials, float* mean_rstd,
                    hipStream_t s);
 // y = (x-mean)*rstd ; if relu1: y = max(y,0) ; if skip: y = max(y + skip, 0)

@@ -274,6 +274,35 @@ def test_gemm_x3_rows_weights_resident(lib, dev, M, N, K, res, act, shuf_g):
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("n,H,W,Cin,Cout", [(2, 32, 48, 64, 64), (1, 33, 17, 96, 100), (2, 18, 35, 128, 256), (3, 16, 16, 32, 128)])
+def test_conv3x3_fused_instnorm_statistics(lib, dev, n, H, W, Cin, Cout):
+    """The halo convolution's epilogue sums the following InstanceNorm's statistics (GemmP::in_part): mean and 1 / sqrt(var + eps)
+    per (image, channel) against fp64 statistics of the very map the kernel wrote — ragged tiles, two column tiles, a non-zero mean."""
+    from sam_pt_amd.pack import split_f16x3
+    g = torch.Generator().manual_seed(n * H + Cout)
+    x = torch.relu(torch.randn(n, H, W, Cin, generator=g)) * 1.7
+    w = torch.randn(Cout, 9 * Cin, generator=g) * (2.0 / (Cout * 9)) ** 0.5
+    b = torch.randn(Cout, generator=g) * 3.0                                   # |mean| >> std in some channels: E[x^2] - mean^2 cancels
+    xd = x.to(dev)
+    xh = xd.half()
+    xhl = torch.stack([xh, (xd - xh.float()).half()]).contiguous()
+    whl, bd = split_f16x3(w).to(dev), b.to(dev)
+    y = torch.full((n, H, W, Cout), 7.0, device=dev)
+    mr = torch.full((n, Cout, 2), 7.0, device=dev)
+    chunks = ((H + 15) // 16) * ((W + 15) // 16)
+    ws = torch.empty(n * chunks * Cout * 2, dtype=torch.float64, device=dev)
+    ok(lib.sampt_conv3x3_planes_instnorm_stats(P(xhl), P(whl), P(bd), P(y), n, H, W, Cin, Cout, 1e-5, P(mr), P(ws), ws.numel() * 8, S()),
+       "conv + stats")
+    y2 = torch.empty_like(y)
+    ok(lib.sampt_conv2d_nhwc(4, P(xhl), P(whl), P(bd), P(y2), n, H, W, Cin, Cout, 3, 3, 1, 1, S()), "conv")
+    assert torch.equal(y, y2)                                                  # the statistics do not disturb the convolution
+    yd = y.double().reshape(n, H * W, Cout)
+    mean, var = yd.mean(1), yd.var(1, unbiased=False)
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    assert (mr[:, :, 0].double() - mean).abs().max().item() < 2e-6 * max(1.0, mean.abs().max().item())
+    assert ((mr[:, :, 1].double() - rstd) / rstd).abs().max().item() < 5e-6
+
+
 def test_conv_f16(lib, dev):
     n, H, W, Cin, Cout = 2, 16, 16, 256, 256
     g = torch.Generator().manual_seed(5)
