@@ -185,6 +185,10 @@ int sampt_gemm_set_stagger(int groups);
  * its read segment, two phases after the half tile's last read; 1 = behind the first MFMAs of its multiply segment, one phase
  * after the last read (the round-3 / round-4 schedule).  Results are bitwise identical. */
 int sampt_gemm_set_schedule(int sched);
+/* Process-wide switch of the persistent fp16 GEMM's launcher: 1 (default) = a launch uses the FEWEST workgroups per XCD that need the
+ * same number of tile rounds as the allowed count (sampt_vit_set_gemm_workgroups, or 32) — same finishing time, whole CUs left to the
+ * streams beside it; 0 = always the allowed count.  Results are bitwise identical. */
+int sampt_gemm_set_trim(int on);
 /* Process-wide knob of the thin f32 GEMM (csrc/gemm.hip gemm_thin_f32: the tracker mixers' token-side products): the launcher grows
  * the (16 * FM) x 16 tile only while at least n workgroups remain (default 256 = one per CU). */
 int sampt_gemm_set_thin_min_wgs(int n);

@@ -99,6 +99,7 @@ _SIGS = {
     "sampt_gemm_set_thin_min_wgs": (c_int, [c_int]),
     "sampt_conv_set_halo": (c_int, [c_int]),
     "sampt_gemm_set_wres": (c_int, [c_int]),
+    "sampt_gemm_set_trim": (c_int, [c_int]),
     "sampt_conv3x3_planes_instnorm_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                                     c_void_p, c_void_p, c_size_t, c_void_p]),
     "sampt_gemm_x3_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
@@ -156,6 +157,8 @@ def load():
         lib.sampt_gemm_set_schedule(int(os.environ["SAMPT_GEMM_SCHED"]))
     if os.environ.get("SAMPT_PIPS_MIXER") or os.environ.get("SAMPT_PIPS_MIXER_WGS") or os.environ.get("SAMPT_PIPS_MIXER_DIAG"):   # csrc/pips_mixer.hip (A / B runs)
         lib.sampt_pips_set_mixer(int(os.environ.get("SAMPT_PIPS_MIXER", "2")), int(os.environ.get("SAMPT_PIPS_MIXER_WGS", "16")))
+    if os.environ.get("SAMPT_GEMM_TRIM"):              # A / B switch of the persistent GEMM's workgroup trimming (sampt_gemm_set_trim)
+        lib.sampt_gemm_set_trim(int(os.environ["SAMPT_GEMM_TRIM"]))
     if os.environ.get("SAMPT_GEMM_WRES"):              # A / B switch of csrc/gemm_x3_wres.hip (sampt_gemm_set_wres)
         lib.sampt_gemm_set_wres(int(os.environ["SAMPT_GEMM_WRES"]))
     if os.environ.get("SAMPT_CONV_HALO"):              # A / B switch of csrc/conv_halo_x3.hip (sampt_conv_set_halo)

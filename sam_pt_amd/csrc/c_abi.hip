@@ -342,6 +342,11 @@ int sampt_conv_set_halo(int on) {
   return SAMPT_OK;
 }
 
+int sampt_gemm_set_trim(int on) {
+  sampt::g_p8_trim = on ? 1 : 0;
+  return SAMPT_OK;
+}
+
 int sampt_gemm_set_wres(int on) {
   sampt::g_gemm_x3_wres = on ? 1 : 0;
   return SAMPT_OK;

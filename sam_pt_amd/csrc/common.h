@@ -207,6 +207,7 @@ struct GemmP {
 
 extern int g_p8_sched;     // gemm_f16_p8.hip: 0 = stage in the read segments (default), 1 = the round-3 schedule (sampt_gemm_set_schedule)
 extern int g_p8_stagger;
+extern int g_p8_trim;
 extern int g_thin_min_wgs; // gemm.hip: workgroups a thin f32 GEMM must keep when it grows its tile (sampt_gemm_set_thin_min_wgs)   // gemm_f16_p8.hip: process-wide default of GemmP::p8_stagger (sampt_gemm_set_stagger)
 int gemm_f32(const GemmP& p, hipStream_t s);
 int gemm_f16(const GemmP& p, hipStream_t s);

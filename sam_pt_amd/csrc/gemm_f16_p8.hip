@@ -67,6 +67,7 @@ typedef __attribute__((address_space(3))) void lds_void_p8;
 typedef const __attribute__((address_space(1))) void glb_void_p8;
 
 int g_p8_sched = 0;         // 0: LDS-DMA issued in the read segments (round 5); 1: behind the first MFMAs (rounds 3 - 4), for A / B runs
+int g_p8_trim = 1;          // sampt_gemm_set_trim: 1 = launch the fewest workgroups per XCD that keep the number of tile rounds
 int g_p8_stagger = 0;       // experiment knob (sampt_gemm_set_stagger): phase groups of the persistent workgroups, 0 / 1 = off
 
 namespace {
@@ -370,7 +371,16 @@ int gemm_f16_p8_launch(const GemmP& p, hipStream_t s) {
   // 128-KiB workgroup owns its CU: nothing else becomes resident beside it)
   const int wgs = p.p8_wgs >= 1 && p.p8_wgs <= 32 ? p.p8_wgs : 32;
   int per_xcd = (int)((ntiles + 7) / 8);
-  if (per_xcd > wgs) per_xcd = wgs;
+  if (per_xcd > wgs) {
+    // An XCD's tiles take ceil(tiles / workgroups) rounds whatever the remainder: the smallest workgroup count with the SAME number
+    // of rounds finishes at the same time and leaves the other CUs to whoever runs beside the launch (ViT-H, 8 frames: proj / fc2
+    // have 80 tiles per XCD = 3 rounds on 30 workgroups and on 27; the tracker's window chain then ends 15 ms earlier beside an
+    // unchanged encoder, profiles/r6_c22_*).  Same tiles, same results.
+    const int tpx = per_xcd, rounds = cdiv(tpx, wgs);
+    per_xcd = wgs;
+    if (g_p8_trim)
+      while (per_xcd > 1 && cdiv(tpx, per_xcd - 1) == rounds) --per_xcd;
+  }
   const dim3 grid(8 * per_xcd), block(512);
 #define P8_LAUNCH(AC, OU, X)                                                                \
   do {                                                                                      \
