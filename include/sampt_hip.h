@@ -197,6 +197,12 @@ int sampt_gemm_set_thin_min_wgs(int n);
  * 2 = halo-tiled with 4-wave workgroups at every tile width (1 uses 8 waves from 96 output channels up); 3 = as 1, but the tracker
  * encoder's InstanceNorms sum their statistics in a pass of their own instead of in the convolution's epilogue. */
 int sampt_conv_set_halo(int on);
+/* The tracker encoder's stem (pips.py:200 BasicEncoder.conv1: Conv2d(3, 64, 7, stride 2, padding 3)) over normalised NHWC4 frames
+ * x [n][H][W][4] (fourth channel 0) with w f32 [64][7][7][4], as 3-term split-fp16 MFMA products — fp32-grade.  y [n][OH][OW][64].
+ * mean_rstd non-null: also the statistics of the InstanceNorm2d that follows ([n][64][2], as sampt_conv3x3_planes_instnorm_stats);
+ * ws then holds n * ceil(OH / 16) * ceil(OW / 16) * 64 * 16 bytes. */
+int sampt_conv_stem7x7(const float* x_nhwc4, const float* w, const float* bias, float* y, int n, int H, int W, float eps,
+                       float* mean_rstd, void* ws, size_t ws_bytes, sampt_stream_t stream);
 /* 3 x 3 stride-1 pad-1 split-fp16 convolution over pre-split planes (sampt_conv2d_nhwc dtype 4) that ALSO produces the statistics of
  * the InstanceNorm2d that follows it in the tracker's encoder (pips.py:191-287 BasicEncoder: every convolution is followed by
  * norm_fn = "instance"): mean_rstd [n][Cout][2] = (mean, 1 / sqrt(biased var + eps)) of y over H x W, summed from the convolution's

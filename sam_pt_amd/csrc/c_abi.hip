@@ -729,6 +729,16 @@ int sampt_gemm_x3_rows(const float* A, const void* w_hl, const float* bias, cons
   return conv_f16x3(p, (hipStream_t)stream);
 }
 
+int sampt_conv_stem7x7(const float* x_nhwc4, const float* w, const float* bias, float* y, int n, int H, int W, float eps,
+                       float* mean_rstd, void* ws, size_t ws_bytes, sampt_stream_t stream) {
+  const int chunks = conv_stem_tiles(H, W);
+  if (mean_rstd && ws_bytes < (size_t)n * chunks * 64 * 2 * sizeof(double)) return SAMPT_ERR_WORKSPACE;
+  SAMPT_TRY(conv_stem7x7_x3(x_nhwc4, w, bias, y, n, H, W, mean_rstd ? (double*)ws : nullptr, (hipStream_t)stream));
+  if (!mean_rstd) return SAMPT_OK;
+  const long hw = (long)((H + 6 - 7) / 2 + 1) * ((W + 6 - 7) / 2 + 1);
+  return instnorm_finalize((const double*)ws, n, chunks, hw, 64, eps, mean_rstd, (hipStream_t)stream);
+}
+
 int sampt_conv3x3_planes_instnorm_stats(const void* x_hl, const void* w_hl, const float* bias, float* y, int n, int H, int W, int Cin,
                                         int Cout, float eps, float* mean_rstd, void* ws, size_t ws_bytes, sampt_stream_t stream) {
   GemmP p;

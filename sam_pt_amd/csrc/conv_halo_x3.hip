@@ -209,9 +209,11 @@ __global__ __launch_bounds__(NWV * 64, (A2 && NWV == 4) ? 1 : 2) void k_conv3x3_
     orow[i] = (float*)p.C + (((long)img * H + (pix_ok[i] ? y : 0)) * W + (pix_ok[i] ? x : 0)) * p.ldc;
   }
   // p.in_part: the InstanceNorm that follows wants sum(v), sum(v^2) per (image, channel) — this tile's share is summed here, from
-  // the registers that are being stored, instead of in a pass of its own over the map: fp32 over the wave's 64 pixels (a 4-term
-  // chain, then a 16-lane butterfly), fp64 across the four row groups of the tile and, in k_instnorm_final, across tiles.
-  float* const red = (float*)lds;               // [row group 4][BN][2] — the staging buffers are dead (barrier below)
+  // the registers that are being stored, instead of in a pass of its own over the map.  A lane adds up its 4 rows in fp32 (three
+  // roundings) and parks the 8 sums in LDS; thread c then adds the 64 (row group, pixel column) terms of channel c in fp64, as
+  // k_instnorm_final does across tiles — nothing in between rounds to fp32, so |mean| >> std costs no digits.
+  float* const red1 = (float*)lds;              // [row group 4][lr 16][BN] sums; the staging buffers are dead (barrier below)
+  float* const red2 = red1 + 64 * BN;           // ... of squares
   if (p.in_part) __syncthreads();
 #pragma unroll
   for (int j = 0; j < FNW; ++j) {
@@ -228,26 +230,16 @@ __global__ __launch_bounds__(NWV * 64, (A2 && NWV == 4) ? 1 : 2) void k_conv3x3_
       }
     }
     if (p.in_part) {
-      float r[8] = {s1.x, s1.y, s1.z, s1.w, s2.x, s2.y, s2.z, s2.w};
-#pragma unroll
-      for (int m = 1; m < 16; m <<= 1)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) r[e] += __shfl_xor(r[e], m, 64);
-      if (lr == 0) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          red[((pw * BN) + jg * 16 + lq * 4 + e) * 2] = r[e];
-          red[((pw * BN) + jg * 16 + lq * 4 + e) * 2 + 1] = r[4 + e];
-        }
-      }
+      *(float4*)(red1 + (pw * 16 + lr) * BN + jg * 16 + lq * 4) = s1;
+      *(float4*)(red2 + (pw * 16 + lr) * BN + jg * 16 + lq * 4) = s2;
     }
   }
   if (p.in_part) {
     __syncthreads();
     if (tid < BN && n0 + tid < p.N) {
       double t1 = 0.0, t2 = 0.0;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) t1 += (double)red[(g * BN + tid) * 2], t2 += (double)red[(g * BN + tid) * 2 + 1];
+#pragma unroll 8
+      for (int g = 0; g < 64; ++g) t1 += (double)red1[g * BN + tid], t2 += (double)red2[g * BN + tid];
       double* o = p.in_part + ((((long)img * nty + ty) * ntx + tx) * p.N + n0 + tid) * 2;
       o[0] = t1, o[1] = t2;
     }

@@ -139,7 +139,16 @@ int PipsEngine::fnet(const uint8_t* frames, int nf, int H, int W, float* const o
   };
   float* cur = ws.f32((size_t)nf * H2 * W2 * 64);
   Planes cur_p = planes((size_t)nf * H2 * W2 * 64, blk[0][0][0]);
-  SAMPT_TRY(run_conv(stem, x0, nf, H, W, cur, h, w, dry, s));
+  if (blk[0][0][0].w_hl && g_conv_halo && stem.k == 7 && stem.stride == 2 && stem.pad == 3 && stem.cin == 4 && stem.cout == 64) {
+    // split-fp16 mode: the stem as 3-term fp16 products too, one K slab per kernel row (conv_stem_x3.hip), InstanceNorm sums fused
+    h = (H + 6 - 7) / 2 + 1, w = (W + 6 - 7) / 2 + 1;
+    if (!dry) {
+      SAMPT_TRY(conv_stem7x7_x3(x0, stem.w, stem.b, cur, nf, H, W, g_conv_in_stats ? nc.partials : nullptr, s));
+      if (g_conv_in_stats) nc.chunks = conv_stem_tiles(H, W);
+    }
+  } else {
+    SAMPT_TRY(run_conv(stem, x0, nf, H, W, cur, h, w, dry, s));
+  }
   SAMPT_TRY(run_inorm(nc, cur, nf, (long)h * w, 64, 1, nullptr, dry, s, cur_p));
   const int dims[4] = {64, 96, 128, 128};
   float* scale_out[4];

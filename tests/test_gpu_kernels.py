@@ -303,6 +303,38 @@ def test_conv3x3_fused_instnorm_statistics(lib, dev, n, H, W, Cin, Cout):
     assert ((mr[:, :, 1].double() - rstd) / rstd).abs().max().item() < 5e-6
 
 
+@pytest.mark.parametrize("n,H,W", [(2, 64, 96), (1, 45, 71), (1, 32, 32), (3, 36, 130)])
+def test_conv_stem7x7_split_fp16(lib, dev, n, H, W):
+    """The tracker encoder's stem as split-fp16 products (csrc/conv_stem_x3.hip): as close to the fp64 convolution as the exact-fp32
+    MFMA path, borders and ragged tiles included; fused InstanceNorm statistics against fp64 statistics of the written map."""
+    g = torch.Generator().manual_seed(H * W)
+    img = torch.randint(0, 256, (n, 3, H, W), generator=g).float()
+    x = 2.0 * (img / 255.0) - 1.0
+    w = torch.randn(64, 3, 7, 7, generator=g) * (2.0 / (64 * 49)) ** 0.5
+    b = torch.randn(64, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=2, padding=3).permute(0, 2, 3, 1)
+    OH, OW = ref.shape[1:3]
+    x4 = torch.cat([x, torch.zeros(n, 1, H, W)], 1).permute(0, 2, 3, 1).contiguous().to(dev)
+    w4 = torch.cat([w, torch.zeros(64, 1, 7, 7)], 1).permute(0, 2, 3, 1).contiguous().to(dev)      # [64][7][7][4]
+    bd = b.to(dev)
+    y = torch.full(ref.shape, 7.0, device=dev)
+    mr = torch.full((n, 64, 2), 7.0, device=dev)
+    chunks = ((OH + 15) // 16) * ((OW + 15) // 16)
+    ws = torch.empty(n * chunks * 64 * 2, dtype=torch.float64, device=dev)
+    ok(lib.sampt_conv_stem7x7(P(x4), P(w4), P(bd), P(y), n, H, W, 1e-5, P(mr), P(ws), ws.numel() * 8, S()), "stem")
+    y32 = torch.empty(ref.shape, device=dev)
+    ok(lib.sampt_conv2d_nhwc(0, P(x4), P(w4.reshape(64, -1)), P(bd), P(y32), n, H, W, 4, 64, 7, 7, 2, 3, S()), "conv f32")
+    e3, e32 = rel_err(y, ref), rel_err(y32, ref)
+    assert e3 < max(2e-6, 1.5 * e32), (e3, e32)
+    yd = y.double().reshape(n, OH * OW, 64)
+    mean, rstd = yd.mean(1), 1.0 / torch.sqrt(yd.var(1, unbiased=False) + 1e-5)
+    assert (mr[:, :, 0].double() - mean).abs().max().item() < 2e-6 * max(1.0, mean.abs().max().item())
+    assert ((mr[:, :, 1].double() - rstd) / rstd).abs().max().item() < 5e-6
+    y2 = torch.full(ref.shape, 7.0, device=dev)                               # without statistics: the same map
+    ok(lib.sampt_conv_stem7x7(P(x4), P(w4), P(bd), P(y2), n, H, W, 1e-5, None, None, 0, S()), "stem, no statistics")
+    assert torch.equal(y, y2)
+
+
 def test_conv_f16(lib, dev):
     n, H, W, Cin, Cout = 2, 16, 16, 256, 256
     g = torch.Generator().manual_seed(5)

@@ -1,12 +1,12 @@
-# scratch script of the current gpurun call: persistent GEMM workgroups per launch kind (qkv / proj / fc1 / fc2) beside the faster window chain
+# scratch script of the current gpurun call: split-fp16 stem convolution with fused InstanceNorm statistics
 set -u
-R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/r6_c22; mkdir -p $OUT; cd $R
-for w in 30 30/27/30/27 30/27/32/27 32/27/32/27 31/27/31/27 30/24/30/24 30; do
-  SAMPT_ENC_WGS=$w timeout 300 python bench.py --steps 6 --warmup 2 --no-secondary --no-cpu-baseline --no-roofline --no-pipelined > $OUT/b.json 2> $OUT/b.err
-  python - <<PY
-import json
-try:
-    d = json.loads(open("$OUT/b.json").read().strip().splitlines()[-1]); print("enc wgs $w", d["value"], d.get("timeline"))
-except Exception as e: print("bench parse failed $w", e)
-PY
-done | tee $OUT/enc_wgs_kind.log
+R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/r6_c23; mkdir -p $OUT; cd $R
+timeout 300 python -m pytest tests/test_gpu_kernels.py -q -k "stem or instnorm" > $OUT/pytest_stem.log 2>&1; tail -5 $OUT/pytest_stem.log | cut -c1-300
+timeout 600 python -m pytest tests/test_gpu_modules.py -q -k "fnet or golden or pips" > $OUT/pytest_fnet.log 2>&1; tail -3 $OUT/pytest_fnet.log | cut -c1-300
+for h in 0 3 1; do SAMPT_CONV_HALO=$h timeout 100 python tools/tracker_bench.py 2>&1 | grep "tracker encoder" | sed "s/^/halo $h: /"; done
+cd /tmp; export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace -d $OUT/prof -o trk -- python $R/tools/tracker_bench.py > $OUT/rocprof.log 2>&1
+DB=$(find $OUT/prof -name "*.db" | head -1)
+python $R/tools/rocprof_by_grid.py "$DB" "" 5 > $OUT/tracker_by_grid.txt 2>&1
+rm -rf $OUT/prof
+grep -v "pips_mix\|k_pips\|thin\|skinny" $OUT/tracker_by_grid.txt | head -30 | cut -c1-150
