@@ -197,6 +197,16 @@ int sampt_gemm_set_thin_min_wgs(int n);
  * 2 = halo-tiled with 4-wave workgroups at every tile width (1 uses 8 waves from 96 output channels up); 3 = as 1, but the tracker
  * encoder's InstanceNorms sum their statistics in a pass of their own instead of in the convolution's epilogue. */
 int sampt_conv_set_halo(int on);
+/* Staging of SamPt's per-frame decode (sam_pt.py:690-757 _apply_sam_to_trajectories: one predict_mask per (frame, object) item,
+ * item = frame * n_objects + object) for a batched chain that reads and writes fixed buffers.  idx: rows int32 item numbers (device).
+ *   scatter = 0: dst[r] = src[idx[r] / n_objects]                                   (item r's frame embedding into the chain's input)
+ *   scatter = 1: dst[(idx[r] % n_objects) * n_frames + idx[r] / n_objects] = src[r]  (masks into logits [n_objects][n_frames][H * W];
+ *                scores with n_objects = 1: dst[idx[r]] = src[r])
+ * row_bytes: a multiple of 16 with 16-byte aligned buffers, or 4.  sampt_fill_f32: dst[0 .. n) = value (the -inf of items without
+ * a prompt, sam_pt.py:766-767). */
+int sampt_move_rows(const void* src, void* dst, const int* idx, int rows, size_t row_bytes, int n_objects, int n_frames, int scatter,
+                    sampt_stream_t stream);
+int sampt_fill_f32(float* dst, size_t n, float value, sampt_stream_t stream);
 /* The tracker encoder's stem (pips.py:200 BasicEncoder.conv1: Conv2d(3, 64, 7, stride 2, padding 3)) over normalised NHWC4 frames
  * x [n][H][W][4] (fourth channel 0) with w f32 [64][7][7][4], as 3-term split-fp16 MFMA products — fp32-grade.  y [n][OH][OW][64].
  * mean_rstd non-null: also the statistics of the InstanceNorm2d that follows ([n][64][2], as sampt_conv3x3_planes_instnorm_stats);

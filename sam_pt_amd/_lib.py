@@ -100,6 +100,8 @@ _SIGS = {
     "sampt_conv_set_halo": (c_int, [c_int]),
     "sampt_gemm_set_wres": (c_int, [c_int]),
     "sampt_gemm_set_trim": (c_int, [c_int]),
+    "sampt_move_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_int, c_int, c_int, c_void_p]),
+    "sampt_fill_f32": (c_int, [c_void_p, c_size_t, c_float, c_void_p]),
     "sampt_conv_stem7x7": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_size_t,
                                    c_void_p]),
     "sampt_conv3x3_planes_instnorm_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,

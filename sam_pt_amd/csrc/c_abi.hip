@@ -337,7 +337,9 @@ int sampt_pips_set_mixer(int fused, int workgroups) {
 }
 
 int sampt_conv_set_halo(int on) {
-  sampt::g_conv_in_stats = on == 3 ? 0 : 1;          // 3: halo kernel without the fused InstanceNorm statistics
+  // 3: halo / stem kernels without the fused InstanceNorm statistics; 4: statistics from the halo kernel only; 5: from the stem only
+  sampt::g_conv_in_stats = on == 3 ? 0 : (on == 4 ? 1 : (on == 5 ? 2 : 3));
+  sampt::g_halo_dbg = on == 6 || on == 7 ? on : 0;
   sampt::g_conv_halo = on < 0 ? 0 : (on > 2 ? 1 : on);
   return SAMPT_OK;
 }
@@ -728,6 +730,13 @@ int sampt_gemm_x3_rows(const float* A, const void* w_hl, const float* bias, cons
   p.shuf_g = shuf_g, p.shuf_n = shuf_g ? N / 4 : 0;
   return conv_f16x3(p, (hipStream_t)stream);
 }
+
+int sampt_move_rows(const void* src, void* dst, const int* idx, int rows, size_t row_bytes, int n_objects, int n_frames, int scatter,
+                    sampt_stream_t stream) {
+  return move_rows(src, dst, idx, rows, (long)row_bytes, n_objects, n_frames, scatter, (hipStream_t)stream);
+}
+
+int sampt_fill_f32(float* dst, size_t n, float value, sampt_stream_t stream) { return fill_f32(dst, (long)n, value, (hipStream_t)stream); }
 
 int sampt_conv_stem7x7(const float* x_nhwc4, const float* w, const float* bias, float* y, int n, int H, int W, float eps,
                        float* mean_rstd, void* ws, size_t ws_bytes, sampt_stream_t stream) {

@@ -220,6 +220,7 @@ int conv_f16x3(const GemmP& p, hipStream_t s);
 // conv_halo_x3.hip: the 3 x 3 stride-1 pad-1 case over pre-split planes with the input halo staged once per 16 x 16 pixel tile;
 // conv_f16x3 hands eligible launches over unless g_conv_halo == 0
 extern int g_conv_halo;
+extern int g_halo_dbg;
 extern int g_conv_in_stats;    // conv_halo_x3.hip: 1 (default) = the tracker encoder's halo convolutions also sum the following InstanceNorm's
                                // statistics (sampt_conv_set_halo(3) turns it off for A / B runs)
 bool conv3x3_halo_eligible(const GemmP& p);

@@ -154,6 +154,12 @@ __global__ __launch_bounds__(NWV * 64, (A2 && NWV == 4) ? 1 : 2) void k_conv3x3_
       if (A2 && t >= 1 && t <= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NW + NA) : "memory");
       else if (!A2 && t == 0 && c > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NW) : "memory");
+      // ... and NO LDS read of this wave may still be in flight when it signals the barrier: hipcc moves a stage's last MFMAs — and
+      // with them the lgkmcnt wait of the last two weight reads — below the barrier, and the slot they read is the one the first
+      // wave through the barrier re-stages at once.  The weights are hot in the vector L1, so that DMA can land within the latency of
+      // a queued ds_read: 1 launch in ~15 of the 64-column variant (two workgroups per CU) had one wave's last column fragment off by
+      // one stage's lo plane (tools/probes/conv_stats_determinism.py, profiles/r6_c29 - c31).
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                                      // publishes all shares; everybody is done with stage s - 1
       asm volatile("" ::: "memory");
       stage_w(s + 3);                                                    // into the slot of stage s - 1
@@ -181,6 +187,7 @@ __global__ __launch_bounds__(NWV * 64, (A2 && NWV == 4) ? 1 : 2) void k_conv3x3_
       }
       if (!A2 && t == 8 && c + 1 < nchunk) {                             // single halo buffer: refill it once nobody reads it any more
         asm volatile("" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         stage_a(c + 1);
       }
@@ -248,7 +255,8 @@ __global__ __launch_bounds__(NWV * 64, (A2 && NWV == 4) ? 1 : 2) void k_conv3x3_
 
 int g_conv_halo = 1;     // sampt_conv_set_halo: 0 = the 3 x 3 stride-1 launches go back to k_conv_f16x3_dma (A / B); 2 = 4-wave
                          // workgroups for every tile width (the first version of this kernel)
-int g_conv_in_stats = 1; // 0 (sampt_conv_set_halo(3)): callers do not ask for GemmP::in_part
+int g_halo_dbg = 0;      // (debug: 6 = the 64-column tile on the double-buffered schedule, 7 = one workgroup per CU)
+int g_conv_in_stats = 3; // bit 0: the halo convolutions, bit 1: the stem sum the following InstanceNorm's statistics (sampt_conv_set_halo(3 / 4 / 5))
 
 bool conv3x3_halo_eligible(const GemmP& p) {
   return p.conv && p.A_lo && p.KH == 3 && p.KW == 3 && p.cstride == 1 && p.cpad == 1 && p.cpadw < 0 && p.cC % 32 == 0 &&
@@ -265,23 +273,23 @@ int conv3x3_halo_x3(const GemmP& p, hipStream_t s) {
   const int BN = p.N <= 64 ? 64 : (p.N <= 96 ? 96 : 128);
   const int ntn = cdiv(p.N, BN);
   dim3 grid((unsigned)((long)nimg * nty * ntx * ntn));
-#define HALO(BNv, NWVv)                                                                                                  \
+#define HALO(BNv, NWVv, A2x)                                                                                             \
   do {                                                                                                                   \
-    constexpr bool A2v = BNv != 64;                                                                                      \
+    constexpr bool A2v = A2x;                                                                                            \
     constexpr int LDSB = (A2v ? 2 : 1) * ABUF + 1024 + 4 * (BNv * 64 * 2);                                               \
     static bool raised = false;                                                                                          \
     auto kern = k_conv3x3_halo_x3<BNv, A2v, NWVv>;                                                                       \
     if (!raised) {                                                                                                       \
-      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) != hipSuccess)        \
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024 > LDSB ? 100 * 1024 : LDSB) != hipSuccess)        \
         return SAMPT_ERR_HIP;                                                                                            \
       raised = true;                                                                                                     \
     }                                                                                                                    \
-    hipLaunchKernelGGL(kern, grid, dim3(NWVv * 64), LDSB, s, p, ntx, nty);                                               \
+    hipLaunchKernelGGL(kern, grid, dim3(NWVv * 64), (g_halo_dbg == 7 && LDSB < 100 * 1024) ? 100 * 1024 : LDSB, s, p, ntx, nty);  \
   } while (0)
   const bool w8 = g_conv_halo != 2;
-  if (BN == 64) HALO(64, 4);
-  else if (BN == 96) { if (w8) HALO(96, 8); else HALO(96, 4); }
-  else { if (w8) HALO(128, 8); else HALO(128, 4); }
+  if (BN == 64) { if (g_halo_dbg == 6) HALO(64, 4, true); else HALO(64, 4, false); }
+  else if (BN == 96) { if (w8) HALO(96, 8, true); else HALO(96, 4, true); }
+  else { if (w8) HALO(128, 8, true); else HALO(128, 4, true); }
 #undef HALO
   SAMPT_CHECK_LAUNCH("conv3x3_halo_x3");
   return SAMPT_OK;

@@ -34,6 +34,62 @@ int rgb_u8chw_to_nhwc4(const void* src, int src_f32, float* dst, int T, int H, i
 }
 
 // ---------------------------------------------------------------------------------------------
+// Row gather / scatter by an index vector of (frame, object) ITEM numbers, item = t * nm + m (SamPt's decode staging: a replayed
+// hipGraph reads and writes fixed buffers, so a chunk's embeddings are gathered into them and its masks / scores scattered out):
+//   gather : dst[r] = src[idx[r] / nm]                       (the embedding of item r's frame)
+//   scatter: dst[(idx[r] % nm) * nf + idx[r] / nm] = src[r]   (logits [nm][nf][H*W]; scores: nm = 1 -> dst[idx[r]])
+// rows of row16 16-byte units; one workgroup walks a row segment of 256 units
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_move_rows(const float4* __restrict__ src, float4* __restrict__ dst, const int* __restrict__ idx,
+                                                   long row16, int nm, int nf, int scatter) {
+  const long r = blockIdx.y, u = (long)blockIdx.x * 256 + threadIdx.x;
+  if (u >= row16) return;
+  const int it = idx[r];
+  const long sr = scatter ? r : it / nm, dr = scatter ? (long)(it % nm) * nf + it / nm : r;
+  dst[dr * row16 + u] = src[sr * row16 + u];
+}
+
+__global__ void k_move_words(const float* __restrict__ src, float* __restrict__ dst, const int* __restrict__ idx, int rows, int nm,
+                             int nf, int scatter) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const int it = idx[r];
+  if (scatter) dst[(long)(it % nm) * nf + it / nm] = src[r];
+  else dst[r] = src[it / nm];
+}
+
+static int move_words(const void* src, void* dst, const int* idx, int rows, int nm, int nf, int scatter, hipStream_t s) {
+  hipLaunchKernelGGL(k_move_words, dim3(cdiv(rows, 256)), dim3(256), 0, s, (const float*)src, (float*)dst, idx, rows, nm, nf, scatter);
+  SAMPT_CHECK_LAUNCH("move_words");
+  return SAMPT_OK;
+}
+
+int move_rows(const void* src, void* dst, const int* idx, int rows, long row_bytes, int nm, int nf, int scatter, hipStream_t s) {
+  if (!src || !dst || !idx || rows <= 0 || row_bytes <= 0 || nm <= 0) return SAMPT_ERR_ARG;
+  if ((row_bytes & 15) || (((uintptr_t)src | (uintptr_t)dst) & 15)) {      // short rows (scores: 4 bytes): one thread per row
+    if (row_bytes != 4) return SAMPT_ERR_UNSUPPORTED;
+    return move_words(src, dst, idx, rows, nm, nf, scatter, s);
+  }
+  const long row16 = row_bytes / 16;
+  hipLaunchKernelGGL(k_move_rows, dim3((unsigned)cdiv(row16, 256), rows), dim3(256), 0, s, (const float4*)src, (float4*)dst, idx, row16,
+                     nm, nf, scatter);
+  SAMPT_CHECK_LAUNCH("move_rows");
+  return SAMPT_OK;
+}
+
+__global__ void k_fill_f32(float* __restrict__ dst, long n, float v) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = v;
+}
+
+int fill_f32(float* dst, long n, float v, hipStream_t s) {
+  if (!dst || n <= 0) return SAMPT_ERR_ARG;
+  hipLaunchKernelGGL(k_fill_f32, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, dst, n, v);
+  SAMPT_CHECK_LAUNCH("fill_f32");
+  return SAMPT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // InstanceNorm2d statistics: deterministic two-stage reduction in fp64
 // ---------------------------------------------------------------------------------------------
 static constexpr int IN_PIX_PER_BLOCK = 512;

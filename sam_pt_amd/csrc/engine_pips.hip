@@ -98,7 +98,7 @@ static int run_conv(const ConvW& c, const float* x, int n, int H, int W, float* 
     p.W = c.w_hl, p.W_lo = c.w_hl + (size_t)c.cout * p.K;
     p.alpha = 1.0f / (float)(1 << F16X3_WSHIFT);
     if (xp.hi) p.A = xp.hi, p.A_lo = xp.lo;     // activations already split by the producing InstanceNorm
-    if (nc && g_conv_halo && g_conv_in_stats && conv3x3_halo_eligible(p)) p.in_part = nc->partials, nc->chunks = conv3x3_halo_tiles(p);
+    if (nc && g_conv_halo && (g_conv_in_stats & 1) && conv3x3_halo_eligible(p)) p.in_part = nc->partials, nc->chunks = conv3x3_halo_tiles(p);
     return conv_f16x3(p, s);
   }
   return gemm_f32(p, s);
@@ -121,8 +121,17 @@ int PipsEngine::fnet(const uint8_t* frames, int nf, int H, int W, float* const o
   NormCtx nc;
   // (chunk partials of instnorm_stats: 512 pixels x <= 256 channels; tile partials of the halo convolution: 16 x 16 pixels x the
   //  layer's channels — 64 at the largest map, 256 at H/4 x W/4)
-  const size_t tile_part = (size_t)nf * 2 * std::max<size_t>((size_t)cdiv(H2, 16) * cdiv(W2, 16) * 64,
-                                                            (size_t)cdiv(H / stride, 16) * cdiv(W / stride, 16) * 256);
+  size_t tile_part = 0;    // doubles: the largest [nf][16 x 16 tiles][channels][2] any convolution of the encoder writes
+  {
+    const int dimsl[4] = {64, 96, 128, 128}, stl[4] = {1, 2, 2, 2};
+    int hh = H2, ww = W2;
+    for (int li = 0; li < 4; ++li) {
+      hh = (hh + 2 - 3) / stl[li] + 1, ww = (ww + 2 - 3) / stl[li] + 1;
+      tile_part = std::max(tile_part, (size_t)cdiv(hh, 16) * cdiv(ww, 16) * dimsl[li]);
+    }
+    tile_part = std::max(tile_part, (size_t)cdiv(H2, 16) * cdiv(W2, 16) * 64);
+    tile_part = std::max(tile_part, (size_t)cdiv(H / stride, 16) * cdiv(W / stride, 16) * 256) * 2 * nf;
+  }
   nc.partials = (double*)ws.get(std::max(instnorm_partial_doubles(nf, (long)H2 * W2, 256), tile_part) * sizeof(double));
   nc.mean_rstd = ws.f32((size_t)nf * 256 * 2);
   NormCtx nc2 = nc;        // a block's conv2 sums its statistics before the downsample branch's InstanceNorm uses nc.partials
@@ -143,8 +152,8 @@ int PipsEngine::fnet(const uint8_t* frames, int nf, int H, int W, float* const o
     // split-fp16 mode: the stem as 3-term fp16 products too, one K slab per kernel row (conv_stem_x3.hip), InstanceNorm sums fused
     h = (H + 6 - 7) / 2 + 1, w = (W + 6 - 7) / 2 + 1;
     if (!dry) {
-      SAMPT_TRY(conv_stem7x7_x3(x0, stem.w, stem.b, cur, nf, H, W, g_conv_in_stats ? nc.partials : nullptr, s));
-      if (g_conv_in_stats) nc.chunks = conv_stem_tiles(H, W);
+      SAMPT_TRY(conv_stem7x7_x3(x0, stem.w, stem.b, cur, nf, H, W, (g_conv_in_stats & 2) ? nc.partials : nullptr, s));
+      if (g_conv_in_stats & 2) nc.chunks = conv_stem_tiles(H, W);
     }
   } else {
     SAMPT_TRY(run_conv(stem, x0, nf, H, W, cur, h, w, dry, s));

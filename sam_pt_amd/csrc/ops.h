@@ -12,6 +12,9 @@ int rgb_u8chw_to_nhwc4(const void* src, int src_f32, float* dst, int T, int H, i
 // per-(image, channel) mean / rstd over H*W of an NHWC f32 tensor (InstanceNorm2d, eps, biased variance)
 // partials: workspace of at least instnorm_partial_floats(nimg, hw, C) doubles
 size_t instnorm_partial_doubles(int nimg, long hw, int C);
+// elementwise.hip: row gather / scatter by (frame, object) item numbers and a plain fill (SamPt's decode staging)
+int move_rows(const void* src, void* dst, const int* idx, int rows, long row_bytes, int nm, int nf, int scatter, hipStream_t s);
+int fill_f32(float* dst, long n, float v, hipStream_t s);
 // conv_stem_x3.hip: the tracker encoder's 7 x 7 stride-2 stem over NHWC4 frames as 3-term split-fp16 products (+ InstanceNorm partial sums)
 int conv_stem_tiles(int H, int W);
 int conv_stem7x7_x3(const float* x, const float* w, const float* bias, float* y, int nimg, int H, int W, double* in_part, hipStream_t s);

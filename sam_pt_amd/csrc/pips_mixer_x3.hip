@@ -99,6 +99,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     if (t + 2 < NSTG) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else if (t + 1 < NSTG) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (no LDS read in flight across the barrier: the slot of stage t - 1 is re-staged right behind it, and hipcc is free to move the
+    //  wait for a stage's last operand reads below the barrier — see conv_halo_x3.hip, where exactly that was caught)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (t + 3 < NSTG) stage(t + 3);

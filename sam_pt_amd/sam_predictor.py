@@ -619,11 +619,30 @@ class SamPredictor:
         st = self._stage.pop(key, None)                    # (re-inserted below: dict order = least recently used first)
         if st is None:
             g, Cc, dev = self.model.cfg.grid, self.model.cfg.out_chans, self._dev
+            # the small per-item inputs are ONE device block [pts | labels | k_item | npos_item | item numbers] mirrored by a
+            # pinned host block: the host packs a chunk's prompts straight into the mirror and one asynchronous copy moves them
+            # (SamPt._enqueue_sam_fused) — no device-side gathers, one H2D per chunk
+            words = F * ld_pts * 2 + F * ld_pts + 3 * F
+            block = torch.empty((words,), dtype=torch.int32, device=dev)
+            o0, o1, o2, o3, o4 = 0, F * ld_pts * 2, F * ld_pts * 3, F * ld_pts * 3 + F, F * ld_pts * 3 + 2 * F
+            offs = (o0, o1, o2, o3, o4)
+
+            def mirror(k, _m=[], _offs=offs, _F=F, _ld=ld_pts, _words=words, _cuda=dev.type == "cuda"):
+                """Pinned host mirror number k of the block (a clip with several chunks in this bucket packs each into its own: the
+                device block is re-used in stream order, a host buffer must stay untouched until its copy has run)."""
+                while len(_m) <= k:
+                    h = torch.empty((_words,), dtype=torch.int32, pin_memory=True) if _cuda else torch.empty((_words,), dtype=torch.int32)
+                    hn = h.numpy()
+                    a0, a1, a2, a3, a4 = _offs
+                    _m.append({"host": h, "free": None, "pts": hn[a0:a1].view(np.float32).reshape(_F, _ld, 2),
+                               "labels": hn[a1:a2].reshape(_F, _ld), "k": hn[a2:a3], "npos": hn[a3:a4], "items": hn[a4:]})
+                return _m[k]
+
             st = {"feats": torch.empty((F, g * g, Cc), dtype=torch.float32, device=dev),
-                  "pts": torch.empty((F, ld_pts, 2), dtype=torch.float32, device=dev),
-                  "labels": torch.empty((F, ld_pts), dtype=torch.int32, device=dev),
-                  "k_item": torch.empty((F,), dtype=torch.int32, device=dev),
-                  "npos_item": torch.empty((F,), dtype=torch.int32, device=dev),
+                  "block": block, "mirror": mirror,
+                  "pts": block[o0:o1].view(torch.float32).view(F, ld_pts, 2),
+                  "labels": block[o1:o2].view(F, ld_pts),
+                  "k_item": block[o2:o3], "npos_item": block[o3:o4], "items": block[o4:],
                   "logits": torch.empty((F,) + tuple(size_hw), dtype=torch.float32, device=dev),
                   "score": torch.empty((F,), dtype=torch.float32, device=dev)}
             if self.model.hq:
@@ -638,7 +657,8 @@ class SamPredictor:
         return st
 
     def _stage_bytes(self) -> int:
-        return sum(t.numel() * t.element_size() for st in self._stage.values() for t in st.values())
+        return sum(t.numel() * t.element_size() for st in self._stage.values() for k, t in st.items()
+                   if k in ("feats", "block", "logits", "score", "hq"))
 
     def graph_stats(self):
         """(cached graphs, captures, replays) of the decoder handle."""

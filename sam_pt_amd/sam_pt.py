@@ -59,6 +59,20 @@ class PointVisibilityType(IntEnum):
     REJECTED_AFTER_PATCH_WAS_NON_SIMILAR = -4
 
 
+def _stack_frames(frames):
+    """torch.stack(frames), without the copy when the frames already ARE consecutive slices of one contiguous buffer (a decoded clip
+    handed over frame by frame, as the reference's list-of-frames format does: sam_pt.py:150 stacks them again)."""
+    f0 = frames[0]
+    if isinstance(f0, torch.Tensor) and f0.is_contiguous() and len(frames) > 1:
+        step = f0.numel() * f0.element_size()
+        base = f0.data_ptr()
+        if all(isinstance(f, torch.Tensor) and f.shape == f0.shape and f.dtype == f0.dtype and f.device == f0.device and f.is_contiguous()
+               and f.data_ptr() == base + i * step and f.untyped_storage().data_ptr() == f0.untyped_storage().data_ptr()
+               for i, f in enumerate(frames)):
+            return torch.as_strided(f0, (len(frames),) + tuple(f0.shape), (f0.numel(),) + tuple(f0.stride()))
+    return torch.stack(list(frames), dim=0)
+
+
 class PendingForward:
     """Handle of a clip submitted with ``SamPt.forward_begin``; ``SamPt.forward_end`` turns it into ``forward``'s result."""
 
@@ -187,7 +201,7 @@ class SamPt(nn.Module):
             yield self.forward_end(prev)
 
     def _forward_impl(self, video, defer=False):
-        images = torch.stack(video["image"], dim=0) if isinstance(video["image"], (list, tuple)) else video["image"]
+        images = _stack_frames(video["image"]) if isinstance(video["image"], (list, tuple)) else video["image"]
         n_frames, channels, height, width = images.shape
         assert images.dtype == torch.uint8, "Input images must be in uint8 format (0-255)"
         fused = hasattr(self.sam_predictor, "encode_frames") and hasattr(self.sam_predictor, "track_decode")
@@ -667,18 +681,13 @@ class SamPt(nn.Module):
         for i, (c, l) in enumerate(prompts):
             xy[i, :len(c)] = c
             lab[i, :len(c)] = l
-        xy_d = torch.from_numpy(xy).to(dev)
-        lab_d = torch.from_numpy(lab).to(dev)
-        logits = torch.full((n_masks, n_frames, height, width), -float("inf"), dtype=torch.float32, device=dev)
-        scores = torch.full((n_frames * n_masks,), -float("inf"), dtype=torch.float32, device=dev)
-        two_pass = self.negative_points_per_mask > 0
         # All (frame, object) items with a non-empty prompt run as ONE batched device-side chain per chunk of Fmax items,
         # whatever their number of visible points: the batch is ragged (per-item point counts, padding tokens masked in
         # the decoder's attention), so an item's result equals its un-batched one.
         items = [i for i, (c, l) in enumerate(prompts) if len(c) > 0]            # empty prompt: sam_pt.py:766-767
         k_all = np.array([len(c) for c, _ in prompts], dtype=np.int32)
         npos_all = np.array([int((l == 1).sum()) for _, l in prompts], dtype=np.int32)
-        k_d, npos_d = torch.from_numpy(k_all).to(dev), torch.from_numpy(npos_all).to(dev)
+        two_pass = self.negative_points_per_mask > 0
         Fmax = getattr(pred.model, "max_decode_batch", 1)
         chunks = []                                                               # [(items, event to wait for or None)]
         if batch_events:
@@ -690,36 +699,76 @@ class SamPt(nn.Module):
         else:
             chunks = [(items[s0:s0 + Fmax], None) for s0 in range(0, len(items), Fmax)]
         cur_stream = torch.cuda.current_stream() if batch_events else None
-        # (host -> device copies first: a pageable copy blocks the host until the stream reaches it, and past the wait for
-        #  the encoder's event that is the end of the encoder — a clip submitted with forward_begin must not wait there)
-        idx_d = [torch.tensor(chunk, dtype=torch.long, device=dev) for chunk, _ in chunks]
-        for (chunk, ev), idx in zip(chunks, idx_d):
+        lib = None
+        if use_graph:
+            from . import _lib
+            lib = _lib.load()
+            # every output element is written by exactly one item; only items WITHOUT a prompt keep the -inf the reference gives them
+            logits = torch.empty((n_masks, n_frames, height, width), dtype=torch.float32, device=dev)
+            scores = torch.empty((n_frames * n_masks,), dtype=torch.float32, device=dev)
+            if len(items) < len(prompts):
+                _lib.check(lib.sampt_fill_f32(_lib.ptr(logits), logits.numel(), -float("inf"), _lib.stream_ptr()), "sampt_fill_f32")
+                _lib.check(lib.sampt_fill_f32(_lib.ptr(scores), scores.numel(), -float("inf"), _lib.stream_ptr()), "sampt_fill_f32")
+            # A chunk's prompts are packed on the host, in chunk order, straight into a pinned mirror of its bucket's device block and
+            # cross in ONE asynchronous copy (enqueued with the chunk below: from pinned memory the host never waits for the stream,
+            # so a clip submitted with forward_begin is not held up behind the encoder's event).
+            staged, used = [], {}
+            for chunk, _ in chunks:
+                st = pred.decode_staging(len(chunk), kmax, size)
+                k = used.get(id(st), 0)                    # the k-th chunk of this clip in this bucket: its own pinned mirror
+                used[id(st)] = k + 1
+                mir = st["mirror"](k)
+                if mir["free"] is not None:
+                    mir["free"].synchronize()              # the previous clip's copy out of this mirror (long done; never waits)
+                ch = np.asarray(chunk, dtype=np.int64)
+                mir["pts"][...] = xy[ch]
+                mir["labels"][...] = lab[ch]
+                mir["k"][...] = k_all[ch]
+                mir["npos"][...] = npos_all[ch]
+                mir["items"][...] = ch
+                staged.append((st, mir))
+        else:
+            xy_d = torch.from_numpy(xy).to(dev)
+            lab_d = torch.from_numpy(lab).to(dev)
+            k_d, npos_d = torch.from_numpy(k_all).to(dev), torch.from_numpy(npos_all).to(dev)
+            logits = torch.full((n_masks, n_frames, height, width), -float("inf"), dtype=torch.float32, device=dev)
+            scores = torch.full((n_frames * n_masks,), -float("inf"), dtype=torch.float32, device=dev)
+            idx_d = [torch.tensor(chunk, dtype=torch.long, device=dev) for chunk, _ in chunks]
+        for ci, (chunk, ev) in enumerate(chunks):
             if ev is not None:
                 cur_stream.wait_event(ev)
-            t_idx, m_idx = idx // n_masks, idx % n_masks
-            F_ = idx.numel()
+            F_ = len(chunk)
             ks, ps = k_all[chunk], npos_all[chunk]
             ragged = bool((ks != ks[0]).any() or (two_pass and (ps != ps[0]).any()))
             if use_graph:
-                # a replayed hipGraph has its pointers baked in: the chunk's inputs are gathered into the bucket's
-                # persistent buffers and its outputs land there (SamPredictor.decode_staging)
-                st = pred.decode_staging(F_, xy_d.shape[1], size)
+                # a replayed hipGraph has its pointers baked in: the chunk's embeddings are gathered into the bucket's
+                # persistent buffers and its outputs land there (SamPredictor.decode_staging), by item number
+                st, mir = staged[ci]
+                # (the bucket's device block is shared by the chunks that use it: filled here, in stream order, from the chunk's own
+                #  pinned mirror — an asynchronous copy, the host does not wait for the encoder)
+                st["block"].copy_(mir["host"], non_blocking=True)
+                mir["free"] = torch.cuda.Event()
+                mir["free"].record()
                 emb, hq = (feats.emb, feats.hq) if hasattr(feats, "emb") else (feats, None)
-                torch.index_select(emb, 0, t_idx, out=st["feats"])
+                sp, P = _lib.stream_ptr(), _lib.ptr
+                _lib.check(lib.sampt_move_rows(P(emb), P(st["feats"]), P(st["items"]), F_, emb[0].numel() * 4, n_masks, n_frames, 0, sp),
+                           "sampt_move_rows")
                 f_in = st["feats"]
                 if hq is not None:
-                    torch.index_select(hq, 0, t_idx, out=st["hq"])
+                    _lib.check(lib.sampt_move_rows(P(hq), P(st["hq"]), P(st["items"]), F_, hq[0].numel() * 4, n_masks, n_frames, 0, sp),
+                               "sampt_move_rows")
                     f_in = type(feats)(st["feats"], st["hq"])
-                torch.index_select(xy_d, 0, idx, out=st["pts"])
-                torch.index_select(lab_d, 0, idx, out=st["labels"])
-                torch.index_select(k_d, 0, idx, out=st["k_item"])
-                torch.index_select(npos_d, 0, idx, out=st["npos_item"])
                 out_l, out_s = st["logits"], st["score"]
                 pred.track_decode(f_in, st["pts"], st["labels"], int(ks.max()), int(ps.max()) if two_pass else -1,
                                   int(self.iterative_refinement_iterations), float(self.sam_iou_threshold), size, out_l,
                                   out_s, k_item=st["k_item"] if ragged else None,
                                   npos_item=st["npos_item"] if (ragged and two_pass) else None, graph=True)
+                _lib.check(lib.sampt_move_rows(P(out_l), P(logits), P(st["items"]), F_, height * width * 4, n_masks, n_frames, 1, sp),
+                           "sampt_move_rows")
+                _lib.check(lib.sampt_move_rows(P(out_s), P(scores), P(st["items"]), F_, 4, 1, 1, 1, sp), "sampt_move_rows")
             else:
+                idx = idx_d[ci]
+                t_idx, m_idx = idx // n_masks, idx % n_masks
                 out_l = torch.empty((F_, height, width), dtype=torch.float32, device=dev)
                 out_s = torch.empty((F_,), dtype=torch.float32, device=dev)
                 pred.track_decode(feats.index_select(0, t_idx), xy_d.index_select(0, idx).contiguous(),
@@ -727,8 +776,8 @@ class SamPt(nn.Module):
                                   int(self.iterative_refinement_iterations), float(self.sam_iou_threshold), size,
                                   out_l, out_s, k_item=k_d.index_select(0, idx).contiguous() if ragged else None,
                                   npos_item=npos_d.index_select(0, idx).contiguous() if (ragged and two_pass) else None)
-            logits[m_idx, t_idx] = out_l
-            scores[idx] = out_s
+                logits[m_idx, t_idx] = out_l
+                scores[idx] = out_s
         host = None
         if scores.is_cuda:                        # asynchronous copy into pinned memory: nobody waits here
             host = torch.empty(scores.shape, dtype=scores.dtype, pin_memory=True)

@@ -86,6 +86,9 @@ class FakeHip:
             vi_o[:, idx] = torch.sigmoid(vlog)
         return 0
 
+    def sampt_pips_round_launches(self, h):
+        return 0
+
     def sampt_pips_track_workspace_bytes(self, h, n, out):
         _set(out, 256)
         return 0

@@ -274,7 +274,8 @@ def test_gemm_x3_rows_weights_resident(lib, dev, M, N, K, res, act, shuf_g):
     assert torch.equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("n,H,W,Cin,Cout", [(2, 32, 48, 64, 64), (1, 33, 17, 96, 100), (2, 18, 35, 128, 256), (3, 16, 16, 32, 128)])
+@pytest.mark.parametrize("n,H,W,Cin,Cout", [(2, 32, 48, 64, 64), (1, 33, 17, 96, 100), (2, 18, 35, 128, 256), (3, 16, 16, 32, 128),
+                                            (4, 192, 256, 64, 64), (4, 96, 128, 96, 96)])
 def test_conv3x3_fused_instnorm_statistics(lib, dev, n, H, W, Cin, Cout):
     """The halo convolution's epilogue sums the following InstanceNorm's statistics (GemmP::in_part): mean and 1 / sqrt(var + eps)
     per (image, channel) against fp64 statistics of the very map the kernel wrote — ragged tiles, two column tiles, a non-zero mean."""
@@ -296,6 +297,10 @@ def test_conv3x3_fused_instnorm_statistics(lib, dev, n, H, W, Cin, Cout):
     y2 = torch.empty_like(y)
     ok(lib.sampt_conv2d_nhwc(4, P(xhl), P(whl), P(bd), P(y2), n, H, W, Cin, Cout, 3, 3, 1, 1, S()), "conv")
     assert torch.equal(y, y2)                                                  # the statistics do not disturb the convolution
+    mr2 = torch.full((n, Cout, 2), 7.0, device=dev)                            # and again: bit for bit (fixed summation order)
+    ok(lib.sampt_conv3x3_planes_instnorm_stats(P(xhl), P(whl), P(bd), P(y2), n, H, W, Cin, Cout, 1e-5, P(mr2), P(ws), ws.numel() * 8, S()),
+       "conv + stats")
+    assert torch.equal(y, y2) and torch.equal(mr, mr2)
     yd = y.double().reshape(n, H * W, Cout)
     mean, var = yd.mean(1), yd.var(1, unbiased=False)
     rstd = 1.0 / torch.sqrt(var + 1e-5)
@@ -303,7 +308,7 @@ def test_conv3x3_fused_instnorm_statistics(lib, dev, n, H, W, Cin, Cout):
     assert ((mr[:, :, 1].double() - rstd) / rstd).abs().max().item() < 5e-6
 
 
-@pytest.mark.parametrize("n,H,W", [(2, 64, 96), (1, 45, 71), (1, 32, 32), (3, 36, 130)])
+@pytest.mark.parametrize("n,H,W", [(2, 64, 96), (1, 45, 71), (1, 32, 32), (3, 36, 130), (4, 384, 512)])   # (last: 768 tiles on 512 workgroups)
 def test_conv_stem7x7_split_fp16(lib, dev, n, H, W):
     """The tracker encoder's stem as split-fp16 products (csrc/conv_stem_x3.hip): as close to the fp64 convolution as the exact-fp32
     MFMA path, borders and ragged tiles included; fused InstanceNorm statistics against fp64 statistics of the written map."""
@@ -333,6 +338,9 @@ def test_conv_stem7x7_split_fp16(lib, dev, n, H, W):
     y2 = torch.full(ref.shape, 7.0, device=dev)                               # without statistics: the same map
     ok(lib.sampt_conv_stem7x7(P(x4), P(w4), P(bd), P(y2), n, H, W, 1e-5, None, None, 0, S()), "stem, no statistics")
     assert torch.equal(y, y2)
+    mr2 = torch.full((n, 64, 2), 7.0, device=dev)                             # and again: bit for bit (fixed summation order)
+    ok(lib.sampt_conv_stem7x7(P(x4), P(w4), P(bd), P(y2), n, H, W, 1e-5, P(mr2), P(ws), ws.numel() * 8, S()), "stem")
+    assert torch.equal(y, y2) and torch.equal(mr, mr2)
 
 
 def test_conv_f16(lib, dev):

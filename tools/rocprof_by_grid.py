@@ -17,7 +17,7 @@ rows = c.execute(f"select name, {gx}, {wx}, count(*), sum(end-start), avg(end-st
                  f"group by name, {gx}, {wx} order by 5 desc").fetchall()
 print(f"{'ms/clip':>9} {'calls/clip':>10} {'avg_us':>9} {'min_us':>9} {'grid':>9} {'wg':>5}  kernel")
 for name, g, w, n, s, a, mn in rows:
-    short = re.sub(r"\(.*", "", name).replace("void ", "").replace("sampt::", "")
+    short = re.sub(r"\(.*", "", name.replace("(anonymous namespace)::", "")).replace("void ", "").replace("sampt::", "")
     if flt and flt not in short:
         continue
     print(f"{s / 1e6 / clips:9.3f} {n / clips:10.1f} {a / 1e3:9.1f} {mn / 1e3:9.1f} {g:9d} {w:5d}  {short[:90]}")

@@ -12,6 +12,6 @@ extra = [k for k in ("grid_x", "workgroup_x", "grid_size_x", "workgroup_size_x")
 rows = c.execute(f"select name, start, end{''.join(', ' + k for k in extra)} from kernels order by start").fetchall()[-n:]
 prev = rows[0][1]
 for r in rows:
-    name = re.sub(r"\(.*", "", r[0]).replace("void ", "").replace("sampt::", "")
+    name = re.sub(r"\(.*", "", r[0].replace("(anonymous namespace)::", "")).replace("void ", "").replace("sampt::", "")
     print(f"{(r[2] - r[1]) / 1e3:9.1f} us  gap {(r[1] - prev) / 1e3:7.1f}  {name[:70]}  {' '.join(str(v) for v in r[3:])}")
     prev = r[2]
