@@ -227,9 +227,22 @@ int sampt_conv3x3_planes_instnorm_stats(const void* x_hl, const void* w_hl, cons
  * 2 GELU (erf). */
 int sampt_gemm_x3_rows(const float* A, const void* w_hl, const float* bias, const float* res, int res_mod, float* C, int M, int N,
                        int K, int act, int shuf_g, sampt_stream_t stream);
+/* sampt_gemm_x3_rows with the NEXT operator of the mask decoder's output_upscaling (mask_decoder.py:53-61, 118-126) done on the rows
+ * while they are in registers (weights-resident kernel only: M >= 16384, shuf_g > 0, act = 2, res null — anything else is refused):
+ *   epi = 1 (K = 256, N = 4 x 64): LayerNorm2d over the 64 channels of every output pixel (epi_a / epi_b = weight / bias [64],
+ *            epi_eps), then GELU: C as sampt_gemm_x3_rows;
+ *   epi = 2 (K = 64, N = 4 x 32): GELU, then <pixel's 32 channels, epi_a[frame * epi_ld + 0 .. 31]> with frame = row / shuf_g^2:
+ *            C [M * 4] holds one float per output pixel (the low-resolution mask logits of predict_masks).
+ * Bit for bit what sampt_gemm_x3_rows followed by sampt_layernorm (D = 64, act 2) / sampt_sam_mask_dot computes. */
+int sampt_gemm_x3_rows_epi(const float* A, const void* w_hl, const float* bias, const float* res, int res_mod, float* C, int M, int N,
+                           int K, int act, int shuf_g, int epi, const float* epi_a, const float* epi_b, float epi_eps, int epi_ld,
+                           sampt_stream_t stream);
+/* low [frames][npix] = <up [frames][npix][C], hyper [frames][ld_hyper]> over C channels (MaskDecoder.predict_masks: hyper_in @ upscaled). */
+int sampt_sam_mask_dot(const float* up, const float* hyper, int ld_hyper, float* low, int frames, int npix, int C, sampt_stream_t stream);
 /* Process-wide A / B switch: 1 (default) = 1 x 1 split-fp16 "convolutions" over f32 activations with M >= 16384 rows and K = 64 /
  * 128 / 256 (the mask decoder's image-side projections and transposed convolutions) run on the weights-resident-in-LDS kernel of
- * csrc/gemm_x3_wres.hip; 0 = on the tiled kernel of rounds 2 - 5 (csrc/conv_f16x3.hip k_conv_f16x3).  Results are bitwise identical. */
+ * csrc/gemm_x3_wres.hip; 0 = on the tiled kernel of rounds 2 - 5 (csrc/conv_f16x3.hip k_conv_f16x3); 2 = weights-resident, but the
+ * decoder's LayerNorm2d + GELU and mask dot product stay kernels of their own.  Results are bitwise identical in all three. */
 int sampt_gemm_set_wres(int on);
 /* Process-wide knob of the PIPS window's MLP-Mixer (csrc/pips_mixer.hip).  fused = 1 (default): two launches per mixer block —
  * [sum of the previous channel MLP's slabs + residual -> token mixing] and [LayerNorm -> fc1 -> GELU -> fc2 over hidden slices];

@@ -107,6 +107,9 @@ _SIGS = {
     "sampt_conv3x3_planes_instnorm_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                                     c_void_p, c_void_p, c_size_t, c_void_p]),
     "sampt_gemm_x3_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "sampt_gemm_x3_rows_epi": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                       c_void_p, c_void_p, c_float, c_int, c_void_p]),
+    "sampt_sam_mask_dot": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "sampt_pips_set_mixer": (c_int, [c_int, c_int]),
     "sampt_stream_create_cu_range": (c_int, [c_int, c_int, C.POINTER(_P)]),
     "sampt_stream_destroy": (c_int, [_P]),

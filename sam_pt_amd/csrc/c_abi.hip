@@ -351,6 +351,7 @@ int sampt_gemm_set_trim(int on) {
 
 int sampt_gemm_set_wres(int on) {
   sampt::g_gemm_x3_wres = on ? 1 : 0;
+  sampt::g_gemm_x3_epi = on == 2 ? 0 : 1;      // 2: the weights-resident kernel without the fused LayerNorm / dot-product tails
   return SAMPT_OK;
 }
 
@@ -722,13 +723,28 @@ int sampt_conv2d_nhwc(int dtype, const void* x, const void* w, const float* bias
 
 int sampt_gemm_x3_rows(const float* A, const void* w_hl, const float* bias, const float* res, int res_mod, float* C, int M, int N,
                        int K, int act, int shuf_g, sampt_stream_t stream) {
+  return sampt_gemm_x3_rows_epi(A, w_hl, bias, res, res_mod, C, M, N, K, act, shuf_g, 0, nullptr, nullptr, 0.f, 0, stream);
+}
+
+int sampt_gemm_x3_rows_epi(const float* A, const void* w_hl, const float* bias, const float* res, int res_mod, float* C, int M, int N,
+                           int K, int act, int shuf_g, int epi, const float* epi_a, const float* epi_b, float epi_eps, int epi_ld,
+                           sampt_stream_t stream) {
   GemmP p;
   p.A = A, p.W = w_hl, p.W_lo = (const half_t*)w_hl + (size_t)N * K, p.bias = bias, p.res = res, p.res_mod = res_mod, p.C = C;
   p.alpha = 1.0f / (float)(1 << F16X3_WSHIFT), p.act = act;
-  p.M = M, p.N = N, p.K = K, p.ldw = K, p.ldc = shuf_g ? N / 4 : N, p.ldr = p.ldc;
+  p.M = M, p.N = N, p.K = K, p.ldw = K, p.ldc = epi == 2 ? 1 : (shuf_g ? N / 4 : N), p.ldr = shuf_g ? N / 4 : N;
   p.conv = 1, p.cH = M, p.cW = 1, p.cC = K, p.KH = 1, p.KW = 1, p.cstride = 1, p.cpad = 0, p.OH = M, p.OW = 1;
   p.shuf_g = shuf_g, p.shuf_n = shuf_g ? N / 4 : 0;
+  p.epi = epi, p.epi_a = epi_a, p.epi_b = epi_b, p.epi_eps = epi_eps, p.epi_ld = epi_ld;
+  if (epi) {       // the fused tails exist in the weights-resident kernel only: refuse rather than compute something else
+    if (!sampt::g_gemm_x3_wres || !gemm_x3_wres_eligible(p)) return fail(SAMPT_ERR_UNSUPPORTED, "sampt_gemm_x3_rows_epi: shape without a fused tail");
+    return gemm_x3_wres(p, (hipStream_t)stream);
+  }
   return conv_f16x3(p, (hipStream_t)stream);
+}
+
+int sampt_sam_mask_dot(const float* up, const float* hyper, int ld_hyper, float* low, int frames, int npix, int C, sampt_stream_t stream) {
+  return sam_mask_dot(up, hyper, ld_hyper, nullptr, nullptr, 0, low, frames, npix, C, (hipStream_t)stream);
 }
 
 int sampt_move_rows(const void* src, void* dst, const int* idx, int rows, size_t row_bytes, int n_objects, int n_frames, int scatter,

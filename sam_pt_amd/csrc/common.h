@@ -203,6 +203,16 @@ struct GemmP {
   // conv3x3_halo_x3 only: non-null = also write this launch's share of the following InstanceNorm's statistics — per (image, 16 x 16
   // pixel tile, channel) the pair sum(v), sum(v^2) as doubles, [nimg][conv3x3_halo_tiles(p)][N][2]: the layout k_instnorm_final reads
   double* in_part = nullptr;
+  // gemm_x3_wres only — work of the NEXT kernel done on the rows while they are in registers (the mask decoder's output_upscaling):
+  //   epi = 1: LayerNorm over each group of 64 output columns (= one pixel of the shuffled output; weights epi_a / epi_b [64], epi_eps),
+  //            then p.act — the arithmetic of k_layernorm_rows_d64, tree for tree;
+  //   epi = 2: p.act, then the dot product of each group of 32 columns with epi_a[frame * epi_ld + 0 .. 31] (frame = row / shuf_g^2):
+  //            C [.] holds ONE float per output pixel (ldc = 1) — the arithmetic of k_sam_mask_dot32, tree for tree.
+  int epi = 0;
+  const float* epi_a = nullptr;
+  const float* epi_b = nullptr;
+  float epi_eps = 0.f;
+  int epi_ld = 0;
 };
 
 extern int g_p8_sched;     // gemm_f16_p8.hip: 0 = stage in the read segments (default), 1 = the round-3 schedule (sampt_gemm_set_schedule)
@@ -227,6 +237,8 @@ bool conv3x3_halo_eligible(const GemmP& p);
 // gemm_x3_wres.hip: the tall short-K 1 x 1 case over f32 activations (the mask decoder's image-side projections) with the weight
 // slice resident in LDS; conv_f16x3 hands eligible launches over unless g_gemm_x3_wres == 0
 extern int g_gemm_x3_wres;
+extern int g_gemm_x3_epi;      // 1 (default): the decoder's LayerNorm2d + GELU and mask dot product run in the weights-resident GEMMs' epilogues
+                               // (sampt_gemm_set_wres(2) keeps the kernel and turns the fused tails off)
 bool gemm_x3_wres_eligible(const GemmP& p);
 int gemm_x3_wres(const GemmP& p, hipStream_t s);
 int conv3x3_halo_x3(const GemmP& p, hipStream_t s);

@@ -530,11 +530,13 @@ __global__ __launch_bounds__(256) void k_layernorm_rows_d64(const float* __restr
   const float4 v = *(const float4*)(x + (live ? row : 0) * 64 + c);
   const float mean = row16_sum((v.x + v.y) + (v.z + v.w)) * (1.0f / 64.0f);
   const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
-  const float rstd = 1.0f / sqrtf(row16_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) * (1.0f / 64.0f) + eps);
+  // (explicit fused multiply-adds: gemm_x3_wres.hip's fused epilogue repeats this arithmetic operation for operation, so a row is the
+  //  same bits whether its LayerNorm ran here or there)
+  const float rstd = 1.0f / sqrtf(row16_sum(__builtin_fmaf(d1, d1, d0 * d0) + __builtin_fmaf(d3, d3, d2 * d2)) * (1.0f / 64.0f) + eps);
   if (!live) return;
   const float4 wv = *(const float4*)(w + c), bv = *(const float4*)(b + c);
-  *(float4*)(y + row * 64 + c) = make_float4(apply_act(d0 * rstd * wv.x + bv.x, act), apply_act(d1 * rstd * wv.y + bv.y, act),
-                                             apply_act(d2 * rstd * wv.z + bv.z, act), apply_act(d3 * rstd * wv.w + bv.w, act));
+  *(float4*)(y + row * 64 + c) = make_float4(apply_act(__builtin_fmaf(d0 * rstd, wv.x, bv.x), act), apply_act(__builtin_fmaf(d1 * rstd, wv.y, bv.y), act),
+                                             apply_act(__builtin_fmaf(d2 * rstd, wv.z, bv.z), act), apply_act(__builtin_fmaf(d3 * rstd, wv.w, bv.w), act));
 }
 
 // out[k] = mean over rows r < M of A[rowmap ? rowmap[r] : r][k] for an fp16 matrix: one workgroup per 64 columns, 4 row groups whose

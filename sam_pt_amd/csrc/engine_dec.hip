@@ -178,10 +178,14 @@ static int attn_block(const L& l, const DecEngine::Attn& a, int heads, int C, in
 
 // two ConvT2x2s2 stages with LayerNorm2d + GELU in between (pixel shuffle through the row maps); the second stage
 // optionally applies `act` and adds `res` (same layout as out):  x [F*P][K0] -> mid [F*4P][N0] -> out [F*16P][N1]
+// dot_hyper non-null (plain SAM, single mask): the second stage's output is never materialised — its rows are dotted with the frame's
+// hypernetwork vector dot_hyper[f * dot_ld + 0 .. N1) in the GEMM's epilogue and land in low_out [F][16 P] (gemm_x3_wres.hip, epi = 2);
+// returns through *fused_dot whether that happened (the caller runs sam_mask_dot otherwise)
 static int convt_pair(const DecEngine& e, int F, const float* x, int K0, const float* w0, const float* b0, int N0,
                       const float* lnw, const float* lnb, const float* w1, const float* b1, int N1, int act,
                       const float* res, float* mid, float* out, float* skws, size_t skn, hipStream_t s,
-                      const half_t* w0_hl = nullptr, const half_t* w1_hl = nullptr) {
+                      const half_t* w0_hl = nullptr, const half_t* w1_hl = nullptr, const float* dot_hyper = nullptr, int dot_ld = 0,
+                      float* low_out = nullptr, bool* fused_dot = nullptr) {
   const long FP = (long)F * e.c.grid * e.c.grid, P = (long)e.c.grid * e.c.grid;
   if (w0_hl && w1_hl && K0 % 32 == 0 && N0 % 32 == 0 && N1 % 4 == 0) {
     // Each stage as ONE 3-term split-fp16 GEMM over all four (dy, dx) sub-pixels (N = 4 * cout): the input is read once
@@ -196,8 +200,34 @@ static int convt_pair(const DecEngine& e, int F, const float* x, int K0, const f
       p.shuf_g = g, p.shuf_n = nsub;
       return conv_f16x3(p, s);
     };
-    SAMPT_TRY(stage(x, FP, K0, w0_hl, b0, N0, e.c.grid, mid, ACT_NONE, nullptr));
-    SAMPT_TRY(layernorm_rows(mid, lnw, lnb, mid, 4L * FP, N0, 1e-6f, nullptr, 0, ACT_GELU, s));
+    // Where the weights-resident kernel takes the launch (gemm_x3_wres.hip: F * P >= 16384 rows, the decoder's own channel counts)
+    // the LayerNorm2d + GELU between the stages runs in the first stage's epilogue, and (dot_hyper) the mask's dot product in the
+    // second's — the same arithmetic as the kernels they replace, operation for operation (tests/test_gpu_kernels.py)
+    auto fused = [&](const float* A, long M, int K, const half_t* hl, const float* bias, int nsub, int g, float* C, int epi) {
+      GemmP p;
+      p.A = A, p.W = hl, p.W_lo = hl + (size_t)4 * nsub * K, p.bias = bias, p.C = C, p.act = ACT_GELU;
+      p.alpha = 1.0f / (float)(1 << F16X3_WSHIFT);
+      p.M = (int)M, p.N = 4 * nsub, p.K = K, p.ldw = K, p.ldc = epi == 2 ? 1 : nsub, p.ldr = nsub;
+      p.conv = 1, p.cH = (int)M, p.cW = 1, p.cC = K, p.KH = 1, p.KW = 1, p.cstride = 1, p.cpad = 0, p.OH = (int)M, p.OW = 1;
+      p.shuf_g = g, p.shuf_n = nsub, p.epi = epi;
+      if (epi == 1) p.epi_a = lnw, p.epi_b = lnb, p.epi_eps = 1e-6f;
+      else p.epi_a = dot_hyper, p.epi_ld = dot_ld;
+      return p;
+    };
+    const GemmP f0 = fused(x, FP, K0, w0_hl, b0, N0, e.c.grid, mid, 1);
+    if (g_gemm_x3_wres && g_gemm_x3_epi && gemm_x3_wres_eligible(f0)) {
+      SAMPT_TRY(gemm_x3_wres(f0, s));
+    } else {
+      SAMPT_TRY(stage(x, FP, K0, w0_hl, b0, N0, e.c.grid, mid, ACT_NONE, nullptr));
+      SAMPT_TRY(layernorm_rows(mid, lnw, lnb, mid, 4L * FP, N0, 1e-6f, nullptr, 0, ACT_GELU, s));
+    }
+    if (dot_hyper && act == ACT_GELU && !res) {
+      const GemmP f1 = fused(mid, 4 * FP, N0, w1_hl, b1, N1, 2 * e.c.grid, low_out, 2);
+      if (g_gemm_x3_wres && g_gemm_x3_epi && gemm_x3_wres_eligible(f1)) {
+        if (fused_dot) *fused_dot = true;
+        return gemm_x3_wres(f1, s);
+      }
+    }
     return stage(mid, 4 * FP, N0, w1_hl, b1, N1, 2 * e.c.grid, out, act, res);
   }
   GemmP p;
@@ -314,8 +344,18 @@ int DecEngine::decode(int F, const float* features, const float* hq_feat, const 
 
   // ---- upscaling: ConvT2x2s2 (C -> C/4) + LN2d + GELU ; ConvT2x2s2 (C/4 -> C/8) + GELU   (pixel shuffle via row maps
   //      that cover max_frames frames: map[(dy,dx)][f*P + p] = f*4P + (2y+dy)*2g + 2x+dx)
+  // (plain SAM, one mask per item: the hypernetwork vector of mask token 0 first — it only needs the tokens — so that the second
+  //  transposed convolution can dot its rows with it instead of writing them)
+  bool dot_done = false;
+  const bool dot_early = !multimask && !is_hq();
+  if (dot_early) {
+    const float* mask_tok0 = queries + 1 * C;
+    SAMPT_TRY(l.lin(mask_tok0, F, C, hyp_w[0], hyp_b[0], b.t0, C, ACT_RELU, nullptr, Nt * C));
+    SAMPT_TRY(l.lin(b.t0, F, C, hyp_w[1], hyp_b[1], b.t1, C, ACT_RELU));
+    SAMPT_TRY(l.lin(b.t1, F, C, hyp_w[2], hyp_b[2], b.t2, C / 8, ACT_NONE));
+  }
   SAMPT_TRY(convt_pair(*this, F, b.keys, C, up0_w, up0_b, C / 4, upln_w, upln_b, up1_w, up1_b, C / 8, ACT_GELU, nullptr,
-                       b.up0, b.up1, nullptr, 0, s, up0_hl, up1_hl));
+                       b.up0, b.up1, nullptr, 0, s, up0_hl, up1_hl, dot_early ? b.t2 : nullptr, C / 8, low_out, &dot_done));
   if (multimask) {
     // multimask_output=True (MaskDecoder.forward: mask_slice = slice(1, None)): masks and IoUs of mask tokens 1..3;
     // low_out [3][4g][4g], logits_out [3][oh][ow], iou_out [3]
@@ -334,11 +374,13 @@ int DecEngine::decode(int F, const float* features, const float* hq_feat, const 
   // ---- hypernetwork MLP of mask token 0 (multimask_output=False keeps slice 0 only) and the IoU head;
   //      A = row 1 (mask token 0) / row 0 (iou token) of every frame's token matrix: lda = Nt*C
   const float* mask_tok = queries + 1 * C;
-  SAMPT_TRY(l.lin(mask_tok, F, C, hyp_w[0], hyp_b[0], b.t0, C, ACT_RELU, nullptr, Nt * C));
-  SAMPT_TRY(l.lin(b.t0, F, C, hyp_w[1], hyp_b[1], b.t1, C, ACT_RELU));
-  SAMPT_TRY(l.lin(b.t1, F, C, hyp_w[2], hyp_b[2], b.t2, C / 8, ACT_NONE));
+  if (!dot_early) {
+    SAMPT_TRY(l.lin(mask_tok, F, C, hyp_w[0], hyp_b[0], b.t0, C, ACT_RELU, nullptr, Nt * C));
+    SAMPT_TRY(l.lin(b.t0, F, C, hyp_w[1], hyp_b[1], b.t1, C, ACT_RELU));
+    SAMPT_TRY(l.lin(b.t1, F, C, hyp_w[2], hyp_b[2], b.t2, C / 8, ACT_NONE));
+  }
   if (!is_hq()) {
-    SAMPT_TRY(sam_mask_dot(b.up1, b.t2, C / 8, nullptr, nullptr, 0, low_out, F, 16 * P, C / 8, s));
+    if (!dot_done) SAMPT_TRY(sam_mask_dot(b.up1, b.t2, C / 8, nullptr, nullptr, 0, low_out, F, 16 * P, C / 8, s));
   } else {
     // HQ-SAM: upscaled_hq = conv3x3(GELU(LN2d(conv3x3(upscaled)))) + hq_features ;  mask = <hyper0, upscaled> +
     // <hf_mlp(hq token), upscaled_hq>   (MaskDecoderHQ.predict_masks, hq_token_only=False)

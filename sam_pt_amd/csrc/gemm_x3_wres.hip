@@ -47,15 +47,17 @@ __device__ __forceinline__ void pin(float4& v) { asm volatile("" : "+v"(v.x), "+
 // KS = K / 32.  RES: p.res travels through the ring (no pixel shuffle then).  Grid: 256 workgroups; workgroup b sits on XCD b & 7,
 // q = b >> 3 is its number there: column slice q % S of row lane q / S (RL = 32 / S row lanes per XCD; workgroups beyond S * RL idle).
 // ACT: ACT_NONE or ACT_GELU (a run-time switch inside the unrolled epilogue would be 64 copies of every activation).
-template <int KS, bool RES, int ACT>
+// EPI: GemmP::epi (0: plain; 1: LayerNorm over 64-column groups, then ACT; 2: ACT, then the 32-column dot product with a per-frame vector)
+template <int KS, bool RES, int ACT, int EPI>
 __global__ __launch_bounds__(512) void k_gemm_x3_wres(GemmP p, int S, int RL) {
   constexpr int K = KS * 32;
   constexpr int U = KS + (RES ? 4 : 0);        // units of a 32-row group
   constexpr int GB = (U % 4) ? 2 : 1;          // groups per loop body: the ring slot of a unit (its number % 4) must be a constant
   constexpr int UB = U * GB;
-  extern __shared__ __attribute__((aligned(1024))) char lds[];      // [W images (ks, j, plane): KS * 16 KB | bias 512 B]
+  extern __shared__ __attribute__((aligned(1024))) char lds[];      // [W images (ks, j, plane): KS * 16 KB | bias 512 B | epilogue table]
   char* const w_lds = lds;
   float* const bias_lds = (float*)(lds + KS * 16 * 1024);
+  float* const epi_lds = bias_lds + 128;       // EPI 1: gamma [64] | beta [64]; EPI 2: the per-frame vectors [frames][32]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lq = lane >> 4;
   const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
@@ -115,6 +117,11 @@ __global__ __launch_bounds__(512) void k_gemm_x3_wres(GemmP p, int S, int RL) {
       const int col = n0 + 4 * tid;                                  // (pixel shuffle: the bias has shuf_n entries, column % shuf_n)
       ((float4*)bias_lds)[tid] = (p.bias && col < N) ? *(const float4*)(p.bias + (p.shuf_g ? col % p.shuf_n : col))
                                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (EPI == 1 && tid < 128) epi_lds[tid] = tid < 64 ? p.epi_a[tid] : p.epi_b[tid - 64];
+    if (EPI == 2) {
+      const int nfr = M / (p.shuf_g * p.shuf_g);
+      for (int i = tid; i < nfr * 32; i += 512) epi_lds[i] = p.epi_a[(long)(i >> 5) * p.epi_ld + (i & 31)];
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -200,8 +207,74 @@ __global__ __launch_bounds__(512) void k_gemm_x3_wres(GemmP p, int S, int RL) {
             const int row = g * 32 + 16 * i + lr;
             const bool ok = gidx < ng && row < M;
             const long orow = out_row(ok ? row : 0);
+            if constexpr (EPI == 0) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) finish(i, j, orow, ok, nullptr);
+              for (int j = 0; j < 8; ++j) finish(i, j, orow, ok, nullptr);
+            } else if constexpr (EPI == 1) {
+              // LayerNorm over the 64 columns of a shuffled pixel = 4 fragments x the 4 lq lanes of this row: lane (lr, lq) of
+              // fragment jj stands where thread 4 jj + lq of k_layernorm_rows_d64 stands, and the sums follow row16_sum's tree
+              // (xor 1, xor 2 across lq = lanes ^ 16, ^ 32; then quads 0 + 1, 2 + 3; then halves), so the result is that kernel's
+#pragma unroll
+              for (int grp = 0; grp < 2; ++grp) {
+                float4 v[4];
+                float q[4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                  const int j = 4 * grp + jj;
+                  const float4 b = ((const float4*)bias_lds)[4 * j + lq];
+                  v[jj] = make_float4(acc[i][j][0] * alpha, acc[i][j][1] * alpha, acc[i][j][2] * alpha, acc[i][j][3] * alpha);
+                  v[jj].x += b.x, v[jj].y += b.y, v[jj].z += b.z, v[jj].w += b.w;          // (the two steps of finish())
+                  acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                  float x = (v[jj].x + v[jj].y) + (v[jj].z + v[jj].w);
+                  x += __shfl_xor(x, 16, 64);
+                  x += __shfl_xor(x, 32, 64);
+                  q[jj] = x;
+                }
+                const float mean = ((q[0] + q[1]) + (q[2] + q[3])) * (1.0f / 64.0f);
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                  v[jj].x -= mean, v[jj].y -= mean, v[jj].z -= mean, v[jj].w -= mean;
+                  float x = __builtin_fmaf(v[jj].y, v[jj].y, v[jj].x * v[jj].x) + __builtin_fmaf(v[jj].w, v[jj].w, v[jj].z * v[jj].z);
+                  x += __shfl_xor(x, 16, 64);
+                  x += __shfl_xor(x, 32, 64);
+                  q[jj] = x;
+                }
+                const float rstd = 1.0f / sqrtf(((q[0] + q[1]) + (q[2] + q[3])) * (1.0f / 64.0f) + p.epi_eps);
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                  const int j = 4 * grp + jj;
+                  const float4 w4 = ((const float4*)epi_lds)[4 * jj + lq], b4 = ((const float4*)epi_lds)[16 + 4 * jj + lq];
+                  const float4 o = make_float4(apply_act(__builtin_fmaf(v[jj].x * rstd, w4.x, b4.x), ACT),
+                                               apply_act(__builtin_fmaf(v[jj].y * rstd, w4.y, b4.y), ACT),
+                                               apply_act(__builtin_fmaf(v[jj].z * rstd, w4.z, b4.z), ACT),
+                                               apply_act(__builtin_fmaf(v[jj].w * rstd, w4.w, b4.w), ACT));
+                  if (ok && n0 + 16 * j + 4 * lq < N) *(float4*)(C + orow * p.ldc + joff[j] + 4 * lq) = o;
+                }
+              }
+            } else {
+              // ACT, then <row's 32 columns of a shuffled pixel, the frame's vector>: 2 fragments x the 4 lq lanes stand where the 8
+              // threads of a pixel stand in k_sam_mask_dot32, and the sum follows oct_sum's tree (xor 1, xor 2, then quads 0 + 1)
+              const int fr = (ok ? row : 0) / sP;
+#pragma unroll
+              for (int zg = 0; zg < 4; ++zg) {
+                float q[2];
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                  const int j = 2 * zg + jj;
+                  const float4 b = ((const float4*)bias_lds)[4 * j + lq];
+                  float4 t = make_float4(acc[i][j][0] * alpha, acc[i][j][1] * alpha, acc[i][j][2] * alpha, acc[i][j][3] * alpha);
+                  t.x += b.x, t.y += b.y, t.z += b.z, t.w += b.w;
+                  t.x = apply_act(t.x, ACT), t.y = apply_act(t.y, ACT), t.z = apply_act(t.z, ACT), t.w = apply_act(t.w, ACT);
+                  acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                  const float4 h = ((const float4*)epi_lds)[fr * 8 + 4 * jj + lq];
+                  float x = __builtin_fmaf(h.w, t.w, __builtin_fmaf(h.z, t.z, __builtin_fmaf(h.y, t.y, h.x * t.x)));
+                  x += __shfl_xor(x, 16, 64);
+                  x += __shfl_xor(x, 32, 64);
+                  q[jj] = x;
+                }
+                if (ok && lq == 0 && n0 + 32 * zg < N) C[orow * p.ldc + joff[2 * zg]] = q[0] + q[1];
+              }
+            }
           }
         }
       } else {                                                          // a residual unit: two column fragments of both row fragments
@@ -225,47 +298,57 @@ __global__ __launch_bounds__(512) void k_gemm_x3_wres(GemmP p, int S, int RL) {
 }
 }  // namespace
 
+int g_gemm_x3_epi = 1;
 int g_gemm_x3_wres = 1;     // sampt_gemm_set_wres: 0 = these launches stay on k_conv_f16x3 (A / B)
 
 // f32 A with contiguous K = 64 / 128 / 256 rows (a 1 x 1 "convolution"), enough rows to fill the persistent grid
 bool gemm_x3_wres_eligible(const GemmP& p) {
   if (!p.conv || p.A_lo || p.KH != 1 || p.KW != 1 || p.cstride != 1 || p.cpad != 0) return false;
   if (p.K != p.cC || (p.K != 64 && p.K != 128 && p.K != 256)) return false;
-  if (p.M < 16384 || p.N < 64 || p.N > 1024 || p.N % 4 || p.ldc % 4) return false;
+  if (p.M < 16384 || p.N < 64 || p.N > 1024 || p.N % 4 || (p.epi != 2 && p.ldc % 4)) return false;
   if (p.shuf_g && (p.res || p.shuf_n % 16)) return false;
   if (p.act != ACT_NONE && (p.act != ACT_GELU || p.res)) return false;
   if (p.res && p.ldr % 4) return false;
+  if (p.epi) {   // the fused tails of the decoder's output_upscaling, at the shapes they have there
+    if (p.res || !p.shuf_g || !p.epi_a || p.act != ACT_GELU) return false;
+    if (p.epi == 1 && (p.K != 256 || p.shuf_n != 64 || !p.epi_b)) return false;
+    if (p.epi == 2 && (p.K != 64 || p.shuf_n != 32 || p.ldc != 1 || p.M / (p.shuf_g * p.shuf_g) > 128 || p.epi_ld < 32)) return false;
+    if (p.epi != 1 && p.epi != 2) return false;
+  }
   return true;
 }
 
 int gemm_x3_wres(const GemmP& p, hipStream_t s) {
   const int S = cdiv(p.N, 128), RL = 32 / S;
   const int KS = p.K / 32;
-  const int ldsb = KS * 16 * 1024 + 512;
-#define WRES(KSv, RESv, ACTv)                                                                                                \
+  const int epib = p.epi == 1 ? 512 : (p.epi == 2 ? (p.M / (p.shuf_g * p.shuf_g)) * 128 : 0);
+  const int ldsb = KS * 16 * 1024 + 512 + epib;
+#define WRES(KSv, RESv, ACTv, EPIv)                                                                                      \
   do {                                                                                                                   \
     static bool raised = false;                                                                                          \
-    auto kern = k_gemm_x3_wres<KSv, RESv, ACTv>;                                                                            \
+    auto kern = k_gemm_x3_wres<KSv, RESv, ACTv, EPIv>;                                                                   \
     if (!raised) {                                                                                                       \
-      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, KSv * 16 * 1024 + 512) !=   \
-          hipSuccess)                                                                                                    \
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,                             \
+                              KSv * 16 * 1024 + 512 + (EPIv == 2 ? 128 * 128 : 512)) != hipSuccess)                      \
         return SAMPT_ERR_HIP;                                                                                            \
       raised = true;                                                                                                     \
     }                                                                                                                    \
     hipLaunchKernelGGL(kern, dim3(256), dim3(512), ldsb, s, p, S, RL);                                                   \
   } while (0)
-  if (p.res) {
-    if (KS == 2) WRES(2, true, ACT_NONE);
-    else if (KS == 4) WRES(4, true, ACT_NONE);
-    else WRES(8, true, ACT_NONE);
+  if (p.epi == 1) WRES(8, false, ACT_GELU, 1);
+  else if (p.epi == 2) WRES(2, false, ACT_GELU, 2);
+  else if (p.res) {
+    if (KS == 2) WRES(2, true, ACT_NONE, 0);
+    else if (KS == 4) WRES(4, true, ACT_NONE, 0);
+    else WRES(8, true, ACT_NONE, 0);
   } else if (p.act == ACT_GELU) {
-    if (KS == 2) WRES(2, false, ACT_GELU);
-    else if (KS == 4) WRES(4, false, ACT_GELU);
-    else WRES(8, false, ACT_GELU);
+    if (KS == 2) WRES(2, false, ACT_GELU, 0);
+    else if (KS == 4) WRES(4, false, ACT_GELU, 0);
+    else WRES(8, false, ACT_GELU, 0);
   } else {
-    if (KS == 2) WRES(2, false, ACT_NONE);
-    else if (KS == 4) WRES(4, false, ACT_NONE);
-    else WRES(8, false, ACT_NONE);
+    if (KS == 2) WRES(2, false, ACT_NONE, 0);
+    else if (KS == 4) WRES(4, false, ACT_NONE, 0);
+    else WRES(8, false, ACT_NONE, 0);
   }
 #undef WRES
   SAMPT_CHECK_LAUNCH("gemm_x3_wres");

@@ -733,7 +733,8 @@ __global__ void k_sam_mask_dot32(const float* __restrict__ up, const float* __re
   const long pe = ((long)f * npix + (live ? p : 0)) * 32 + part * 4;
   const float4 t = *(const float4*)(up + pe);
   const float4 h = *(const float4*)(hyper + (long)f * ld_hyper + part * 4);
-  float a = oct_sum(h.x * t.x + h.y * t.y + h.z * t.z + h.w * t.w);
+  // (explicit fused multiply-adds: the same chain as gemm_x3_wres.hip's fused epilogue, see k_layernorm_rows_d64)
+  float a = oct_sum(__builtin_fmaf(h.w, t.w, __builtin_fmaf(h.z, t.z, __builtin_fmaf(h.y, t.y, h.x * t.x))));
   if (up2) {
     const float4 t2 = *(const float4*)(up2 + pe);
     const float4 h2 = *(const float4*)(hyper2 + (long)f * ld_hyper2 + part * 4);

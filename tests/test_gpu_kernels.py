@@ -343,6 +343,49 @@ def test_conv_stem7x7_split_fp16(lib, dev, n, H, W):
     assert torch.equal(y, y2) and torch.equal(mr, mr2)
 
 
+@pytest.mark.parametrize("F_", [4, 7])
+def test_gemm_x3_rows_fused_upscaling_tails(lib, dev, F_):
+    """output_upscaling with its LayerNorm2d + GELU and the mask's dot product done in the weights-resident GEMMs' epilogues
+    (csrc/gemm_x3_wres.hip epi = 1 / 2): bit for bit the separate kernels' results, and fp32-grade against fp64."""
+    from sam_pt_amd.pack import split_f16x3
+    g = torch.Generator().manual_seed(F_)
+    G_, P_ = 64, 4096
+    keys = torch.randn(F_ * P_, 256, generator=g)
+    w0, b0 = torch.randn(4 * 64, 256, generator=g) / 16, torch.randn(64, generator=g)
+    lnw, lnb = 1.0 + 0.2 * torch.randn(64, generator=g), 0.3 * torch.randn(64, generator=g)
+    w1, b1 = torch.randn(4 * 32, 64, generator=g) / 8, torch.randn(32, generator=g)
+    hyp = torch.randn(F_, 32, generator=g)
+    kd, w0d, w1d = keys.to(dev), split_f16x3(w0).to(dev), split_f16x3(w1).to(dev)
+    b0d, b1d, lnwd, lnbd, hypd = b0.to(dev), b1.to(dev), lnw.to(dev), lnb.to(dev), hyp.to(dev)
+    # separate kernels
+    mid = torch.empty(4 * F_ * P_, 64, device=dev)
+    ok(lib.sampt_gemm_x3_rows(P(kd), P(w0d), P(b0d), None, 0, P(mid), F_ * P_, 256, 256, 0, G_, S()), "stage 0")
+    ok(lib.sampt_layernorm(P(mid), P(lnwd), P(lnbd), P(mid), 4 * F_ * P_, 64, 1e-6, 0, 2, S()), "LayerNorm2d + GELU")
+    up1 = torch.empty(16 * F_ * P_, 32, device=dev)
+    ok(lib.sampt_gemm_x3_rows(P(mid), P(w1d), P(b1d), None, 0, P(up1), 4 * F_ * P_, 128, 64, 2, 2 * G_, S()), "stage 1")
+    low = torch.empty(F_, 16 * P_, device=dev)
+    ok(lib.sampt_sam_mask_dot(P(up1), P(hypd), 32, P(low), F_, 16 * P_, 32, S()), "mask dot")
+    # fused tails
+    mid2 = torch.full((4 * F_ * P_, 64), 7.0, device=dev)
+    ok(lib.sampt_gemm_x3_rows_epi(P(kd), P(w0d), P(b0d), None, 0, P(mid2), F_ * P_, 256, 256, 2, G_, 1, P(lnwd), P(lnbd), 1e-6, 0, S()),
+       "stage 0 + LayerNorm2d + GELU")
+    assert torch.equal(mid, mid2)
+    low2 = torch.full((F_, 16 * P_), 7.0, device=dev)
+    ok(lib.sampt_gemm_x3_rows_epi(P(mid2), P(w1d), P(b1d), None, 0, P(low2), 4 * F_ * P_, 128, 64, 2, 2 * G_, 2, P(hypd), None, 0.0, 32, S()),
+       "stage 1 + mask dot")
+    assert torch.equal(low, low2)
+    # fp64 reference of the whole tail for one frame
+    f = F_ - 1
+    x = keys[f * P_:(f + 1) * P_].double() @ w0.double().T                                   # (P, 4 * 64): columns (dy, dx, c)
+    x = x.view(G_, G_, 2, 2, 64).permute(0, 2, 1, 3, 4).reshape(4 * P_, 64) + b0.double()
+    x = F.gelu(F.layer_norm(x, (64,), lnw.double(), lnb.double(), 1e-6))
+    y = (x @ w1.double().T).view(2 * G_, 2 * G_, 2, 2, 32).permute(0, 2, 1, 3, 4).reshape(16 * P_, 32) + b1.double()
+    ref = F.gelu(y) @ hyp[f].double()
+    assert rel_err(low2[f], ref) < 5e-6
+    # shapes without a fused tail are refused, not computed another way
+    assert lib.sampt_gemm_x3_rows_epi(P(kd), P(w0d), P(b0d), None, 0, P(mid2), 2 * P_, 256, 256, 2, G_, 1, P(lnwd), P(lnbd), 1e-6, 0, S()) == -3
+
+
 def test_conv_f16(lib, dev):
     n, H, W, Cin, Cout = 2, 16, 16, 256, 256
     g = torch.Generator().manual_seed(5)
