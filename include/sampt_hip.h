@@ -232,8 +232,10 @@ int sampt_gemm_x3_rows(const float* A, const void* w_hl, const float* bias, cons
  *   epi = 1 (K = 256, N = 4 x 64): LayerNorm2d over the 64 channels of every output pixel (epi_a / epi_b = weight / bias [64],
  *            epi_eps), then GELU: C as sampt_gemm_x3_rows;
  *   epi = 2 (K = 64, N = 4 x 32): GELU, then <pixel's 32 channels, epi_a[frame * epi_ld + 0 .. 31]> with frame = row / shuf_g^2:
- *            C [M * 4] holds one float per output pixel (the low-resolution mask logits of predict_masks).
- * Bit for bit what sampt_gemm_x3_rows followed by sampt_layernorm (D = 64, act 2) / sampt_sam_mask_dot computes. */
+ *            C [M * 4] holds one float per output pixel (the low-resolution mask logits of predict_masks);
+ *   epi = 3 (K = 128, N = 256, shuf_g = 0, act = 0, res [M][256] non-null): C = LayerNorm(res + A W^T + bias) over the row, weights
+ *            epi_a / epi_b [256] (transformer.py:145-150: keys = norm4(keys + attn_out)); C may be res (in place).
+ * Bit for bit what sampt_gemm_x3_rows followed by sampt_layernorm (D = 64, act 2 / D = 256) / sampt_sam_mask_dot computes. */
 int sampt_gemm_x3_rows_epi(const float* A, const void* w_hl, const float* bias, const float* res, int res_mod, float* C, int M, int N,
                            int K, int act, int shuf_g, int epi, const float* epi_a, const float* epi_b, float epi_eps, int epi_ld,
                            sampt_stream_t stream);

@@ -737,7 +737,7 @@ int sampt_gemm_x3_rows_epi(const float* A, const void* w_hl, const float* bias, 
   p.shuf_g = shuf_g, p.shuf_n = shuf_g ? N / 4 : 0;
   p.epi = epi, p.epi_a = epi_a, p.epi_b = epi_b, p.epi_eps = epi_eps, p.epi_ld = epi_ld;
   if (epi) {       // the fused tails exist in the weights-resident kernel only: refuse rather than compute something else
-    if (!sampt::g_gemm_x3_wres || !gemm_x3_wres_eligible(p)) return fail(SAMPT_ERR_UNSUPPORTED, "sampt_gemm_x3_rows_epi: shape without a fused tail");
+    if (!sampt::g_gemm_x3_wres || !(epi == 3 ? gemm_x3_wres_ln_eligible(p) : gemm_x3_wres_eligible(p))) return fail(SAMPT_ERR_UNSUPPORTED, "sampt_gemm_x3_rows_epi: shape without a fused tail");
     return gemm_x3_wres(p, (hipStream_t)stream);
   }
   return conv_f16x3(p, (hipStream_t)stream);

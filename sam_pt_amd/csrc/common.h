@@ -207,7 +207,9 @@ struct GemmP {
   //   epi = 1: LayerNorm over each group of 64 output columns (= one pixel of the shuffled output; weights epi_a / epi_b [64], epi_eps),
   //            then p.act — the arithmetic of k_layernorm_rows_d64, tree for tree;
   //   epi = 2: p.act, then the dot product of each group of 32 columns with epi_a[frame * epi_ld + 0 .. 31] (frame = row / shuf_g^2):
-  //            C [.] holds ONE float per output pixel (ldc = 1) — the arithmetic of k_sam_mask_dot32, tree for tree.
+  //            C [.] holds ONE float per output pixel (ldc = 1) — the arithmetic of k_sam_mask_dot32, tree for tree;
+  //   epi = 3 (N = 256, K = 128, res): LayerNorm over the whole row after the residual (weights epi_a / epi_b [256], epi_eps) — the
+  //            arithmetic of k_layernorm_rows_v4<1>, tree for tree.
   int epi = 0;
   const float* epi_a = nullptr;
   const float* epi_b = nullptr;
@@ -241,6 +243,7 @@ extern int g_gemm_x3_epi;      // 1 (default): the decoder's LayerNorm2d + GELU 
                                // (sampt_gemm_set_wres(2) keeps the kernel and turns the fused tails off)
 bool gemm_x3_wres_eligible(const GemmP& p);
 int gemm_x3_wres(const GemmP& p, hipStream_t s);
+bool gemm_x3_wres_ln_eligible(const GemmP& p);   // epi = 3: LayerNorm(res + A W^T + bias), N = 256, K = 128
 int conv3x3_halo_x3(const GemmP& p, hipStream_t s);
 int conv3x3_halo_tiles(const GemmP& p);
 

@@ -485,17 +485,18 @@ __global__ __launch_bounds__(256) void k_layernorm_rows_v4(const float* __restri
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     float d0 = v[i].x - mean, d1 = v[i].y - mean, d2 = v[i].z - mean, d3 = v[i].w - mean;
-    sq += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    // (explicit fused multiply-adds here and below: gemm_x3_wres.hip k_gemm_x3_wres_ln repeats this arithmetic operation for operation)
+    sq += __builtin_fmaf(d1, d1, d0 * d0) + __builtin_fmaf(d3, d3, d2 * d2);
   }
   const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)D + eps);
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = (lane + 64 * i) * 4;
     const float4 wv = *(const float4*)(w + c), bv = *(const float4*)(b + c);
-    float o0 = apply_act((v[i].x - mean) * rstd * wv.x + bv.x, act);
-    float o1 = apply_act((v[i].y - mean) * rstd * wv.y + bv.y, act);
-    float o2 = apply_act((v[i].z - mean) * rstd * wv.z + bv.z, act);
-    float o3 = apply_act((v[i].w - mean) * rstd * wv.w + bv.w, act);
+    float o0 = apply_act(__builtin_fmaf((v[i].x - mean) * rstd, wv.x, bv.x), act);
+    float o1 = apply_act(__builtin_fmaf((v[i].y - mean) * rstd, wv.y, bv.y), act);
+    float o2 = apply_act(__builtin_fmaf((v[i].z - mean) * rstd, wv.z, bv.z), act);
+    float o3 = apply_act(__builtin_fmaf((v[i].w - mean) * rstd, wv.w, bv.w), act);
     if (out_f16 == 2) {
       h4 hi, lo;
       half_t a, bb;

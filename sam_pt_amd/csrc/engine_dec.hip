@@ -156,6 +156,18 @@ static int fused_proj(const L& l, const DecEngine::FusedProj& f, const float* A,
 // tail of an attention block: out = LN(resid + out_proj(att))
 static int attn_tail(const L& l, const DecEngine::Attn& a, int C, long rows, const float* att, const float* resid, float* out,
                      const float* lnw, const float* lnb, hipStream_t s) {
+  if (l.w_hl && resid && g_gemm_x3_wres && g_gemm_x3_epi) {      // image-token side at scale: projection + residual + LayerNorm in one kernel
+    auto it = l.w_hl->find(a.ow);
+    if (it != l.w_hl->end()) {
+      GemmP p;
+      p.A = att, p.W = it->second, p.W_lo = it->second + (size_t)C * a.inner, p.bias = a.ob, p.C = out, p.res = resid;
+      p.M = (int)rows, p.N = C, p.K = a.inner, p.ldw = a.inner, p.ldc = C, p.ldr = C;
+      p.alpha = 1.0f / (float)(1 << F16X3_WSHIFT);
+      p.conv = 1, p.cH = (int)rows, p.cW = 1, p.cC = a.inner, p.KH = 1, p.KW = 1, p.cstride = 1, p.cpad = 0, p.OH = (int)rows, p.OW = 1;
+      p.epi = 3, p.epi_a = lnw, p.epi_b = lnb, p.epi_eps = 1e-5f;
+      if (gemm_x3_wres_ln_eligible(p)) return gemm_x3_wres(p, s);
+    }
+  }
   SAMPT_TRY(l.lin(att, (int)rows, a.inner, a.ow, a.ob, out, C, ACT_NONE, resid));
   return layernorm_rows(out, lnw, lnb, out, rows, C, 1e-5f, nullptr, 0, ACT_NONE, s);
 }

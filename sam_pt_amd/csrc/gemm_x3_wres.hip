@@ -296,6 +296,159 @@ __global__ __launch_bounds__(512) void k_gemm_x3_wres(GemmP p, int S, int RL) {
     });
   }
 }
+
+// ---------------------------------------------------------------------------------------------
+// out = LayerNorm(res + A W^T + bias) for N = 256, K = 128: the tail of the decoder's image -> token attention block
+// (transformer.py:145-150: keys = norm4(keys + attn_out)).  All 256 columns of a row sit in ONE workgroup (W: 256 x 128 x 2 planes
+// = 128 KB of LDS), so the LayerNorm that used to be a pass of its own over the 100 MB the GEMM had just written runs on the
+// registers: a wave owns 16-row groups (64 accumulator registers), the A and residual units (16 rows x 32 k / x 32 columns, 8
+// registers) go round a 6-slot register ring, the residual units finish two column fragments each into the accumulator registers
+// and the last one normalises the row.  The sums follow k_layernorm_rows_v4<1>'s wave_sum tree — thread 4 j + lq of that kernel is
+// lane (lr, lq) of fragment j here: xor 32 / 16 / 8 / 4 pair the fragments j ^ 8, ^ 4, ^ 2, ^ 1 in registers, xor 2 / 1 the lanes
+// ^ 32, ^ 16 — and its arithmetic operation for operation, so a row is the same bits whichever kernel normalised it.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pin2(float4& a, float4& b) {
+  asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w));
+}
+
+__global__ __launch_bounds__(512) void k_gemm_x3_wres_ln(GemmP p) {
+  constexpr int KS = 4, K = 128, NJ = 16, U = KS + 8, NS = 6;   // 12 units per 16-row group, 6 ring slots (slot = unit % 6)
+  extern __shared__ __attribute__((aligned(1024))) char lds[];      // [W images (ks, j, plane): 128 KB | bias 1 KB | gamma 1 KB | beta 1 KB]
+  char* const w_lds = lds;
+  float* const bias_lds = (float*)(lds + KS * NJ * 2 * 1024);
+  float* const gam_lds = bias_lds + 256;
+  float* const bet_lds = gam_lds + 256;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lq = lane >> 4;
+  const int M = p.M;
+  const int WL = blockIdx.x * 8 + wave, NWL = gridDim.x * 8;
+  const int G = (M + 15) >> 4;
+  const int ng = WL < G ? (G - WL + NWL - 1) / NWL : 0;
+  const float* __restrict__ A = (const float*)p.A;
+  const float* __restrict__ res = p.res;
+
+  float4 ring[NS][2];
+  auto issue = [&](auto slotc, auto posc, int gidx) {
+    constexpr int slot = decltype(slotc)::value, pos = decltype(posc)::value;
+    const int g = WL + NWL * (gidx < ng ? gidx : ng - 1);
+    int row = g * 16 + lr;
+    row = row < M ? row : M - 1;
+    if constexpr (pos < KS) {
+      const float* pa = A + (long)row * K + pos * 32 + 8 * lq;
+      ring[slot][0] = *(const float4*)pa;
+      ring[slot][1] = *(const float4*)(pa + 4);
+    } else {
+      constexpr int rr = pos - KS;
+      const float* pr = res + (long)row * p.ldr + 32 * rr + 4 * lq;
+      ring[slot][0] = *(const float4*)pr;
+      ring[slot][1] = *(const float4*)(pr + 16);
+    }
+  };
+  if (ng > 0) static_for<0, NS>([&](auto uc) {
+    constexpr int u = decltype(uc)::value;
+    issue(uc, std::integral_constant<int, u % U>{}, u / U);
+  });
+  {
+    const char* Wh = (const char*)p.W;
+    const char* Wl = (const char*)p.W_lo;
+    for (int im = wave; im < KS * NJ * 2; im += 8) {
+      const int pl = im & 1, j = (im >> 1) & 15, ks = im >> 5;
+      const char* src = (pl ? Wl : Wh) + ((long)(16 * j + lr) * p.ldw + 32 * ks + 8 * lq) * 2;
+      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(w_lds + im * 1024), 16, 0, 0);
+    }
+    if (tid < 256) bias_lds[tid] = p.bias ? p.bias[tid] : 0.f, gam_lds[tid] = p.epi_a[tid], bet_lds[tid] = p.epi_b[tid];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  if (ng == 0) return;
+  const float alpha = p.alpha, eps = p.epi_eps;
+  float* __restrict__ C = (float*)p.C;
+
+  f32x4 acc[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // sum over the row of one value per (fragment, lane): wave_sum's pairing order (see the header)
+  auto row_sum = [&](float (&x)[NJ]) -> float {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] += x[j + 8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] += x[j + 4];
+    x[0] += x[2], x[1] += x[3];
+    float t = x[0] + x[1];
+    t += __shfl_xor(t, 32, 64);
+    t += __shfl_xor(t, 16, 64);
+    return t;
+  };
+
+  for (int gb0 = 0; gb0 < ng; ++gb0) {
+    static_for<0, U>([&](auto uc) {
+      constexpr int u = decltype(uc)::value;
+      constexpr int gi = 0, pos = u, slot = u % NS;
+      const int gidx = gb0 + gi;
+      std::integral_constant<int, slot> slotc;
+      std::integral_constant<int, (u + NS) % U> npos;
+      pin2(ring[slot][0], ring[slot][1]);
+      if constexpr (pos < KS) {
+        h8 ah, al;
+        const float4 v0 = ring[slot][0], v1 = ring[slot][1];
+        const float vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          half_t a, b;
+          split_f16(vv[e], a, b);
+          ah[e] = a, al[e] = b;
+        }
+        issue(slotc, npos, gb0 + (u + NS) / U);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const h8 bh = *(const h8*)(w_lds + ((pos * NJ + j) * 2) * 1024 + lane * 16);
+          const h8 bl = *(const h8*)(w_lds + ((pos * NJ + j) * 2 + 1) * 1024 + lane * 16);
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, al, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ah, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, ah, acc[j], 0, 0, 0);
+        }
+      } else {
+        constexpr int rr = pos - KS;
+        const float4 r4[2] = {ring[slot][0], ring[slot][1]};
+        issue(slotc, npos, gb0 + (u + NS) / U);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {                                // finish(): alpha, bias, (no activation), residual
+          const int j = 2 * rr + jj;
+          const float4 b = ((const float4*)bias_lds)[4 * j + lq];
+          float4 v = make_float4(acc[j][0] * alpha, acc[j][1] * alpha, acc[j][2] * alpha, acc[j][3] * alpha);
+          v.x += b.x, v.y += b.y, v.z += b.z, v.w += b.w;
+          v.x += r4[jj].x, v.y += r4[jj].y, v.z += r4[jj].z, v.w += r4[jj].w;
+          acc[j] = (f32x4){v.x, v.y, v.z, v.w};
+        }
+        if constexpr (rr == 7) {                                        // the row is complete: LayerNorm, store
+          const int row = (WL + NWL * gidx) * 16 + lr;
+          const bool ok = gidx < ng && row < M;
+          float x[NJ];
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) x[j] = (acc[j][0] + acc[j][1]) + (acc[j][2] + acc[j][3]);
+          const float mean = row_sum(x) / 256.0f;
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            const float d0 = acc[j][0] - mean, d1 = acc[j][1] - mean, d2 = acc[j][2] - mean, d3 = acc[j][3] - mean;
+            x[j] = __builtin_fmaf(d1, d1, d0 * d0) + __builtin_fmaf(d3, d3, d2 * d2);
+          }
+          const float rstd = 1.0f / sqrtf(row_sum(x) / 256.0f + eps);
+          float* orow = C + (long)(ok ? row : 0) * p.ldc + 4 * lq;
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            const float4 w4 = ((const float4*)gam_lds)[4 * j + lq], b4 = ((const float4*)bet_lds)[4 * j + lq];
+            const float4 o = make_float4(__builtin_fmaf((acc[j][0] - mean) * rstd, w4.x, b4.x), __builtin_fmaf((acc[j][1] - mean) * rstd, w4.y, b4.y),
+                                         __builtin_fmaf((acc[j][2] - mean) * rstd, w4.z, b4.z), __builtin_fmaf((acc[j][3] - mean) * rstd, w4.w, b4.w));
+            if (ok) *(float4*)(orow + 16 * j) = o;
+            acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          }
+        }
+      }
+    });
+  }
+}
 }  // namespace
 
 int g_gemm_x3_epi = 1;
@@ -309,6 +462,7 @@ bool gemm_x3_wres_eligible(const GemmP& p) {
   if (p.shuf_g && (p.res || p.shuf_n % 16)) return false;
   if (p.act != ACT_NONE && (p.act != ACT_GELU || p.res)) return false;
   if (p.res && p.ldr % 4) return false;
+  if (p.epi == 3) return gemm_x3_wres_ln_eligible(p);
   if (p.epi) {   // the fused tails of the decoder's output_upscaling, at the shapes they have there
     if (p.res || !p.shuf_g || !p.epi_a || p.act != ACT_GELU) return false;
     if (p.epi == 1 && (p.K != 256 || p.shuf_n != 64 || !p.epi_b)) return false;
@@ -318,7 +472,27 @@ bool gemm_x3_wres_eligible(const GemmP& p) {
   return true;
 }
 
+// epi = 3: out = LayerNorm(res + A W^T + bias) over the whole 256-column row (k_gemm_x3_wres_ln)
+bool gemm_x3_wres_ln_eligible(const GemmP& p) {
+  return p.epi == 3 && p.conv && !p.A_lo && p.KH == 1 && p.KW == 1 && p.cstride == 1 && p.cpad == 0 && p.K == 128 && p.cC == 128 && p.N == 256 &&
+         p.M >= 16384 && p.res && !p.res_mod && !p.shuf_g && p.act == ACT_NONE && p.ldc % 4 == 0 && p.ldr % 4 == 0 && p.ldw == 128 && p.epi_a &&
+         p.epi_b && !(((uintptr_t)p.A | (uintptr_t)p.res | (uintptr_t)p.C | (uintptr_t)p.W | (uintptr_t)p.W_lo) & 15);
+}
+
+int gemm_x3_wres_ln(const GemmP& p, hipStream_t s) {
+  constexpr int LDSB = 4 * 16 * 2 * 1024 + 3 * 1024;
+  static bool raised = false;
+  if (!raised) {
+    if (hipFuncSetAttribute((const void*)k_gemm_x3_wres_ln, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) != hipSuccess) return SAMPT_ERR_HIP;
+    raised = true;
+  }
+  hipLaunchKernelGGL(k_gemm_x3_wres_ln, dim3(256), dim3(512), LDSB, s, p);
+  SAMPT_CHECK_LAUNCH("gemm_x3_wres_ln");
+  return SAMPT_OK;
+}
+
 int gemm_x3_wres(const GemmP& p, hipStream_t s) {
+  if (p.epi == 3) return gemm_x3_wres_ln_eligible(p) ? gemm_x3_wres_ln(p, s) : SAMPT_ERR_UNSUPPORTED;
   const int S = cdiv(p.N, 128), RL = 32 / S;
   const int KS = p.K / 32;
   const int epib = p.epi == 1 ? 512 : (p.epi == 2 ? (p.M / (p.shuf_g * p.shuf_g)) * 128 : 0);

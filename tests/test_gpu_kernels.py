@@ -386,6 +386,26 @@ def test_gemm_x3_rows_fused_upscaling_tails(lib, dev, F_):
     assert lib.sampt_gemm_x3_rows_epi(P(kd), P(w0d), P(b0d), None, 0, P(mid2), 2 * P_, 256, 256, 2, G_, 1, P(lnwd), P(lnbd), 1e-6, 0, S()) == -3
 
 
+def test_gemm_x3_rows_fused_layernorm_tail(lib, dev):
+    """keys = LayerNorm(keys + attn_out W^T + b) of the decoder's image -> token block in one kernel (gemm_x3_wres.hip epi = 3):
+    bit for bit the projection followed by sampt_layernorm, in place, with a ragged last group of rows."""
+    from sam_pt_amd.pack import split_f16x3
+    g = torch.Generator().manual_seed(11)
+    M = 5 * 4096 + 5
+    att, keys = torch.randn(M, 128, generator=g), torch.randn(M, 256, generator=g) * 2.0
+    w, b = torch.randn(256, 128, generator=g) / 11, torch.randn(256, generator=g)
+    lnw, lnb = 1.0 + 0.2 * torch.randn(256, generator=g), 0.3 * torch.randn(256, generator=g)
+    ad, whl, bd, lnwd, lnbd = att.to(dev), split_f16x3(w).to(dev), b.to(dev), lnw.to(dev), lnb.to(dev)
+    k1 = keys.to(dev).clone()
+    ok(lib.sampt_gemm_x3_rows(P(ad), P(whl), P(bd), P(k1), 0, P(k1), M, 256, 128, 0, 0, S()), "projection + residual (in place)")
+    ok(lib.sampt_layernorm(P(k1), P(lnwd), P(lnbd), P(k1), M, 256, 1e-5, 0, 0, S()), "LayerNorm")
+    k2 = keys.to(dev).clone()
+    ok(lib.sampt_gemm_x3_rows_epi(P(ad), P(whl), P(bd), P(k2), 0, P(k2), M, 256, 128, 0, 0, 3, P(lnwd), P(lnbd), 1e-5, 0, S()), "fused")
+    assert torch.equal(k1, k2)
+    ref = F.layer_norm(keys.double() + att.double() @ w.double().T + b.double(), (256,), lnw.double(), lnb.double(), 1e-5)
+    assert rel_err(k2, ref) < 3e-6
+
+
 def test_conv_f16(lib, dev):
     n, H, W, Cin, Cout = 2, 16, 16, 256, 256
     g = torch.Generator().manual_seed(5)
