@@ -1,12 +1,14 @@
-# scratch script of the current gpurun call: projection + residual + LayerNorm of the image -> token block in one kernel
+# scratch script of the current gpurun call: the round's validation on the final tree — full GPU suite, smoke(), the default bench line
+# (live oracle, cpu_baseline, roofline, secondaries, f16x3 side line), kernel trace of the bench command
 set -u
-R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/r6_c36; mkdir -p $OUT; cd $R
-timeout 300 python -m pytest tests/test_gpu_kernels.py -q -k "fused or weights_resident or layernorm" > $OUT/pytest_epi.log 2>&1; tail -6 $OUT/pytest_epi.log | cut -c1-300
-timeout 900 python -m pytest tests/test_gpu_modules.py tests/test_gpu_bench_parity.py -x -q -k "dec or sam or golden or predictor or parity or stream or vit" > $OUT/pytest_mod.log 2>&1; tail -3 $OUT/pytest_mod.log | cut -c1-300
-for h in 2 1; do SAMPT_GEMM_WRES=$h timeout 400 python bench.py --steps 6 --warmup 2 --no-secondary --no-roofline --no-pipelined --no-cpu-baseline > $OUT/bench_wres$h.json 2> $OUT/bench_wres$h.err; python - <<PY
-import json
-try:
-    d = json.loads(open("$OUT/bench_wres$h.json").read().strip().splitlines()[-1]); print("wres $h", d["value"], d.get("timeline"))
-except Exception as e: print("bench parse failed", e)
-PY
-done
+R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/r6_final; mkdir -p $OUT; cd $R
+timeout 1500 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; tail -3 $OUT/pytest_gpu.log | cut -c1-300
+timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log | cut -c1-300
+timeout 2400 python bench.py > $OUT/bench_default.log 2> $OUT/bench_default.err; tail -1 $OUT/bench_default.log | cut -c1-1500
+cd /tmp; export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o vith -- python $R/bench.py --no-cpu-baseline --no-secondary --no-roofline --steps 5 --warmup 2 > $OUT/rocprof.log 2>&1
+DB=$(find $OUT/prof -name "*.db" | head -1)
+python $R/tools/rocprof_summary.py "$DB" 288 > $OUT/vith_kernel_stats.txt 2>&1
+python $R/tools/rocprof_by_grid.py "$DB" "" 12 > $OUT/vith_kernels_by_grid.txt 2>&1
+rm -rf $OUT/prof
+head -14 $OUT/vith_kernel_stats.txt | cut -c1-160

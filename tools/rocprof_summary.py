@@ -18,7 +18,7 @@ def main():
           + (f"; {tot / 1e6 / frames:.3f} ms/frame over {frames:.0f} frames" if frames else ""))
     print(f"{'total_ms':>10} {'pct':>6} {'calls':>8} {'avg_us':>10} {'min_us':>9} {'max_us':>9}  kernel")
     for name, n, s, a, mn, mx in rows:
-        short = re.sub(r"\(.*", "", name)
+        short = re.sub(r"\(.*", "", name.replace("(anonymous namespace)::", ""))
         print(f"{s / 1e6:10.2f} {100 * s / tot:6.2f} {n:8d} {a / 1e3:10.1f} {mn / 1e3:9.1f} {mx / 1e3:9.1f}  {short}")
 
 
