@@ -35,7 +35,7 @@ namespace {
 //   [5..8] bbox of the CURRENT eroded mask               [9] pixels in it         [10] k of the current erosion (-1: mask itself)
 //   [11] 1 = the current eroded mask is final            [12] number of corners found
 //   [13] ordered-float bits of the max eigenvalue over the eroded mask
-enum { QS_BB = 0, QS_CNT = 4, QS_EBB = 5, QS_ECNT = 9, QS_K = 10, QS_FINAL = 11, QS_NFOUND = 12, QS_MAX = 13, QS_INTS = 16 };
+enum { QS_BB = 0, QS_CNT = 4, QS_EBB = 5, QS_ECNT = 9, QS_K = 10, QS_FINAL = 11, QS_NFOUND = 12, QS_MAX = 13, QS_NCAND = 14, QS_INTS = 16 };
 
 __device__ __forceinline__ unsigned ord_bits(float v) {          // monotone map float -> uint32
   const unsigned b = __float_as_uint(v);
@@ -187,8 +187,12 @@ __global__ __launch_bounds__(256) void k_qp_max_masked(const float* __restrict__
 }
 
 // candidate keys: THRESH_TOZERO at max * quality, 3 x 3 local maximum, inside the eroded mask, off the image border
+// ... and, compacted: the non-zero keys appended to `list` (capacity `cap`; st[QS_NCAND] counts every candidate, so a count above the
+// capacity tells the greedy kernel to scan the dense array instead).  The order of the list is arbitrary — each greedy round takes the
+// maximum key, and a key carries its position, so the result does not depend on it.
 __global__ __launch_bounds__(256) void k_qp_candidates(const float* __restrict__ eig, const uint8_t* __restrict__ m, int H, int W,
-                                                       const int* st, float quality, unsigned long long* __restrict__ keys) {
+                                                       int* st, float quality, unsigned long long* __restrict__ keys,
+                                                       unsigned long long* __restrict__ list, int cap) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)H * W) return;
   const int y = (int)(i / W), x = (int)(i - (long)y * W);
@@ -209,15 +213,22 @@ __global__ __launch_bounds__(256) void k_qp_candidates(const float* __restrict__
     }
   }
   keys[i] = key;
+  if (key) {
+    const int slot = atomicAdd(st + QS_NCAND, 1);
+    if (slot < cap) list[slot] = key;
+  }
 }
 
-// n rounds of the masked arg-max, ONE workgroup of 1024 threads
-__global__ __launch_bounds__(1024) void k_qp_greedy(const unsigned long long* __restrict__ keys, int H, int W, int* st, int n_points,
-                                                    float* __restrict__ out_xy) {
+// n rounds of the masked arg-max, ONE workgroup of 1024 threads, over the compacted candidate list (a frame has a few hundred to a few
+// thousand candidates; the dense array — H * W keys, nearly all zero, re-read on every round — only when the list overflowed)
+__global__ __launch_bounds__(1024) void k_qp_greedy(const unsigned long long* __restrict__ keys_dense, const unsigned long long* __restrict__ list,
+                                                    int cap, int H, int W, int* st, int n_points, float* __restrict__ out_xy) {
   __shared__ unsigned long long red[16];
   __shared__ int ax[64], ay[64];
   __shared__ int n_acc;
-  const long n = (long)H * W;
+  const bool dense = st[QS_NCAND] > cap;
+  const unsigned long long* __restrict__ keys = dense ? keys_dense : list;
+  const long n = dense ? (long)H * W : (long)st[QS_NCAND];
   const double md = bbox_diameter(st + QS_EBB) / (double)n_points;
   const bool check = !(md < 1.0);
   const double md2 = md * md;
@@ -229,7 +240,8 @@ __global__ __launch_bounds__(1024) void k_qp_greedy(const unsigned long long* __
     for (long i = threadIdx.x; i < n; i += blockDim.x) {
       const unsigned long long k = keys[i];
       if (k <= best) continue;
-      const int y = (int)(i / W), x = (int)(i - (long)y * W);
+      const unsigned pos = (unsigned)(k & 0xffffffffu);                    // (the key's low word is the pixel index)
+      const int y = (int)(pos / (unsigned)W), x = (int)(pos - (unsigned)y * (unsigned)W);
       bool good = true;
       for (int j = 0; j < na; ++j) {
         const long dx = x - ax[j], dy = y - ay[j];
@@ -312,8 +324,12 @@ int qp_corners(const uint8_t* image, const uint8_t* mask, int H, int W, int n_po
   hipLaunchKernelGGL(k_qp_gray, grid, block, 0, s, image, n, gray);
   hipLaunchKernelGGL(k_qp_min_eig, grid, block, 0, s, (const uint8_t*)gray, H, W, eig);
   hipLaunchKernelGGL(k_qp_max_masked, rgrid, block, 0, s, (const float*)eig, (const uint8_t*)er, n, st);
-  hipLaunchKernelGGL(k_qp_candidates, grid, block, 0, s, (const float*)eig, (const uint8_t*)er, H, W, (const int*)st, quality, keys);
-  hipLaunchKernelGGL(k_qp_greedy, dim3(1), dim3(1024), 0, s, (const unsigned long long*)keys, H, W, st, n_points, out_xy);
+  // (the candidate list lives in tmp | gray, both dead by now: 2 * pad bytes)
+  unsigned long long* list = (unsigned long long*)tmp;
+  const int cap = (int)(2 * pad / 8);
+  hipLaunchKernelGGL(k_qp_candidates, grid, block, 0, s, (const float*)eig, (const uint8_t*)er, H, W, st, quality, keys, list, cap);
+  hipLaunchKernelGGL(k_qp_greedy, dim3(1), dim3(1024), 0, s, (const unsigned long long*)keys, (const unsigned long long*)list, cap, H, W, st,
+                     n_points, out_xy);
   SAMPT_CHECK_LAUNCH("qp_corners");
   if (hipMemcpyAsync(out_info, st, QS_INTS * sizeof(int), hipMemcpyDeviceToDevice, s) != hipSuccess) return SAMPT_ERR_HIP;
   return SAMPT_OK;

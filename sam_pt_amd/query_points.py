@@ -247,7 +247,7 @@ def shi_tomasi_device(image: torch.Tensor, mask: torch.Tensor, n_points: int, de
                                            _lib.ptr(info), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "sampt_qp_shi_tomasi")
         inf = info.cpu().tolist()                                  # the one synchronisation
         return xy.cpu()[:inf[12]], {"k": inf[10], "eroded_pixels": inf[9], "eroded_bbox": inf[5:9], "mask_bbox": inf[0:4],
-                                    "mask_pixels": inf[4]}
+                                    "mask_pixels": inf[4], "candidates": inf[14]}
 
 
 def extract_corner_points(image: torch.Tensor, mask: torch.Tensor, n_points_to_select: int,

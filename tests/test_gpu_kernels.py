@@ -883,6 +883,7 @@ def test_shi_tomasi_device_equals_host_restatement(lib, dev):
         want = Q.good_features_to_track(Q._rgb_to_gray_u8(img), n, 0.001, ediam / n, eroded.numpy().astype(np.uint8))
         got, info = Q.shi_tomasi_device(it, mt, n, dev)
         assert info["k"] == k_used and info["eroded_pixels"] == int(eroded.sum()), (case, info, k_used, int(eroded.sum()))
+        assert len(want) <= info["candidates"] <= eroded.numel() // 4 + 64   # the greedy rounds ran over the compacted list (corners.hip)
         assert info["eroded_bbox"] == [int(epx[:, 0].min()), int(epx[:, 0].max()), int(epx[:, 1].min()), int(epx[:, 1].max())]
         assert got.shape == want.shape and np.array_equal(got.numpy(), want), f"case {case} (n={n}): {got.tolist()} != {want.tolist()}"
         n_with_corners += len(want) > 0
