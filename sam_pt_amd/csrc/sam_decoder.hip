@@ -290,7 +290,10 @@ int attn_rowblock(const float* q, const float* k, const float* v, float* out, in
 //     row shuffles; partial (max, sum, acc) states go to a workspace and k_attn_t2i_merge combines the KS splits.
 // ---------------------------------------------------------------------------------------------
 namespace {
-constexpr int T2I_NQ = 8;           // queries per workgroup (their running softmax states live in registers)
+constexpr int T2I_NQ = 8;           // queries per workgroup (their running softmax states live in registers).  (SAM-PT's 13 - 21 prompt
+                                    // tokens are two blocks, so K / V are streamed twice; 16 per workgroup — one stream — was measured in
+                                    // round 6: 256 VGPRs, two waves per SIMD, 78 us against 46: the kernel is bound by its exp / FMA work
+                                    // per (query, key) and the occupancy that hides its loads, not by the bytes; profiles/r6_c39_*)
 constexpr int T2I_REC = 128 + 16;   // floats per (split, query): acc[128] + max[8] + sum[8]
 constexpr float T2I_SCALE = 0.25f * 1.4426950408889634f;   // scores are kept in log2 units: softmax via v_exp_f32 alone
 #define T2I_EXP(x) __builtin_amdgcn_exp2f(x)
