@@ -1034,3 +1034,20 @@ dist.barrier(); dist.destroy_process_group()
         os.unlink(path)
     assert r.returncode == 0, r.stderr[-2500:]
     assert "EIGHT_OK" in r.stdout
+
+
+def test_stack_frames_takes_consecutive_views_without_a_copy():
+    """SamPt accepts the reference's list-of-frames clip; frames that already are consecutive slices of one buffer are stacked as a
+    view (no device copy kernel in the fused forward), anything else falls back to torch.stack with the same values."""
+    import torch
+    from sam_pt_amd.sam_pt import _stack_frames
+    clip = torch.randint(0, 256, (5, 3, 6, 7), dtype=torch.uint8)
+    v = _stack_frames([f for f in clip])
+    assert v.data_ptr() == clip.data_ptr() and torch.equal(v, clip) and v.is_contiguous()
+    w = _stack_frames([clip[i] for i in (0, 2, 1, 3, 4)])                       # not in order: a real stack
+    assert w.data_ptr() != clip.data_ptr() and torch.equal(w, clip[[0, 2, 1, 3, 4]])
+    x = _stack_frames([clip[0], clip[1].clone(), clip[2]])                      # another storage in between
+    assert torch.equal(x, clip[:3]) and x.data_ptr() != clip.data_ptr()
+    y = _stack_frames([f for f in clip[1:4]])                                   # a sub-range of the buffer is a view too
+    assert y.data_ptr() == clip[1].data_ptr() and torch.equal(y, clip[1:4])
+    assert torch.equal(_stack_frames([clip[0]]), clip[:1])
