@@ -467,6 +467,9 @@ __global__ __launch_bounds__(256) void k_layernorm_rows_v4(const float* __restri
       if (out_f16 == 2) {
         *(h4*)((half_t*)y + row * 2 * D + x3_col(c)) = (h4){0, 0, 0, 0};
         *(h4*)((half_t*)y + row * 2 * D + x3_col(c) + 32) = (h4){0, 0, 0, 0};
+      } else if (out_f16 == 3) {
+        *(h4*)((half_t*)y + row * D + c) = (h4){0, 0, 0, 0};
+        *(h4*)((half_t*)y + (M + row) * D + c) = (h4){0, 0, 0, 0};
       } else if (out_f16) *(h4*)((half_t*)y + row * D + c) = (h4){0, 0, 0, 0};
       else *(float4*)((float*)y + row * D + c) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -507,6 +510,16 @@ __global__ __launch_bounds__(256) void k_layernorm_rows_v4(const float* __restri
       half_t* yp = (half_t*)y + row * 2 * D + x3_col(c);
       *(h4*)yp = hi;
       *(h4*)(yp + 32) = lo;
+    } else if (out_f16 == 3) {      // two fp16 planes [2][M][D] (hi, lo): the pre-split operand of the halo convolution (conv_halo_x3.hip)
+      h4 hi, lo;
+      half_t a, bb;
+      split_f16(o0, a, bb), hi[0] = a, lo[0] = bb;
+      split_f16(o1, a, bb), hi[1] = a, lo[1] = bb;
+      split_f16(o2, a, bb), hi[2] = a, lo[2] = bb;
+      split_f16(o3, a, bb), hi[3] = a, lo[3] = bb;
+      half_t* yp = (half_t*)y + row * D + c;
+      *(h4*)yp = hi;
+      *(h4*)(yp + M * D) = lo;
     } else if (out_f16) *(h4*)((half_t*)y + row * D + c) = (h4){(half_t)o0, (half_t)o1, (half_t)o2, (half_t)o3};
     else *(float4*)((float*)y + row * D + c) = make_float4(o0, o1, o2, o3);
   }
@@ -568,6 +581,9 @@ int layernorm_rows(const float* x, const float* w, const float* b, void* y, long
                    const int* src_rows, int out_f16, int act, hipStream_t s) {
   if (D <= 0 || D > 2048 || M <= 0) return SAMPT_ERR_ARG;
   if (out_f16 == 2 && (D % 32)) return SAMPT_ERR_ARG;     // x3 rows are made of whole 32-blocks
+  // out_f16 == 3 (two fp16 planes [2][M][D]): the vectorised kernel only
+  if (out_f16 == 3 && !(D % 256 == 0 && D <= 1536 && ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)w | (uintptr_t)b) & 15) == 0)))
+    return SAMPT_ERR_UNSUPPORTED;
   if (D == 64 && !src_rows && !out_f16 && ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)w | (uintptr_t)b) & 15) == 0)) {
     hipLaunchKernelGGL(k_layernorm_rows_d64, dim3((unsigned)cdiv(M, 16)), dim3(256), 0, s, x, w, b, (float*)y, M, eps, act);
     SAMPT_CHECK_LAUNCH("layernorm_rows_d64");

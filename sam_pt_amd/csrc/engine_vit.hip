@@ -277,7 +277,11 @@ int VitEngine::encode(const uint8_t* frames, int chw, int B, int H, int W, float
   //      fp32 in both modes: the neck's operand roundings would land on the embedding undamped
   SAMPT_TRY(gm.run(x, (int)Mg, D, neck0_w, nullptr, neck_a, c.out_chans, ACT_NONE, 0, nullptr, 0, nullptr, 0, nullptr,
                    true, neck0_hl));
-  SAMPT_TRY(layernorm_rows(neck_a, neck1w, neck1b, neck_b, Mg, c.out_chans, 1e-6f, nullptr, 0, ACT_NONE, s));
+  // (split-fp16 neck: the first LayerNorm2d writes its output as the two fp16 planes the halo-tiled 3 x 3 convolution stages by
+  //  LDS-DMA — same bytes as the f32 map in the same buffer, same hi / lo values the tiled kernel split on the fly, ~165 -> 110 us
+  //  per 8 frames (profiles/r6_c40_*); conv_halo_x3.hip)
+  const bool planes = neck2_hl && g_conv_halo && c.out_chans % 256 == 0 && c.out_chans <= 1536;
+  SAMPT_TRY(layernorm_rows(neck_a, neck1w, neck1b, neck_b, Mg, c.out_chans, 1e-6f, nullptr, planes ? 3 : 0, ACT_NONE, s));
   {
     GemmP p;
     p.A = neck_b, p.W = neck2_w, p.C = neck_a;
@@ -286,6 +290,7 @@ int VitEngine::encode(const uint8_t* frames, int chw, int B, int H, int W, float
     if (neck2_hl) {
       p.W = neck2_hl, p.W_lo = neck2_hl + (size_t)p.N * p.K;
       p.alpha = 1.0f / (float)(1 << F16X3_WSHIFT);
+      if (planes) p.A_lo = (const half_t*)neck_b + (size_t)Mg * c.out_chans;
       SAMPT_TRY(conv_f16x3(p, s));
     } else {
       SAMPT_TRY(gemm_f32(p, s));
