@@ -434,7 +434,7 @@ def test_instance_norm(lib, dev, C_):
 
 
 @pytest.mark.parametrize("D,f16,act", [(64, 0, 2), (256, 0, 0), (512, 0, 0), (768, 1, 0), (1280, 1, 0), (4, 0, 2), (16, 0, 0),
-                                       (1280, 2, 0), (768, 2, 0), (64, 2, 0), (96, 2, 2)])
+                                       (1280, 2, 0), (768, 2, 0), (64, 2, 0), (96, 2, 2), (256, 3, 0), (768, 3, 2)])
 def test_layernorm(lib, dev, D, f16, act):
     M = 333
     g = torch.Generator().manual_seed(D)
@@ -442,10 +442,16 @@ def test_layernorm(lib, dev, D, f16, act):
     w, b = torch.randn(D, generator=g), torch.randn(D, generator=g)
     ref = F.layer_norm(x.double(), (D,), w.double(), b.double(), 1e-6)
     ref = F.gelu(ref) if act == 2 else ref
-    y = torch.empty(M, 2 * D if f16 == 2 else D, device=dev, dtype=torch.float16 if f16 else torch.float32)
+    y = torch.empty((2, M, D) if f16 == 3 else (M, 2 * D if f16 == 2 else D), device=dev, dtype=torch.float16 if f16 else torch.float32)
     xd, wd, bd = x.to(dev), w.to(dev), b.to(dev)  # keep the device copies alive across the async launch
     ok(lib.sampt_layernorm(P(xd), P(wd), P(bd), P(y), M, D, 1e-6, f16, act, S()), "layernorm")
-    if f16 == 2:                                  # x3 rows: hi + lo is the fp32 result
+    if f16 == 3:                                  # two fp16 planes (the halo convolution's operand): hi = fp16(result), hi + lo the fp32 result
+        y32 = torch.empty(M, D, device=dev)
+        ok(lib.sampt_layernorm(P(xd), P(wd), P(bd), P(y32), M, D, 1e-6, 0, act, S()), "layernorm f32")
+        assert torch.equal(y[0], y32.half()) and torch.equal(y[1], (y32 - y[0].float()).half())
+        assert max_abs(y[0].float() + y[1].float(), ref) < 1e-5
+        assert lib.sampt_layernorm(P(xd), P(wd), P(bd), P(y), M, 96, 1e-6, 3, act, S()) == -3     # planes: the vectorised kernel's widths only
+    elif f16 == 2:                                # x3 rows: hi + lo is the fp32 result
         from sam_pt_amd.pack import x3_unrows
         assert max_abs(x3_unrows(y.cpu()), ref) < 1e-5
     else:
