@@ -1,16 +1,14 @@
-# scratch script of the current gpurun call: the ViT neck's 3 x 3 convolution on the halo kernel (LayerNorm2d writes fp16 planes)
+# scratch script of the current gpurun call: the round's validation on the final tree — full GPU suite, smoke(), the default bench line
+# (live oracle, cpu_baseline, roofline, secondaries, f16x3 side line), kernel trace of the bench command
 set -u
-R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/r6_c40; mkdir -p $OUT; cd $R
-timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_modules.py tests/test_gpu_bench_parity.py -x -q -k "vit or layernorm or sam or golden or predictor or parity or smoke" > $OUT/pytest_vit.log 2>&1; tail -3 $OUT/pytest_vit.log | cut -c1-300
+R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/r6_final; mkdir -p $OUT; cd $R
+timeout 1500 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; tail -3 $OUT/pytest_gpu.log | cut -c1-300
+timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log | cut -c1-300
+timeout 2400 python bench.py > $OUT/bench_default.log 2> $OUT/bench_default.err; tail -1 $OUT/bench_default.log | cut -c1-700
 cd /tmp; export TMPDIR=/tmp
-timeout 400 rocprofv3 --kernel-trace -d $OUT/prof -o clip -- python $R/bench.py --no-cpu-baseline --no-secondary --no-roofline --no-pipelined --steps 4 --warmup 2 > $OUT/rocprof.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o vith -- python $R/bench.py --no-cpu-baseline --no-secondary --no-roofline --steps 5 --warmup 2 > $OUT/rocprof.log 2>&1
 DB=$(find $OUT/prof -name "*.db" | head -1)
-python $R/tools/rocprof_by_grid.py "$DB" "" 6 > $OUT/clip_by_grid.txt 2>&1; rm -rf $OUT/prof
-grep "k_conv_f16x3<\|halo_x3<128\|layernorm_rows_v4<1>" $OUT/clip_by_grid.txt | cut -c1-140
-grep "^{" $OUT/rocprof.log | python -c "
-import json,sys
-for l in sys.stdin: d=json.loads(l); print(d['value'], d.get('timeline'))"
-cd $R; timeout 600 python bench.py --steps 4 --warmup 2 --no-secondary --no-roofline --no-pipelined > $OUT/bench.json 2> $OUT/bench.err; python - <<PY
-import json
-d = json.loads(open("$OUT/bench.json").read().strip().splitlines()[-1]); p=d["parity"]; print(d["value"], d.get("timeline"), p["pass"], p["mask_iou_min"], p["logit_max_abs"])
-PY
+python $R/tools/rocprof_summary.py "$DB" 288 > $OUT/vith_kernel_stats.txt 2>&1
+python $R/tools/rocprof_by_grid.py "$DB" "" 12 > $OUT/vith_kernels_by_grid.txt 2>&1
+rm -rf $OUT/prof
+head -8 $OUT/vith_kernel_stats.txt | cut -c1-160
