@@ -1,14 +1,21 @@
-# scratch script of the current gpurun call: the round's validation on the final tree — full GPU suite, smoke(), the default bench line
-# (live oracle, cpu_baseline, roofline, secondaries, f16x3 side line), kernel trace of the bench command
 set -u
-R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/r6_final; mkdir -p $OUT; cd $R
-timeout 1500 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; tail -3 $OUT/pytest_gpu.log | cut -c1-300
-timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log | cut -c1-300
-timeout 2400 python bench.py > $OUT/bench_default.log 2> $OUT/bench_default.err; tail -1 $OUT/bench_default.log | cut -c1-700
-cd /tmp; export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o vith -- python $R/bench.py --no-cpu-baseline --no-secondary --no-roofline --steps 5 --warmup 2 > $OUT/rocprof.log 2>&1
-DB=$(find $OUT/prof -name "*.db" | head -1)
-python $R/tools/rocprof_summary.py "$DB" 288 > $OUT/vith_kernel_stats.txt 2>&1
-python $R/tools/rocprof_by_grid.py "$DB" "" 12 > $OUT/vith_kernels_by_grid.txt 2>&1
-rm -rf $OUT/prof
-head -8 $OUT/vith_kernel_stats.txt | cut -c1-160
+R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/r6_c41; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 300 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_wres_$c -- python $R/tools/gemm_wres_bench.py > $OUT/wres_$c.log 2>&1
+done
+cd $R
+python - <<'PY' > $OUT/pmc_traffic_wres.txt
+import csv, glob, os, re, collections
+out = os.environ.get("OUT", "gpurun_out/r6_c41")
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    acc = collections.defaultdict(list)
+    for f in glob.glob(os.path.join("gpurun_out/r6_c41", "pmc_wres_" + c, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            n = re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", "")).replace("void sampt::", "")
+            if "wres" in n or "conv_f16x3" in n:
+                acc[(n, r["Grid_Size"] if "Grid_Size" in r else "")].append(float(r["Counter_Value"]))
+    for (n, g), v in sorted(acc.items()):
+        print(f"{c:11s} {n:34s} grid {g:>9s}  n={len(v):4d}  mean {sum(v) / len(v) / 1e3:9.1f} MB (counter KB; x2 for FETCH_SIZE on gfx950)")
+PY
+rm -rf $OUT/pmc_*_SIZE
+cat $OUT/pmc_traffic_wres.txt | cut -c1-170

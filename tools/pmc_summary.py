@@ -14,7 +14,7 @@ def main():
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            name = re.sub(r"\(.*", "", r["Kernel_Name"])
+            name = re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", ""))
             if sub in name:
                 acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for name, cs in acc.items():
