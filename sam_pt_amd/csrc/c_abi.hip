@@ -339,7 +339,7 @@ int sampt_pips_set_mixer(int fused, int workgroups) {
 int sampt_conv_set_halo(int on) {
   // 3: halo / stem kernels without the fused InstanceNorm statistics; 4: statistics from the halo kernel only; 5: from the stem only
   sampt::g_conv_in_stats = on == 3 ? 0 : (on == 4 ? 1 : (on == 5 ? 2 : 3));
-  sampt::g_halo_dbg = on == 6 || on == 7 ? on : 0;
+  sampt::g_halo_dbg = on >= 6 && on <= 8 ? on : 0;
   sampt::g_conv_halo = on < 0 ? 0 : (on > 2 ? 1 : on);
   return SAMPT_OK;
 }

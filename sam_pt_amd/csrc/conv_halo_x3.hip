@@ -45,7 +45,7 @@ constexpr int ABUF = 2 * APL;                           // one halo chunk: hi | 
 // workgroup per CU): waves w and w + 4 share the 4 rows and split the channels, so every SIMD holds TWO waves — one multiplies while
 // the other issues its LDS-DMA (60 - 185 issue cycles per instruction) or waits for LDS.
 template <int BN, bool A2, int NWV>
-__global__ __launch_bounds__(NWV * 64, (A2 && NWV == 4) ? 1 : 2) void k_conv3x3_halo_x3(GemmP p, int ntx, int nty) {
+__global__ __launch_bounds__(NWV * 64, (A2 && NWV == 4) ? 1 : 2) void k_conv3x3_halo_x3(GemmP p, int ntx, int nty, int xcd_order) {
   constexpr int FN = BN / 16;                  // output-channel fragments of the tile
   constexpr int FNW = FN / (NWV / 4);          // ... of one wave
   constexpr int NBP = 2 * FN;                  // W DMA pieces per stage: [hi rows | lo rows], 16 rows each
@@ -61,9 +61,19 @@ __global__ __launch_bounds__(NWV * 64, (A2 && NWV == 4) ? 1 : 2) void k_conv3x3_
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int pw = wave & 3, ch = wave >> 2;     // pixel-row group, channel half
   const int lr = lane & 15, lq = lane >> 4;
-  // ---- tile: blockIdx.x = ((img * nty + ty) * ntx + tx) * ntn + tn
+  // ---- tile number b = ((img * nty + ty) * ntx + tx) * ntn + tn.  Workgroups go round robin over the 8 XCDs (blockIdx & 7), each
+  // with its own L2: XCD x takes the CONTIGUOUS tile range [x * per, (x + 1) * per), so that the tiles that share halo rows and
+  // columns (and the column tiles that share the whole halo) meet in one L2 (g_halo_xcd = 0: plain order, for A / B runs)
   const int ntn = (p.N + BN - 1) / BN;
+  const int ntiles_all = p.M / (p.OH * p.OW) * nty * ntx * ntn;
   int b = blockIdx.x;
+  if (xcd_order) {
+    const int per = (ntiles_all + 7) >> 3;
+    b = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per || b >= ntiles_all) return;
+  } else if (b >= ntiles_all) {
+    return;
+  }
   const int tn = b % ntn;  b /= ntn;
   const int tx = b % ntx;  b /= ntx;
   const int ty = b % nty;
@@ -255,7 +265,7 @@ __global__ __launch_bounds__(NWV * 64, (A2 && NWV == 4) ? 1 : 2) void k_conv3x3_
 
 int g_conv_halo = 1;     // sampt_conv_set_halo: 0 = the 3 x 3 stride-1 launches go back to k_conv_f16x3_dma (A / B); 2 = 4-wave
                          // workgroups for every tile width (the first version of this kernel)
-int g_halo_dbg = 0;      // (debug: 6 = the 64-column tile on the double-buffered schedule, 7 = one workgroup per CU)
+int g_halo_dbg = 0;      // (debug: 6 = the 64-column tile on the double-buffered schedule, 7 = one workgroup per CU, 8 = plain tile order)
 int g_conv_in_stats = 3; // bit 0: the halo convolutions, bit 1: the stem sum the following InstanceNorm's statistics (sampt_conv_set_halo(3 / 4 / 5))
 
 bool conv3x3_halo_eligible(const GemmP& p) {
@@ -272,7 +282,8 @@ int conv3x3_halo_x3(const GemmP& p, hipStream_t s) {
   const int ntx = cdiv(p.cW, HT), nty = cdiv(p.cH, HT);
   const int BN = p.N <= 64 ? 64 : (p.N <= 96 ? 96 : 128);
   const int ntn = cdiv(p.N, BN);
-  dim3 grid((unsigned)((long)nimg * nty * ntx * ntn));
+  const long ntiles = (long)nimg * nty * ntx * ntn;
+  dim3 grid((unsigned)(((ntiles + 7) / 8) * 8));                      // (8 x per: see the XCD order in the kernel)
 #define HALO(BNv, NWVv, A2x)                                                                                             \
   do {                                                                                                                   \
     constexpr bool A2v = A2x;                                                                                            \
@@ -284,7 +295,7 @@ int conv3x3_halo_x3(const GemmP& p, hipStream_t s) {
         return SAMPT_ERR_HIP;                                                                                            \
       raised = true;                                                                                                     \
     }                                                                                                                    \
-    hipLaunchKernelGGL(kern, grid, dim3(NWVv * 64), (g_halo_dbg == 7 && LDSB < 100 * 1024) ? 100 * 1024 : LDSB, s, p, ntx, nty);  \
+    hipLaunchKernelGGL(kern, grid, dim3(NWVv * 64), (g_halo_dbg == 7 && LDSB < 100 * 1024) ? 100 * 1024 : LDSB, s, p, ntx, nty, g_halo_dbg == 8 ? 0 : 1);  \
   } while (0)
   const bool w8 = g_conv_halo != 2;
   if (BN == 64) { if (g_halo_dbg == 6) HALO(64, 4, true); else HALO(64, 4, false); }

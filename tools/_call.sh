@@ -1,21 +1,6 @@
 set -u
-R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/r6_c41; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
-for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_wres_$c -- python $R/tools/gemm_wres_bench.py > $OUT/wres_$c.log 2>&1
-done
-cd $R
-python - <<'PY' > $OUT/pmc_traffic_wres.txt
-import csv, glob, os, re, collections
-out = os.environ.get("OUT", "gpurun_out/r6_c41")
-for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    acc = collections.defaultdict(list)
-    for f in glob.glob(os.path.join("gpurun_out/r6_c41", "pmc_wres_" + c, "**", "*counter_collection.csv"), recursive=True):
-        for r in csv.DictReader(open(f)):
-            n = re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", "")).replace("void sampt::", "")
-            if "wres" in n or "conv_f16x3" in n:
-                acc[(n, r["Grid_Size"] if "Grid_Size" in r else "")].append(float(r["Counter_Value"]))
-    for (n, g), v in sorted(acc.items()):
-        print(f"{c:11s} {n:34s} grid {g:>9s}  n={len(v):4d}  mean {sum(v) / len(v) / 1e3:9.1f} MB (counter KB; x2 for FETCH_SIZE on gfx950)")
-PY
-rm -rf $OUT/pmc_*_SIZE
-cat $OUT/pmc_traffic_wres.txt | cut -c1-170
+R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/r6_c42; mkdir -p $OUT; cd $R
+timeout 300 python -m pytest tests/test_gpu_kernels.py -q -k "conv or instnorm" > $OUT/pytest_conv.log 2>&1; tail -3 $OUT/pytest_conv.log | cut -c1-300
+timeout 200 python tools/conv_halo_bench.py 2>&1 | grep -v amdgpu.ids | tee $OUT/conv_halo_bench.log | cut -c1-300
+timeout 400 python tools/probes/conv_stats_determinism.py 100 1 2>&1 | grep -v "amdgpu.ids" | tail -12 | cut -c1-200
+for h in 8 1; do SAMPT_CONV_HALO=$h timeout 100 python tools/tracker_bench.py 2>&1 | grep "tracker encoder" | sed "s/^/halo $h: /"; done
