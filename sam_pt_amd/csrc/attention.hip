@@ -282,7 +282,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void k_flash_f16(const ha
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           h8 tf = (h8){0, 0, 0, 0, 0, 0, 0, 0};
-          if (row < NR) {
+          if (pad.rel_ops) {           // ready-made operand image (FlashPad::rel_ops): one 16-byte load
+            tf = *(const h8*)(pad.rel_ops + ((((long)tb * NTIL + t) * KS + ks) * 64 + lane) * 8);
+          } else if (row < NR) {
             const float4* tp = (const float4*)(tab + (long)row * HD + ks * 16 + hi * 8);
             float4 t0 = tp[0], t1 = tp[1];
             tf = (h8){(half_t)t0.x, (half_t)t0.y, (half_t)t0.z, (half_t)t0.w,

@@ -148,6 +148,7 @@ struct VitEngine {
   VitConfig c;
   struct Blk {
     const float *ln1w, *ln1b, *ln2w, *ln2b, *qkv_b, *proj_b, *b1, *b2, *rel_h, *rel_w;
+    const half_t* rel_ops = nullptr;   // optional: rel_h / rel_w as fp16 MFMA operand images (pack.rel_pos_operand_images)
     const void *qkv_w, *proj_w, *w1, *w2;  // f16 or f32 depending on c.f16
     const half_t* qkv_b16 = nullptr;       // 16-bit modes: the qkv bias as one row of the qkv matrix's format (fp16 / x3 row)
   };

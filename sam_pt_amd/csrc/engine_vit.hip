@@ -34,6 +34,7 @@ int VitEngine::init(const WeightMap& w, const VitConfig& cfg, int wrb) {
     if (c.f16) b.qkv_b16 = w.h(p + ".attn.qkv.bias" + sfx);
     b.proj_w = w.get(p + ".attn.proj.weight" + sfx), b.proj_b = w.f(p + ".attn.proj.bias");
     b.rel_h = w.f(p + ".attn.rel_pos_h"), b.rel_w = w.f(p + ".attn.rel_pos_w");
+    b.rel_ops = w.has(p + ".attn.rel_pos_ops") ? w.h(p + ".attn.rel_pos_ops") : nullptr;
     b.w1 = w.get(p + ".mlp.lin1.weight" + sfx), b.b1 = w.f(p + ".mlp.lin1.bias");
     b.w2 = w.get(p + ".mlp.lin2.weight" + sfx), b.b2 = w.f(p + ".mlp.lin2.bias");
   }
@@ -236,6 +237,7 @@ int VitEngine::encode(const uint8_t* frames, int chw, int B, int H, int W, float
       SAMPT_TRY(fill_rows_bias(qkv, 0, win_pad, (int)(M - Mg), b.qkv_b, 3 * D, s));
     }
     if (c.f16 == 1) {
+      fp.rel_ops = b.rel_ops;
       SAMPT_TRY(vit_flash_attention_f16((const half_t*)qkv, b.rel_h, b.rel_w, (half_t*)att, Bw, S, c.heads, hd, s, fp));
     } else if (c.f16 == 2) {
       SAMPT_TRY(vit_flash_attention_x3((const half_t*)qkv, b.rel_h, b.rel_w, (half_t*)att, Bw, S, c.heads, hd, s, fp));

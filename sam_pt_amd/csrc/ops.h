@@ -70,6 +70,10 @@ int softmax_rel_rows(float* scores, const float* relh, const float* relw, long B
 struct FlashPad {
   const half_t* bias_row = nullptr;
   int nwx = 0, nwin = 0, gh = 0, gw = 0;
+  // vit_flash_attention_f16 only, optional: the block's rel-pos tables as fp16 MFMA operand images (pack.rel_pos_operand_images:
+  // [2][ceil((2 S - 1) / 32)][hd / 16][64][8] halves) — the prologue then loads 16 bytes per lane and k-step instead of converting
+  // the f32 tables in every workgroup.  Same halves, same results.
+  const half_t* rel_ops = nullptr;
 };
 // Fused flash-style attention, f16 operands, fp32 softmax/accumulate.  qkv f16 [B*S*S][3*D]; out f16 [B*S*S][D];
 // rel_h / rel_w: rel_pos tables f32 [2S-1][hd] (the decomposed bias is computed inside the kernel).

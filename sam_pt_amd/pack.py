@@ -243,6 +243,24 @@ def window_row_map(grid: int, window: int, batches: int, rows: int = 0) -> torch
     return m.reshape(-1).to(torch.int32)
 
 
+def rel_pos_operand_images(rel_h: torch.Tensor, rel_w: torch.Tensor) -> torch.Tensor:
+    """The decomposed rel-pos tables of one block ([2 S - 1][hd] each) as the fp16 MFMA operand images the flash kernel's prologue
+    multiplies with the query fragments (csrc/attention.hip: G[rho][q] = <rel_pos[rho], q>): half [2 tables][tiles of 32 rows][hd / 16
+    k-steps][64 lanes][8], lane l of tile t, k-step ks holds rel_pos[32 t + (l & 31)][16 ks + 8 (l >> 5) .. + 8] (rows past the table:
+    0).  The kernel used to build them from the f32 tables in every workgroup: 11 % of a windowed launch (profiles/r6_c43_*)."""
+    assert rel_h.shape == rel_w.shape and rel_h.shape[1] % 16 == 0
+    nr, hd = rel_h.shape
+    nt, ks = -(-nr // 32), hd // 16
+    lane = torch.arange(64)
+    row = torch.arange(nt)[:, None, None] * 32 + (lane & 31)[None, None, :]                                   # [nt][1][64]
+    col = torch.arange(ks)[None, :, None, None] * 16 + (lane >> 5)[None, None, :, None] * 8 + torch.arange(8)  # [1][ks][64][8]
+    out = torch.zeros(2, nt, ks, 64, 8, dtype=torch.float16)
+    for i, tab in enumerate((rel_h, rel_w)):
+        t = torch.cat([tab.float(), torch.zeros(nt * 32 - nr, hd)])
+        out[i] = t[row[..., None].expand(nt, ks, 64, 8), col.expand(nt, ks, 64, 8)].half()
+    return out.contiguous()
+
+
 def pack_vit(sd: Dict[str, torch.Tensor], cfg: SamConfig, device, f16, win_batches: int) -> Dict[str, torch.Tensor]:
     """``f16``: False / 0 = exact fp32, True / 1 = fp16 block GEMMs (".f16" copies), 2 = split-fp16 block GEMMs (".x3" x3 rows
     of w * 2^8); the encoder's two ends are split-fp16 planes ("_hl") in both 16-bit modes."""
@@ -291,6 +309,11 @@ def pack_vit(sd: Dict[str, torch.Tensor], cfg: SamConfig, device, f16, win_batch
                 out[k + (".f16" if f16 else "")] = w.half() if f16 else w
         else:
             out[k] = v.contiguous()
+    if mode == 1 and os.environ.get("SAMPT_ATTN_REL_OPS", "1") != "0":    # fp16 attention: the rel-pos tables as ready-made operand images
+        for i in range(cfg.depth):
+            p = f"{e}blocks.{i}.attn."
+            if p + "rel_pos_h" in out and out[p + "rel_pos_h"].shape[1] % 16 == 0:
+                out[p + "rel_pos_ops"] = rel_pos_operand_images(out[p + "rel_pos_h"], out[p + "rel_pos_w"])
     rows = window_row_map(cfg.grid, cfg.window_size, win_batches)
     out["__win_rows"] = rows
     # token row -> row in window order (a permutation into the padded layout), and the padded rows themselves: the

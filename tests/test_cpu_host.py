@@ -1051,3 +1051,23 @@ def test_stack_frames_takes_consecutive_views_without_a_copy():
     y = _stack_frames([f for f in clip[1:4]])                                   # a sub-range of the buffer is a view too
     assert y.data_ptr() == clip[1].data_ptr() and torch.equal(y, clip[1:4])
     assert torch.equal(_stack_frames([clip[0]]), clip[:1])
+
+
+def test_rel_pos_operand_images_layout():
+    """pack.rel_pos_operand_images: lane l of tile t, k-step ks holds rel_pos[32 t + (l & 31)][16 ks + 8 (l >> 5) .. + 8] as halves,
+    zero past the table — what csrc/attention.hip's prologue used to convert per workgroup."""
+    import torch
+    from sam_pt_amd.pack import rel_pos_operand_images
+    for S_, hd in ((14, 80), (64, 80), (14, 64), (6, 32)):
+        g = torch.Generator().manual_seed(S_)
+        rh, rw = torch.randn(2 * S_ - 1, hd, generator=g), torch.randn(2 * S_ - 1, hd, generator=g)
+        o = rel_pos_operand_images(rh, rw)
+        nt = -(-(2 * S_ - 1) // 32)
+        assert o.shape == (2, nt, hd // 16, 64, 8) and o.dtype == torch.float16
+        for tb, tab in enumerate((rh, rw)):
+            for t in range(nt):
+                for ks in range(hd // 16):
+                    for l in (0, 5, 26, 31, 32, 47, 63):
+                        row = 32 * t + (l & 31)
+                        want = tab[row, 16 * ks + 8 * (l >> 5): 16 * ks + 8 * (l >> 5) + 8].half() if row < 2 * S_ - 1 else torch.zeros(8).half()
+                        assert torch.equal(o[tb, t, ks, l], want)

@@ -212,6 +212,23 @@ def test_vit_b_f16_bias_correction_off_distribution(dev, monkeypatch, kind):
     assert errs["1"] <= 1.02 * errs["0"]
 
 
+@pytest.mark.parametrize("variant,hw", [("vit_test", (100, 256)), ("vit_b", (576, 1024))])
+def test_vit_f16_rel_pos_operand_images_are_exact(dev, monkeypatch, variant, hw):
+    """The fp16 attention kernel takes the decomposed rel-pos tables as host-packed MFMA operand images (pack.rel_pos_operand_images,
+    FlashPad::rel_ops) instead of converting the f32 tables in every workgroup: the same halves, so the embeddings are the same bits."""
+    from sam_pt_amd.sam_predictor import SamHip, SamPredictor
+    from sam_pt_amd.weights import SAM_CONFIGS
+    cfg = SAM_CONFIGS[variant]
+    g = torch.Generator().manual_seed(3)
+    frames = torch.randint(0, 256, (2, 3) + hw, generator=g, dtype=torch.uint8).to(dev)
+    embs = {}
+    for ops in ("1", "0"):
+        monkeypatch.setenv("SAMPT_ATTN_REL_OPS", ops)
+        pred = SamPredictor(SamHip(config=cfg, seed=72, precision="f16", max_batch=2).to(dev))
+        embs[ops] = pred.encode_frames(frames).clone()
+    assert torch.equal(embs["1"], embs["0"])
+
+
 @pytest.mark.parametrize("variant,precision,hw,T", [("vit_test", "f32", (144, 256), 3), ("vit_test", "f16", (100, 256), 3),
                                                      ("vit_b", "f16", (576, 1024), 3), ("vit_b", "f32", (480, 1024), 1),
                                                      ("vit_test", "f16x3", (100, 256), 3), ("vit_b", "f16x3", (576, 1024), 3)])
